@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+It imports the reference package (pure Python) from /root/reference with two tiny stand-in modules for the
+absent third-party packages `xarray` and `numba` (tests/golden/_refstubs), drives the reference exactly the way
+`Model.run` drives it (prepare_simulations -> run_single_simulation, smrt/core/model.py:415-619), and stores
+inputs + outputs (+ a few intermediate stages) as small .npz fixtures next to this script.
+
+Nothing here travels as code to the GPU box: the fixtures are data (inputs and expected outputs).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "_refstubs"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+from smrt import make_model, make_snowpack, sensor_list  # noqa: E402
+from smrt.core.sensor import active, passive  # noqa: E402
+from smrt.rtsolver.dort import DORT  # noqa: E402
+from smrt.rtsolver.rtsolver_utils import compute_interface_properties  # noqa: E402
+
+
+def snowpack_arrays(sp):
+    """Flatten a reference Snowpack into plain arrays (the layout our own boundary consumes)."""
+    L = len(sp.layers)
+    out = dict(
+        thickness=np.array([lay.thickness for lay in sp.layers], float),
+        density=np.array([lay.density for lay in sp.layers], float),
+        temperature=np.array([lay.temperature for lay in sp.layers], float),
+        frac_volume=np.array([lay.frac_volume for lay in sp.layers], float),
+    )
+    ms = sp.layers[0].microstructure
+    if hasattr(ms, "corr_length"):
+        out["microstructure"] = "exponential"
+        out["corr_length"] = np.array([lay.microstructure.corr_length for lay in sp.layers], float)
+    elif hasattr(ms, "stickiness"):
+        out["microstructure"] = "sticky_hard_spheres"
+        out["radius"] = np.array([lay.microstructure.radius for lay in sp.layers], float)
+        out["stickiness"] = np.array([lay.microstructure.stickiness for lay in sp.layers], float)
+    else:
+        raise RuntimeError("unexpected microstructure")
+    assert L == len(out["thickness"])
+    return out
+
+
+def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_layers=(0,)):
+    """Run the reference for every (frequency) configuration of `sensor` on snowpack `sp`."""
+    rtsolver_options = dict(rtsolver_options or {})
+    m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options)
+    sims, dims = m.prepare_simulations(sensor, sp, None, "snowpack")
+    sims = list(sims)
+    out = dict(snowpack_arrays(sp))
+    out["emmodel"] = emmodel
+    out["mode"] = sensor.mode
+    freqs, datas = [], []
+    for isim, sim in enumerate(sims):
+        se, spk = sim
+        r = m.run_single_simulation(sim, None, None)
+        freqs.append(float(se.frequency))
+        datas.append(np.asarray(r.data.values))
+        tag = "f%d_" % isim
+        for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+            out[tag + k] = np.asarray(r.other_data[k].values)
+        if stages:
+            dump_stages(out, tag, m, se, spk, rtsolver_options, stage_layers)
+    out["frequency"] = np.array(freqs)
+    out["result"] = np.array(datas)  # (nfreq, pol, theta) or (nfreq, pol_inc, pol, theta_inc)
+    out["theta_deg"] = np.asarray(sensor.theta_deg, float)
+    if sensor.mode == "A":
+        out["theta_inc_deg"] = np.asarray(sensor.theta_inc_deg, float)
+    for k, v in rtsolver_options.items():
+        out["opt_" + k] = np.asarray(v)
+    return out
+
+
+def dump_stages(out, tag, m, se, spk, rtsolver_options, stage_layers):
+    """Intermediate tensors of one solve: streams, interface diagonals, A matrices, sorted eigenvalues."""
+    ems = m.prepare_emmodels(se, spk)
+    solver = DORT(**rtsolver_options)
+    solver.init_solve(spk, ems, se, None)
+    solver.prepare_streams()
+    st = solver.streams
+    L = len(ems)
+    nmax = max(st.n)
+    mu = np.zeros((L, nmax))
+    w = np.zeros((L, nmax))
+    for l in range(L):
+        mu[l, : st.n[l]] = st.mu[l]
+        w[l, : st.n[l]] = st.weight[l]
+    out[tag + "streams_n"] = np.asarray(st.n, int)
+    out[tag + "streams_mu"] = mu
+    out[tag + "streams_weight"] = w
+    out[tag + "streams_outmu"] = np.asarray(st.outmu)
+    out[tag + "streams_outweight"] = np.asarray(st.outweight)
+    npol = 2 if se.mode == "P" else 3
+    m_max = solver.m_max if se.mode == "A" else 0
+    itf = compute_interface_properties(
+        se.frequency, spk.interfaces, spk.substrate, solver.effective_permittivity, st, m_max, npol
+    )
+    for name, fn in (
+        ("Rtop", itf.reflection_top),
+        ("Ttop", itf.transmission_top),
+        ("Rbottom", itf.reflection_bottom),
+        ("Tbottom", itf.transmission_bottom),
+    ):
+        for mode in range(m_max + 1):
+            P = 2 if mode == 0 else 3
+            arr = np.zeros((L + 1, nmax * P))
+            for l in list(range(L)) + [-1]:
+                if l == -1 and name in ("Rtop", "Ttop"):
+                    continue
+                d = fn(l, mode, False)
+                d = np.zeros(0) if np.isscalar(d) or getattr(d, "shape", None) == () else np.asarray(d.diagonal())
+                arr[l if l >= 0 else L, : len(d)] = d  # row L holds the air->snow side (index -1)
+            out[tag + "itf_%s_m%d" % (name, mode)] = arr
+    from smrt.rtsolver.dort import EigenValueSolver
+
+    for mode in range(m_max + 1):
+        P = 2 if mode == 0 else 3
+        betas = np.zeros((L, 2 * nmax * P))
+        for l in range(L):
+            es = EigenValueSolver(
+                ke=ems[l].ke,
+                ks=ems[l].ks,
+                ft_even_phase_function=ems[l].ft_even_phase,
+                mu=st.mu[l],
+                weight=st.weight[l],
+                m_max=m_max,
+                method="schur_forcedtriu",
+                normalization=getattr(ems[l], "_respect_reciprocity_principle", True),
+                symmetrization=False,
+                cache=False,
+            )
+            if mode > 0:
+                es.solve(0, False)  # normalisation of mode m needs mode 0 first (dort.py:803-807)
+            if l in stage_layers:
+                A = es.solve_generic(mode, False, debug_A=True)
+                out[tag + "A_m%d_l%d" % (mode, l)] = np.asarray(A)
+            beta, Eu, Ed = es.solve(mode, False)
+            betas[l, : len(beta)] = np.sort(beta)
+        out[tag + "beta_sorted_m%d" % mode] = betas
+
+
+def save(name, d):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
+    print("wrote", os.path.relpath(path), "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def random_snowpack(rng, L, micro, thick_lo=0.05, thick_hi=0.30, last=100.0):
+    """Synthetic snowpack laws of SURVEY.md section 8d."""
+    thickness = np.append(rng.uniform(thick_lo, thick_hi, L - 1), last)
+    density = rng.uniform(150, 450, L)
+    temperature = rng.uniform(230, 270, L)
+    if micro == "exponential":
+        size = rng.uniform(5e-5, 3e-4, L)
+        return make_snowpack(thickness, "exponential", density=density, temperature=temperature, corr_length=size)
+    size = rng.uniform(5e-5, 1.5e-4, L)
+    return make_snowpack(
+        thickness, "sticky_hard_spheres", density=density, temperature=temperature, radius=size, stickiness=0.2
+    )
+
+
+def main():
+    # (i) config 1: examples/iba_onelayer_example.py:6-27
+    sp = make_snowpack([100], "exponential", density=[320], temperature=[270], corr_length=[5e-5])
+    d = run_case("iba", sensor_list.amsre("37V"), sp, stages=True)
+    em = make_model("iba", "dort").prepare_emmodels(next(sensor_list.amsre("37V").iterate("frequency")) if False else
+                                                    sensor_list.passive(36.5e9, 55), sp)[0]
+    d["iba_coeff"] = em.iba_coeff
+    save("cfg1_iba_onelayer", d)
+
+    # (ii) smrt/test/test_integration_iba.py:13-69 (2-layer passive 37 GHz, active 19 GHz 55 deg)
+    sp2 = make_snowpack(
+        thickness=[0.1, 100], microstructure_model="exponential", density=[200, 400],
+        temperature=[250.0, 250.0], corr_length=[5e-5, 5e-5],
+    )
+    save("iba_2layer_passive37", run_case("iba", sensor_list.amsre("37V"), sp2, stages=True, stage_layers=(0, 1)))
+    save("iba_2layer_active19", run_case("iba", active(frequency=19e9, theta_inc=55), sp2, stages=True,
+                                         stage_layers=(0,)))
+
+    # (iii) smrt/test/test_dmrtdort.py:20-37 snowpack with dmrt_qca_shortrange
+    sp3 = make_snowpack(
+        [0.1, 1000], "sticky_hard_spheres", density=[200, 400], temperature=[250.0, 250.0],
+        radius=[2e-4, 2e-4], stickiness=[0.1, 0.1],
+    )
+    save("dmrt_2layer_passive37", run_case("dmrt_qca_shortrange", sensor_list.amsre("37V"), sp3, stages=True,
+                                           stage_layers=(0,)))
+
+    # (iv) random multilayer cases
+    rng = np.random.default_rng(2)
+    sps = [random_snowpack(rng, 20, "exponential") for _ in range(3)]
+    for i, spx in enumerate(sps[:2]):
+        save("cfg2_iba_L20_n32_sp%d" % i, run_case("iba", sensor_list.amsre(), spx, stages=(i == 0),
+                                                   stage_layers=(0, 19)))
+    # reduced-size passive cases for fast oracle checks, several viewing angles incl. extrapolation to nadir
+    rng = np.random.default_rng(12)
+    spx = random_snowpack(rng, 6, "exponential")
+    save("iba_L6_n8_angles", run_case("iba", passive([10.65e9, 36.5e9, 89e9], [0, 5, 30, 55, 70]), spx,
+                                      rtsolver_options=dict(n_max_stream=8), stages=True, stage_layers=(0, 5)))
+    spx = random_snowpack(rng, 3, "exponential", last=0.5)  # optically shallow, no substrate
+    save("iba_L3_n16_shallow", run_case("iba", passive([18.7e9, 36.5e9], [40, 55]), spx,
+                                        rtsolver_options=dict(n_max_stream=16), stages=True, stage_layers=(0,)))
+    rng = np.random.default_rng(3)
+    spx = random_snowpack(rng, 50, "sticky_hard_spheres")
+    save("cfg3_dmrt_L50_n64_sp0", run_case("dmrt_qca_shortrange", passive([6.925e9, 36.5e9, 89e9], 55), spx,
+                                           rtsolver_options=dict(n_max_stream=64)))
+    spx = random_snowpack(rng, 8, "sticky_hard_spheres")
+    save("dmrt_L8_n16", run_case("dmrt_qca_shortrange", passive([10.65e9, 89e9], [30, 55]), spx,
+                                 rtsolver_options=dict(n_max_stream=16), stages=True, stage_layers=(0,)))
+    # active, reduced size (cfg4 laws: thin layers, C band) and one at 32 streams
+    rng = np.random.default_rng(4)
+    spx = random_snowpack(rng, 5, "exponential", 0.02, 0.10, 1000.0)
+    save("cfg4_iba_active_L5_n16", run_case("iba", sensor_list.sentinel1(), spx,
+                                            rtsolver_options=dict(n_max_stream=16, m_max=2), stages=True,
+                                            stage_layers=(0,)))
+    spx = random_snowpack(rng, 4, "exponential", 0.02, 0.10, 1000.0)
+    save("iba_active_L4_n32_ku", run_case("iba", active(13.4e9, [30, 40]), spx,
+                                          rtsolver_options=dict(n_max_stream=32, m_max=2)))
+
+    # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
+    # known answer smrt/rtsolver/test_rtsolver.py:64-73
+    from smrt.emmodel.iba import IBA
+
+    ks_tab = []
+    pcs = [0.3e-3, 0.25e-3, 0.2e-3, 0.15e-3, 0.1e-3, 0.05e-3]
+    for pc in pcs:
+        spk = make_snowpack([1], "exponential", density=[300], temperature=[265], corr_length=[pc])
+        e = IBA(sensor_list.passive(37e9, 0), spk.layers[0])
+        ks_tab.append([pc, e._ks, e.ka, e.effective_permittivity().real, e.effective_permittivity().imag,
+                       e.iba_coeff])
+    save("iba_ks_table", dict(table=np.array(ks_tab), frequency=37e9, density=300.0, temperature=265.0,
+                              memls_reference=np.array([4.14237510549, 2.58473097058, 1.41504051e00,
+                                                        0.630947615752, 0.194948835313, 0.0250132475909])))
+
+    # (vi) simulation order and result layout of Model.run for 3 snowpacks x AMSR-E (frequency-major)
+    m = make_model("iba", "dort")
+    sims, dims = m.prepare_simulations(sensor_list.amsre(), sps, None, "snowpack")
+    order = [(float(se.frequency), sps.index(s)) for se, s in sims]
+    save("model_run_order", dict(order=np.array(order), dims=np.array([str(dm[0]) for dm in dims])))
+
+
+if __name__ == "__main__":
+    main()

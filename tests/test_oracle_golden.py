@@ -1,0 +1,125 @@
+"""Pin the CPU oracle (oracle/dort_oracle.py) against golden vectors produced by the real reference
+(tests/golden/make_golden.py) -- including the reference's own known answers.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import ACTIVE_FIXTURES, PASSIVE_FIXTURES, fixture_options, load_golden, snowpack_dict
+from oracle import dort_oracle as O
+
+TB_TOL = 1e-6  # K      (BASELINE.json north_star)
+SIGMA_RTOL = 1e-8  # relative
+
+
+def test_reference_known_answers_are_in_the_fixtures():
+    # smrt/test/test_integration_iba.py:48-49 and :67-69, examples/iba_onelayer_example.py
+    d = load_golden("iba_2layer_passive37")
+    np.testing.assert_allclose(d["result"][0, :, 0], [248.09044325849692, 237.3487270223389], atol=1e-4)
+    d = load_golden("iba_2layer_active19")
+    r = d["result"][0]
+    db = O.sigma_dB(np.array([r[0, 0, 0], r[1, 1, 0], r[1, 0, 0]]), 55.0)
+    np.testing.assert_allclose(db, [-24.044882546524693, -24.416295329469907, -51.544272924876886], atol=1e-4)
+    d = load_golden("cfg1_iba_onelayer")
+    np.testing.assert_allclose(d["result"][0, :, 0], [268.22172695, 251.75293753], atol=1e-7)
+
+
+@pytest.mark.parametrize("name", PASSIVE_FIXTURES)
+@pytest.mark.parametrize("method", ["half_rank_eig", "schur_forcedtriu"])
+def test_passive_tb(name, method):
+    d = load_golden(name)
+    if name.startswith("cfg3") and method == "schur_forcedtriu":
+        pytest.skip("same code path as the other fixtures; 18 s")
+    sp = snowpack_dict(d)
+    for i, f in enumerate(d["frequency"]):
+        tb = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), method=method, **fixture_options(d))
+        assert np.abs(tb - d["result"][i]).max() < TB_TOL
+
+
+@pytest.mark.parametrize("name", ACTIVE_FIXTURES)
+@pytest.mark.parametrize("method", ["half_rank_eig", "schur_forcedtriu"])
+def test_active_backscatter(name, method):
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    for i, f in enumerate(d["frequency"]):
+        r = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), mode="A",
+                    theta_inc_deg=d["theta_inc_deg"], method=method, **fixture_options(d))
+        ref = d["result"][i]
+        # co- and cross-polarised intensities (V,H x V,H): relative to the co-pol level
+        scale = np.abs(ref[:2, :2]).max(axis=(0, 1))
+        assert (np.abs(r - ref)[:2, :2] / scale).max() < SIGMA_RTOL
+        # cross-pol on its own scale (40-50 dB below co-pol)
+        assert np.allclose(r[0, 1], ref[0, 1], rtol=1e-6, atol=0)
+        assert np.allclose(r[1, 0], ref[1, 0], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["cfg1_iba_onelayer", "iba_2layer_passive37", "cfg2_iba_L20_n32_sp0",
+                                  "iba_L6_n8_angles", "dmrt_L8_n16", "cfg4_iba_active_L5_n16"])
+def test_stages(name):
+    """Layer electromagnetics, streams, interface diagonals, A matrices and eigenvalues, stage by stage."""
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    active = str(d["mode"]) == "A"
+    opts = fixture_options(d)
+    for i, f in enumerate(d["frequency"]):
+        tag = "f%d_" % i
+        det = {}
+        kw = dict(mode="A", theta_inc_deg=d["theta_inc_deg"]) if active else {}
+        O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), details=det, **opts, **kw)
+        ems, st, itf = det["ems"], det["streams"], det["itf"]
+        np.testing.assert_allclose([e.eps_eff for e in ems], d[tag + "effective_permittivity"], rtol=1e-13)
+        np.testing.assert_allclose([e.ks for e in ems], d[tag + "ks"], rtol=1e-12)
+        np.testing.assert_allclose([e.ka for e in ems], d[tag + "ka"], rtol=1e-11)
+        if tag + "streams_n" not in d:
+            continue
+        assert list(st.n) == list(d[tag + "streams_n"])
+        for l in range(len(ems)):
+            np.testing.assert_allclose(st.mu[l], d[tag + "streams_mu"][l, : st.n[l]], rtol=1e-13)
+            np.testing.assert_allclose(st.weight[l], d[tag + "streams_weight"][l, : st.n[l]], rtol=1e-11, atol=1e-16)
+        np.testing.assert_allclose(st.outmu, d[tag + "streams_outmu"], rtol=1e-13)
+        outmu = st.outmu[det["incident_streams"]] if active else st.outmu  # rtsolver_utils.py:315,339
+        np.testing.assert_allclose(np.rad2deg(np.arccos(outmu)), d[tag + "stream_angles"], rtol=1e-12)
+        L = len(ems)
+        for m in range((opts["m_max"] if active else 0) + 1):
+            P = 2 if m == 0 else 3
+            for l in range(L):
+                for ours, theirs in (("Rtop", "Rtop"), ("Ttop", "Ttop"), ("Rbot", "Rbottom"), ("Tbot", "Tbottom")):
+                    v = O._flatten_pol(itf[ours][l], m)
+                    np.testing.assert_allclose(v, d[tag + "itf_%s_m%d" % (theirs, m)][l, : len(v)],
+                                               rtol=1e-10, atol=1e-15)
+            for ours, theirs in (("Rbot_air", "Rbottom"), ("Tbot_air", "Tbottom")):
+                v = O._flatten_pol(itf[ours], m)
+                np.testing.assert_allclose(v, d[tag + "itf_%s_m%d" % (theirs, m)][L, : len(v)], rtol=1e-10,
+                                           atol=1e-15)
+            for l in range(L):
+                key = tag + "A_m%d_l%d" % (m, l)
+                eig = det["eig"][l]
+                if m > 0:
+                    eig.build_A(0)
+                if key in d:
+                    np.testing.assert_allclose(eig.build_A(m), d[key], rtol=1e-9, atol=1e-12 * np.abs(d[key]).max())
+                beta, _, _ = eig.solve(m)
+                ref = d[tag + "beta_sorted_m%d" % m][l, : len(beta)]
+                np.testing.assert_allclose(np.sort(beta), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+
+
+def test_iba_ks_table():
+    """smrt/emmodel/test_iba.py:111-127 (MEMLS table, 1 % tolerance there) and exact reference values."""
+    d = load_golden("iba_ks_table")
+    for row, memls in zip(d["table"], d["memls_reference"]):
+        pc, ks, ka, er, ei, coeff = row
+        e = O.IBALayer(float(d["frequency"]), float(d["density"]) / O.DENSITY_OF_ICE, float(d["temperature"]),
+                       "exponential", corr_length=pc)
+        assert abs(e.ks - ks) < 1e-12 * ks
+        assert abs(e.ka - ka) < 1e-11 * ka
+        assert abs(e.iba_coeff - coeff) < 1e-12 * coeff
+        assert abs(e.eps_eff - (er + 1j * ei)) < 1e-13
+        assert abs(e.ks - memls) < 0.01 * memls
+
+
+def test_albedo_above_one_is_flagged():
+    """smrt/test/test_dmrtdort.py:20-37 snowpack with dmrt_qca_shortrange gives ks > ke in the top layer
+    (SURVEY 7 'hard parts'); the half-rank route must flag it instead of returning NaN silently."""
+    d = load_golden("dmrt_2layer_passive37")
+    assert d["f0_ka"][0] < 0
+    with pytest.raises(O.OracleError) as ei:
+        O.solve(snowpack_dict(d), float(d["frequency"][0]), d["theta_deg"], emmodel="dmrt_qca_shortrange")
+    assert ei.value.status == 3
