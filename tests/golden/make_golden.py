@@ -235,10 +235,10 @@ def main():
     pcs = [0.3e-3, 0.25e-3, 0.2e-3, 0.15e-3, 0.1e-3, 0.05e-3]
     for pc in pcs:
         spk = make_snowpack([1], "exponential", density=[300], temperature=[265], corr_length=[pc])
-        e = IBA(sensor_list.passive(37e9, 0), spk.layers[0])
+        e = IBA(sensor_list.amsre("37V"), spk.layers[0])
         ks_tab.append([pc, e._ks, e.ka, e.effective_permittivity().real, e.effective_permittivity().imag,
                        e.iba_coeff])
-    save("iba_ks_table", dict(table=np.array(ks_tab), frequency=37e9, density=300.0, temperature=265.0,
+    save("iba_ks_table", dict(table=np.array(ks_tab), frequency=36.5e9, density=300.0, temperature=265.0,
                               memls_reference=np.array([4.14237510549, 2.58473097058, 1.41504051e00,
                                                         0.630947615752, 0.194948835313, 0.0250132475909])))
 
