@@ -1,0 +1,132 @@
+/*
+ * smrt_dort.h -- C ABI of the MI355X-native DORT hot path (libsmrt_dort.so).
+ *
+ * The reference (smrt-model/smrt) is pure Python and has no FFI; the interface these entry points replace is the
+ * reference's plugin surface for this path (all paths relative to /root/reference):
+ *
+ *   smrt_dort_run()      <->  one call of runner(function, argument_list)        smrt/core/model.py:395-398
+ *                             = for every (sensor_f, snowpack): Model.run_single_simulation
+ *                                                                                smrt/core/model.py:584-619
+ *                             = prepare_emmodels (IBA / DMRT_QCA_ShortRange ctor) smrt/core/model.py:529-582,
+ *                               smrt/emmodel/iba.py:85-137, smrt/emmodel/dmrt_qca_shortrange.py:65-112
+ *                             + DORT.solve                                       smrt/rtsolver/dort.py:189-261
+ *   smrt_batch           <->  the flattened (frequency-major) simulation list    smrt/core/model.py:476-527
+ *                             and the DORT constructor options                   smrt/rtsolver/dort.py:148-178
+ *   status[]             <->  SMRTError / error_handling="nan"                   smrt/rtsolver/dort.py:327-334
+ *   layer_out/stream_out <->  Result.other_data                                  smrt/rtsolver/rtsolver_utils.py:338-342,373-398
+ *
+ * Plain C types only: the caller owns every host buffer (C-contiguous float64 / int32); the library owns the
+ * device memory inside the context.  One context per GPU, one host thread per context, no global state.
+ */
+#ifndef SMRT_DORT_H
+#define SMRT_DORT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smrt_dort_ctx smrt_dort_ctx;
+
+/* emmodel (smrt/emmodel/iba.py, smrt/emmodel/dmrt_qca_shortrange.py) */
+#define SMRT_EM_IBA 0
+#define SMRT_EM_DMRT_QCA_SHORTRANGE 1
+/* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
+#define SMRT_MS_EXPONENTIAL 0
+#define SMRT_MS_STICKY_HARD_SPHERES 1
+/* sensor mode (smrt/core/sensor.py:330-339) */
+#define SMRT_MODE_PASSIVE 0
+#define SMRT_MODE_ACTIVE 1
+/* DORT phase_normalization (smrt/rtsolver/dort.py:94-103): False / "auto"|True / "forced" */
+#define SMRT_NORM_OFF 0
+#define SMRT_NORM_ON 1
+#define SMRT_NORM_FORCED 2
+
+/* per-pair status word */
+#define SMRT_OK 0
+#define SMRT_ERR_EIGEN 1           /* eigen iteration did not converge (dort.py:1068-1085)                */
+#define SMRT_ERR_NORMALIZATION 2   /* phase renormalisation beyond 30 % (dort.py:792-801)                 */
+#define SMRT_ERR_ALBEDO 3          /* single scattering albedo >= 1: no real eigenvalues (dort.py:941)    */
+#define SMRT_ERR_SINGULAR 4        /* singular boundary-condition system                                  */
+#define SMRT_ERR_INPUT 5           /* invalid layer input (e.g. T > 273.15 K, ice.py:56-57; < 2 streams)   */
+
+/*
+ * A batch = S snowpacks x F frequencies, flattened frequency-major exactly like Model.prepare_simulations
+ * (pair p = f * S + s).  Per-layer arrays are row-major [S][n_layers_max], layer 0 at the top.
+ */
+typedef struct smrt_batch {
+    int32_t n_snowpacks;      /* S */
+    int32_t n_layers_max;     /* row length of the per-layer arrays */
+    int32_t n_frequencies;    /* F */
+    int32_t n_theta;          /* number of viewing angles (passive) or incidence angles (active) */
+    int32_t emmodel;          /* SMRT_EM_* */
+    int32_t microstructure;   /* SMRT_MS_* */
+    int32_t mode;             /* SMRT_MODE_* */
+    int32_t n_max_stream;     /* DORT n_max_stream (dort.py:150) */
+    int32_t m_max;            /* DORT m_max, used in active mode only (dort.py:151,209) */
+    int32_t phase_normalization; /* SMRT_NORM_* */
+    int32_t rayleigh_jeans;   /* DORT rayleigh_jeans_approximation (dort.py:160) */
+    int32_t reserved;
+    const int32_t* n_layers;  /* [S] */
+    const double* thickness;  /* [S][Lmax] m */
+    const double* frac_volume;/* [S][Lmax] ice volume fraction (SnowLayer.compute_frac_volumes, make_medium.py:390-434) */
+    const double* temperature;/* [S][Lmax] K */
+    const double* micro_p1;   /* [S][Lmax] corr_length (exponential) | radius (sticky_hard_spheres), m */
+    const double* micro_p2;   /* [S][Lmax] unused (exponential) | stickiness (sticky_hard_spheres) */
+    const double* frequency;  /* [F] Hz */
+    const double* theta;      /* [n_theta] rad: Sensor.theta (== theta_inc in active/backscatter mode) */
+    double phi;               /* active: azimuth (rad), pi for backscatter (sensor.py:179-180) */
+} smrt_batch;
+
+/* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]
+ * with 3 x 3 polarisations V,H,U (layout of Result.data in the reference, rtsolver_utils.py:327-332). */
+int32_t smrt_dort_out_stride(const smrt_batch* b);
+
+/* Create / destroy a context bound to HIP device `device`.  Returns 0 on success. */
+int32_t smrt_dort_create(smrt_dort_ctx** ctx, int32_t device);
+void smrt_dort_destroy(smrt_dort_ctx* ctx);
+const char* smrt_dort_last_error(const smrt_dort_ctx* ctx);
+
+/*
+ * One shot: H2D of the packed batch, kernel, D2H.  pair range [pair_begin, pair_begin + pair_count) of the
+ * flattened list (pair_count < 0: all).  out: [pair_count][out_stride]; status: [pair_count];
+ * layer_out (optional, may be NULL): [pair_count][Lmax][5] = Re eps_eff, Im eps_eff, ks, ka, n_streams;
+ * stream_out (optional): [pair_count][1 + n_max_stream] = n_air, outmu[0..n_air).
+ */
+int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count,
+                      double* out, int32_t* status, double* layer_out, double* stream_out);
+
+/*
+ * Split form for resident data and timing: upload once, launch many times, download.
+ * smrt_dort_launch is asynchronous on the context's stream; smrt_dort_sync waits for it.
+ * If out_dev / status_dev are non-NULL they are DEVICE pointers (e.g. torch CUDA tensors used as the send
+ * buffers of an RCCL gather) that receive the results instead of the context's own buffers.
+ */
+int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count);
+int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev);
+int32_t smrt_dort_sync(smrt_dort_ctx* ctx);
+int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, double* layer_out,
+                           double* stream_out);
+
+/* HIP-event time (ms) of the most recent smrt_dort_launch on the context's stream (valid after sync),
+ * and accumulated over all launches since the last reset (count returned through n_launches). */
+double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
+double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset);
+
+/* Tuning knob: threads per workgroup of the pair kernel (64..1024, multiple of 64). 0 = default. */
+int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
+
+/* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3
+ * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
+double smrt_dort_sum_n3(smrt_dort_ctx* ctx);
+
+/* Positive Gauss-Legendre nodes of order 2n in descending order (smrt/rtsolver/streams.py:300-313). Host only. */
+int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight);
+
+const char* smrt_dort_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMRT_DORT_H */

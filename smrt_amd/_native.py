@@ -1,0 +1,258 @@
+"""ctypes binding of libsmrt_dort.so (include/smrt_dort.h).
+
+This is the ONLY way the package computes anything: there is no CPU fallback.  If the shared library is missing or no
+MI355X is visible, `DortContext()` raises `SMRTError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .core.error import SMRTError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmrt_dort.so")
+
+EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1}
+MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
+NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}
+STATUS_MESSAGES = {
+    1: "The eigen-decomposition did not converge in DORT.",
+    2: "The re-normalization of the phase function exceeds the predefined threshold of 30%. This is likely because "
+       "of a too large grain size or a bug in the phase function.",
+    3: "The diagonalization failed in DORT: single scattering albedo >= 1 in a layer (too large grain size for the "
+       "emmodel?).",
+    4: "The boundary-condition system is singular.",
+    5: "Invalid layer properties (temperature above the freezing point, or fewer than two streams in a layer).",
+}
+
+
+class SmrtBatch(C.Structure):
+    """struct smrt_batch of include/smrt_dort.h."""
+
+    _fields_ = [
+        ("n_snowpacks", C.c_int32),
+        ("n_layers_max", C.c_int32),
+        ("n_frequencies", C.c_int32),
+        ("n_theta", C.c_int32),
+        ("emmodel", C.c_int32),
+        ("microstructure", C.c_int32),
+        ("mode", C.c_int32),
+        ("n_max_stream", C.c_int32),
+        ("m_max", C.c_int32),
+        ("phase_normalization", C.c_int32),
+        ("rayleigh_jeans", C.c_int32),
+        ("reserved", C.c_int32),
+        ("n_layers", C.POINTER(C.c_int32)),
+        ("thickness", C.POINTER(C.c_double)),
+        ("frac_volume", C.POINTER(C.c_double)),
+        ("temperature", C.POINTER(C.c_double)),
+        ("micro_p1", C.POINTER(C.c_double)),
+        ("micro_p2", C.POINTER(C.c_double)),
+        ("frequency", C.POINTER(C.c_double)),
+        ("theta", C.POINTER(C.c_double)),
+        ("phi", C.c_double),
+    ]
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PackedBatch:
+    """Host-side packed batch: S snowpacks x F frequencies (pair p = f * S + s, frequency-major like
+    Model.prepare_simulations, smrt/core/model.py:485-502)."""
+
+    def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
+                 emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
+                 phase_normalization="auto", rayleigh_jeans=False, phi=np.pi):
+        self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
+        S = len(self.n_layers)
+        two_d = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(S, -1))  # noqa: E731
+        self.thickness = two_d(thickness)
+        self.frac_volume = two_d(frac_volume)
+        self.temperature = two_d(temperature)
+        self.micro_p1 = two_d(micro_p1)
+        self.micro_p2 = two_d(micro_p2 if micro_p2 is not None else np.zeros_like(self.micro_p1))
+        Lmax = self.thickness.shape[1]
+        for a in (self.frac_volume, self.temperature, self.micro_p1, self.micro_p2):
+            if a.shape != (S, Lmax):
+                raise SMRTError("per-layer arrays of a batch must share the shape (n_snowpacks, n_layers_max)")
+        if self.n_layers.min() < 1 or self.n_layers.max() > Lmax:
+            raise SMRTError("n_layers out of range")
+        self.frequency = np.ascontiguousarray(np.atleast_1d(frequency), dtype=np.float64)
+        self.theta = np.ascontiguousarray(np.atleast_1d(theta), dtype=np.float64)
+        self.mode = mode
+        s = SmrtBatch()
+        s.n_snowpacks, s.n_layers_max, s.n_frequencies, s.n_theta = S, Lmax, len(self.frequency), len(self.theta)
+        s.emmodel = EM_CODES[emmodel]
+        s.microstructure = MS_CODES[microstructure]
+        s.mode = 0 if mode == "P" else 1
+        s.n_max_stream = int(n_max_stream)
+        s.m_max = int(m_max)
+        s.phase_normalization = NORM_CODES[phase_normalization]
+        s.rayleigh_jeans = 1 if rayleigh_jeans else 0
+        s.n_layers = self.n_layers.ctypes.data_as(C.POINTER(C.c_int32))
+        s.thickness, s.frac_volume, s.temperature = _dptr(self.thickness), _dptr(self.frac_volume), _dptr(self.temperature)
+        s.micro_p1, s.micro_p2 = _dptr(self.micro_p1), _dptr(self.micro_p2)
+        s.frequency, s.theta = _dptr(self.frequency), _dptr(self.theta)
+        s.phi = float(phi)
+        self.struct = s
+
+    @property
+    def n_pairs(self):
+        return int(self.struct.n_snowpacks) * int(self.struct.n_frequencies)
+
+    @property
+    def out_stride(self):
+        return (2 if self.mode == "P" else 9) * int(self.struct.n_theta)
+
+    def out_shape(self):
+        nt = int(self.struct.n_theta)
+        return (2, nt) if self.mode == "P" else (3, 3, nt)
+
+
+_lib = None
+
+
+def load_library():
+    """Load libsmrt_dort.so; fail loudly when it is not built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SMRTError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+                        "smrt_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.smrt_dort_version.restype = C.c_char_p
+    lib.smrt_dort_out_stride.argtypes = [P(SmrtBatch)]
+    lib.smrt_dort_out_stride.restype = C.c_int32
+    lib.smrt_dort_create.argtypes = [P(C.c_void_p), C.c_int32]
+    lib.smrt_dort_create.restype = C.c_int32
+    lib.smrt_dort_destroy.argtypes = [C.c_void_p]
+    lib.smrt_dort_destroy.restype = None
+    lib.smrt_dort_last_error.argtypes = [C.c_void_p]
+    lib.smrt_dort_last_error.restype = C.c_char_p
+    lib.smrt_dort_run.argtypes = [C.c_void_p, P(SmrtBatch), C.c_int64, C.c_int64, P(C.c_double), P(C.c_int32),
+                                  P(C.c_double), P(C.c_double)]
+    lib.smrt_dort_run.restype = C.c_int32
+    lib.smrt_dort_upload.argtypes = [C.c_void_p, P(SmrtBatch), C.c_int64, C.c_int64]
+    lib.smrt_dort_upload.restype = C.c_int32
+    lib.smrt_dort_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.smrt_dort_launch.restype = C.c_int32
+    lib.smrt_dort_sync.argtypes = [C.c_void_p]
+    lib.smrt_dort_sync.restype = C.c_int32
+    lib.smrt_dort_download.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int32), P(C.c_double), P(C.c_double)]
+    lib.smrt_dort_download.restype = C.c_int32
+    lib.smrt_dort_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.smrt_dort_last_kernel_ms.restype = C.c_double
+    lib.smrt_dort_total_kernel_ms.argtypes = [C.c_void_p, P(C.c_int64), C.c_int32]
+    lib.smrt_dort_total_kernel_ms.restype = C.c_double
+    lib.smrt_dort_set_block_threads.argtypes = [C.c_void_p, C.c_int32]
+    lib.smrt_dort_set_block_threads.restype = C.c_int32
+    lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
+    lib.smrt_dort_sum_n3.restype = C.c_double
+    lib.smrt_gauss_legendre_positive.argtypes = [C.c_int32, P(C.c_double), P(C.c_double)]
+    lib.smrt_gauss_legendre_positive.restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
+    "smrt_dort_upload", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
+    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_gauss_legendre_positive",
+    "smrt_dort_version",
+]
+
+
+class BatchOutput:
+    def __init__(self, batch, pair_count):
+        Lmax, nmax = int(batch.struct.n_layers_max), int(batch.struct.n_max_stream)
+        self.values = np.empty((pair_count,) + batch.out_shape(), dtype=np.float64)
+        self.status = np.empty(pair_count, dtype=np.int32)
+        self.layers = np.empty((pair_count, Lmax, 5), dtype=np.float64)
+        self.streams = np.empty((pair_count, 1 + nmax), dtype=np.float64)
+
+
+class DortContext:
+    """One context per GPU (smrt_dort_create / smrt_dort_destroy)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.smrt_dort_create(C.byref(self._h), int(device))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise SMRTError(f"smrt_dort_create(device={device}) failed with code {rc}: no usable MI355X GPU. "
+                            "smrt_amd has no CPU fallback.")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.smrt_dort_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SMRTError(f"{what} failed: {self._lib.smrt_dort_last_error(self._h).decode()}")
+
+    def set_block_threads(self, n):
+        self._check(self._lib.smrt_dort_set_block_threads(self._h, int(n)), "smrt_dort_set_block_threads")
+
+    def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1) -> BatchOutput:
+        if pair_count < 0:
+            pair_count = batch.n_pairs - pair_begin
+        o = BatchOutput(batch, pair_count)
+        self._check(self._lib.smrt_dort_run(self._h, C.byref(batch.struct), pair_begin, pair_count, _dptr(o.values),
+                                            o.status.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(o.layers),
+                                            _dptr(o.streams)), "smrt_dort_run")
+        return o
+
+    def upload(self, batch: PackedBatch, pair_begin=0, pair_count=-1):
+        if pair_count < 0:
+            pair_count = batch.n_pairs - pair_begin
+        self._check(self._lib.smrt_dort_upload(self._h, C.byref(batch.struct), pair_begin, pair_count), "smrt_dort_upload")
+        self._resident = (batch, pair_count)
+
+    def launch(self, out_dev=None, status_dev=None):
+        self._check(self._lib.smrt_dort_launch(self._h, C.c_void_p(out_dev or 0), C.c_void_p(status_dev or 0)),
+                    "smrt_dort_launch")
+
+    def sync(self):
+        self._check(self._lib.smrt_dort_sync(self._h), "smrt_dort_sync")
+
+    def download(self) -> BatchOutput:
+        batch, pair_count = self._resident
+        o = BatchOutput(batch, pair_count)
+        self._check(self._lib.smrt_dort_download(self._h, _dptr(o.values), o.status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 _dptr(o.layers), _dptr(o.streams)), "smrt_dort_download")
+        return o
+
+    def last_kernel_ms(self):
+        return float(self._lib.smrt_dort_last_kernel_ms(self._h))
+
+    def total_kernel_ms(self, reset=False):
+        n = C.c_int64()
+        ms = float(self._lib.smrt_dort_total_kernel_ms(self._h, C.byref(n), 1 if reset else 0))
+        return ms, int(n.value)
+
+    def sum_n3(self):
+        return float(self._lib.smrt_dort_sum_n3(self._h))
+
+
+def gauss_legendre_positive(n):
+    lib = load_library()
+    mu = np.empty(n)
+    w = np.empty(n)
+    lib.smrt_gauss_legendre_positive(n, _dptr(mu), _dptr(w))
+    return mu, w

@@ -1,0 +1,959 @@
+// DORT hot path, device code (gfx950 / CDNA4).  One workgroup solves one (snowpack, frequency) pair with every
+// N x N matrix (N = streams x polarisations <= 64 on the LDS path) resident in LDS.
+//
+// What is computed is fixed by the reference (paths relative to /root/reference); HOW is our own design:
+//   layer electromagnetics   smrt/emmodel/iba.py:85-265, dmrt_qca_shortrange.py:65-112, permittivity/ice.py:52-73,
+//                            permittivity/generic_mixing_formula.py:117-145, microstructure_model/*.py
+//   streams                  smrt/rtsolver/streams.py:136-223,300-330
+//   interfaces (Flat)        smrt/core/fresnel.py:99-146,417-474, smrt/rtsolver/rtsolver_utils.py:473-644
+//   phase matrix modes       smrt/emmodel/common.py:9-131 (IBA: discrete azimuth mean), rayleigh.py:52-127
+//   eigenproblem             smrt/rtsolver/dort.py:699-749 (matrix A), :891-962 (half-rank reduction)
+//   boundary conditions      smrt/rtsolver/dort.py:263-488
+//   Planck / interpolation   smrt/core/lib.py:594-620, smrt/rtsolver/rtsolver_utils.py:179-239
+//
+// Design: for azimuth mode 0 the reduced problem (alpha-beta)(alpha+beta) is similar to X- X+ with
+// X+-, both symmetric positive definite (diagonal similarity by sqrt(norm*w/mu)).  With X+ = L+ L+^T and
+// X- = L- L-^T, the singular values of B = L+^T L- are the eigenvalues beta, and the eigenvectors follow from
+// B' = B V (one-sided Jacobi, wavefront-parallel column rotations in LDS) by one triangular solve and one
+// triangular product.  The boundary system is solved by a bottom-up layer reflection-matrix recursion
+// (two pivoted N x N solves per layer) instead of a banded LU of the global (2 N L) system.
+//
+// All storage is column-major with an ODD leading dimension LD so that row- and column-wise wavefront accesses
+// are both LDS bank-conflict free (ds_read_b64: 32 eight-byte slots per 32-lane group).
+#pragma once
+#include "spmd.hpp"
+#include <math.h>
+
+namespace smrt {
+
+// ------------------------------------------------------------------------------------------------------------
+// batch descriptor as seen by the device
+// ------------------------------------------------------------------------------------------------------------
+struct DevBatch {
+    int S, Lmax, F, n_theta;
+    int emmodel, micro, mode, n_max_stream, m_max, normalization, rayleigh_jeans;
+    int want_layer_out, want_stream_out;
+    long long pair_begin, pair_count;
+    const int* n_layers;
+    const double* thickness;
+    const double* frac_volume;
+    const double* temperature;
+    const double* p1;
+    const double* p2;
+    const double* frequency;
+    const double* theta;
+    const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
+    double phi;
+    double* out;
+    int* status;
+    double* layer_out;
+    double* stream_out;
+    double* n3_out;  // [pair_count] sum_l N_l^3 (work counter for the roofline)
+};
+
+constexpr double kCSpeed = 299792458.0;
+constexpr double kPlanck = 6.62607015e-34;
+constexpr double kBoltzmann = 1.380649e-23;
+constexpr double kFreezing = 273.15;
+constexpr double kPi = 3.14159265358979323846;
+
+enum { EM_IBA = 0, EM_DMRT = 1 };
+enum { MS_EXP = 0, MS_SHS = 1 };
+enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5 };
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS layout (shared by host sizing code and the kernel)
+// ------------------------------------------------------------------------------------------------------------
+struct LdsPlan {
+    int NMAX, LD, nmax, Lmax, nphi, ntheta;
+    int o_M[4];
+    int o_rowvec;   // 17 vectors of NMAX
+    int o_strvec;   // 6 vectors of nmax
+    int o_layvec;   // 11 vectors of Lmax
+    int o_phi;      // 3 vectors of nphi
+    int o_tb;       // NMAX
+    int o_int;      // 16 ints (8 doubles)
+    int total;      // doubles
+};
+
+#if defined(SMRT_HOST_EMU)
+#define SMRT_HD inline
+#else
+#define SMRT_HD __host__ __device__ inline
+#endif
+
+SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi) {
+    LdsPlan p;
+    p.nmax = n_max_stream;
+    p.NMAX = n_max_stream * P;
+    p.LD = p.NMAX | 1;
+    p.Lmax = Lmax;
+    p.nphi = nphi;
+    p.ntheta = ntheta;
+    int o = 0;
+    for (int i = 0; i < 4; ++i) { p.o_M[i] = o; o += p.NMAX * p.LD; }
+    p.o_rowvec = o; o += 17 * p.NMAX;
+    p.o_strvec = o; o += 6 * p.nmax;
+    p.o_layvec = o; o += 11 * Lmax;
+    p.o_phi = o; o += 3 * nphi;
+    p.o_tb = o; o += p.NMAX;
+    p.o_int = o; o += 8;
+    p.total = o;
+    return p;
+}
+
+struct Lds {
+    double *M0, *M1, *M2, *M3;
+    double *mrow, *wrow, *u, *d, *sigma, *rsig, *t, *Rtop, *Ttop, *Rbu, *Tbu, *cvec, *tq, *svec, *g, *upb, *up;
+    double *gmu, *gsin, *outmu, *mu, *w, *muu;
+    double *eps_re, *eps_im, *ks, *ka, *pa, *pb, *pc, *BT, *thick, *ri, *nl;
+    double *cphi, *s2phi, *wphi;
+    double* tb;
+    int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air
+};
+
+SMRT_DEV Lds carve(double* base, const LdsPlan& p) {
+    Lds s;
+    s.M0 = base + p.o_M[0]; s.M1 = base + p.o_M[1]; s.M2 = base + p.o_M[2]; s.M3 = base + p.o_M[3];
+    double* v = base + p.o_rowvec;
+    const int n = p.NMAX;
+    s.mrow = v; s.wrow = v + n; s.u = v + 2 * n; s.d = v + 3 * n; s.sigma = v + 4 * n; s.rsig = v + 5 * n;
+    s.t = v + 6 * n; s.Rtop = v + 7 * n; s.Ttop = v + 8 * n; s.Rbu = v + 9 * n; s.Tbu = v + 10 * n;
+    s.cvec = v + 11 * n; s.tq = v + 12 * n; s.svec = v + 13 * n; s.g = v + 14 * n; s.upb = v + 15 * n;
+    s.up = v + 16 * n;
+    v = base + p.o_strvec;
+    const int m = p.nmax;
+    s.gmu = v; s.gsin = v + m; s.outmu = v + 2 * m; s.mu = v + 3 * m; s.w = v + 4 * m; s.muu = v + 5 * m;
+    v = base + p.o_layvec;
+    const int L = p.Lmax;
+    s.eps_re = v; s.eps_im = v + L; s.ks = v + 2 * L; s.ka = v + 3 * L; s.pa = v + 4 * L; s.pb = v + 5 * L;
+    s.pc = v + 6 * L; s.BT = v + 7 * L; s.thick = v + 8 * L; s.ri = v + 9 * L; s.nl = v + 10 * L;
+    v = base + p.o_phi;
+    s.cphi = v; s.s2phi = v + p.nphi; s.wphi = v + 2 * p.nphi;
+    s.tb = base + p.o_tb;
+    s.ints = (int*)(base + p.o_int);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------------------------
+struct cplx { double re, im; };
+SMRT_DEV cplx cmk(double a, double b) { cplx z; z.re = a; z.im = b; return z; }
+SMRT_DEV cplx cadd(cplx a, cplx b) { return cmk(a.re + b.re, a.im + b.im); }
+SMRT_DEV cplx csub(cplx a, cplx b) { return cmk(a.re - b.re, a.im - b.im); }
+SMRT_DEV cplx cmul(cplx a, cplx b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+SMRT_DEV cplx cscale(cplx a, double s) { return cmk(a.re * s, a.im * s); }
+SMRT_DEV cplx cconj(cplx a) { return cmk(a.re, -a.im); }
+SMRT_DEV double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
+SMRT_DEV cplx cdiv(cplx a, cplx b) {
+    double d = 1.0 / cabs2(b);
+    return cmk((a.re * b.re + a.im * b.im) * d, (a.im * b.re - a.re * b.im) * d);
+}
+SMRT_DEV cplx csqrt_(cplx z) {  // principal branch
+    if (z.re == 0.0 && z.im == 0.0) return cmk(0.0, 0.0);
+    double m = sqrt(cabs2(z));
+    double tt = sqrt(0.5 * (fabs(z.re) + m));
+    if (z.re >= 0.0) return cmk(tt, z.im / (2.0 * tt));
+    return cmk(fabs(z.im) / (2.0 * tt), z.im >= 0.0 ? tt : -tt);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layer electromagnetics
+// ------------------------------------------------------------------------------------------------------------
+SMRT_DEV cplx ice_permittivity(double frequency, double T) {  // Maetzler 2006, permittivity/ice.py:52-73
+    double fg = frequency * 1e-9;
+    double tc = T - kFreezing;
+    double er = 3.1884 + 9.1e-4 * tc;
+    double th = 300.0 / T - 1.0;
+    double alpha = (0.00504 + 0.0062 * th) * exp(-22.1 * th);
+    double eb = exp(335.0 / T);
+    double betam = (0.0207 / T) * (eb / ((eb - 1.0) * (eb - 1.0))) + 1.16e-11 * fg * fg;
+    double dbeta = exp(-9.963 + 0.0372 * tc);
+    return cmk(er, alpha / fg + (betam + dbeta) * fg);
+}
+
+SMRT_DEV double sinc_(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
+
+// FT of the autocorrelation function at wavenumber k (k2 = k*k)
+SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
+    if (micro == MS_EXP) {  // exponential.py:53-58
+        double x = k2 * p1 * p1;
+        double den = 1.0 + x;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
+    }
+    // sticky hard spheres, sticky_hard_spheres.py:63-130
+    double f = fv, tau = p2, radius = p1;
+    double x = sqrt(k2) * radius;
+    double tt = 0.0;
+    if (isfinite(tau) && f > 0.0) {
+        double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
+                      36 * tau * tau - 12 * f;
+        tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
+    }
+    double vd = 4.0 / 3.0 * kPi * radius * radius * radius;
+    double fr = f / (1.0 - f);
+    double c1 = 1.0 - tt * f + 3.0 * fr;
+    double c2 = 3.0 - tt * (1.0 - f);
+    if (fabs(x) <= 1e-3) {
+        double den = fr * (c1 + c2) + 1.0;
+        return f * vd / (den * den);
+    }
+    double vint = 3.0 * (sinc_(x) - cos(x)) / (x * x);
+    double psi = sinc_(x) / vint;
+    double a = fr * (c1 + c2 * psi) + cos(x) / vint;
+    double b = fr * x + sin(x) / vint;
+    return f * vd / (a * a + b * b);
+}
+
+SMRT_DEV double shs_t(double f, double tau, int* bad) {  // sticky_hard_spheres.py:132-167
+    if (isinf(tau)) return 0.0;
+    double a = f / 12.0, b = -(tau + f / (1.0 - f)), c = (1.0 + 0.5 * f) / ((1.0 - f) * (1.0 - f));
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) { *bad = 1; return 0.0; }
+    double sq = sqrt(disc);
+    double tt = (-b - sq) / (2.0 * a);
+    if (tt * f * (1.0 - f) > 1.0 + 2.0 * f) tt = (-b + sq) / (2.0 * a);
+    if (tt * f * (1.0 - f) > 1.0 + 2.0 * f) *bad = 1;
+    return tt;
+}
+
+SMRT_DEV double planck_radiance(double frequency, double T) {  // core/lib.py:594-607
+    if (!(T > 1e-10)) return 0.0;
+    return (2.0 * kPlanck / (kCSpeed * kCSpeed)) * frequency * frequency * frequency /
+           expm1((kPlanck / kBoltzmann) * frequency / T);
+}
+SMRT_DEV double planck_inverse(double frequency, double radiance) {  // core/lib.py:610-620
+    if (!(radiance > 1e-40)) return 0.0;
+    double x = (2.0 * kPlanck / (kCSpeed * kCSpeed)) * frequency * frequency * frequency / radiance;
+    return (kPlanck / kBoltzmann) * frequency / log1p(x);
+}
+
+// One layer: effective permittivity, ks, ka and the parameters of its phase function.
+// pa/pb/pc: IBA+exponential -> C(cosT) = pa / (1 + pb (1 - cosT))^2 ; IBA+SHS -> pa = iba_coeff, pb = kfac^2/2;
+// DMRT -> pa = 1.5 ks.
+SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
+                       double* ks, double* ka, double* pa, double* pb, int* bad) {
+    cplx es = ice_permittivity(frequency, T);
+    if (T > kFreezing) *bad = 1;
+    double k0 = 2.0 * kPi * frequency / kCSpeed;
+    if (b.emmodel == EM_IBA) {
+        // Polder-van Santen, spheres: 2x^2 + bx - eps e0 = 0 (generic_mixing_formula.py:117-145), e0 = 1
+        cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
+        cplx disc = cadd(cmul(bq, bq), cscale(es, 8.0));
+        cplx ee = cscale(csub(csqrt_(disc), bq), 0.25);
+        if (ee.im < -1e-10) *bad = 1;
+        *eps_eff = ee;
+        // mean squared field ratio with depolarisation factors 1/3 (iba.py:152-162)
+        cplx app = cadd(cscale(ee, 2.0 / 3.0), cmk(1.0 / 3.0, 0.0));
+        cplx den = cadd(app, cscale(csub(es, cmk(1.0, 0.0)), 1.0 / 3.0));
+        double y2 = cabs2(cdiv(app, den));
+        double coeff = (1.0 / (4.0 * kPi)) * cabs2(csub(es, cmk(1.0, 0.0))) * y2 * (k0 * k0) * (k0 * k0);
+        cplx sq = csqrt_(ee);
+        *ka = 2.0 * k0 * sq.im;  // iba.py:265
+        // ks: Romberg on 65 samples of mu = 1 - j/32 (iba.py:176-226; scipy.integrate.romb), |sqrt(eps)| here
+        double nabs2 = sqrt(cabs2(ee));  // |sqrt(eps)|^2 = |eps|
+        double S[7];
+        for (int i = 0; i < 7; ++i) S[i] = 0.0;
+        double yend = 0.0;
+        for (int j = 0; j <= 64; ++j) {
+            double mu = 1.0 - j * 0.03125;
+            double k2 = 4.0 * k0 * k0 * (0.5 * (1.0 - mu)) * nabs2;
+            double y = coeff * ft_corr(b.micro, k2, fv, p1, p2) * (mu * mu + 1.0);
+            if (j == 0 || j == 64) { yend += 0.5 * y; continue; }
+            int tz = 0;
+            while (((j >> tz) & 1) == 0) ++tz;
+            for (int i = 6 - tz; i <= 6; ++i) S[i] += y;
+        }
+        double R[7];
+        for (int i = 0; i < 7; ++i) R[i] = (double)(64 >> i) * 0.03125 * (yend + S[i]);
+        double pw = 1.0;
+        for (int j = 1; j <= 6; ++j) {
+            pw *= 4.0;
+            for (int i = 0; i <= 6 - j; ++i) R[i] = (pw * R[i + 1] - R[i]) / (pw - 1.0);
+        }
+        *ks = 0.25 * R[0];
+        double kfac = 2.0 * k0 * sq.re;  // iba.py:233
+        if (b.micro == MS_EXP) {
+            *pa = coeff * fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1;
+            *pb = 0.5 * kfac * kfac * p1 * p1;
+        } else {
+            *pa = coeff;
+            *pb = 0.5 * kfac * kfac;
+        }
+    } else {
+        // DMRT QCA short range (dmrt_qca_shortrange.py:65-112), dense_snow_correction="auto"
+        double f = fv;
+        cplx e0 = cmk(1.0, 0.0), e1 = es;
+        if (f > 0.5) { f = 1.0 - f; e0 = es; e1 = cmk(1.0, 0.0); }
+        int tb = 0;
+        double tt = shs_t(f, p2, &tb);
+        if (tb) *bad = 1;
+        cplx y = cdiv(csub(e1, e0), cadd(e1, cscale(e0, 2.0)));
+        cplx fy = cscale(y, f);
+        double kk = k0 * csqrt_(e0).re;
+        double kr3 = (kk * p1) * (kk * p1) * (kk * p1);
+        double den = 1.0 + 2.0 * f - tt * f * (1.0 - f);
+        double omf4 = (1.0 - f) * (1.0 - f) * (1.0 - f) * (1.0 - f);
+        cplx one_m_fy = csub(cmk(1.0, 0.0), fy);
+        // Eeff = e0 + 3 fy e0/(1-fy) * (1 + 2j/3 kr3 y (1-f)^4 / ((1-fy) den^2))
+        cplx corr = cdiv(cscale(cmul(cmk(0.0, 2.0 / 3.0 * kr3 * omf4 / (den * den)), y), 1.0), one_m_fy);
+        cplx fac = cadd(cmk(1.0, 0.0), corr);
+        cplx ee = cadd(e0, cmul(cdiv(cmul(cscale(fy, 3.0), e0), one_m_fy), fac));
+        *eps_eff = ee;
+        double Ks = 2.0 / (9.0 * f) * kk * kr3 * (cabs2(csub(cdiv(ee, e0), cmk(1.0, 0.0))) * omf4 / (den * den));
+        double beta = 2.0 * kk * csqrt_(ee).im;
+        *ks = Ks;
+        *ka = beta - Ks;
+        *pa = 1.5 * Ks;
+        *pb = 0.0;
+    }
+}
+
+// Flat interface, Maezawa & Miyauchi 2009 "rigorous" Fresnel (core/fresnel.py:99-146): power R for V and H.
+SMRT_DEV void fresnel_RvRh(cplx e1, cplx e2, double mu1, double* Rv, double* Rh) {
+    cplx n1 = csqrt_(e1);
+    double kz2 = n1.re * n1.re * (1.0 - mu1 * mu1);
+    cplx kyi = cscale(csqrt_(cmk(e1.re - kz2, e1.im)), -1.0);
+    cplx kyt = cscale(csqrt_(cmk(e2.re - kz2, e2.im)), -1.0);
+    cplx rh = cdiv(csub(kyi, kyt), cadd(cconj(kyi), kyt));
+    cplx num = cmul(cconj(n1), csub(cmul(e2, kyi), cmul(e1, kyt)));
+    cplx den = cmul(n1, cadd(cmul(e2, cconj(kyi)), cmul(cconj(e1), kyt)));
+    cplx rv = cdiv(num, den);
+    *Rv = cabs2(rv);
+    *Rh = cabs2(rh);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dense kernels in LDS.  Element (r, c) of every matrix lives at [c * LD + r].
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
+    // Two right-looking Cholesky factorisations side by side (lower triangles, in place).
+    const int t = tid();
+    for (int k = 0; k < N; ++k) {
+        const double akk = A[k * LD + k], bkk = Bm[k * LD + k];
+        if (!(akk > 0.0) || !(bkk > 0.0)) return false;  // uniform: every thread reads the same words
+        const double ra = 1.0 / sqrt(akk), rb = 1.0 / sqrt(bkk);
+        for (int i = k + 1 + t; i < N; i += NT) {
+            A[k * LD + i] *= ra;
+            Bm[k * LD + i] *= rb;
+        }
+        block_sync();
+        if (t == 0) {
+            A[k * LD + k] = akk * ra;
+            Bm[k * LD + k] = bkk * rb;
+        }
+        const int m = N - k - 1;
+        for (int idx = t; idx < m * m; idx += NT) {
+            const int i = k + 1 + idx % m, j = k + 1 + idx / m;
+            if (i >= j) {
+                A[j * LD + i] -= A[k * LD + i] * A[k * LD + j];
+                Bm[j * LD + i] -= Bm[k * LD + i] * Bm[k * LD + j];
+            }
+        }
+        block_sync();
+    }
+    return true;
+}
+
+// C = Lp^T Lm for lower-triangular Lp, Lm
+template <int NT>
+SMRT_DEV void lt_times_l(const double* Lp, const double* Lm, double* C, int N, int LD) {
+    const int t = tid();
+    for (int idx = t; idx < N * N; idx += NT) {
+        const int i = idx % N, j = idx / N;
+        double acc = 0.0;
+        for (int k = (i > j ? i : j); k < N; ++k) acc += Lp[i * LD + k] * Lm[j * LD + k];
+        C[j * LD + i] = acc;
+    }
+    block_sync();
+}
+
+// One-sided (Hestenes) Jacobi: rotate column pairs of Bm until all columns are mutually orthogonal.
+// GS consecutive lanes own one pair; the round-robin schedule gives N/2 disjoint pairs per step.
+// On exit sigma[c] = |column c| and rsig[c] = 1 / sigma[c].  Returns false if it did not converge.
+template <int NT, int GS>
+SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag) {
+    const int t = tid();
+    const int grp = t / GS, sub = t % GS;
+    constexpr int NG = NT / GS;
+    const int Ne = N + (N & 1);
+    const int npairs = Ne / 2;
+    const int rounds = (npairs + NG - 1) / NG;
+    const double tol2 = 1e-28;  // (1e-14)^2 on the squared cosine between two columns
+    bool converged = false;
+    for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+        block_sync();  // everyone has read the previous flag
+        if (t == 0) *flag = 0;
+        block_sync();
+        for (int s = 0; s < Ne - 1; ++s) {
+            for (int rd = 0; rd < rounds; ++rd) {
+                const int pi = grp + rd * NG;
+                int p, q;
+                if (pi == 0) { p = Ne - 1; q = s; }
+                else { p = (s + pi) % (Ne - 1); q = (s - pi + (Ne - 1)) % (Ne - 1); }
+                const bool valid = (pi < npairs) && (p < N) && (q < N);
+                double a = 0.0, bb = 0.0, gg = 0.0;
+                if (valid) {
+                    const double* cp = Bm + p * LD;
+                    const double* cq = Bm + q * LD;
+                    for (int r = sub; r < N; r += GS) {
+                        const double x = cp[r], y = cq[r];
+                        a += x * x; bb += y * y; gg += x * y;
+                    }
+                }
+                for (int m = GS / 2; m >= 1; m >>= 1) {
+                    a += shfl_xor(a, m); bb += shfl_xor(bb, m); gg += shfl_xor(gg, m);
+                }
+                if (valid && gg * gg > tol2 * a * bb) {
+                    const double zeta = (bb - a) / (2.0 * gg);
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+                    double* cp = Bm + p * LD;
+                    double* cq = Bm + q * LD;
+                    for (int r = sub; r < N; r += GS) {
+                        const double x = cp[r], y = cq[r];
+                        cp[r] = c * x - sn * y;
+                        cq[r] = sn * x + c * y;
+                    }
+                    if (sub == 0) lds_or(flag, 1);
+                }
+            }
+            block_sync();
+        }
+        converged = (*flag == 0);
+    }
+    block_sync();
+    // column norms
+    {
+        const int rounds2 = (N + NG - 1) / NG;
+        for (int rd = 0; rd < rounds2; ++rd) {
+            const int c = grp + rd * NG;
+            double a = 0.0;
+            if (c < N)
+                for (int r = sub; r < N; r += GS) { const double x = Bm[c * LD + r]; a += x * x; }
+            for (int m = GS / 2; m >= 1; m >>= 1) a += shfl_xor(a, m);
+            if (c < N && sub == 0) { const double sg = sqrt(a); sigma[c] = sg; rsig[c] = 1.0 / sg; }
+        }
+    }
+    block_sync();
+    return converged;
+}
+
+// C = Lp * Bm (Lp lower triangular)
+template <int NT>
+SMRT_DEV void l_times_m(const double* Lp, const double* Bm, double* C, int N, int LD) {
+    const int t = tid();
+    for (int idx = t; idx < N * N; idx += NT) {
+        const int i = idx % N, c = idx / N;
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc += Lp[k * LD + i] * Bm[c * LD + k];
+        C[c * LD + i] = acc;
+    }
+    block_sync();
+}
+
+// Bm <- Lp^-T Bm (back substitution with the upper-triangular Lp^T, all columns at once)
+template <int NT>
+SMRT_DEV void lt_solve(const double* Lp, double* Bm, int N, int LD) {
+    const int t = tid();
+    for (int i = N - 1; i >= 1; --i) {
+        const double rd = 1.0 / Lp[i * LD + i];
+        for (int idx = t; idx < i * N; idx += NT) {
+            const int r = idx % i, c = idx / i;
+            Bm[c * LD + r] -= Lp[r * LD + i] * (Bm[c * LD + i] * rd);
+        }
+        block_sync();
+    }
+    for (int idx = t; idx < N * N; idx += NT) {
+        const int i = idx % N, c = idx / N;
+        Bm[c * LD + i] *= 1.0 / Lp[i * LD + i];
+    }
+    block_sync();
+}
+
+// Solve A X = Bm (+ one extra right-hand-side vector v, may be null) by LU with partial pivoting; X overwrites
+// Bm / v, A is destroyed.  TR selects the storage view: element (r, c) at [c*LD + r] (false) or [r*LD + c]
+// (true, i.e. the routine then solves A^T X^T = Bm^T on the same buffers).
+template <bool TR>
+SMRT_DEV double& at(double* M, int r, int c, int LD) { return TR ? M[r * LD + c] : M[c * LD + r]; }
+
+template <int NT, bool TR>
+SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, int N, int LD, int* piv) {
+    const int t = tid();
+    const int lane = t % SMRT_LANES;
+    const int nv = (v != nullptr) ? 1 : 0;
+    for (int k = 0; k < N; ++k) {
+        if (t < SMRT_LANES) {  // wavefront 0 finds the pivot row
+            double best = -1.0;
+            int bi = k;
+            for (int r = k + lane; r < N; r += SMRT_LANES) {
+                const double x = fabs(at<TR>(A, r, k, LD));
+                if (x > best) { best = x; bi = r; }
+            }
+            for (int m = SMRT_LANES / 2; m >= 1; m >>= 1) {
+                const double ob = shfl_xor(best, m);
+                const int oi = shfl_xor(bi, m);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { piv[0] = bi; piv[1] = (best > 0.0 && best < 1e300) ? 0 : 1; }
+        }
+        block_sync();
+        const int p = piv[0];
+        if (piv[1]) return false;
+        if (p != k) {
+            const int na = N - k;
+            for (int idx = t; idx < na + N + nv; idx += NT) {
+                if (idx < na) {
+                    const int c = k + idx;
+                    const double x = at<TR>(A, k, c, LD);
+                    at<TR>(A, k, c, LD) = at<TR>(A, p, c, LD);
+                    at<TR>(A, p, c, LD) = x;
+                } else if (idx < na + N) {
+                    const int c = idx - na;
+                    const double x = at<TR>(Bm, k, c, LD);
+                    at<TR>(Bm, k, c, LD) = at<TR>(Bm, p, c, LD);
+                    at<TR>(Bm, p, c, LD) = x;
+                } else {
+                    const double x = v[k]; v[k] = v[p]; v[p] = x;
+                }
+            }
+            block_sync();
+        }
+        const double rp = 1.0 / at<TR>(A, k, k, LD);
+        const int m = N - k - 1;
+        if (m > 0) {
+            const int ncols = m + N + nv;
+            for (int idx = t; idx < m * ncols; idx += NT) {
+                const int r = k + 1 + idx % m, cc = idx / m;
+                const double l = at<TR>(A, r, k, LD) * rp;
+                if (cc < m) {
+                    const int c = k + 1 + cc;
+                    at<TR>(A, r, c, LD) -= l * at<TR>(A, k, c, LD);
+                } else if (cc < m + N) {
+                    const int c = cc - m;
+                    at<TR>(Bm, r, c, LD) -= l * at<TR>(Bm, k, c, LD);
+                } else {
+                    v[r] -= l * v[k];
+                }
+            }
+        }
+        block_sync();
+    }
+    // back substitution
+    for (int i = N - 1; i >= 1; --i) {
+        const double rd = 1.0 / at<TR>(A, i, i, LD);
+        const int ncols = N + nv;
+        for (int idx = t; idx < i * ncols; idx += NT) {
+            const int r = idx % i, c = idx / i;
+            const double l = at<TR>(A, r, i, LD);
+            if (c < N) at<TR>(Bm, r, c, LD) -= l * (at<TR>(Bm, i, c, LD) * rd);
+            else v[r] -= l * (v[i] * rd);
+        }
+        block_sync();
+    }
+    for (int idx = t; idx < N * (N + nv); idx += NT) {
+        const int i = idx % N, c = idx / N;
+        const double rd = 1.0 / at<TR>(A, i, i, LD);
+        if (c < N) at<TR>(Bm, i, c, LD) *= rd;
+        else v[i] *= rd;
+    }
+    block_sync();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the per-pair solve (passive mode, azimuth mode 0, 2 polarisations)
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride) {
+    const int t = tid();
+    for (int i = t; i < out_stride; i += NT) b.out[p * out_stride + i] = NAN;
+    if (t == 0) b.status[p] = code;
+}
+
+
+#ifdef SMRT_EMU_DEBUG
+#include <cstdio>
+#define SMRT_DUMP(tag, M, NN) do { block_sync(); if (t == 0) { char fn[128]; snprintf(fn, 128, "/tmp/dump_l%d_%s.bin", l, tag); FILE* f = fopen(fn, "wb"); for (int c_ = 0; c_ < (NN); ++c_) fwrite((M) + c_ * LD, 8, (NN), f); fclose(f);} block_sync(); } while (0)
+#else
+#define SMRT_DUMP(tag, M, NN) do {} while (0)
+#endif
+// rows-per-wavefront register blocking of the two "row times matrix" passes
+constexpr int RB = 2;
+
+template <int NT, int CH>
+SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base) {
+    constexpr int P = 2;
+    constexpr int GS = (NT / 32 >= 1) ? ((NT / 32 > 64) ? 64 : NT / 32) : 1;
+    const int t = tid();
+    const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
+    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi);
+    const Lds s = carve(lds_base, plan);
+    const int LD = plan.LD;
+    const int nmax = b.n_max_stream;
+    const int out_stride = P * b.n_theta;
+
+    const long long gp = b.pair_begin + p;
+    const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
+    const double frequency = b.frequency[fi];
+    const int L = b.n_layers[si];
+    const double* thickness = b.thickness + (long long)si * b.Lmax;
+    const double* fracvol = b.frac_volume + (long long)si * b.Lmax;
+    const double* temperature = b.temperature + (long long)si * b.Lmax;
+    const double* mp1 = b.p1 + (long long)si * b.Lmax;
+    const double* mp2 = b.p2 + (long long)si * b.Lmax;
+
+    // ---- stage 0: layer scalars, azimuth table, Gauss-Legendre sines -------------------------------------
+    if (t < 8) s.ints[t] = 0;
+    block_sync();
+    for (int l = t; l < L; l += NT) {
+        cplx ee; double ks, ka, pa, pb; int bad = 0;
+        layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
+        s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
+        s.thick[l] = thickness[l];
+        s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
+        if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
+    }
+    for (int k = t; k < nphi; k += NT) {
+        const double ph = kPi * (double)k / (double)(nphi - 1);
+        const double c = cos(ph), sn = sin(ph);
+        s.cphi[k] = c; s.s2phi[k] = sn * sn;
+        s.wphi[k] = ((k == 0 || k == nphi - 1) ? 1.0 : 2.0) / (double)(2 * (nphi - 1));
+    }
+    for (int j = t; j < nmax; j += NT) {
+        const double m = b.gl_mu[j];
+        s.gmu[j] = m; s.gsin[j] = sqrt(1.0 - m * m);
+    }
+    block_sync();
+    if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+
+    // ---- stage 1: streams (streams.py:136-223) -----------------------------------------------------------
+    if (t == 0) {
+        int ks_ = 0;
+        for (int l = 1; l < L; ++l)  // np.argmax on complex: lexicographic, first maximum
+            if (s.eps_re[l] > s.eps_re[ks_] || (s.eps_re[l] == s.eps_re[ks_] && s.eps_im[l] > s.eps_im[ks_])) ks_ = l;
+        s.ints[4] = ks_;
+    }
+    block_sync();
+    {
+        const cplx estar = cmk(s.eps_re[s.ints[4]], s.eps_im[s.ints[4]]);
+        for (int l = t; l < L; l += NT) {
+            const double ri = csqrt_(cdiv(estar, cmk(s.eps_re[l], s.eps_im[l]))).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) n += (ri * s.gsin[j] < 1.0) ? 1 : 0;
+            s.ri[l] = ri; s.nl[l] = (double)n;
+            if (n < 2) lds_max(&s.ints[0], ST_INPUT);
+        }
+        if (t == NT - 1) {
+            const double ria = csqrt_(estar).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) {
+                const double rs = ria * s.gsin[j];
+                if (rs < 1.0) { s.outmu[n] = sqrt(1.0 - rs * rs); ++n; }
+            }
+            s.ints[5] = n;
+            if (n < 1) lds_max(&s.ints[0], ST_INPUT);
+        }
+    }
+    block_sync();
+    if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+    const int n_air = s.ints[5];
+
+    if (b.want_layer_out) {
+        double* lo = b.layer_out + p * (long long)b.Lmax * 5;
+        for (int l = t; l < b.Lmax; l += NT) {
+            const bool in = l < L;
+            lo[l * 5 + 0] = in ? s.eps_re[l] : 0.0; lo[l * 5 + 1] = in ? s.eps_im[l] : 0.0;
+            lo[l * 5 + 2] = in ? s.ks[l] : 0.0; lo[l * 5 + 3] = in ? s.ka[l] : 0.0;
+            lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
+        }
+    }
+    if (b.want_stream_out) {
+        double* so = b.stream_out + p * (long long)(1 + nmax);
+        if (t == 0) so[0] = (double)n_air;
+        for (int j = t; j < nmax; j += NT) so[1 + j] = (j < n_air) ? s.outmu[j] : 0.0;
+    }
+
+    double n3 = 0.0;
+    // ---- bottom-up over the layers -------------------------------------------------------------------------
+    for (int l = L - 1; l >= 0; --l) {
+        const int n = (int)s.nl[l];
+        const int N = n * P;
+        n3 += (double)N * N * N;
+        const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
+        const double ks = s.ks[l], ke = s.ks[l] + s.ka[l];
+        const double Bl = s.BT[l];
+        const int nu = (l > 0) ? (int)s.nl[l - 1] : 0;
+        const int Nu = nu * P;
+
+        // -- stream cosines of this layer and of the layer above
+        for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
+        if (l > 0)
+            for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
+        if (l == L - 1) {  // nothing below the last layer (rtsolver_utils.py:548-551,601-603)
+            for (int idx = t; idx < N * N; idx += NT) s.M3[(idx / N) * LD + idx % N] = 0.0;
+            for (int r = t; r < N; r += NT) s.svec[r] = 0.0;
+        }
+        block_sync();
+        // -- weights (streams.py:324-330), per-row copies, interface diagonals
+        for (int j = t; j < n; j += NT) {
+            double w;
+            if (j == 0) w = 1.0 - 0.5 * (s.mu[0] + s.mu[1]);
+            else if (j == n - 1) w = fabs(0.5 * (s.mu[n - 2] + s.mu[n - 1]));
+            else w = fabs(0.5 * (s.mu[j - 1] - s.mu[j + 1]));
+            s.w[j] = w;
+            s.mrow[2 * j] = s.mu[j]; s.mrow[2 * j + 1] = s.mu[j];
+            s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
+            double Rv, Rh;
+            const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
+            fresnel_RvRh(el, eup, s.mu[j], &Rv, &Rh);
+            s.Rtop[2 * j] = Rv; s.Rtop[2 * j + 1] = Rh;
+            s.Ttop[2 * j] = 1.0 - Rv; s.Ttop[2 * j + 1] = 1.0 - Rh;
+        }
+        if (l > 0)
+            for (int j = t; j < nu; j += NT) {
+                double Rv, Rh;
+                fresnel_RvRh(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], &Rv, &Rh);
+                s.Rbu[2 * j] = Rv; s.Rbu[2 * j + 1] = Rh;
+                s.Tbu[2 * j] = 1.0 - Rv; s.Tbu[2 * j + 1] = 1.0 - Rh;
+            }
+
+        // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
+        //    (lower triangle by stream blocks; the matrices are symmetric)
+        {
+            const int T = n * (n + 1) / 2;
+            const double pa = s.pa[l], pb = s.pb[l];
+            const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+            for (int idx = t; idx < T; idx += NT) {
+                int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                while (i * (i + 1) / 2 > idx) --i;
+                const int j = idx - i * (i + 1) / 2;
+                const double mi = s.mu[i], mj = s.mu[j];
+                double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
+                if (b.emmodel == EM_DMRT) {  // closed form, rayleigh.py:70-76; even in mu'
+                    const double a2 = mi * mi, b2 = mj * mj;
+                    pvv_p = pa * (0.5 * a2 * b2 + (1.0 - a2) * (1.0 - b2));
+                    pvh_p = pa * 0.5 * a2; phv_p = pa * 0.5 * b2; phh_p = pa * 0.5;
+                    pvv_m = pvv_p; pvh_m = pvh_p; phv_m = phv_p; phh_m = phh_p;
+                } else {
+                    const double sisj = sqrt(1.0 - mi * mi) * sqrt(1.0 - mj * mj);
+                    const double mm = mi * mj;
+                    const double a2 = mi * mi, b2 = mj * mj;
+                    pvv_p = pvh_p = phv_p = phh_p = pvv_m = pvh_m = phv_m = phh_m = 0.0;
+                    for (int k = 0; k < nphi; ++k) {
+                        const double c = s.cphi[k], s2 = s.s2phi[k], wk = s.wphi[k];
+                        double ct_p = mm + sisj * c;       // cos(scattering angle), mu' = +mu_j
+                        double ct_m = -mm + sisj * c;      // mu' = -mu_j
+                        ct_p = ct_p > 1.0 ? 1.0 : (ct_p < -1.0 ? -1.0 : ct_p);
+                        ct_m = ct_m > 1.0 ? 1.0 : (ct_m < -1.0 ? -1.0 : ct_m);
+                        double Cp, Cm;
+                        if (b.micro == MS_EXP) {
+                            const double dp = 1.0 + pb * (1.0 - ct_p), dm = 1.0 + pb * (1.0 - ct_m);
+                            Cp = pa / (dp * dp); Cm = pa / (dm * dm);
+                        } else {
+                            Cp = pa * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
+                            Cm = pa * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
+                        }
+                        Cp *= wk; Cm *= wk;
+                        const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
+                        pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;
+                        pvh_p += s2 * a2 * Cp; pvh_m += s2 * a2 * Cm;
+                        phv_p += s2 * b2 * Cp; phv_m += s2 * b2 * Cm;
+                        phh_p += c * c * Cp; phh_m += c * c * Cm;
+                    }
+                }
+                const int r0 = 2 * i, c0 = 2 * j;
+                s.M0[c0 * LD + r0] = pvv_p + pvv_m;             s.M1[c0 * LD + r0] = pvv_p - pvv_m;
+                s.M0[(c0 + 1) * LD + r0] = pvh_p + pvh_m;       s.M1[(c0 + 1) * LD + r0] = pvh_p - pvh_m;
+                s.M0[c0 * LD + r0 + 1] = phv_p + phv_m;         s.M1[c0 * LD + r0 + 1] = phv_p - phv_m;
+                s.M0[(c0 + 1) * LD + r0 + 1] = phh_p + phh_m;   s.M1[(c0 + 1) * LD + r0 + 1] = phh_p - phh_m;
+            }
+        }
+        block_sync();
+        // -- energy-conserving renormalisation (dort.py:782-819): norm_r = ks / (c sum_c S+[r,c] w_c), c = 1/2
+        for (int r = t; r < N; r += NT) {
+            double rs = 0.0;
+            for (int c = 0; c <= r; ++c) rs += s.M0[c * LD + r] * s.wrow[c];
+            for (int c = r + 1; c < N; ++c) rs += s.M0[r * LD + c] * s.wrow[c];
+            double nr = 1.0;
+            if (b.normalization != 0 && ks != 0.0) {
+                nr = ks / (0.5 * rs);
+                if (b.normalization == 1 && !(fabs(nr - 1.0) <= 0.3)) lds_max(&s.ints[0], ST_NORM);
+            }
+            const double uu = sqrt(nr * s.wrow[r] / s.mrow[r]);
+            s.u[r] = uu;
+            s.d[r] = uu / s.wrow[r];
+        }
+        block_sync();
+        if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+        // -- X+- = M^-1/2 T (ke I - c N S+- W) T^-1 M^-1/2, symmetric positive definite (lower triangles)
+        for (int idx = t; idx < N * N; idx += NT) {
+            const int r = idx % N, c = idx / N;
+            if (r >= c) {
+                const double uu = 0.5 * s.u[r] * s.u[c];
+                const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
+                s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
+                s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
+            }
+        }
+        block_sync();
+        if (!chol2<NT>(s.M0, s.M1, N, LD)) { fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return; }
+        lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);                       // B = L+^T L-
+        if (!jacobi_onesided<NT, GS>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1])) {
+            fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+        }
+        l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);                        // Em' = L+ B'
+        lt_solve<NT>(s.M0, s.M2, N, LD);                               // Ep' = L+^-T B'
+        // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
+        for (int idx = t; idx < N * N; idx += NT) {
+            const int i = idx % N, c = idx / N;
+            const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];
+            const double hd = 0.5 * s.d[i];
+            s.M2[c * LD + i] = hd * (ep + em);
+            s.M1[c * LD + i] = hd * (ep - em);
+        }
+        for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
+        block_sync();
+        double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+        SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
+
+        // -- R1: Wk = F - Rt G ; Rt <- Rt F - G (row-wise in place) ; cvec = (Rt 1) B - B + svec
+        for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
+            double a1[RB][CH], a2[RB][CH], rsum[RB];
+            for (int bb = 0; bb < RB; ++bb) { rsum[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] = 0.0; a2[bb][ch] = 0.0; } }
+            for (int k = 0; k < N; ++k) {
+                double fk[CH], gk[CH];
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int c = ch * SMRT_LANES + lane;
+                    fk[ch] = (c < N) ? F[c * LD + k] : 0.0;
+                    gk[ch] = (c < N) ? G[c * LD + k] : 0.0;
+                }
+                for (int bb = 0; bb < RB; ++bb) {
+                    const int i = i0 + bb;
+                    const double r = (i < N) ? Rt[k * LD + i] : 0.0;
+                    rsum[bb] += r;
+                    for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] += r * gk[ch]; a2[bb][ch] += r * fk[ch]; }
+                }
+            }
+            wave_sync();  // every lane has read rows i0.. of Rt before they are overwritten
+            for (int bb = 0; bb < RB; ++bb) {
+                const int i = i0 + bb;
+                if (i < N) {
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int c = ch * SMRT_LANES + lane;
+                        if (c < N) {
+                            Wk[c * LD + i] = F[c * LD + i] - a1[bb][ch];
+                            Rt[c * LD + i] = a2[bb][ch] - G[c * LD + i];
+                        }
+                    }
+                    if (lane == 0) s.cvec[i] = rsum[bb] * Bl - Bl + s.svec[i];
+                }
+            }
+        }
+        block_sync();
+        SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
+        // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
+        if (!lu_solve<NT, false>(Wk, Rt, s.cvec, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        double* Q = Rt;
+        SMRT_DUMP("Q", Q, N);
+        for (int idx = t; idx < N * N; idx += NT) {
+            const int r = idx % N, c = idx / N;
+            Q[c * LD + r] *= s.t[r] * s.t[c];
+        }
+        for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
+        block_sync();
+        // -- R4/R5: Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (row-wise in place)
+        //    upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
+        for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
+            double ay[RB][CH], aw[RB][CH], vy[RB], vg[RB];
+            for (int bb = 0; bb < RB; ++bb) { vy[bb] = 0.0; vg[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] = 0.0; aw[bb][ch] = 0.0; } }
+            for (int k = 0; k < N; ++k) {
+                double tk[CH];
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int c = ch * SMRT_LANES + lane;
+                    tk[ch] = (c < N) ? Q[c * LD + k] : 0.0;
+                }
+                const double tqk = s.tq[k];
+                for (int bb = 0; bb < RB; ++bb) {
+                    const int i = i0 + bb;
+                    double fik = 0.0, wik = 0.0;
+                    if (i < N) { fik = F[k * LD + i]; wik = G[k * LD + i] - s.Rtop[i] * fik; }
+                    vy[bb] += fik * tqk; vg[bb] += wik * tqk;
+                    for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] += fik * tk[ch]; aw[bb][ch] += wik * tk[ch]; }
+                }
+            }
+            wave_sync();  // every lane has read rows i0.. of F before they are overwritten
+            for (int bb = 0; bb < RB; ++bb) {
+                const int i = i0 + bb;
+                if (i < N) {
+                    const double rt = s.Rtop[i];
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int c = ch * SMRT_LANES + lane;
+                        if (c < N) {
+                            const double fic = F[c * LD + i], gic = G[c * LD + i];
+                            Wk[c * LD + i] = ay[bb][ch] + gic;
+                            F[c * LD + i] = aw[bb][ch] + fic - rt * gic;
+                        }
+                    }
+                    if (lane == 0) { s.upb[i] = vy[bb] + Bl; s.g[i] = vg[bb] + (1.0 - rt) * Bl; }
+                }
+            }
+        }
+        block_sync();
+        SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
+        // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
+        if (!lu_solve<NT, true>(F, Wk, nullptr, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        double* K = Wk;
+        SMRT_DUMP("K", K, N);
+        // -- upwelling intensity just below the top interface of layer l: up = F tq + B - K g
+        for (int i = t; i < N; i += NT) {
+            double acc = s.upb[i];
+            for (int k = 0; k < N; ++k) acc -= K[k * LD + i] * s.g[k];
+            s.up[i] = acc;
+        }
+        block_sync();
+        if (l > 0) {
+            // reflection matrix and source seen from the bottom of layer l-1 (streams paired by index)
+            const int nc = (N < Nu) ? N : Nu;
+            for (int idx = t; idx < Nu * Nu; idx += NT) {
+                const int i = idx % Nu, j = idx / Nu;
+                double v = (i == j) ? s.Rbu[i] : 0.0;
+                if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
+                s.M3[j * LD + i] = v;
+            }
+            for (int i = t; i < Nu; i += NT) s.svec[i] = (i < nc) ? s.Ttop[i] * s.up[i] : 0.0;
+            block_sync();
+        }
+    }
+
+    // ---- emerging brightness temperature at the air streams, then at the sensor angles ---------------------
+    for (int i = t; i < n_air * P; i += NT) {
+        const double I0 = s.Ttop[i] * s.up[i];  // dort.py:484 with no downwelling sky radiation
+        s.tb[i] = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
+    }
+    block_sync();
+    for (int idx = t; idx < P * b.n_theta; idx += NT) {
+        const int pol = idx / b.n_theta, it = idx % b.n_theta;
+        const double um = cos(b.theta[it]);
+        // outmu is descending; a virtual node mu = 1 holding mean(V,H) of the steepest stream is prepended when the
+        // request is steeper than every stream (rtsolver_utils.py:191-198); linear inter/extrapolation otherwise
+        double x0, x1, y0, y1;
+        const double top = 0.5 * (s.tb[0] + s.tb[1]);
+        if (um > s.outmu[0]) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = s.tb[pol]; }
+        else if (n_air == 1) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = s.tb[pol]; }
+        else {
+            int k = 0;  // segment [outmu[k+1], outmu[k]] containing um, clamped for extrapolation
+            while (k < n_air - 2 && um < s.outmu[k + 1]) ++k;
+            x0 = s.outmu[k]; y0 = s.tb[2 * k + pol]; x1 = s.outmu[k + 1]; y1 = s.tb[2 * (k + 1) + pol];
+        }
+        b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
+    }
+    if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+}
+
+}  // namespace smrt

@@ -1,0 +1,269 @@
+// libsmrt_dort.so -- HIP implementation of include/smrt_dort.h for gfx950 (MI355X).
+// Host code: context, device buffers, packing, launch, HIP-event timing.  Kernels: dort_device.hpp.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dort_device.hpp"
+#include "dort_host_common.hpp"
+
+using namespace smrt;
+
+template <int NT, int CH>
+__global__ __launch_bounds__(NT) void dort_passive_kernel(DevBatch b) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct smrt_dort_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3;
+    DevBatch dev{};
+    bool uploaded = false;
+    int out_stride = 0;
+    int nt = 256;
+    size_t lds_bytes = 0;
+    float last_ms = 0.f;
+    double total_ms = 0.0;
+    int64_t n_launch = 0;
+    bool timing_pending = false;
+    int max_lds = 0;
+};
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return -1;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+static int upload_array(smrt_dort_ctx* ctx, DevBuf& buf, const void* src, size_t bytes) {
+    HIPCHK(buf.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+template <int NT>
+static hipError_t launch_nt(smrt_dort_ctx* ctx, const DevBatch& d) {
+    auto kern = dort_passive_kernel<NT, 1>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)d.pair_count), dim3(NT), ctx->lds_bytes, ctx->stream, d);
+    return hipGetLastError();
+}
+
+extern "C" {
+
+const char* smrt_dort_version(void) { return "smrt_dort 0.1 (gfx950)"; }
+
+int32_t smrt_dort_out_stride(const smrt_batch* b) { return smrt_host::out_stride(b); }
+
+int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight) {
+    if (n < 1 || !mu) return -1;
+    smrt_host::gauss_legendre_positive(n, mu, weight);
+    return 0;
+}
+
+int32_t smrt_dort_create(smrt_dort_ctx** out, int32_t device) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2;  // no GPU: the product has no CPU fallback
+    if (device < 0 || device >= ndev) return -3;
+    smrt_dort_ctx* ctx = new smrt_dort_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return -4;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->max_lds = (int)prop.sharedMemPerBlock;
+    if (ctx->max_lds < 160 * 1024) ctx->max_lds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+    *out = ctx;
+    return 0;
+}
+
+void smrt_dort_destroy(smrt_dort_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
+                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* smrt_dort_last_error(const smrt_dort_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
+    if (!ctx) return -1;
+    if (threads == 0) threads = 256;
+    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) {
+        ctx->err = "block threads must be 64, 128, 256, 512 or 1024";
+        return -1;
+    }
+    ctx->nt = threads;
+    return 0;
+}
+
+int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count) {
+    if (!ctx) return -1;
+    const char* why = smrt_host::validate(b);
+    if (why) { ctx->err = why; return -1; }
+    if (b->mode != SMRT_MODE_PASSIVE) { ctx->err = "active mode is not available in this build"; return -1; }
+    const int64_t npairs = (int64_t)b->n_snowpacks * b->n_frequencies;
+    if (pair_count < 0) pair_count = npairs - pair_begin;
+    if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
+    const int P = 2;
+    const LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9);
+    const size_t lds = (size_t)plan.total * sizeof(double);
+    if (plan.NMAX > 64 || lds > (size_t)ctx->max_lds) {
+        ctx->err = "n_max_stream too large for the LDS-resident kernel of this build";
+        return -1;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
+    if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;
+    if (upload_array(ctx, ctx->d_thick, b->thickness, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_fv, b->frac_volume, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_temp, b->temperature, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_p1, b->micro_p1, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_p2, b->micro_p2 ? b->micro_p2 : b->micro_p1, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_freq, b->frequency, sizeof(double) * b->n_frequencies)) return -1;
+    if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
+    std::vector<double> gl(b->n_max_stream);
+    smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
+    if (upload_array(ctx, ctx->d_gl, gl.data(), sizeof(double) * gl.size())) return -1;
+    ctx->out_stride = smrt_host::out_stride(b);
+    HIPCHK(ctx->d_out.reserve(sizeof(double) * pair_count * ctx->out_stride));
+    HIPCHK(ctx->d_status.reserve(sizeof(int32_t) * pair_count));
+    HIPCHK(ctx->d_layer.reserve(sizeof(double) * pair_count * b->n_layers_max * 5));
+    HIPCHK(ctx->d_stream.reserve(sizeof(double) * pair_count * (1 + b->n_max_stream)));
+    HIPCHK(ctx->d_n3.reserve(sizeof(double) * pair_count));
+    DevBatch& d = ctx->dev;
+    d.S = b->n_snowpacks; d.Lmax = b->n_layers_max; d.F = b->n_frequencies; d.n_theta = b->n_theta;
+    d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
+    d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
+    d.want_layer_out = 1; d.want_stream_out = 1;
+    d.pair_begin = pair_begin; d.pair_count = pair_count;
+    d.n_layers = (const int*)ctx->d_nl.p; d.thickness = (const double*)ctx->d_thick.p;
+    d.frac_volume = (const double*)ctx->d_fv.p; d.temperature = (const double*)ctx->d_temp.p;
+    d.p1 = (const double*)ctx->d_p1.p; d.p2 = (const double*)ctx->d_p2.p;
+    d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
+    d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
+    d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
+    d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p;
+    ctx->lds_bytes = lds;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vector `gl` and the caller's arrays may go away
+    ctx->uploaded = true;
+    return 0;
+}
+
+int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
+    if (!ctx) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBatch d = ctx->dev;
+    if (out_dev) d.out = (double*)out_dev;
+    if (status_dev) d.status = (int*)status_dev;
+    if (ctx->timing_pending) {  // fold the previous launch into the totals before reusing the events
+        HIPCHK(hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms = ms; ctx->total_ms += ms; ctx->n_launch++;
+        ctx->timing_pending = false;
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipError_t e;
+    switch (ctx->nt) {
+        case 64: e = launch_nt<64>(ctx, d); break;
+        case 128: e = launch_nt<128>(ctx, d); break;
+        case 512: e = launch_nt<512>(ctx, d); break;
+        case 1024: e = launch_nt<1024>(ctx, d); break;
+        default: e = launch_nt<256>(ctx, d); break;
+    }
+    HIPCHK(e);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timing_pending = true;
+    return 0;
+}
+
+int32_t smrt_dort_sync(smrt_dort_ctx* ctx) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing_pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms = ms; ctx->total_ms += ms; ctx->n_launch++;
+        ctx->timing_pending = false;
+    }
+    return 0;
+}
+
+double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx) { return ctx ? (double)ctx->last_ms : -1.0; }
+
+double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset) {
+    if (!ctx) return -1.0;
+    const double tot = ctx->total_ms;
+    if (n_launches) *n_launches = ctx->n_launch;
+    if (reset) { ctx->total_ms = 0.0; ctx->n_launch = 0; }
+    return tot;
+}
+
+int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, double* layer_out, double* stream_out) {
+    if (!ctx) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const DevBatch& d = ctx->dev;
+    const size_t np = (size_t)d.pair_count;
+    if (out) HIPCHK(hipMemcpyAsync(out, d.out, sizeof(double) * np * ctx->out_stride, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIPCHK(hipMemcpyAsync(status, d.status, sizeof(int32_t) * np, hipMemcpyDeviceToHost, ctx->stream));
+    if (layer_out) HIPCHK(hipMemcpyAsync(layer_out, d.layer_out, sizeof(double) * np * d.Lmax * 5, hipMemcpyDeviceToHost, ctx->stream));
+    if (stream_out) HIPCHK(hipMemcpyAsync(stream_out, d.stream_out, sizeof(double) * np * (1 + d.n_max_stream), hipMemcpyDeviceToHost, ctx->stream));
+    return smrt_dort_sync(ctx);
+}
+
+double smrt_dort_sum_n3(smrt_dort_ctx* ctx) {
+    if (!ctx || !ctx->uploaded) return -1.0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1.0;
+    std::vector<double> h((size_t)ctx->dev.pair_count);
+    if (hipMemcpy(h.data(), ctx->dev.n3_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    double s = 0.0;
+    for (double v : h) s += v;
+    return s;
+}
+
+int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count, double* out,
+                      int32_t* status, double* layer_out, double* stream_out) {
+    if (smrt_dort_upload(ctx, batch, pair_begin, pair_count)) return -1;
+    if (smrt_dort_launch(ctx, nullptr, nullptr)) return -1;
+    return smrt_dort_download(ctx, out, status, layer_out, stream_out);
+}
+
+}  // extern "C"

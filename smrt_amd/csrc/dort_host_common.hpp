@@ -1,0 +1,64 @@
+// Host-side helpers shared by the HIP library (dort_hip.hip) and the emulator build used by the CPU tests.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+#include "../../include/smrt_dort.h"
+
+namespace smrt_host {
+
+// Positive nodes (descending) and weights of the Gauss-Legendre rule of order 2n, by Newton iteration on the
+// three-term recurrence (what scipy.special.roots_legendre provides to smrt/rtsolver/streams.py:300-313).
+inline void gauss_legendre_positive(int n, double* mu, double* weight) {
+    const int m = 2 * n;
+    for (int i = 0; i < n; ++i) {
+        double x = std::cos(M_PI * (i + 0.75) / (m + 0.5));  // i-th largest root
+        double dp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p0 = 1.0, p1 = x;
+            for (int k = 2; k <= m; ++k) {
+                const double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+                p0 = p1;
+                p1 = pk;
+            }
+            dp = m * (x * p1 - p0) / (x * x - 1.0);
+            const double dx = p1 / dp;
+            x -= dx;
+            if (std::fabs(dx) < 1e-16) break;
+        }
+        // final derivative at the converged node
+        double p0 = 1.0, p1 = x;
+        for (int k = 2; k <= m; ++k) {
+            const double pk = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k;
+            p0 = p1;
+            p1 = pk;
+        }
+        dp = m * (x * p1 - p0) / (x * x - 1.0);
+        mu[i] = x;
+        if (weight) weight[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+    }
+}
+
+inline int out_stride(const smrt_batch* b) {
+    return (b->mode == SMRT_MODE_PASSIVE) ? 2 * b->n_theta : 9 * b->n_theta;
+}
+
+inline const char* validate(const smrt_batch* b) {
+    if (!b) return "null batch";
+    if (b->n_snowpacks <= 0 || b->n_frequencies <= 0 || b->n_layers_max <= 0) return "empty batch";
+    if (b->n_theta <= 0) return "n_theta must be positive";
+    if (b->n_max_stream < 2) return "n_max_stream must be >= 2";
+    if (b->emmodel != SMRT_EM_IBA && b->emmodel != SMRT_EM_DMRT_QCA_SHORTRANGE) return "unknown emmodel";
+    if (b->microstructure != SMRT_MS_EXPONENTIAL && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
+        return "unknown microstructure";
+    if (b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
+        return "dmrt_qca_shortrange is only compatible with sticky_hard_spheres";
+    if (b->mode != SMRT_MODE_PASSIVE && b->mode != SMRT_MODE_ACTIVE) return "unknown mode";
+    if (!b->n_layers || !b->thickness || !b->frac_volume || !b->temperature || !b->micro_p1 || !b->frequency ||
+        !b->theta)
+        return "null input array";
+    if (b->microstructure == SMRT_MS_STICKY_HARD_SPHERES && !b->micro_p2) return "stickiness array missing";
+    return nullptr;
+}
+
+}  // namespace smrt_host

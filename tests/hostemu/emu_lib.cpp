@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE ONLY: runs the *device* code of smrt_amd/csrc/dort_device.hpp on the CPU under the fiber
+// emulator, one workgroup at a time, behind a tiny C entry point.  Lets the CPU test-suite exercise the kernel
+// logic (and check it is barrier-order independent) in a container without a GPU.  Never loaded by smrt_amd.
+#define SMRT_HOST_EMU 1
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../smrt_amd/csrc/dort_device.hpp"
+#include "../../smrt_amd/csrc/dort_host_common.hpp"
+
+using namespace smrt;
+
+template <int NT>
+static long run_pairs(DevBatch& d, int order, size_t lds_doubles) {
+    long nb = 0;
+    std::vector<double> lds(lds_doubles);
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;  // uninitialised LDS must never be consumed
+        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1>(d, p, lds.data()); });
+    }
+    return nb;
+}
+
+extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long pair_count, int nt, int order,
+                            double* out, int32_t* status, double* layer_out, double* stream_out, double* n3_out,
+                            long* n_barriers) {
+    const char* why = smrt_host::validate(b);
+    if (why) { fprintf(stderr, "smrt_emu_run: %s\n", why); return -1; }
+    if (b->mode != SMRT_MODE_PASSIVE) return -1;
+    const LdsPlan plan = make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9);
+    if (plan.NMAX > 64) return -2;
+    std::vector<double> gl(b->n_max_stream);
+    smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
+    DevBatch d{};
+    d.S = b->n_snowpacks; d.Lmax = b->n_layers_max; d.F = b->n_frequencies; d.n_theta = b->n_theta;
+    d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
+    d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
+    d.want_layer_out = layer_out ? 1 : 0; d.want_stream_out = stream_out ? 1 : 0;
+    d.pair_begin = pair_begin; d.pair_count = pair_count;
+    d.n_layers = b->n_layers; d.thickness = b->thickness; d.frac_volume = b->frac_volume;
+    d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
+    d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
+    d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out;
+    long nb;
+    switch (nt) {
+        case 64: nb = run_pairs<64>(d, order, plan.total); break;
+        case 128: nb = run_pairs<128>(d, order, plan.total); break;
+        case 256: nb = run_pairs<256>(d, order, plan.total); break;
+        default: return -3;
+    }
+    if (n_barriers) *n_barriers = nb;
+    return 0;
+}
+
+extern "C" int smrt_emu_gauss_legendre(int n, double* mu, double* w) {
+    smrt_host::gauss_legendre_positive(n, mu, w);
+    return 0;
+}
