@@ -121,6 +121,11 @@ int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
 double smrt_dort_sum_n3(smrt_dort_ctx* ctx);
 
+/* Profiling builds only (-DSMRT_STAGE_TIMING): shader cycles of workgroup thread 0 per kernel stage, summed over
+ * the pairs of the last launch (setup, assemble, cholesky, L^T L, jacobi, triangular, R1, LU1, R45, LU2, R78, out).
+ * A regular build returns zeros. */
+int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16);
+
 /* Positive Gauss-Legendre nodes of order 2n in descending order (smrt/rtsolver/streams.py:300-313). Host only. */
 int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight);
 

@@ -155,6 +155,8 @@ def load_library():
     lib.smrt_dort_set_block_threads.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
     lib.smrt_dort_sum_n3.restype = C.c_double
+    lib.smrt_dort_stage_cycles.argtypes = [C.c_void_p, P(C.c_double)]
+    lib.smrt_dort_stage_cycles.restype = C.c_int32
     lib.smrt_gauss_legendre_positive.argtypes = [C.c_int32, P(C.c_double), P(C.c_double)]
     lib.smrt_gauss_legendre_positive.restype = C.c_int32
     _lib = lib
@@ -164,7 +166,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
     "smrt_dort_upload", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
-    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_gauss_legendre_positive",
+    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_gauss_legendre_positive",
     "smrt_dort_version",
 ]
 
@@ -245,6 +247,14 @@ class DortContext:
         n = C.c_int64()
         ms = float(self._lib.smrt_dort_total_kernel_ms(self._h, C.byref(n), 1 if reset else 0))
         return ms, int(n.value)
+
+    STAGE_NAMES = ["setup", "assemble", "cholesky", "LtL", "jacobi", "triangular", "R1", "LU1", "R45", "LU2", "R78",
+                   "out"]
+
+    def stage_cycles(self):
+        a = np.zeros(16)
+        self._check(self._lib.smrt_dort_stage_cycles(self._h, _dptr(a)), "smrt_dort_stage_cycles")
+        return dict(zip(self.STAGE_NAMES, a[: len(self.STAGE_NAMES)]))
 
     def sum_n3(self):
         return float(self._lib.smrt_dort_sum_n3(self._h))

@@ -49,6 +49,7 @@ struct DevBatch {
     double* layer_out;
     double* stream_out;
     double* n3_out;  // [pair_count] sum_l N_l^3 (work counter for the roofline)
+    double* stage_out;  // [pair_count][16] shader cycles per stage (only written by -DSMRT_STAGE_TIMING builds)
 };
 
 constexpr double kCSpeed = 299792458.0;
@@ -580,6 +581,14 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 #else
 #define SMRT_DUMP(tag, M, NN) do {} while (0)
 #endif
+// Optional per-stage cycle accounting (profiling builds only): thread 0 accumulates s_memtime deltas.
+#ifdef SMRT_STAGE_TIMING
+#define SMRT_STAGE(k) do { const long long now_ = cycle_counter(); stage_acc[stage_cur] += (double)(now_ - stage_t0); stage_t0 = now_; stage_cur = (k); } while (0)
+#else
+#define SMRT_STAGE(k) do {} while (0)
+#endif
+enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_LU1, SG_R45, SG_LU2, SG_R78, SG_OUT, SG_COUNT };
+
 // rows-per-wavefront register blocking of the two "row times matrix" passes
 constexpr int RB = 2;
 
@@ -607,6 +616,12 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const double* mp1 = b.p1 + (long long)si * b.Lmax;
     const double* mp2 = b.p2 + (long long)si * b.Lmax;
 
+#ifdef SMRT_STAGE_TIMING
+    double stage_acc[SG_COUNT];
+    for (int k = 0; k < SG_COUNT; ++k) stage_acc[k] = 0.0;
+    long long stage_t0 = cycle_counter();
+    int stage_cur = SG_SETUP;
+#endif
     // ---- stage 0: layer scalars, azimuth table, Gauss-Legendre sines -------------------------------------
     if (t < 8) s.ints[t] = 0;
     block_sync();
@@ -690,6 +705,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         const int nu = (l > 0) ? (int)s.nl[l - 1] : 0;
         const int Nu = nu * P;
 
+        SMRT_STAGE(SG_SETUP);
         // -- stream cosines of this layer and of the layer above
         for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
         if (l > 0)
@@ -722,6 +738,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 s.Tbu[2 * j] = 1.0 - Rv; s.Tbu[2 * j + 1] = 1.0 - Rh;
             }
 
+        SMRT_STAGE(SG_ASSEMBLE);
         // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
         //    (lower triangle by stream blocks; the matrices are symmetric)
         {
@@ -802,11 +819,15 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             }
         }
         block_sync();
+        SMRT_STAGE(SG_CHOL);
         if (!chol2<NT>(s.M0, s.M1, N, LD)) { fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return; }
+        SMRT_STAGE(SG_BTL);
         lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);                       // B = L+^T L-
+        SMRT_STAGE(SG_JACOBI);
         if (!jacobi_onesided<NT, GS>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1])) {
             fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
         }
+        SMRT_STAGE(SG_TRI);
         l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);                        // Em' = L+ B'
         lt_solve<NT>(s.M0, s.M2, N, LD);                               // Ep' = L+^-T B'
         // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
@@ -822,6 +843,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
         SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
 
+        SMRT_STAGE(SG_R1);
         // -- R1: Wk = F - Rt G ; Rt <- Rt F - G (row-wise in place) ; cvec = (Rt 1) B - B + svec
         for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
             double a1[RB][CH], a2[RB][CH], rsum[RB];
@@ -857,8 +879,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         block_sync();
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
+        SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
         if (!lu_solve<NT, false>(Wk, Rt, s.cvec, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        SMRT_STAGE(SG_R45);
         double* Q = Rt;
         SMRT_DUMP("Q", Q, N);
         for (int idx = t; idx < N * N; idx += NT) {
@@ -906,8 +930,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         block_sync();
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
+        SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
         if (!lu_solve<NT, true>(F, Wk, nullptr, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);
         // -- upwelling intensity just below the top interface of layer l: up = F tq + B - K g
@@ -931,6 +957,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
     }
 
+    SMRT_STAGE(SG_OUT);
     // ---- emerging brightness temperature at the air streams, then at the sensor angles ---------------------
     for (int i = t; i < n_air * P; i += NT) {
         const double I0 = s.Ttop[i] * s.up[i];  // dort.py:484 with no downwelling sky radiation
@@ -954,6 +981,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
     }
     if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+#ifdef SMRT_STAGE_TIMING
+    SMRT_STAGE(SG_OUT);
+    if (t == 0 && b.stage_out) for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+#endif
 }
 
 }  // namespace smrt

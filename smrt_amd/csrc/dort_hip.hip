@@ -37,7 +37,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage;
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -110,7 +110,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
-                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3};
+                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -165,6 +165,8 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     HIPCHK(ctx->d_layer.reserve(sizeof(double) * pair_count * b->n_layers_max * 5));
     HIPCHK(ctx->d_stream.reserve(sizeof(double) * pair_count * (1 + b->n_max_stream)));
     HIPCHK(ctx->d_n3.reserve(sizeof(double) * pair_count));
+    HIPCHK(ctx->d_stage.reserve(sizeof(double) * pair_count * 16));
+    HIPCHK(hipMemsetAsync(ctx->d_stage.p, 0, sizeof(double) * pair_count * 16, ctx->stream));
     DevBatch& d = ctx->dev;
     d.S = b->n_snowpacks; d.Lmax = b->n_layers_max; d.F = b->n_frequencies; d.n_theta = b->n_theta;
     d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
@@ -177,7 +179,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
     d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
-    d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p;
+    d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
     ctx->lds_bytes = lds;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vector `gl` and the caller's arrays may go away
     ctx->uploaded = true;
@@ -257,6 +259,17 @@ double smrt_dort_sum_n3(smrt_dort_ctx* ctx) {
     double s = 0.0;
     for (double v : h) s += v;
     return s;
+}
+
+int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16) {
+    if (!ctx || !ctx->uploaded || !out16) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<double> h((size_t)ctx->dev.pair_count * 16);
+    HIPCHK(hipMemcpy(h.data(), ctx->dev.stage_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) out16[k] = 0.0;
+    for (size_t p = 0; p < (size_t)ctx->dev.pair_count; ++p)
+        for (int k = 0; k < 16; ++k) out16[k] += h[p * 16 + k];
+    return 0;
 }
 
 int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count, double* out,

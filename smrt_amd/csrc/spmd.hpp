@@ -22,6 +22,7 @@ SMRT_DEV void block_sync() { emu::block_barrier(); }
 SMRT_DEV void wave_sync() { emu::wave_barrier(); }
 SMRT_DEV double shfl_xor(double v, int mask) { return emu::shfl_xor(v, mask); }
 SMRT_DEV int shfl_xor(int v, int mask) { return (int)emu::shfl_xor((double)v, mask); }
+SMRT_DEV long long cycle_counter() { return 0; }
 SMRT_DEV void lds_or(int* p, int v) { *p |= v; }
 SMRT_DEV void lds_max(int* p, int v) { if (v > *p) *p = v; }
 }  // namespace smrt
@@ -39,6 +40,7 @@ SMRT_DEV void block_sync() { __syncthreads(); }
 SMRT_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 SMRT_DEV double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 SMRT_DEV int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+SMRT_DEV long long cycle_counter() { return (long long)clock64(); }
 SMRT_DEV void lds_or(int* p, int v) { atomicOr(p, v); }
 SMRT_DEV void lds_max(int* p, int v) { atomicMax(p, v); }
 }  // namespace smrt

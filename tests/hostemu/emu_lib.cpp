@@ -40,7 +40,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.n_layers = b->n_layers; d.thickness = b->thickness; d.frac_volume = b->frac_volume;
     d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
-    d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out;
+    d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
     switch (nt) {
         case 64: nb = run_pairs<64>(d, order, plan.total); break;
