@@ -186,7 +186,7 @@ def main():
                 "solves_per_step_per_gpu": n_pairs,
                 "parallelism": "%d independent rank(s), results gathered to rank 0" % world,
                 "failed_solves": n_fail,
-                "block_threads": args.threads or 256,
+                "block_threads": args.threads or 512,
             },
             "roofline": {
                 "bound": "mfma",

@@ -254,7 +254,9 @@ class DortContext:
     def stage_cycles(self):
         a = np.zeros(16)
         self._check(self._lib.smrt_dort_stage_cycles(self._h, _dptr(a)), "smrt_dort_stage_cycles")
-        return dict(zip(self.STAGE_NAMES, a[: len(self.STAGE_NAMES)]))
+        d = dict(zip(self.STAGE_NAMES, a[: len(self.STAGE_NAMES)]))
+        d["_jacobi_sweeps"] = a[12]
+        return d
 
     def sum_n3(self):
         return float(self._lib.smrt_dort_sum_n3(self._h))

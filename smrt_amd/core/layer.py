@@ -1,0 +1,66 @@
+"""Snow layer container: the attributes of smrt/core/layer.py:35-156 and of SnowLayer
+(smrt/inputs/make_medium.py:320-434) that the DORT path reads."""
+import numpy as np
+
+from .error import SMRTError
+from .globalconstants import DENSITY_OF_ICE, DENSITY_OF_WATER, FREEZING_POINT
+
+
+class Microstructure:
+    """Parameters of one of the two supported microstructure models (exponential: corr_length;
+    sticky_hard_spheres: radius, stickiness)."""
+
+    def __init__(self, name, frac_volume, **params):
+        self.name = name
+        self.frac_volume = frac_volume
+        for k, v in params.items():
+            setattr(self, k, v)
+
+    @property
+    def device_params(self):
+        if self.name == "exponential":
+            return float(self.corr_length), 0.0
+        return float(self.radius), float(getattr(self, "stickiness", np.inf))
+
+
+MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness")}
+
+
+class Layer:
+    def __init__(self, thickness, microstructure_model, density, temperature=FREEZING_POINT, medium="snow",
+                 liquid_water=None, volumetric_liquid_water=None, salinity=0, emmodel=None, emmodel_options=None,
+                 **params):
+        if isinstance(microstructure_model, str):
+            name = microstructure_model
+        else:
+            name = getattr(microstructure_model, "__name__", str(microstructure_model)).lower()
+        if name not in MICROSTRUCTURE_ARGS:
+            raise SMRTError(f"microstructure model '{name}' is outside the scope of smrt_amd "
+                            f"(available: {', '.join(MICROSTRUCTURE_ARGS)})")
+        if (liquid_water or 0) > 0 or (volumetric_liquid_water or 0) > 0 or (salinity or 0) > 0:
+            raise SMRTError("wet or saline snow is outside the scope of smrt_amd (dry snow only)")
+        missing = [a for a in MICROSTRUCTURE_ARGS[name] if a not in params and a != "stickiness"]
+        if missing:
+            raise SMRTError(f"missing microstructure parameter(s) {missing} for '{name}'")
+        self.thickness = float(thickness)
+        self.density = float(density)
+        self.temperature = float(temperature)
+        self.medium = medium
+        self.emmodel = emmodel
+        self.emmodel_options = emmodel_options
+        # SnowLayer.compute_frac_volumes with no liquid water (make_medium.py:390-434)
+        frac_volume = self.density / DENSITY_OF_ICE
+        if not (0 <= frac_volume <= 1.01):
+            raise SMRTError(f"the frac_volume of ice in snow is {frac_volume} but must be between 0 and 1.")
+        frac_volume = min(frac_volume, 1.0)
+        self.microstructure_model = name
+        mparams = {k: float(params[k]) for k in MICROSTRUCTURE_ARGS[name] if k in params}
+        if name == "sticky_hard_spheres":
+            mparams.setdefault("stickiness", np.inf)
+        self.microstructure = Microstructure(name, frac_volume, **mparams)
+        for k, v in mparams.items():
+            setattr(self, k, v)
+
+    @property
+    def frac_volume(self):
+        return self.microstructure.frac_volume

@@ -23,6 +23,7 @@
 #pragma once
 #include "spmd.hpp"
 #include <math.h>
+#include <string.h>
 
 namespace smrt {
 
@@ -328,6 +329,34 @@ SMRT_DEV void fresnel_RvRh(cplx e1, cplx e2, double mu1, double* Rv, double* Rh)
 // ------------------------------------------------------------------------------------------------------------
 // dense kernels in LDS.  Element (r, c) of every matrix lives at [c * LD + r].
 // ------------------------------------------------------------------------------------------------------------
+// Power-of-two 2-D tiling of an (R rows) x (C columns) index space over the workgroup without integer division:
+// a wavefront covers RW = pow2 >= min(R, 64) rows and 64 / RW columns at a time (consecutive lanes -> consecutive
+// rows -> consecutive LDS addresses).  body(r, c) is called for every r < R, c < C exactly once.
+struct Tile2D { int rmask, cshift, cols_per_wave; };
+SMRT_DEV Tile2D make_tile(int R) {
+    Tile2D t;
+    int sh = 6;                       // RW = 64
+    if (R <= 32) sh = 5;
+    if (R <= 16) sh = 4;
+    if (R <= 8) sh = 3;
+    if (R <= 4) sh = 2;
+    t.rmask = (1 << sh) - 1; t.cshift = sh; t.cols_per_wave = SMRT_LANES >> sh;
+    return t;
+}
+template <int NT, class Body>
+SMRT_DEV void for_2d(int R, int C, Body body) {
+    const int t = tid();
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const Tile2D tl = make_tile(R);
+    const int rl = lane & tl.rmask, cs = lane >> tl.cshift;
+    for (int r0 = 0; r0 < R; r0 += SMRT_LANES) {
+        const int r = r0 + rl;
+        for (int c = wave * tl.cols_per_wave + cs; c < C; c += NW * tl.cols_per_wave)
+            if (r < R) body(r, c);
+    }
+}
+
 template <int NT>
 SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
     // Two right-looking Cholesky factorisations side by side (lower triangles, in place).
@@ -335,7 +364,7 @@ SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
     for (int k = 0; k < N; ++k) {
         const double akk = A[k * LD + k], bkk = Bm[k * LD + k];
         if (!(akk > 0.0) || !(bkk > 0.0)) return false;  // uniform: every thread reads the same words
-        const double ra = 1.0 / sqrt(akk), rb = 1.0 / sqrt(bkk);
+        const double ra = fast_rsqrt(akk), rb = fast_rsqrt(bkk);
         for (int i = k + 1 + t; i < N; i += NT) {
             A[k * LD + i] *= ra;
             Bm[k * LD + i] *= rb;
@@ -346,13 +375,13 @@ SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
             Bm[k * LD + k] = bkk * rb;
         }
         const int m = N - k - 1;
-        for (int idx = t; idx < m * m; idx += NT) {
-            const int i = k + 1 + idx % m, j = k + 1 + idx / m;
+        for_2d<NT>(m, m, [&](int ri, int ci) {
+            const int i = k + 1 + ri, j = k + 1 + ci;
             if (i >= j) {
                 A[j * LD + i] -= A[k * LD + i] * A[k * LD + j];
                 Bm[j * LD + i] -= Bm[k * LD + i] * Bm[k * LD + j];
             }
-        }
+        });
         block_sync();
     }
     return true;
@@ -361,28 +390,27 @@ SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
 // C = Lp^T Lm for lower-triangular Lp, Lm
 template <int NT>
 SMRT_DEV void lt_times_l(const double* Lp, const double* Lm, double* C, int N, int LD) {
-    const int t = tid();
-    for (int idx = t; idx < N * N; idx += NT) {
-        const int i = idx % N, j = idx / N;
+    for_2d<NT>(N, N, [&](int i, int j) {
         double acc = 0.0;
         for (int k = (i > j ? i : j); k < N; ++k) acc += Lp[i * LD + k] * Lm[j * LD + k];
         C[j * LD + i] = acc;
-    }
+    });
     block_sync();
 }
 
 // One-sided (Hestenes) Jacobi: rotate column pairs of Bm until all columns are mutually orthogonal.
-// GS consecutive lanes own one pair; the round-robin schedule gives N/2 disjoint pairs per step.
-// On exit sigma[c] = |column c| and rsig[c] = 1 / sigma[c].  Returns false if it did not converge.
-template <int NT, int GS>
-SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag) {
+// GS consecutive lanes own one pair and keep their RPL rows of both columns in registers between the three dot
+// products and the rotation; the round-robin schedule gives N/2 disjoint pairs per step.
+// A sweep in which no pair had cos^2 > 1e-15 before its rotation is the last one (the residual non-orthogonality
+// is second order).  On exit sigma[c] = |column c| and rsig[c] = 1 / sigma[c].  Returns false if not converged.
+template <int NT, int GS, int RPL>
+SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag, int* n_sweeps) {
     const int t = tid();
     const int grp = t / GS, sub = t % GS;
     constexpr int NG = NT / GS;
     const int Ne = N + (N & 1);
     const int npairs = Ne / 2;
     const int rounds = (npairs + NG - 1) / NG;
-    const double tol2 = 1e-28;  // (1e-14)^2 on the squared cosine between two columns
     bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         block_sync();  // everyone has read the previous flag
@@ -393,37 +421,47 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
                 const int pi = grp + rd * NG;
                 int p, q;
                 if (pi == 0) { p = Ne - 1; q = s; }
-                else { p = (s + pi) % (Ne - 1); q = (s - pi + (Ne - 1)) % (Ne - 1); }
+                else {
+                    p = s + pi; if (p >= Ne - 1) p -= Ne - 1;
+                    q = s - pi; if (q < 0) q += Ne - 1;
+                }
                 const bool valid = (pi < npairs) && (p < N) && (q < N);
+                double x[RPL], y[RPL];
                 double a = 0.0, bb = 0.0, gg = 0.0;
-                if (valid) {
-                    const double* cp = Bm + p * LD;
-                    const double* cq = Bm + q * LD;
-                    for (int r = sub; r < N; r += GS) {
-                        const double x = cp[r], y = cq[r];
-                        a += x * x; bb += y * y; gg += x * y;
-                    }
+                double* cp = Bm + p * LD;
+                double* cq = Bm + q * LD;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const int r = sub + i * GS;
+                    const bool in = valid && (r < N);
+                    x[i] = in ? cp[r] : 0.0;
+                    y[i] = in ? cq[r] : 0.0;
+                    a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i];
                 }
-                for (int m = GS / 2; m >= 1; m >>= 1) {
-                    a += shfl_xor(a, m); bb += shfl_xor(bb, m); gg += shfl_xor(gg, m);
-                }
-                if (valid && gg * gg > tol2 * a * bb) {
-                    const double zeta = (bb - a) / (2.0 * gg);
-                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
-                    double* cp = Bm + p * LD;
-                    double* cq = Bm + q * LD;
-                    for (int r = sub; r < N; r += GS) {
-                        const double x = cp[r], y = cq[r];
-                        cp[r] = c * x - sn * y;
-                        cq[r] = sn * x + c * y;
+                a = group_sum<GS>(a); bb = group_sum<GS>(bb); gg = group_sum<GS>(gg);
+                const double g2 = gg * gg, ab = a * bb;
+                if (valid && g2 > 1e-30 * ab) {
+                    // tan of the rotation angle: t = 2 g sign(d) / (|d| + sqrt(d^2 + 4 g^2)), d = b - a
+                    const double dd = bb - a;
+                    const double hh = dd * dd + 4.0 * g2;
+                    const double h = hh * fast_rsqrt(hh);
+                    const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp(fabs(dd) + h);
+                    const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        const int r = sub + i * GS;
+                        if (r < N) {
+                            cp[r] = c * x[i] - sn * y[i];
+                            cq[r] = sn * x[i] + c * y[i];
+                        }
                     }
-                    if (sub == 0) lds_or(flag, 1);
+                    if (sub == 0 && g2 > 1e-15 * ab) lds_or(flag, 1);
                 }
             }
             block_sync();
         }
         converged = (*flag == 0);
+        ++*n_sweeps;
     }
     block_sync();
     // column norms
@@ -433,9 +471,9 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
             const int c = grp + rd * NG;
             double a = 0.0;
             if (c < N)
-                for (int r = sub; r < N; r += GS) { const double x = Bm[c * LD + r]; a += x * x; }
-            for (int m = GS / 2; m >= 1; m >>= 1) a += shfl_xor(a, m);
-            if (c < N && sub == 0) { const double sg = sqrt(a); sigma[c] = sg; rsig[c] = 1.0 / sg; }
+                for (int r = sub; r < N; r += GS) { const double xx = Bm[c * LD + r]; a += xx * xx; }
+            a = group_sum<GS>(a);
+            if (c < N && sub == 0) { const double rs = fast_rsqrt(a); sigma[c] = a * rs; rsig[c] = rs; }
         }
     }
     block_sync();
@@ -445,90 +483,85 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
 // C = Lp * Bm (Lp lower triangular)
 template <int NT>
 SMRT_DEV void l_times_m(const double* Lp, const double* Bm, double* C, int N, int LD) {
-    const int t = tid();
-    for (int idx = t; idx < N * N; idx += NT) {
-        const int i = idx % N, c = idx / N;
+    for_2d<NT>(N, N, [&](int i, int c) {
         double acc = 0.0;
         for (int k = 0; k <= i; ++k) acc += Lp[k * LD + i] * Bm[c * LD + k];
         C[c * LD + i] = acc;
-    }
+    });
     block_sync();
 }
 
 // Bm <- Lp^-T Bm (back substitution with the upper-triangular Lp^T, all columns at once)
 template <int NT>
 SMRT_DEV void lt_solve(const double* Lp, double* Bm, int N, int LD) {
-    const int t = tid();
     for (int i = N - 1; i >= 1; --i) {
-        const double rd = 1.0 / Lp[i * LD + i];
-        for (int idx = t; idx < i * N; idx += NT) {
-            const int r = idx % i, c = idx / i;
-            Bm[c * LD + r] -= Lp[r * LD + i] * (Bm[c * LD + i] * rd);
-        }
+        const double rd = fast_rcp(Lp[i * LD + i]);
+        for_2d<NT>(i, N, [&](int r, int c) { Bm[c * LD + r] -= Lp[r * LD + i] * (Bm[c * LD + i] * rd); });
         block_sync();
     }
-    for (int idx = t; idx < N * N; idx += NT) {
-        const int i = idx % N, c = idx / N;
-        Bm[c * LD + i] *= 1.0 / Lp[i * LD + i];
-    }
+    for_2d<NT>(N, N, [&](int i, int c) { Bm[c * LD + i] *= fast_rcp(Lp[i * LD + i]); });
     block_sync();
 }
 
 // Solve A X = Bm (+ one extra right-hand-side vector v, may be null) by LU with partial pivoting; X overwrites
 // Bm / v, A is destroyed.  TR selects the storage view: element (r, c) at [c*LD + r] (false) or [r*LD + c]
 // (true, i.e. the routine then solves A^T X^T = Bm^T on the same buffers).
+// Every thread scans the pivot column itself (LDS broadcast reads): no cross-lane reduction and no barrier
+// between the search and the row swap.
 template <bool TR>
 SMRT_DEV double& at(double* M, int r, int c, int LD) { return TR ? M[r * LD + c] : M[c * LD + r]; }
 
 template <int NT, bool TR>
-SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, int N, int LD, int* piv) {
+SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, int LD) {
+    // Column k is never written once step k starts: the row swap skips it (the multipliers are taken from the
+    // unswapped column) and the pivot U[k][k] goes to udiag[k].  That makes the redundant pivot scan race-free
+    // against the swap of faster threads without an extra barrier.
     const int t = tid();
-    const int lane = t % SMRT_LANES;
+    const int lane = t & (SMRT_LANES - 1);
     const int nv = (v != nullptr) ? 1 : 0;
     for (int k = 0; k < N; ++k) {
-        if (t < SMRT_LANES) {  // wavefront 0 finds the pivot row
-            double best = -1.0;
-            int bi = k;
-            for (int r = k + lane; r < N; r += SMRT_LANES) {
-                const double x = fabs(at<TR>(A, r, k, LD));
-                if (x > best) { best = x; bi = r; }
-            }
-            for (int m = SMRT_LANES / 2; m >= 1; m >>= 1) {
-                const double ob = shfl_xor(best, m);
-                const int oi = shfl_xor(bi, m);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { piv[0] = bi; piv[1] = (best > 0.0 && best < 1e300) ? 0 : 1; }
+        // pivot row: every wavefront finds it on its own (one LDS load per lane, DPP arg-max on a key made of the
+        // magnitude bits with the row index in the 7 low mantissa bits: exactness of the choice is irrelevant)
+        unsigned long long key = 0ull;
+        for (int r = k + lane; r < N; r += SMRT_LANES) {
+            const double xr = fabs(at<TR>(A, r, k, LD));
+            unsigned long long bits;
+            memcpy(&bits, &xr, 8);
+            bits = (bits & ~0x7Full) | (unsigned long long)(127 - (r - k < 127 ? r - k : 127));
+            if (bits > key) key = bits;
         }
-        block_sync();
-        const int p = piv[0];
-        if (piv[1]) return false;
+        key = wave_max_u64(key);
+        if (key < 128ull) return false;  // zero (or NaN-free denormal) column: singular, uniform exit
+        const int p = k + 127 - (int)(key & 0x7Full);
+        const double pv = at<TR>(A, p, k, LD);
+        const double akk = at<TR>(A, k, k, LD);
+        if (!(fabs(pv) > 0.0 && fabs(pv) < 1e300)) return false;  // uniform
         if (p != k) {
-            const int na = N - k;
+            const int na = N - k - 1;
             for (int idx = t; idx < na + N + nv; idx += NT) {
                 if (idx < na) {
-                    const int c = k + idx;
-                    const double x = at<TR>(A, k, c, LD);
+                    const int c = k + 1 + idx;
+                    const double xx = at<TR>(A, k, c, LD);
                     at<TR>(A, k, c, LD) = at<TR>(A, p, c, LD);
-                    at<TR>(A, p, c, LD) = x;
+                    at<TR>(A, p, c, LD) = xx;
                 } else if (idx < na + N) {
                     const int c = idx - na;
-                    const double x = at<TR>(Bm, k, c, LD);
+                    const double xx = at<TR>(Bm, k, c, LD);
                     at<TR>(Bm, k, c, LD) = at<TR>(Bm, p, c, LD);
-                    at<TR>(Bm, p, c, LD) = x;
+                    at<TR>(Bm, p, c, LD) = xx;
                 } else {
-                    const double x = v[k]; v[k] = v[p]; v[p] = x;
+                    const double xx = v[k]; v[k] = v[p]; v[p] = xx;
                 }
             }
             block_sync();
         }
-        const double rp = 1.0 / at<TR>(A, k, k, LD);
+        if (t == 0) udiag[k] = pv;
+        const double rp = fast_rcp(pv);
         const int m = N - k - 1;
         if (m > 0) {
-            const int ncols = m + N + nv;
-            for (int idx = t; idx < m * ncols; idx += NT) {
-                const int r = k + 1 + idx % m, cc = idx / m;
-                const double l = at<TR>(A, r, k, LD) * rp;
+            for_2d<NT>(m, m + N + nv, [&](int ri, int cc) {
+                const int r = k + 1 + ri;
+                const double l = ((r == p) ? akk : at<TR>(A, r, k, LD)) * rp;
                 if (cc < m) {
                     const int c = k + 1 + cc;
                     at<TR>(A, r, c, LD) -= l * at<TR>(A, k, c, LD);
@@ -538,28 +571,25 @@ SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, int N, int LD, int* piv
                 } else {
                     v[r] -= l * v[k];
                 }
-            }
+            });
         }
         block_sync();
     }
     // back substitution
     for (int i = N - 1; i >= 1; --i) {
-        const double rd = 1.0 / at<TR>(A, i, i, LD);
-        const int ncols = N + nv;
-        for (int idx = t; idx < i * ncols; idx += NT) {
-            const int r = idx % i, c = idx / i;
+        const double rd = fast_rcp(udiag[i]);
+        for_2d<NT>(i, N + nv, [&](int r, int c) {
             const double l = at<TR>(A, r, i, LD);
             if (c < N) at<TR>(Bm, r, c, LD) -= l * (at<TR>(Bm, i, c, LD) * rd);
             else v[r] -= l * (v[i] * rd);
-        }
+        });
         block_sync();
     }
-    for (int idx = t; idx < N * (N + nv); idx += NT) {
-        const int i = idx % N, c = idx / N;
-        const double rd = 1.0 / at<TR>(A, i, i, LD);
+    for_2d<NT>(N, N + nv, [&](int i, int c) {
+        const double rd = fast_rcp(udiag[i]);
         if (c < N) at<TR>(Bm, i, c, LD) *= rd;
         else v[i] *= rd;
-    }
+    });
     block_sync();
     return true;
 }
@@ -595,7 +625,8 @@ constexpr int RB = 2;
 template <int NT, int CH>
 SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base) {
     constexpr int P = 2;
-    constexpr int GS = (NT / 32 >= 1) ? ((NT / 32 > 64) ? 64 : NT / 32) : 1;
+    constexpr int GS = (NT / 32 >= 1) ? ((NT / 32 > 64) ? 64 : NT / 32) : 1;  // lanes per Jacobi column pair
+    constexpr int RPL = (64 * CH + GS - 1) / GS;                              // rows per lane (N <= 64 CH)
     const int t = tid();
     const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
@@ -694,6 +725,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     }
 
     double n3 = 0.0;
+    int n_sweeps = 0;
     // ---- bottom-up over the layers -------------------------------------------------------------------------
     for (int l = L - 1; l >= 0; --l) {
         const int n = (int)s.nl[l];
@@ -711,7 +743,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (l > 0)
             for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
         if (l == L - 1) {  // nothing below the last layer (rtsolver_utils.py:548-551,601-603)
-            for (int idx = t; idx < N * N; idx += NT) s.M3[(idx / N) * LD + idx % N] = 0.0;
+            for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
             for (int r = t; r < N; r += NT) s.svec[r] = 0.0;
         }
         block_sync();
@@ -809,35 +841,33 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         block_sync();
         if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
         // -- X+- = M^-1/2 T (ke I - c N S+- W) T^-1 M^-1/2, symmetric positive definite (lower triangles)
-        for (int idx = t; idx < N * N; idx += NT) {
-            const int r = idx % N, c = idx / N;
+        for_2d<NT>(N, N, [&](int r, int c) {
             if (r >= c) {
                 const double uu = 0.5 * s.u[r] * s.u[c];
                 const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
                 s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
                 s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
             }
-        }
+        });
         block_sync();
         SMRT_STAGE(SG_CHOL);
         if (!chol2<NT>(s.M0, s.M1, N, LD)) { fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return; }
         SMRT_STAGE(SG_BTL);
         lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);                       // B = L+^T L-
         SMRT_STAGE(SG_JACOBI);
-        if (!jacobi_onesided<NT, GS>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1])) {
+        if (!jacobi_onesided<NT, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps)) {
             fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
         }
         SMRT_STAGE(SG_TRI);
         l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);                        // Em' = L+ B'
         lt_solve<NT>(s.M0, s.M2, N, LD);                               // Ep' = L+^-T B'
         // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
-        for (int idx = t; idx < N * N; idx += NT) {
-            const int i = idx % N, c = idx / N;
+        for_2d<NT>(N, N, [&](int i, int c) {
             const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];
             const double hd = 0.5 * s.d[i];
             s.M2[c * LD + i] = hd * (ep + em);
             s.M1[c * LD + i] = hd * (ep - em);
-        }
+        });
         for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
         block_sync();
         double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
@@ -881,14 +911,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
-        if (!lu_solve<NT, false>(Wk, Rt, s.cvec, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = Rt;
         SMRT_DUMP("Q", Q, N);
-        for (int idx = t; idx < N * N; idx += NT) {
-            const int r = idx % N, c = idx / N;
-            Q[c * LD + r] *= s.t[r] * s.t[c];
-        }
+        for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
         for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
         block_sync();
         // -- R4/R5: Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (row-wise in place)
@@ -932,7 +959,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
-        if (!lu_solve<NT, true>(F, Wk, nullptr, N, LD, &s.ints[2])) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);
@@ -946,12 +973,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (l > 0) {
             // reflection matrix and source seen from the bottom of layer l-1 (streams paired by index)
             const int nc = (N < Nu) ? N : Nu;
-            for (int idx = t; idx < Nu * Nu; idx += NT) {
-                const int i = idx % Nu, j = idx / Nu;
+            for_2d<NT>(Nu, Nu, [&](int i, int j) {
                 double v = (i == j) ? s.Rbu[i] : 0.0;
                 if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
                 s.M3[j * LD + i] = v;
-            }
+            });
             for (int i = t; i < Nu; i += NT) s.svec[i] = (i < nc) ? s.Ttop[i] * s.up[i] : 0.0;
             block_sync();
         }
@@ -983,7 +1009,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
 #ifdef SMRT_STAGE_TIMING
     SMRT_STAGE(SG_OUT);
-    if (t == 0 && b.stage_out) for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+    if (t == 0 && b.stage_out) {
+        for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+        b.stage_out[p * 16 + 12] = (double)n_sweeps;
+    }
 #endif
 }
 

@@ -41,7 +41,7 @@ struct smrt_dort_ctx {
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
-    int nt = 256;
+    int nt = 512;
     size_t lds_bytes = 0;
     float last_ms = 0.f;
     double total_ms = 0.0;
@@ -122,7 +122,7 @@ const char* smrt_dort_last_error(const smrt_dort_ctx* ctx) { return ctx ? ctx->e
 
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
     if (!ctx) return -1;
-    if (threads == 0) threads = 256;
+    if (threads == 0) threads = 512;
     if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) {
         ctx->err = "block threads must be 64, 128, 256, 512 or 1024";
         return -1;
@@ -205,9 +205,9 @@ int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     switch (ctx->nt) {
         case 64: e = launch_nt<64>(ctx, d); break;
         case 128: e = launch_nt<128>(ctx, d); break;
-        case 512: e = launch_nt<512>(ctx, d); break;
+        case 256: e = launch_nt<256>(ctx, d); break;
         case 1024: e = launch_nt<1024>(ctx, d); break;
-        default: e = launch_nt<256>(ctx, d); break;
+        default: e = launch_nt<512>(ctx, d); break;
     }
     HIPCHK(e);
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

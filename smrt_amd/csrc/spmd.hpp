@@ -13,6 +13,7 @@
 #if defined(SMRT_HOST_EMU)
 
 #include <cmath>
+#include <cstring>
 #include "emu_runtime.hpp"
 #define SMRT_DEV inline
 #define SMRT_LANES 64
@@ -23,6 +24,24 @@ SMRT_DEV void wave_sync() { emu::wave_barrier(); }
 SMRT_DEV double shfl_xor(double v, int mask) { return emu::shfl_xor(v, mask); }
 SMRT_DEV int shfl_xor(int v, int mask) { return (int)emu::shfl_xor((double)v, mask); }
 SMRT_DEV long long cycle_counter() { return 0; }
+// max of a 64-bit key over the 64 lanes of the wavefront, result in every lane
+SMRT_DEV unsigned long long wave_max_u64(unsigned long long k) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        double d; std::memcpy(&d, &k, 8);
+        d = emu::shfl_xor(d, m);
+        unsigned long long o; std::memcpy(&o, &d, 8);
+        if (o > k) k = o;
+    }
+    return k;
+}
+SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
+SMRT_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+// sum over aligned groups of GS consecutive lanes (GS power of two <= 64); every lane gets the group total
+template <int GS>
+SMRT_DEV double group_sum(double v) {
+    for (int m = GS / 2; m >= 1; m >>= 1) v += emu::shfl_xor(v, m);
+    return v;
+}
 SMRT_DEV void lds_or(int* p, int v) { *p |= v; }
 SMRT_DEV void lds_max(int* p, int v) { if (v > *p) *p = v; }
 }  // namespace smrt
@@ -41,6 +60,74 @@ SMRT_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"
 SMRT_DEV double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 SMRT_DEV int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 SMRT_DEV long long cycle_counter() { return (long long)clock64(); }
+// v_rcp_f64 / v_rsq_f64 seeds refined by two Newton steps (full double accuracy for normal operands; no
+// denormal / inf fix-up, which the callers do not need).  Replaces the ~30-instruction IEEE division sequences
+// that sat on the critical path of every factorisation step.
+SMRT_DEV double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+SMRT_DEV double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-h * y, y, 0.5);
+    return __builtin_fma(y, e, y);
+}
+// DPP cross-lane move of a double (two 32-bit DPP movs); CTRL is a DPP control word
+template <int CTRL>
+SMRT_DEV double dpp_move(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, false);
+    return r.d;
+}
+template <int CTRL>
+SMRT_DEV unsigned long long dpp_move_u64(unsigned long long v) {
+    union { unsigned long long u; int i[2]; } a, r;
+    a.u = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, false);
+    return r.u;
+}
+SMRT_DEV unsigned long long readlane_u64(unsigned long long v, int lane) {
+    union { unsigned long long u; int i[2]; } a, r;
+    a.u = v;
+    r.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return r.u;
+}
+// max of a 64-bit key over the 64 lanes of the wavefront, result in every lane: four DPP steps give every
+// 16-lane row its maximum, four readlanes combine the rows.
+SMRT_DEV unsigned long long wave_max_u64(unsigned long long k) {
+    unsigned long long o;
+    o = dpp_move_u64<0xB1>(k); k = o > k ? o : k;
+    o = dpp_move_u64<0x4E>(k); k = o > k ? o : k;
+    o = dpp_move_u64<0x141>(k); k = o > k ? o : k;
+    o = dpp_move_u64<0x140>(k); k = o > k ? o : k;
+    const unsigned long long r0 = readlane_u64(k, 0), r1 = readlane_u64(k, 16), r2 = readlane_u64(k, 32),
+                             r3 = readlane_u64(k, 48);
+    const unsigned long long a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+}
+// Sum over aligned groups of GS consecutive lanes; every lane gets the group total.  quad_perm swaps inside a
+// quad, row_half_mirror / row_mirror reach the other quad / the other half of a 16-lane row (the source lane
+// already holds its own partial total, so a mirror works as well as a butterfly); 32 and 64 fall back to bpermute.
+template <int GS>
+SMRT_DEV double group_sum(double v) {
+    if (GS >= 2) v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (GS >= 4) v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (GS >= 8) v += dpp_move<0x141>(v);  // row_half_mirror
+    if (GS >= 16) v += dpp_move<0x140>(v); // row_mirror
+    if (GS >= 32) v += __shfl_xor(v, 16, 64);
+    if (GS >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
 SMRT_DEV void lds_or(int* p, int v) { atomicOr(p, v); }
 SMRT_DEV void lds_max(int* p, int v) { atomicMax(p, v); }
 }  // namespace smrt

@@ -1,0 +1,52 @@
+"""make_snowpack / make_snow_layer with the reference's signature (smrt/inputs/make_medium.py:158-314) for dry snow,
+Flat interfaces, no substrate."""
+import collections.abc
+
+import numpy as np
+
+from ..core.error import SMRTError
+from ..core.globalconstants import FREEZING_POINT
+from ..core.layer import Layer
+from ..core.snowpack import Snowpack
+from ..interface.flat import Flat
+
+
+def _get(x, i):
+    if isinstance(x, str) or x is None or not isinstance(x, (collections.abc.Sequence, np.ndarray)):
+        return x
+    return x[i]
+
+
+def _check_size(x, n, name):
+    if isinstance(x, (collections.abc.Sequence, np.ndarray)) and not isinstance(x, str) and len(x) != n:
+        raise SMRTError(f"The length of '{name}' must be the same as the number of layers ({n}).")
+
+
+def make_snow_layer(layer_thickness, microstructure_model, density, temperature=FREEZING_POINT, **kwargs):
+    return Layer(layer_thickness, microstructure_model, density, temperature=temperature, **kwargs)
+
+
+def make_snowpack(thickness, microstructure_model, density, interface=None, surface=None, substrate=None,
+                  atmosphere=None, **kwargs):
+    """Build a multi-layered snowpack; every parameter can be an array, a list or a constant."""
+    if not isinstance(thickness, collections.abc.Iterable):
+        raise SMRTError("The thickness argument must be iterable, that is, a list of numbers, numpy array or pandas "
+                        "Series or DataFrame.")
+    thickness = list(thickness)
+    n = len(thickness)
+    _check_size(density, n, "density")
+    for k, v in kwargs.items():
+        _check_size(v, n, k)
+    for itf in (interface, surface):
+        if itf is not None and not (isinstance(itf, Flat) or itf in ("flat", Flat)):
+            raise SMRTError("only Flat interfaces are in the scope of smrt_amd")
+    sp = Snowpack(substrate=substrate, atmosphere=atmosphere)
+    for i, dz in enumerate(thickness):
+        if dz <= 0:
+            continue
+        layer = make_snow_layer(dz, _get(microstructure_model, i), density=_get(density, i),
+                                **{k: _get(v, i) for k, v in kwargs.items()})
+        sp.append(layer, interface=Flat())
+    if sp.nlayer == 0:
+        raise SMRTError("a snowpack needs at least one layer with a positive thickness")
+    return sp

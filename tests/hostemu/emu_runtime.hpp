@@ -6,6 +6,7 @@
 #pragma once
 #include <ucontext.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -30,6 +31,7 @@ struct Runtime {
     std::vector<double> exch;
     std::function<void()> body;
     long n_barriers = 0;
+    long progress = 0;  // bumped whenever a barrier releases or a fiber finishes
 };
 
 inline Runtime*& rt() {
@@ -51,6 +53,7 @@ inline void block_barrier() {
         r->bar_count = 0;
         r->bar_gen++;
         r->n_barriers++;
+        r->progress++;
     } else {
         while (r->bar_gen == g) yield();
     }
@@ -64,6 +67,7 @@ inline void wave_barrier() {
     if (++r->wave_count[w] == lanes) {
         r->wave_count[w] = 0;
         r->wave_gen[w]++;
+        r->progress++;
     } else {
         while (r->wave_gen[w] == g) yield();
     }
@@ -113,6 +117,7 @@ inline long run_block(int nt, int order, std::function<void()> body) {
     int ndone = 0;
     while (ndone < nt) {
         ndone = 0;
+        const long progress_before = R.progress;
         for (int k = 0; k < nt; ++k) {
             int i = k;
             if (order == 1) i = nt - 1 - k;
@@ -120,7 +125,11 @@ inline long run_block(int nt, int order, std::function<void()> body) {
             if (R.done[i]) { ndone++; continue; }
             R.cur = i;
             swapcontext(&R.main_ctx, &R.ctx[i]);
-            if (R.done[i]) ndone++;
+            if (R.done[i]) { ndone++; R.progress++; }
+        }
+        if (ndone < nt && R.progress == progress_before) {
+            fprintf(stderr, "emu: DEADLOCK -- a full scheduler pass made no progress (non-uniform barrier?)\n");
+            abort();
         }
     }
     for (int i = 0; i < nt; ++i) free(R.stacks[i]);

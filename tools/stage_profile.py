@@ -25,6 +25,8 @@ ctx.launch(); ctx.sync()
 ctx.launch(); ctx.sync()
 ms = ctx.last_kernel_ms()
 st = ctx.stage_cycles()
+sweeps = st.pop("_jacobi_sweeps")
+print("jacobi sweeps per layer-problem: %.2f" % (sweeps / batch.n_pairs / bench.N_LAYERS))
 tot = sum(st.values())
 print("threads=%d pairs=%d kernel_ms=%.2f  solves/s=%.0f" % (threads, batch.n_pairs, ms, batch.n_pairs / ms * 1e3))
 for k, v in st.items():
