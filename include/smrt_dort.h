@@ -83,6 +83,9 @@ typedef struct smrt_batch {
  * with 3 x 3 polarisations V,H,U (layout of Result.data in the reference, rtsolver_utils.py:327-332). */
 int32_t smrt_dort_out_stride(const smrt_batch* b);
 
+/* Number of visible HIP devices (0 if none). */
+int32_t smrt_dort_device_count(void);
+
 /* Create / destroy a context bound to HIP device `device`.  Returns 0 on success. */
 int32_t smrt_dort_create(smrt_dort_ctx** ctx, int32_t device);
 void smrt_dort_destroy(smrt_dort_ctx* ctx);

@@ -157,6 +157,8 @@ def load_library():
     lib.smrt_dort_sum_n3.restype = C.c_double
     lib.smrt_dort_stage_cycles.argtypes = [C.c_void_p, P(C.c_double)]
     lib.smrt_dort_stage_cycles.restype = C.c_int32
+    lib.smrt_dort_device_count.argtypes = []
+    lib.smrt_dort_device_count.restype = C.c_int32
     lib.smrt_gauss_legendre_positive.argtypes = [C.c_int32, P(C.c_double), P(C.c_double)]
     lib.smrt_gauss_legendre_positive.restype = C.c_int32
     _lib = lib
@@ -166,7 +168,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
     "smrt_dort_upload", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
-    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_gauss_legendre_positive",
+    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version",
 ]
 
@@ -260,6 +262,11 @@ class DortContext:
 
     def sum_n3(self):
         return float(self._lib.smrt_dort_sum_n3(self._h))
+
+
+def device_count():
+    """Number of visible GPUs (smrt_dort_device_count); 0 when there is none."""
+    return int(load_library().smrt_dort_device_count())
 
 
 def gauss_legendre_positive(n):

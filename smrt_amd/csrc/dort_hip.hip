@@ -86,6 +86,12 @@ int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight) {
     return 0;
 }
 
+int32_t smrt_dort_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
+}
+
 int32_t smrt_dort_create(smrt_dort_ctx** out, int32_t device) {
     if (!out) return -1;
     *out = nullptr;

@@ -33,9 +33,9 @@ inline void gauss_legendre_positive(int n, double* mu, double* weight) {
             p0 = p1;
             p1 = pk;
         }
-        dp = m * (x * p1 - p0) / (x * x - 1.0);
+        (void)dp;
         mu[i] = x;
-        if (weight) weight[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+        if (weight) weight[i] = 2.0 * (1.0 - x * x) / ((double)m * (double)m * p0 * p0);  // 2(1-x^2)/(m P_{m-1}(x))^2
     }
 }
 

@@ -1,0 +1,67 @@
+"""IBA electromagnetic model (smrt/emmodel/iba.py:53-265) as a host-side descriptor: the per-layer quantities
+(effective permittivity, ks, ka) and the phase-matrix assembly are evaluated inside the HIP kernel; this class records
+what the kernel needs and exposes the scalar accessors of the emmodel protocol (iba.py:36-40) by asking the device."""
+import numpy as np
+
+from ..core.error import SMRTError
+
+
+class _DeviceEMModel:
+    device_name = None
+
+    def __init__(self, sensor, layer, **options):
+        if np.ndim(sensor.frequency) != 0:
+            raise SMRTError("an emmodel instance needs a single-frequency sensor")
+        self.sensor = sensor
+        self.layer = layer
+        self.frequency = float(sensor.frequency)
+        self.npol = 2 if sensor.mode == "P" else 3
+        self.options = options
+        self._props = None
+
+    def _device_properties(self):
+        if self._props is None:
+            from .._native import DortContext, PackedBatch
+
+            p1, p2 = self.layer.microstructure.device_params
+            batch = PackedBatch([1], [100.0], [self.layer.frac_volume], [self.layer.temperature], [p1], [p2],
+                                [self.frequency], [0.0], emmodel=self.device_name,
+                                microstructure=self.layer.microstructure_model, n_max_stream=4,
+                                phase_normalization="forced")
+            ctx = DortContext(0)
+            out = ctx.run(batch)
+            ctx.close()
+            lay = out.layers[0, 0]
+            self._props = dict(eps=complex(lay[0], lay[1]), ks=float(lay[2]), ka=float(lay[3]))
+        return self._props
+
+    def effective_permittivity(self):
+        return self._device_properties()["eps"]
+
+    @property
+    def ka(self):
+        return self._device_properties()["ka"]
+
+    @property
+    def _ks(self):
+        return self._device_properties()["ks"]
+
+    def ks(self, mu, npol=2):
+        """(npol, len(mu)) isotropic scattering coefficient (emmodel/common.py:309-324,134-152)."""
+        return np.full((npol, np.size(mu)), self._ks)
+
+    def ke(self, mu, npol=2):
+        return np.full((npol, np.size(mu)), self._ks + self.ka)
+
+    def ft_even_phase(self, *args, **kwargs):
+        raise NotImplementedError("the azimuthal modes of the phase matrix are assembled inside the HIP kernel "
+                                  "(smrt_amd/csrc/dort_device.hpp) and are not materialised on the host")
+
+
+class IBA(_DeviceEMModel):
+    device_name = "iba"
+
+    def __init__(self, sensor, layer, dense_snow_correction=None):
+        if dense_snow_correction not in (None, False):
+            raise SMRTError("dense_snow_correction is outside the scope of smrt_amd's IBA")
+        super().__init__(sensor, layer)

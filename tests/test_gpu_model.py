@@ -1,0 +1,121 @@
+"""The plugin surface on the GPU: make_model()/Model.run()/Result against the reference's known answers."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def two_layer():
+    from smrt_amd import make_snowpack
+
+    return make_snowpack([0.1, 100], "exponential", density=[200, 400], temperature=[250.0, 250.0],
+                         corr_length=[5e-5, 5e-5])
+
+
+def test_iba_dort_oneconfig_passive():
+    """smrt/test/test_integration_iba.py:33-49, every diagonalization_method name of the reference."""
+    from smrt_amd import make_model, sensor_list
+
+    for method in ("eig", "schur", "half_rank_eig", "schur_forcedtriu"):
+        m = make_model("iba", "dort", rtsolver_options=dict(diagonalization_method=method))
+        res = m.run(sensor_list.amsre("37V"), two_layer())
+        np.testing.assert_allclose(res.TbV(), 248.09044325849692, atol=1e-4)
+        np.testing.assert_allclose(res.TbH(), 237.3487270223389, atol=1e-4)
+
+
+def test_onelayer_example():
+    """examples/iba_onelayer_example.py."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    sp = make_snowpack(thickness=[100], microstructure_model="exponential", density=[320], temperature=[270],
+                       corr_length=[5e-5])
+    res = make_model("iba", "dort").run(sensor_list.amsre("37V"), sp)
+    assert abs(res.TbV() - 268.22172695) < 1e-6 and abs(res.TbH() - 251.75293753) < 1e-6
+    d = load_golden("cfg1_iba_onelayer")
+    np.testing.assert_allclose(res.other_data["ks"].values, d["f0_ks"], rtol=1e-11)
+    np.testing.assert_allclose(res.other_data["ka"].values, d["f0_ka"], rtol=1e-10)
+    np.testing.assert_allclose(res.other_data["stream_angles"].values, d["f0_stream_angles"], rtol=1e-11)
+    assert res.optical_depth().values[0] > 5
+
+
+def test_model_run_many_snowpacks_and_channels():
+    """Model.run over snowpacks x AMSR-E frequencies: dims, labels, channel selection, batch == sequential."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.runner.sequential_runner import SequentialRunner
+
+    rng = np.random.default_rng(5)
+    sps = [make_snowpack(np.append(rng.uniform(0.05, 0.3, 4), 100.0), "exponential", density=rng.uniform(150, 450, 5),
+                         temperature=rng.uniform(230, 270, 5), corr_length=rng.uniform(5e-5, 3e-4, 5))
+           for _ in range(4)]
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16))
+    res = m.run(sensor_list.amsre(), sps)
+    assert res.data.dims == ("frequency", "snowpack", "polarization", "theta")
+    assert res.data.shape == (6, 4, 2, 1)
+    assert res.Tb(channel="37V").shape == (4,)
+    seq = m.run(sensor_list.amsre(), sps, runner=SequentialRunner())
+    assert np.array_equal(seq.data.values, res.data.values)
+    df = res.to_dataframe()
+    assert df.shape == (4, 12) and "89H" in df.columns
+    one = m.run(sensor_list.amsre("19"), sps[2])
+    assert abs(one.TbV() - res.Tb(channel="19V")[2]) == 0.0
+
+
+def test_dmrt_model_run():
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    d = load_golden("dmrt_L8_n16")
+    sp = make_snowpack(d["thickness"], "sticky_hard_spheres", density=d["density"], temperature=d["temperature"],
+                       radius=d["radius"], stickiness=d["stickiness"])
+    m = make_model("dmrt_qca_shortrange", "dort", rtsolver_options=dict(n_max_stream=16))
+    res = m.run(sensor_list.passive(list(d["frequency"]), list(d["theta_deg"])), sp)
+    assert res.data.dims == ("frequency", "polarization", "theta")
+    assert np.abs(res.data.values - d["result"]).max() < 1e-6
+
+
+def test_error_handling_exception_and_nan():
+    """Albedo >= 1 layer (smrt/test/test_dmrtdort.py:20-37 snowpack with dmrt_qca_shortrange): SMRTError by default,
+    NaN result with error_handling='nan' (dort.py:327-334)."""
+    from smrt_amd import SMRTError, make_model, make_snowpack, sensor_list
+
+    sp = make_snowpack([0.1, 1000], "sticky_hard_spheres", density=[200, 400], temperature=[250.0, 250.0],
+                       radius=[2e-4, 2e-4], stickiness=[0.1, 0.1])
+    with pytest.raises(SMRTError, match="albedo"):
+        make_model("dmrt_qca_shortrange", "dort").run(sensor_list.amsre("37V"), sp)
+    res = make_model("dmrt_qca_shortrange", "dort", rtsolver_options=dict(error_handling="nan")).run(
+        sensor_list.amsre("37V"), sp)
+    assert np.isnan(res.TbV())
+
+
+def test_emmodel_scalar_accessors():
+    """IBA ks against the reference values and the MEMLS table (smrt/emmodel/test_iba.py:111-127)."""
+    from smrt_amd import make_snowpack, sensor_list
+    from smrt_amd.emmodel.iba import IBA
+
+    d = load_golden("iba_ks_table")
+    for row, memls in zip(d["table"], d["memls_reference"]):
+        pc, ks, ka, er, ei, _ = row
+        lay = make_snowpack([0.1], "exponential", density=300, temperature=265, corr_length=pc).layers[0]
+        em = IBA(next(sensor_list.amsre("37V").iterate("frequency")) if False else sensor_list.passive(36.5e9, 55), lay)
+        assert abs(em.ks(0).mean() - ks) < 1e-11 * ks and abs(em.ka - ka) < 1e-10 * ka
+        assert abs(em.effective_permittivity() - (er + 1j * ei)) < 1e-13
+        assert abs(em.ks(0).mean() - memls) < 0.01 * memls
+
+
+def test_physics_nonscattering_limit_and_kirchhoff():
+    """Physics invariants (smrt/test/test_physics_law.py, rtsolver/test_rtsolver.py:37-45 in spirit): an isothermal
+    snowpack with vanishing scattering emits Tb = (1 - R_surface) T, so e_V >= e_H and Tb <= T; and Tb scales with
+    T under the Rayleigh-Jeans option."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    T = 260.0
+    sp = make_snowpack([1, 100], "exponential", density=[300, 300], temperature=T, corr_length=1e-7)
+    m = make_model("iba", "dort", rtsolver_options=dict(rayleigh_jeans_approximation=True))
+    res = m.run(sensor_list.passive(10e9, [20, 40, 55]), sp)
+    tbv, tbh = res.TbV(), res.TbH()
+    assert (tbv <= T + 1e-9).all() and (tbh <= tbv + 1e-9).all() and (tbv > 0.9 * T).all()
+    sp2 = make_snowpack([1, 100], "exponential", density=[300, 300], temperature=T / 2, corr_length=1e-7)
+    res2 = m.run(sensor_list.passive(10e9, [20, 40, 55]), sp2)
+    # emissivity depends (weakly) on T through the ice permittivity only: compare e = Tb / T
+    assert np.allclose(res2.TbV() / (T / 2), tbv / T, atol=2e-3)

@@ -1,0 +1,76 @@
+"""The DEVICE code (smrt_amd/csrc/dort_device.hpp) executed on the CPU by the fiber emulator (tests/hostemu):
+checks the kernel logic against the reference's golden vectors without a GPU, and that the result does not depend on
+the order in which the emulated threads run between barriers (a missing barrier would)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, fixture_options, load_golden, snowpack_dict
+from smrt_amd._native import PackedBatch, SmrtBatch
+
+EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
+EMU_LIB = os.path.join(EMU_DIR, "libsmrt_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp"),
+            os.path.join(ROOT, "smrt_amd", "csrc", "dort_device.hpp"), os.path.join(ROOT, "smrt_amd", "csrc", "spmd.hpp")]
+    if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR, "-o", EMU_LIB, srcs[0]])
+    lib = C.CDLL(EMU_LIB)
+    P = C.POINTER
+    lib.smrt_emu_run.argtypes = [P(SmrtBatch), C.c_longlong, C.c_longlong, C.c_int, C.c_int, P(C.c_double),
+                                 P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_long)]
+    return lib
+
+
+def run_fixture(lib, name, nt=64, order=0, freqs=None):
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    ms = sp["microstructure"]
+    p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
+    p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
+    fr = d["frequency"] if freqs is None else d["frequency"][freqs]
+    b = PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2, fr,
+                    np.deg2rad(d["theta_deg"]), emmodel=str(d["emmodel"]), microstructure=ms,
+                    n_max_stream=fixture_options(d)["n_max_stream"])
+    n = b.n_pairs
+    out = np.empty((n,) + b.out_shape())
+    st = np.empty(n, np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    nb = C.c_long()
+    rc = lib.smrt_emu_run(C.byref(b.struct), 0, n, nt, order, dp(out), st.ctypes.data_as(C.POINTER(C.c_int32)), None,
+                          None, None, C.byref(nb))
+    assert rc == 0
+    ref = d["result"] if freqs is None else d["result"][freqs]
+    return out, st, ref
+
+
+@pytest.mark.parametrize("name", ["cfg1_iba_onelayer", "iba_2layer_passive37", "iba_L6_n8_angles",
+                                  "iba_L3_n16_shallow", "dmrt_L8_n16"])
+def test_emulated_kernel_matches_reference(emu, name):
+    out, st, ref = run_fixture(emu, name)
+    assert (st == 0).all()
+    assert np.abs(out - ref).max() < 1e-6
+
+
+def test_emulated_kernel_is_schedule_independent(emu):
+    base, _, _ = run_fixture(emu, "iba_L6_n8_angles", nt=128, order=0)
+    for order in (1, 2):
+        other, _, _ = run_fixture(emu, "iba_L6_n8_angles", nt=128, order=order)
+        assert np.array_equal(base, other)
+
+
+def test_emulated_kernel_full_size_pair(emu):
+    """One 20-layer, 32-stream pair of the headline configuration at 89 GHz (strongest scattering)."""
+    out, st, ref = run_fixture(emu, "cfg2_iba_L20_n32_sp1", nt=64, order=1, freqs=[5])
+    assert (st == 0).all() and np.abs(out - ref).max() < 1e-6
+
+
+def test_emulated_kernel_flags_albedo_above_one(emu):
+    out, st, _ = run_fixture(emu, "dmrt_2layer_passive37")
+    assert st[0] == 3 and np.isnan(out).all()
