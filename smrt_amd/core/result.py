@@ -87,6 +87,36 @@ class LabeledArray:
         o = other.values if isinstance(other, LabeledArray) else other
         return LabeledArray(op(self.values, o), list(self.coords.items()), name=self.name, attrs=self.attrs)
 
+    def __getitem__(self, key):
+        return self.values[key]
+
+    def __len__(self):
+        return len(self.values)
+
+    def __iter__(self):
+        return iter(self.values)
+
+    def __sub__(self, o):
+        return self._binary(o, np.subtract)
+
+    def __rsub__(self, o):
+        return self._binary(o, lambda a, b: np.subtract(b, a))
+
+    def __neg__(self):
+        return LabeledArray(-self.values, list(self.coords.items()), name=self.name, attrs=self.attrs)
+
+    def __lt__(self, o):
+        return self.values < (o.values if isinstance(o, LabeledArray) else o)
+
+    def __le__(self, o):
+        return self.values <= (o.values if isinstance(o, LabeledArray) else o)
+
+    def __gt__(self, o):
+        return self.values > (o.values if isinstance(o, LabeledArray) else o)
+
+    def __ge__(self, o):
+        return self.values >= (o.values if isinstance(o, LabeledArray) else o)
+
     def __mul__(self, o):
         return self._binary(o, np.multiply)
 
@@ -94,6 +124,8 @@ class LabeledArray:
 
     def __add__(self, o):
         return self._binary(o, np.add)
+
+    __radd__ = __add__
 
     def __truediv__(self, o):
         return self._binary(o, np.divide)
