@@ -359,31 +359,39 @@ SMRT_DEV void for_2d(int R, int C, Body body) {
 
 template <int NT>
 SMRT_DEV bool chol2(double* A, double* Bm, int N, int LD) {
-    // Two right-looking Cholesky factorisations side by side (lower triangles, in place).
+    // Two right-looking Cholesky factorisations side by side (lower triangles, in place), ONE barrier per column:
+    // during step k column k stays unscaled (read-only) and the trailing update carries the 1/pivot factor; the
+    // columns are scaled by 1/sqrt(pivot) in a final pass.
     const int t = tid();
     for (int k = 0; k < N; ++k) {
         const double akk = A[k * LD + k], bkk = Bm[k * LD + k];
         if (!(akk > 0.0) || !(bkk > 0.0)) return false;  // uniform: every thread reads the same words
-        const double ra = fast_rsqrt(akk), rb = fast_rsqrt(bkk);
-        for (int i = k + 1 + t; i < N; i += NT) {
-            A[k * LD + i] *= ra;
-            Bm[k * LD + i] *= rb;
-        }
-        block_sync();
-        if (t == 0) {
-            A[k * LD + k] = akk * ra;
-            Bm[k * LD + k] = bkk * rb;
-        }
         const int m = N - k - 1;
-        for_2d<NT>(m, m, [&](int ri, int ci) {
-            const int i = k + 1 + ri, j = k + 1 + ci;
-            if (i >= j) {
-                A[j * LD + i] -= A[k * LD + i] * A[k * LD + j];
-                Bm[j * LD + i] -= Bm[k * LD + i] * Bm[k * LD + j];
-            }
-        });
-        block_sync();
+        if (m > 0) {
+            const double ra = fast_rcp(akk), rb = fast_rcp(bkk);
+            for_2d<NT>(m, m, [&](int ri, int ci) {
+                const int i = k + 1 + ri, j = k + 1 + ci;
+                if (i >= j) {
+                    A[j * LD + i] -= A[k * LD + i] * (A[k * LD + j] * ra);
+                    Bm[j * LD + i] -= Bm[k * LD + i] * (Bm[k * LD + j] * rb);
+                }
+            });
+            block_sync();
+        }
     }
+    for_2d<NT>(N, N, [&](int i, int k) {
+        if (i > k) {
+            A[k * LD + i] *= fast_rsqrt(A[k * LD + k]);
+            Bm[k * LD + i] *= fast_rsqrt(Bm[k * LD + k]);
+        }
+    });
+    block_sync();
+    for (int k = t; k < N; k += NT) {
+        const double akk = A[k * LD + k], bkk = Bm[k * LD + k];
+        A[k * LD + k] = akk * fast_rsqrt(akk);
+        Bm[k * LD + k] = bkk * fast_rsqrt(bkk);
+    }
+    block_sync();
     return true;
 }
 
@@ -398,74 +406,139 @@ SMRT_DEV void lt_times_l(const double* Lp, const double* Lm, double* C, int N, i
     block_sync();
 }
 
-// One-sided (Hestenes) Jacobi: rotate column pairs of Bm until all columns are mutually orthogonal.
-// GS consecutive lanes own one pair and keep their RPL rows of both columns in registers between the three dot
-// products and the rotation; the round-robin schedule gives N/2 disjoint pairs per step.
-// A sweep in which no pair had cos^2 > 1e-15 before its rotation is the last one (the residual non-orthogonality
-// is second order).  On exit sigma[c] = |column c| and rsig[c] = 1 / sigma[c].  Returns false if not converged.
+// One-sided (Hestenes) Jacobi, two-level ordering.
+//
+// The columns are cut into NB = 2 * (number of wavefronts) blocks of m columns.  An outer round-robin over the
+// blocks gives every wavefront one pair of blocks (I, J) per outer step; inside the step the wavefront rotates all
+// m*m cross pairs (m inner steps of m disjoint pairs) -- and, at the first outer step of a sweep, the pairs inside
+// its two blocks -- touching only its own 2m columns, so the inner steps need a wavefront-level sync only.  One
+// workgroup barrier per OUTER step (NB-1 per sweep instead of N-1).
+// GS lanes own one column pair and keep their RPL rows of both columns in registers between the three dot products
+// and the rotation.  A sweep in which no pair had cos^2 > 1e-15 before its rotation is the last one (the residual
+// non-orthogonality is second order).  On exit sigma[c] = |column c|, rsig[c] = 1/sigma[c].
+#ifndef SMRT_JACOBI_EXIT_COS2
+#define SMRT_JACOBI_EXIT_COS2 1e-15
+#endif
+template <int GS, int RPL>
+SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, int sub, int* flag) {
+    double x[RPL], y[RPL];
+    double a = 0.0, bb = 0.0, gg = 0.0;
+    double* cp = Bm + p * LD;
+    double* cq = Bm + q * LD;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int r = sub + i * GS;
+        const bool in = valid && (r < N);
+        x[i] = in ? cp[r] : 0.0;
+        y[i] = in ? cq[r] : 0.0;
+        a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i];
+    }
+#if !defined(SMRT_ABLATE) || SMRT_ABLATE < 2
+    a = group_sum<GS>(a); bb = group_sum<GS>(bb); gg = group_sum<GS>(gg);
+#endif
+    const double g2 = gg * gg, ab = a * bb;
+#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 4
+    if (g2 == 12345.678) lds_or(flag, 1);  // keep the dot products alive
+    return;
+#endif
+    if (valid && g2 > 1e-30 * ab) {
+        // tan of the rotation angle: t = 2 g sign(d) / (|d| + sqrt(d^2 + 4 g^2)), d = b - a
+        const double dd = bb - a;
+#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 1
+        const double tt = dd * 1e-300;
+#else
+        const double hh = dd * dd + 4.0 * g2;
+        const double h = hh * fast_rsqrt(hh);
+        const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp(fabs(dd) + h);
+#endif
+#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 1
+        const double c = 0.8 + 1e-300 * tt * 0.0, sn = 0.6 + gg * 1e-300;
+#else
+        const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
+#endif
+#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 3
+        if (c * x[0] - sn * y[0] + sn * x[RPL - 1] + c * y[RPL - 1] == 12345.678) lds_or(flag, 1);
+#else
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = sub + i * GS;
+            if (r < N) {
+                cp[r] = c * x[i] - sn * y[i];
+                cq[r] = sn * x[i] + c * y[i];
+            }
+        }
+#endif
+        if (sub == 0 && g2 > SMRT_JACOBI_EXIT_COS2 * ab) lds_or(flag, 1);
+    }
+}
+
 template <int NT, int GS, int RPL>
 SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag, int* n_sweeps) {
     const int t = tid();
-    const int grp = t / GS, sub = t % GS;
-    constexpr int NG = NT / GS;
-    const int Ne = N + (N & 1);
-    const int npairs = Ne / 2;
-    const int rounds = (npairs + NG - 1) / NG;
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    constexpr int NB = 2 * NW;               // column blocks
+    constexpr int SLOTS = SMRT_LANES / GS;   // column pairs a wavefront rotates at once
+    const int slot = lane / GS, sub = lane % GS;
+    const int m = (N + NB - 1) / NB;         // columns per block
+    const int me = m + (m & 1);              // even player count of the in-block tournament
     bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         block_sync();  // everyone has read the previous flag
         if (t == 0) *flag = 0;
         block_sync();
-        for (int s = 0; s < Ne - 1; ++s) {
-            for (int rd = 0; rd < rounds; ++rd) {
-                const int pi = grp + rd * NG;
-                int p, q;
-                if (pi == 0) { p = Ne - 1; q = s; }
-                else {
-                    p = s + pi; if (p >= Ne - 1) p -= Ne - 1;
-                    q = s - pi; if (q < 0) q += Ne - 1;
-                }
-                const bool valid = (pi < npairs) && (p < N) && (q < N);
-                double x[RPL], y[RPL];
-                double a = 0.0, bb = 0.0, gg = 0.0;
-                double* cp = Bm + p * LD;
-                double* cq = Bm + q * LD;
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    const int r = sub + i * GS;
-                    const bool in = valid && (r < N);
-                    x[i] = in ? cp[r] : 0.0;
-                    y[i] = in ? cq[r] : 0.0;
-                    a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i];
-                }
-                a = group_sum<GS>(a); bb = group_sum<GS>(bb); gg = group_sum<GS>(gg);
-                const double g2 = gg * gg, ab = a * bb;
-                if (valid && g2 > 1e-30 * ab) {
-                    // tan of the rotation angle: t = 2 g sign(d) / (|d| + sqrt(d^2 + 4 g^2)), d = b - a
-                    const double dd = bb - a;
-                    const double hh = dd * dd + 4.0 * g2;
-                    const double h = hh * fast_rsqrt(hh);
-                    const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp(fabs(dd) + h);
-                    const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
-#pragma unroll
-                    for (int i = 0; i < RPL; ++i) {
-                        const int r = sub + i * GS;
-                        if (r < N) {
-                            cp[r] = c * x[i] - sn * y[i];
-                            cq[r] = sn * x[i] + c * y[i];
+        for (int s = 0; s < NB - 1; ++s) {
+            int I, J;
+            if (wave == 0) { I = NB - 1; J = s; }
+            else {
+                I = s + wave; if (I >= NB - 1) I -= NB - 1;
+                J = s - wave; if (J < 0) J += NB - 1;
+            }
+            const int i0 = I * m, j0 = J * m;
+            if (s == 0 && m > 1) {
+                // pairs inside block I and inside block J: (me - 1) steps of me/2 pairs per block
+                const int half = me / 2;
+                for (int u = 0; u < me - 1; ++u) {
+                    for (int ps0 = 0; ps0 < 2 * half; ps0 += SLOTS) {  // uniform trip count over the wavefront
+                        const int ps = ps0 + slot;
+                        const int base = (ps < half) ? i0 : j0;
+                        const int k = (ps < half) ? ps : ps - half;
+                        int a, b;
+                        if (k == 0) { a = me - 1; b = u; }
+                        else {
+                            a = u + k; if (a >= me - 1) a -= me - 1;
+                            b = u - k; if (b < 0) b += me - 1;
                         }
+                        const int p = base + a, q = base + b;
+                        const bool valid = (ps < 2 * half) && (a < m) && (b < m) && (p < N) && (q < N);
+                        rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, flag);
                     }
-                    if (sub == 0 && g2 > 1e-15 * ab) lds_or(flag, 1);
+                    wave_sync();
                 }
+            }
+            for (int j = 0; j < m; ++j) {
+                for (int ps0 = 0; ps0 < m; ps0 += SLOTS) {  // uniform trip count over the wavefront
+                    const int ps = ps0 + slot;
+                    int bq = ps + j; if (bq >= m) bq -= m;
+                    const int p = i0 + ps, q = j0 + bq;
+                    const bool valid = (ps < m) && (p < N) && (q < N);
+                    rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, flag);
+                }
+                wave_sync();
             }
             block_sync();
         }
         converged = (*flag == 0);
+#ifdef SMRT_ABLATE
+        converged = (sweep >= 5);  // fixed six sweeps for timing ablations (results are meaningless)
+#endif
         ++*n_sweeps;
     }
     block_sync();
     // column norms
     {
+        constexpr int NG = NT / GS;
+        const int grp = t / GS;
         const int rounds2 = (N + NG - 1) / NG;
         for (int rd = 0; rd < rounds2; ++rd) {
             const int c = grp + rd * NG;
@@ -513,9 +586,11 @@ SMRT_DEV double& at(double* M, int r, int c, int LD) { return TR ? M[r * LD + c]
 
 template <int NT, bool TR>
 SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, int LD) {
-    // Column k is never written once step k starts: the row swap skips it (the multipliers are taken from the
-    // unswapped column) and the pivot U[k][k] goes to udiag[k].  That makes the redundant pivot scan race-free
-    // against the swap of faster threads without an extra barrier.
+    // Gauss-Jordan elimination with partial pivoting: every step eliminates column k from ALL other rows, so there
+    // is no back-substitution phase (one third fewer barriers than LU + back substitution; the path is latency
+    // bound, not flop bound).  Column k is never written once step k starts: the row swap skips it (the multipliers
+    // are taken from the unswapped column) and the pivot goes to udiag[k]; that makes the per-wavefront pivot
+    // search race-free against the swap of faster wavefronts without an extra barrier.
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1);
     const int nv = (v != nullptr) ? 1 : 0;
@@ -531,7 +606,7 @@ SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, i
             if (bits > key) key = bits;
         }
         key = wave_max_u64(key);
-        if (key < 128ull) return false;  // zero (or NaN-free denormal) column: singular, uniform exit
+        if (key < 128ull) return false;  // zero column: singular, uniform exit
         const int p = k + 127 - (int)(key & 0x7Full);
         const double pv = at<TR>(A, p, k, LD);
         const double akk = at<TR>(A, k, k, LD);
@@ -558,30 +633,18 @@ SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, i
         if (t == 0) udiag[k] = pv;
         const double rp = fast_rcp(pv);
         const int m = N - k - 1;
-        if (m > 0) {
-            for_2d<NT>(m, m + N + nv, [&](int ri, int cc) {
-                const int r = k + 1 + ri;
-                const double l = ((r == p) ? akk : at<TR>(A, r, k, LD)) * rp;
-                if (cc < m) {
-                    const int c = k + 1 + cc;
-                    at<TR>(A, r, c, LD) -= l * at<TR>(A, k, c, LD);
-                } else if (cc < m + N) {
-                    const int c = cc - m;
-                    at<TR>(Bm, r, c, LD) -= l * at<TR>(Bm, k, c, LD);
-                } else {
-                    v[r] -= l * v[k];
-                }
-            });
-        }
-        block_sync();
-    }
-    // back substitution
-    for (int i = N - 1; i >= 1; --i) {
-        const double rd = fast_rcp(udiag[i]);
-        for_2d<NT>(i, N + nv, [&](int r, int c) {
-            const double l = at<TR>(A, r, i, LD);
-            if (c < N) at<TR>(Bm, r, c, LD) -= l * (at<TR>(Bm, i, c, LD) * rd);
-            else v[r] -= l * (v[i] * rd);
+        for_2d<NT>(N - 1, m + N + nv, [&](int ri, int cc) {
+            const int r = ri + (ri >= k ? 1 : 0);  // every row but k
+            const double l = ((r == p) ? akk : at<TR>(A, r, k, LD)) * rp;
+            if (cc < m) {
+                const int c = k + 1 + cc;
+                at<TR>(A, r, c, LD) -= l * at<TR>(A, k, c, LD);
+            } else if (cc < m + N) {
+                const int c = cc - m;
+                at<TR>(Bm, r, c, LD) -= l * at<TR>(Bm, k, c, LD);
+            } else {
+                v[r] -= l * v[k];
+            }
         });
         block_sync();
     }
