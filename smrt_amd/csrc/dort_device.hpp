@@ -68,6 +68,8 @@ enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_
 // ------------------------------------------------------------------------------------------------------------
 struct LdsPlan {
     int NMAX, LD, nmax, Lmax, nphi, ntheta;
+    int matrices_in_lds;  // 1: the four N x N work matrices are LDS-resident; 0: they live in a global workspace
+    int mat_doubles;      // doubles of matrix workspace per workgroup (4 * NMAX * LD)
     int o_M[4];
     int o_rowvec;   // 17 vectors of NMAX
     int o_strvec;   // 6 vectors of nmax
@@ -84,7 +86,7 @@ struct LdsPlan {
 #define SMRT_HD __host__ __device__ inline
 #endif
 
-SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi) {
+SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1) {
     LdsPlan p;
     p.nmax = n_max_stream;
     p.NMAX = n_max_stream * P;
@@ -92,8 +94,11 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.Lmax = Lmax;
     p.nphi = nphi;
     p.ntheta = ntheta;
+    p.matrices_in_lds = matrices_in_lds;
+    p.mat_doubles = 4 * p.NMAX * p.LD;
     int o = 0;
-    for (int i = 0; i < 4; ++i) { p.o_M[i] = o; o += p.NMAX * p.LD; }
+    for (int i = 0; i < 4; ++i) { p.o_M[i] = i * p.NMAX * p.LD; }
+    if (matrices_in_lds) o = p.mat_doubles;
     p.o_rowvec = o; o += 17 * p.NMAX;
     p.o_strvec = o; o += 6 * p.nmax;
     p.o_layvec = o; o += 11 * Lmax;
@@ -114,9 +119,9 @@ struct Lds {
     int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air
 };
 
-SMRT_DEV Lds carve(double* base, const LdsPlan& p) {
+SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
     Lds s;
-    s.M0 = base + p.o_M[0]; s.M1 = base + p.o_M[1]; s.M2 = base + p.o_M[2]; s.M3 = base + p.o_M[3];
+    s.M0 = mat_base + p.o_M[0]; s.M1 = mat_base + p.o_M[1]; s.M2 = mat_base + p.o_M[2]; s.M3 = mat_base + p.o_M[3];
     double* v = base + p.o_rowvec;
     const int n = p.NMAX;
     s.mrow = v; s.wrow = v + n; s.u = v + 2 * n; s.d = v + 3 * n; s.sigma = v + 4 * n; s.rsig = v + 5 * n;
@@ -686,7 +691,7 @@ enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_
 constexpr int RB = 2;
 
 template <int NT, int CH>
-SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base) {
+SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr) {
     constexpr int P = 2;
     constexpr int GS = (NT / 32 >= 1) ? ((NT / 32 > 64) ? 64 : NT / 32) : 1;  // lanes per Jacobi column pair
     constexpr int RPL = (64 * CH + GS - 1) / GS;                              // rows per lane (N <= 64 CH)
@@ -694,8 +699,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
-    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi);
-    const Lds s = carve(lds_base, plan);
+    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0);
+    const Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     const int LD = plan.LD;
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;

@@ -1,6 +1,7 @@
 // libsmrt_dort.so -- HIP implementation of include/smrt_dort.h for gfx950 (MI355X).
 // Host code: context, device buffers, packing, launch, HIP-event timing.  Kernels: dort_device.hpp.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -15,6 +16,18 @@ template <int NT, int CH>
 __global__ __launch_bounds__(NT) void dort_passive_kernel(DevBatch b) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
+}
+
+// N > 64 (n_max_stream up to 64 x CH/2): same device functions, work matrices in a per-workgroup global workspace
+// (L2 / Infinity-Cache resident), grid-stride over the pairs so the workspace stays bounded.
+template <int NT, int CH>
+__global__ __launch_bounds__(NT) void dort_passive_kernel_gmem(DevBatch b, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, CH>(b, p, smrt_lds, mat);
+        __syncthreads();
+    }
 }
 
 struct DevBuf {
@@ -37,7 +50,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work;
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -48,6 +61,10 @@ struct smrt_dort_ctx {
     int64_t n_launch = 0;
     bool timing_pending = false;
     int max_lds = 0;
+    bool gmem_path = false;
+    int gmem_grid = 0;
+    long long ws_stride = 0;
+    int nmax_rows = 0;
 };
 
 #define HIPCHK(call)                                                                              \
@@ -63,6 +80,16 @@ static int upload_array(smrt_dort_ctx* ctx, DevBuf& buf, const void* src, size_t
     HIPCHK(buf.reserve(bytes));
     HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return 0;
+}
+
+template <int NT, int CH>
+static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
+    auto kern = dort_passive_kernel_gmem<NT, CH>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ctx->gmem_grid), dim3(NT), ctx->lds_bytes, ctx->stream, d,
+                       (double*)ctx->d_work.p, ctx->ws_stride);
+    return hipGetLastError();
 }
 
 template <int NT>
@@ -116,7 +143,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
-                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage};
+                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -146,12 +173,19 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     if (pair_count < 0) pair_count = npairs - pair_begin;
     if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
     const int P = 2;
-    const LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9);
-    const size_t lds = (size_t)plan.total * sizeof(double);
-    if (plan.NMAX > 64 || lds > (size_t)ctx->max_lds) {
-        ctx->err = "n_max_stream too large for the LDS-resident kernel of this build";
-        return -1;
+    LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9, 1);
+    size_t lds = (size_t)plan.total * sizeof(double);
+    ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds);
+    if (ctx->gmem_path) {
+        if (plan.NMAX > 256) { ctx->err = "n_max_stream above 128 is not supported by this build"; return -1; }
+        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9, 0);
+        lds = (size_t)plan.total * sizeof(double);
+        if (lds > (size_t)ctx->max_lds) { ctx->err = "too many layers for the LDS-resident per-layer tables"; return -1; }
+        ctx->gmem_grid = (int)std::min<int64_t>(pair_count, 1024);
+        ctx->ws_stride = plan.mat_doubles;
+        HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * plan.mat_doubles));
     }
+    ctx->nmax_rows = plan.NMAX;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
     if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;
@@ -208,6 +242,14 @@ int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
+    if (ctx->gmem_path) {
+        if (ctx->nmax_rows <= 128) e = launch_gmem<256, 2>(ctx, d);
+        else e = launch_gmem<256, 4>(ctx, d);
+        HIPCHK(e);
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->timing_pending = true;
+        return 0;
+    }
     switch (ctx->nt) {
         case 64: e = launch_nt<64>(ctx, d); break;
         case 128: e = launch_nt<128>(ctx, d); break;

@@ -10,13 +10,15 @@
 
 using namespace smrt;
 
-template <int NT>
-static long run_pairs(DevBatch& d, int order, size_t lds_doubles) {
+template <int NT, int CH>
+static long run_pairs(DevBatch& d, int order, size_t lds_doubles, size_t mat_doubles) {
     long nb = 0;
-    std::vector<double> lds(lds_doubles);
+    std::vector<double> lds(lds_doubles), mat(mat_doubles);
     for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;  // uninitialised LDS must never be consumed
-        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1>(d, p, lds.data()); });
+        for (auto& x : lds) x = NAN;  // uninitialised LDS / workspace must never be consumed
+        for (auto& x : mat) x = NAN;
+        double* gm = mat_doubles ? mat.data() : nullptr;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, CH>(d, p, lds.data(), gm); });
     }
     return nb;
 }
@@ -27,8 +29,10 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     const char* why = smrt_host::validate(b);
     if (why) { fprintf(stderr, "smrt_emu_run: %s\n", why); return -1; }
     if (b->mode != SMRT_MODE_PASSIVE) return -1;
-    const LdsPlan plan = make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9);
-    if (plan.NMAX > 64) return -2;
+    const bool gmem = b->n_max_stream * 2 > 64;
+    const LdsPlan plan = make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1);
+    if (plan.NMAX > 128) return -2;
+    const size_t matd = gmem ? (size_t)plan.mat_doubles : 0;
     std::vector<double> gl(b->n_max_stream);
     smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
     DevBatch d{};
@@ -42,11 +46,19 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    switch (nt) {
-        case 64: nb = run_pairs<64>(d, order, plan.total); break;
-        case 128: nb = run_pairs<128>(d, order, plan.total); break;
-        case 256: nb = run_pairs<256>(d, order, plan.total); break;
-        default: return -3;
+    if (gmem) {
+        switch (nt) {
+            case 64: nb = run_pairs<64, 2>(d, order, plan.total, matd); break;
+            case 256: nb = run_pairs<256, 2>(d, order, plan.total, matd); break;
+            default: return -3;
+        }
+    } else {
+        switch (nt) {
+            case 64: nb = run_pairs<64, 1>(d, order, plan.total, 0); break;
+            case 128: nb = run_pairs<128, 1>(d, order, plan.total, 0); break;
+            case 256: nb = run_pairs<256, 1>(d, order, plan.total, 0); break;
+            default: return -3;
+        }
     }
     if (n_barriers) *n_barriers = nb;
     return 0;
