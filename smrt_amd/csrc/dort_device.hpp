@@ -425,17 +425,22 @@ SMRT_DEV void lt_times_l(const double* Lp, const double* Lm, double* C, int N, i
 #define SMRT_JACOBI_EXIT_COS2 1e-15
 #endif
 template <int GS, int RPL>
-SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, int sub, int* flag) {
+SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, int sub, int slot, int* flag) {
+    // Branch-free: every lane always loads and stores its RPL rows.  Rows >= N of a column are padding inside the
+    // N_max x LD buffer (never read by any other stage), loads from them are masked to zero with a select instead
+    // of being predicated (per-element exec-mask branches were costing more than the arithmetic).
     double x[RPL], y[RPL];
     double a = 0.0, bb = 0.0, gg = 0.0;
     double* cp = Bm + p * LD;
     double* cq = Bm + q * LD;
 #pragma unroll
     for (int i = 0; i < RPL; ++i) {
-        const int r = sub + i * GS;
-        const bool in = valid && (r < N);
-        x[i] = in ? cp[r] : 0.0;
-        y[i] = in ? cq[r] : 0.0;
+        const int r0 = sub + i * GS;
+        const int r = r0 < LD - 1 ? r0 : LD - 1;  // row LD-1 is always padding (LD = N_max + 1)
+        const bool in = valid && (r0 < N);
+        const double xv = cp[r], yv = cq[r];
+        x[i] = in ? xv : 0.0;
+        y[i] = in ? yv : 0.0;
         a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i];
     }
 #if !defined(SMRT_ABLATE) || SMRT_ABLATE < 2
@@ -466,23 +471,24 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
 #else
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
-            const int r = sub + i * GS;
-            if (r < N) {
-                cp[r] = c * x[i] - sn * y[i];
-                cq[r] = sn * x[i] + c * y[i];
-            }
+            const int r0 = sub + i * GS;
+            const int r = r0 < LD - 1 ? r0 : LD - 1;
+            cp[r] = c * x[i] - sn * y[i];
+            cq[r] = sn * x[i] + c * y[i];
         }
 #endif
         if (sub == 0 && g2 > SMRT_JACOBI_EXIT_COS2 * ab) lds_or(flag, 1);
     }
 }
 
-template <int NT, int GS, int RPL>
+template <int NT, int JW, int GS, int RPL>
 SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag, int* n_sweeps) {
+    // JW = wavefronts that take part (the others only meet the workgroup barriers): with few lanes per pair and many
+    // rows per lane the fixed per-rotation cost (index math, reductions, rotation parameters) is amortised better
+    // than by spreading every pair over more lanes of more wavefronts.
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
-    constexpr int NW = NT / SMRT_LANES;
-    constexpr int NB = 2 * NW;               // column blocks
+    constexpr int NB = 2 * JW;               // column blocks
     constexpr int SLOTS = SMRT_LANES / GS;   // column pairs a wavefront rotates at once
     const int slot = lane / GS, sub = lane % GS;
     const int m = (N + NB - 1) / NB;         // columns per block
@@ -493,6 +499,7 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
         if (t == 0) *flag = 0;
         block_sync();
         for (int s = 0; s < NB - 1; ++s) {
+            if (wave >= JW) { block_sync(); continue; }
             int I, J;
             if (wave == 0) { I = NB - 1; J = s; }
             else {
@@ -516,7 +523,7 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
                         }
                         const int p = base + a, q = base + b;
                         const bool valid = (ps < 2 * half) && (a < m) && (b < m) && (p < N) && (q < N);
-                        rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, flag);
+                        rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, slot, flag);
                     }
                     wave_sync();
                 }
@@ -527,7 +534,7 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
                     int bq = ps + j; if (bq >= m) bq -= m;
                     const int p = i0 + ps, q = j0 + bq;
                     const bool valid = (ps < m) && (p < N) && (q < N);
-                    rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, flag);
+                    rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, slot, flag);
                 }
                 wave_sync();
             }
@@ -693,8 +700,9 @@ constexpr int RB = 2;
 template <int NT, int CH>
 SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr) {
     constexpr int P = 2;
-    constexpr int GS = (NT / 32 >= 1) ? ((NT / 32 > 64) ? 64 : NT / 32) : 1;  // lanes per Jacobi column pair
-    constexpr int RPL = (64 * CH + GS - 1) / GS;                              // rows per lane (N <= 64 CH)
+    constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;  // wavefronts rotating columns (one per SIMD)
+    constexpr int GS = 8;                                             // lanes per Jacobi column pair
+    constexpr int RPL = (64 * CH + GS - 1) / GS;                      // rows per lane (N <= 64 CH)
     const int t = tid();
     const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
@@ -923,7 +931,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_BTL);
         lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);                       // B = L+^T L-
         SMRT_STAGE(SG_JACOBI);
-        if (!jacobi_onesided<NT, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps)) {
+        if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps)) {
             fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
         }
         SMRT_STAGE(SG_TRI);
