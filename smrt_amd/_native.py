@@ -258,6 +258,7 @@ class DortContext:
         self._check(self._lib.smrt_dort_stage_cycles(self._h, _dptr(a)), "smrt_dort_stage_cycles")
         d = dict(zip(self.STAGE_NAMES, a[: len(self.STAGE_NAMES)]))
         d["_jacobi_sweeps"] = a[12]
+        d["_gj_panel"], d["_gj_update"], d["_gj_perm"] = a[13], a[14], a[15]
         return d
 
     def sum_n3(self):

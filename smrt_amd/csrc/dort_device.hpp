@@ -77,6 +77,7 @@ struct LdsPlan {
     int o_phi;      // 3 vectors of nphi
     int o_tb;       // NMAX
     int o_int;      // 16 ints (8 doubles)
+    int o_gj;       // blocked Gauss-Jordan scratch: 12 * NMAX + 8 doubles, then (NMAX + 8) ints
     int total;      // doubles
 };
 
@@ -105,6 +106,7 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_phi = o; o += 3 * nphi;
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
+    p.o_gj = o; o += 12 * p.NMAX + 8 + (p.NMAX + 8 + 1) / 2;
     p.total = o;
     return p;
 }
@@ -117,6 +119,9 @@ struct Lds {
     double *cphi, *s2phi, *wphi;
     double* tb;
     int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air
+    double* gj;  // blocked Gauss-Jordan scratch
+    int gj_nmax;
+    double* sub_acc;  // profiling builds: [0] GJ panel cycles, [1] GJ update cycles, [2] GJ permutation cycles
 };
 
 SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
@@ -139,6 +144,9 @@ SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
     s.cphi = v; s.s2phi = v + p.nphi; s.wphi = v + 2 * p.nphi;
     s.tb = base + p.o_tb;
     s.ints = (int*)(base + p.o_int);
+    s.gj = base + p.o_gj;
+    s.gj_nmax = p.NMAX;
+    s.sub_acc = nullptr;
     return s;
 }
 
@@ -669,6 +677,374 @@ SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, i
     return true;
 }
 
+// ---- 16x16 tile GEMM on the FP64 matrix core ---------------------------------------------------------------
+// c (the 16x16 tile at tile-row ti, tile-column tj, in MFMA accumulator layout) += sum_k A[i][k] B[k][j];
+// fa(i, k) / fb(k, j) fetch operands (they must return 0 outside the matrix); K is rounded up to 4.
+template <class FA, class FB>
+SMRT_DEV void gemm_tile(double (&c)[4], int K, int ti, int tj, FA fa, FB fb) {
+    const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) mfma_f64_16x16x4(fa(ti * 16 + lr, k0 + lk), fb(k0 + lk, tj * 16 + lr), c);
+}
+// store / load an accumulator tile to a column-major matrix (element (r, c) at [c*LD + r]), rows/cols < N only
+template <class F>
+SMRT_DEV void tile_foreach(int ti, int tj, int N, F f) {
+    const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
+    const int col = tj * 16 + lr;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = ti * 16 + lk + 4 * reg;
+        if (row < N && col < N) f(reg, row, col);
+    }
+}
+
+// C = Lp^T Lm (both lower triangular; whatever sits above their diagonals is ignored)
+template <int NT>
+SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int N, int LD) {
+    const int wave = tid() / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int RT = (N + 15) >> 4;
+    for (int tix = wave; tix < RT * RT; tix += NW) {
+        const int ti = tix % RT, tj = tix / RT;
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+        const int kmin = 16 * (ti > tj ? ti : tj);  // k >= max(i, j)
+        const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
+        const int i = ti * 16 + lr, j = tj * 16 + lr;
+        const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+        for (int k0 = kmin; k0 < N; k0 += 4) {
+            const int k = k0 + lk, kc = k < N ? k : N - 1;
+            const double av = Lp[ic * LD + kc], bv = Lm[jc * LD + kc];
+            mfma_f64_16x16x4((i < N && k < N && k >= i) ? av : 0.0, (j < N && k < N && k >= j) ? bv : 0.0, c);
+        }
+        tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[col * LD + row] = c[reg]; });
+    }
+    block_sync();
+}
+
+// C = Lp * Bm (Lp lower triangular)
+template <int NT>
+SMRT_DEV void l_times_m_mfma(const double* Lp, const double* Bm, double* C, int N, int LD) {
+    const int wave = tid() / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int RT = (N + 15) >> 4;
+    for (int tix = wave; tix < RT * RT; tix += NW) {
+        const int ti = tix % RT, tj = tix / RT;
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+        const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
+        const int i = ti * 16 + lr, j = tj * 16 + lr;
+        const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+        const int kend = (ti * 16 + 16 < N) ? ti * 16 + 16 : N;  // k <= i
+        for (int k0 = 0; k0 < kend; k0 += 4) {
+            const int k = k0 + lk, kc = k < N ? k : N - 1;
+            const double av = Lp[kc * LD + ic], bv = Bm[jc * LD + kc];
+            mfma_f64_16x16x4((i < N && k <= i) ? av : 0.0, (j < N && k < N) ? bv : 0.0, c);
+        }
+        tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[col * LD + row] = c[reg]; });
+    }
+    block_sync();
+}
+
+// ---- the two "row block times matrix" passes of the layer recursion on the matrix core (N <= 64) -------------
+// Every wavefront owns one (or, for small workgroups, a few) 16-row tile(s): it first pulls the A operands of its
+// rows -- the whole 16 x N row block, 16 registers per lane -- into registers, the workgroup synchronises, and only
+// then are results written; that is what makes the in-place updates (rows of Rt, rows of F) safe.
+template <int NT>
+struct RowTiles {
+    static constexpr int NW = NT / SMRT_LANES;
+    static constexpr int RPW = (4 + NW - 1) / NW;               // row tiles per wavefront (RT <= 4)
+    static constexpr int CS = (NW >= 4) ? NW / 4 : 1;           // wavefronts sharing one row tile (column split)
+};
+
+// Wk = F - Rt G ; Rt <- Rt F - G (in place) ; cvec = (Rt 1) B - B + svec
+template <int NT>
+SMRT_DEV void r1_mfma(const double* F, const double* G, double* Rt, double* Wk, double* cvec, const double* svec,
+                      double Bl, int N, int LD) {
+    using RTc = RowTiles<NT>;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    double a[RTc::RPW][16];
+    int tis[RTc::RPW];
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        tis[o] = ti;
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        double rs = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double x = Rt[kc * LD + ic];
+            a[o][kk] = (ti < RT && i < N && k < N) ? x : 0.0;
+            rs += a[o][kk];
+        }
+        rs += shfl_xor(rs, 16);
+        rs += shfl_xor(rs, 32);
+        const bool owner = (RTc::NW >= 4) ? (wave < 4) : true;
+        if (owner && ti < RT && lk == 0 && i < N) cvec[i] = rs * Bl - Bl + svec[i];
+    }
+    block_sync();
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = tis[o];
+        if (ti >= RT) continue;
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+        for (int tj = cs; tj < RT; tj += RTc::CS) {
+            double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+            const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                if (4 * kk < N) {
+                    const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                    const bool in = (j < N && k < N);
+                    const double gv = G[jc * LD + kc], fv = F[jc * LD + kc];
+                    mfma_f64_16x16x4(a[o][kk], in ? gv : 0.0, c1);
+                    mfma_f64_16x16x4(a[o][kk], in ? fv : 0.0, c2);
+                }
+            }
+            tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                Wk[col * LD + row] = F[col * LD + row] - c1[reg];
+                Rt[col * LD + row] = c2[reg] - G[col * LD + row];
+            });
+        }
+    }
+    block_sync();
+}
+
+// Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (in place)
+// upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
+template <int NT>
+SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
+                       double* upb, double* gvec, double Bl, int N, int LD) {
+    using RTc = RowTiles<NT>;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    double af[RTc::RPW][16], aw[RTc::RPW][16];
+    int tis[RTc::RPW];
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        tis[o] = ti;
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        const double rt = Rtop[ic];
+        double vy = 0.0, vg = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
+            const bool in = (ti < RT && i < N && k < N);
+            af[o][kk] = in ? fv : 0.0;
+            aw[o][kk] = in ? gv - rt * fv : 0.0;
+            vy += af[o][kk] * tk;
+            vg += aw[o][kk] * tk;
+        }
+        vy += shfl_xor(vy, 16); vy += shfl_xor(vy, 32);
+        vg += shfl_xor(vg, 16); vg += shfl_xor(vg, 32);
+        const bool owner = (RTc::NW >= 4) ? (wave < 4) : true;
+        if (owner && ti < RT && lk == 0 && i < N) { upb[i] = vy + Bl; gvec[i] = vg + (1.0 - rt) * Bl; }
+    }
+    block_sync();
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = tis[o];
+        if (ti >= RT) continue;
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+        for (int tj = cs; tj < RT; tj += RTc::CS) {
+            double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
+            const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                if (4 * kk < N) {
+                    const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                    const double qv = Q[jc * LD + kc];
+                    const double bop = (j < N && k < N) ? qv : 0.0;
+                    mfma_f64_16x16x4(af[o][kk], bop, cy);
+                    mfma_f64_16x16x4(aw[o][kk], bop, cw);
+                }
+            }
+            tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                const double fic = F[col * LD + row], gic = G[col * LD + row];
+                Wk[col * LD + row] = cy[reg] + gic;
+                F[col * LD + row] = cw[reg] + fic - Rtop[row] * gic;
+            });
+        }
+    }
+    block_sync();
+}
+
+// Blocked Gauss-Jordan with implicit partial pivoting and rank-4 trailing updates on the FP64 matrix core
+// (N <= 64).  Per block of four columns:
+//   panel   (wavefront 0, lane = row, the four panel entries of the row in registers): four pivot rows by
+//           wavefront arg-max among the rows not used yet (rows are never swapped: the permutation is applied once at
+//           the end), then W^-1 of the 4x4 pivot block and the multipliers M' = A[:,K] W^-1 (I - W^-1 on the pivot
+//           rows); the four pivot rows of everything still to update are copied aside;
+//   update  (all wavefronts): C <- C - M' R_P for every 16x16 tile of [A(rest) | B], one v_mfma_f64_16x16x4_f64
+//           per tile (K = 4 is exactly the block width); the pivot rows come out normalised, so after the last block
+//           row perm[k] of B IS row k of the solution.
+// Two workgroup barriers per block (N/4 blocks) instead of two per column, and ~10x fewer issued instructions per
+// eliminated element than the scalar rank-1 update.
+template <int NT, bool TR>
+SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
+    const int t = tid();
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int NMX = s.gj_nmax;            // 64 on this path
+    double* Mp = s.gj;                    // [4][NMX]   multipliers (negated), zero for rows >= N
+    double* Rp = s.gj + 4 * NMX;          // [4][2*NMX] pivot rows of [A(rest) | B]
+    double* vp = s.gj + 12 * NMX;         // [4] pivot entries of the extra right-hand side
+    int* perm = (int*)(s.gj + 12 * NMX + 8);  // [NMX] pivot row of every column; perm[NMX] = failure flag
+    const int RW = 2 * NMX;
+    const bool has_v = (v != nullptr);
+    bool used = false;                    // wavefront 0: this lane's row has been a pivot row
+    if (t == 0) perm[NMX] = 0;
+#ifdef SMRT_STAGE_TIMING
+    long long tq0 = cycle_counter();
+#define SMRT_SUB(k) do { const long long n_ = cycle_counter(); if (t == 0 && s.sub_acc) s.sub_acc[k] += (double)(n_ - tq0); tq0 = n_; } while (0)
+#else
+#define SMRT_SUB(k) do {} while (0)
+#endif
+    for (int k0 = 0; k0 < N; k0 += 4) {
+        const int nbk = (N - k0 < 4) ? N - k0 : 4;
+        const int ma = N - k0 - nbk;      // columns of A still to update
+        if (wave == 0) {
+            double a[4], a0[4];
+            int prow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (lane < N && j < nbk) ? at<TR>(A, lane, k0 + j, LD) : 0.0;
+                a0[j] = a[j];
+                prow[j] = 0;
+            }
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nbk) {
+                    unsigned long long key = 0ull;
+                    if (lane < N && !used) {
+                        const double xr = fabs(a[j]);
+                        memcpy(&key, &xr, 8);
+                        key = (key & ~0x7Full) | (unsigned long long)(127 - lane);
+                    }
+                    key = wave_max_u64(key);
+                    if (key < 128ull) ok = false;
+                    const int p = ok ? 127 - (int)(key & 0x7Full) : 0;
+                    prow[j] = p;
+                    const double pv = wave_bcast(a[j], p);
+                    if (lane == p) used = true;
+                    const double l = (lane == p || !ok) ? 0.0 : a[j] * fast_rcp(pv);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (jj > j) { const double pj = wave_bcast(a[jj], p); a[jj] -= l * pj; }
+                }
+            }
+            // W = original panel entries of the pivot rows (identity padding for a short last block), W^-1 by
+            // Gauss-Jordan in pivot order (that order is the partial-pivoting order, no further pivoting needed)
+            double W[4][4], Wi[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double w = wave_bcast(a0[j], prow[i]);
+                    W[i][j] = (i < nbk && j < nbk) ? w : (i == j ? 1.0 : 0.0);
+                    Wi[i][j] = (i == j) ? 1.0 : 0.0;
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double rp = fast_rcp(W[c][c]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { W[c][j] *= rp; Wi[c][j] *= rp; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i != c) {
+                        const double f = W[i][c];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { W[i][j] -= f * W[c][j]; Wi[i][j] -= f * Wi[c][j]; }
+                    }
+            }
+            // multipliers
+            double M[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += a0[i] * Wi[i][j];
+                M[j] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nbk && lane == prow[i]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) M[j] = (i == j ? 1.0 : 0.0) - Wi[i][j];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane < NMX) Mp[j * NMX + lane] = (lane < N && j < nbk && ok) ? -M[j] : 0.0;
+            if (lane < 4 && lane < nbk) perm[k0 + lane] = prow[lane];
+            if (lane == 0 && !ok) perm[NMX] = 1;
+            // copy of the pivot rows of [A(rest) | B] and of v
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pr = prow[j];
+                for (int ci = lane; ci < ma + N; ci += SMRT_LANES) {
+                    double val = 0.0;
+                    if (j < nbk) val = (ci < ma) ? at<TR>(A, pr, k0 + nbk + ci, LD) : at<TR>(Bm, pr, ci - ma, LD);
+                    Rp[j * RW + ci] = val;
+                }
+                if (lane == 0) vp[j] = (has_v && j < nbk) ? v[pr] : 0.0;
+            }
+        }
+        block_sync();
+        SMRT_SUB(0);
+        if (perm[NMX]) return false;  // uniform
+        // ---- rank-4 update of every 16x16 tile of [A(rest) | B]
+        {
+            const int RT = (N + 15) >> 4, CT = (ma + N + 15) >> 4;
+            const int lr = lane & 15, lk = lane >> 4;
+            for (int tix = wave; tix < RT * CT; tix += NW) {
+                const int ti = tix % RT, tj = tix / RT;
+                const int ci = tj * 16 + lr;                 // column index in the concatenated space
+                const bool cin = ci < ma + N;
+                double* Mat = (ci < ma) ? A : Bm;
+                const int col = (ci < ma) ? (k0 + nbk + ci) : (ci - ma);
+                const int colc = cin ? col : 0;
+                double c[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    const int rowc = row < N ? row : 0;
+                    const double x = at<TR>(Mat, rowc, colc, LD);
+                    c[reg] = (cin && row < N) ? x : 0.0;
+                }
+                const int arow = ti * 16 + lr;
+                const double aop = (arow < NMX) ? Mp[lk * NMX + arow] : 0.0;
+                const double bop = cin ? Rp[lk * RW + ci] : 0.0;
+                mfma_f64_16x16x4(aop, bop, c);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    if (cin && row < N) at<TR>(Mat, row, col, LD) = c[reg];
+                }
+            }
+            if (has_v && t < N) {
+                double acc = v[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += Mp[j * NMX + t] * vp[j];
+                v[t] = acc;
+            }
+        }
+        block_sync();
+        SMRT_SUB(1);
+    }
+    // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
+    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
+    double vk = 0.0;
+    if (has_v && t < N) vk = v[perm[t]];
+    block_sync();
+    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
+    if (has_v && t < N) v[t] = vk;
+    block_sync();
+    SMRT_SUB(2);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // the per-pair solve (passive mode, azimuth mode 0, 2 polarisations)
 // ------------------------------------------------------------------------------------------------------------
@@ -708,7 +1084,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0);
-    const Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+    Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+#ifdef SMRT_STAGE_TIMING
+    double sub_acc_store[4] = {0.0, 0.0, 0.0, 0.0};
+    s.sub_acc = sub_acc_store;
+#endif
     const int LD = plan.LD;
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
@@ -929,13 +1309,15 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_CHOL);
         if (!chol2<NT>(s.M0, s.M1, N, LD)) { fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return; }
         SMRT_STAGE(SG_BTL);
-        lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);                       // B = L+^T L-
+        if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
+        else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
         SMRT_STAGE(SG_JACOBI);
         if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps)) {
             fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
         }
         SMRT_STAGE(SG_TRI);
-        l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);                        // Em' = L+ B'
+        if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
+        else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
         lt_solve<NT>(s.M0, s.M2, N, LD);                               // Ep' = L+^-T B'
         // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
         for_2d<NT>(N, N, [&](int i, int c) {
@@ -950,6 +1332,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
 
         SMRT_STAGE(SG_R1);
+        if (CH == 1) {
+            r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        } else {
         // -- R1: Wk = F - Rt G ; Rt <- Rt F - G (row-wise in place) ; cvec = (Rt 1) B - B + svec
         for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
             double a1[RB][CH], a2[RB][CH], rsum[RB];
@@ -984,16 +1369,20 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             }
         }
         block_sync();
+        }
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
-        if (!lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH == 1 ? gj_solve_mfma<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = Rt;
         SMRT_DUMP("Q", Q, N);
         for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
         for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
         block_sync();
+        if (CH == 1) {
+            r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
+        } else {
         // -- R4/R5: Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (row-wise in place)
         //    upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
         for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
@@ -1032,10 +1421,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             }
         }
         block_sync();
+        }
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
-        if (!lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH == 1 ? gj_solve_mfma<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);
@@ -1088,6 +1478,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     if (t == 0 && b.stage_out) {
         for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
         b.stage_out[p * 16 + 12] = (double)n_sweeps;
+        for (int k = 0; k < 3; ++k) b.stage_out[p * 16 + 13 + k] = sub_acc_store[k];
     }
 #endif
 }

@@ -34,6 +34,8 @@ SMRT_DEV unsigned long long wave_max_u64(unsigned long long k) {
     }
     return k;
 }
+SMRT_DEV double wave_bcast(double v, int src_lane) { return emu::wave_bcast(v, src_lane); }
+SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f64_16x16x4(a, b, c); }
 SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
 SMRT_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 // sum over aligned groups of GS consecutive lanes (GS power of two <= 64); every lane gets the group total
@@ -114,6 +116,23 @@ SMRT_DEV unsigned long long wave_max_u64(unsigned long long k) {
                              r3 = readlane_u64(k, 48);
     const unsigned long long a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
     return a > b ? a : b;
+}
+// value of lane src_lane (wavefront-uniform index) in every lane: two v_readlane_b32
+SMRT_DEV double wave_bcast(double v, int src_lane) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(a.i[0], src_lane);
+    r.i[1] = __builtin_amdgcn_readlane(a.i[1], src_lane);
+    return r.d;
+}
+// D = A(16x4) B(4x16) + C on the matrix core, v_mfma_f64_16x16x4_f64.  Lane layout (pinned on gfx950 by
+// tools/micro/mfma_f64_layout.hip): a = A[i = l&15][k = l>>4], b = B[k = l>>4][j = l&15],
+// c[reg] = C[row = (l>>4) + 4*reg][col = l&15].
+typedef double smrt_v4d __attribute__((ext_vector_type(4)));
+SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
+    smrt_v4d cv = {c[0], c[1], c[2], c[3]};
+    cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cv, 0, 0, 0);
+    c[0] = cv[0]; c[1] = cv[1]; c[2] = cv[2]; c[3] = cv[3];
 }
 // Sum over aligned groups of GS consecutive lanes; every lane gets the group total.  quad_perm swaps inside a
 // quad, row_half_mirror / row_mirror reach the other quad / the other half of a 16-lane row (the source lane

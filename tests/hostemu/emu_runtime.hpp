@@ -29,6 +29,7 @@ struct Runtime {
     std::vector<int> wave_count;
     std::vector<long> wave_gen;
     std::vector<double> exch;
+    std::vector<double> exch2;
     std::function<void()> body;
     long n_barriers = 0;
     long progress = 0;  // bumped whenever a barrier releases or a fiber finishes
@@ -84,6 +85,34 @@ inline double shfl_xor(double v, int mask) {
     return out;
 }
 
+// value of lane `src` of the calling thread's wavefront, in every lane
+inline double wave_bcast(double v, int src) {
+    Runtime* r = rt();
+    int me = r->cur;
+    r->exch[me] = v;
+    wave_barrier();
+    double out = r->exch[(me & ~63) | (src & 63)];
+    wave_barrier();
+    return out;
+}
+
+// D = A(16x4) * B(4x16) + C with the gfx950 v_mfma_f64_16x16x4_f64 lane layout:
+// a: A[i = l&15][k = l>>4], b: B[k = l>>4][j = l&15], c[reg]: C[row = (l>>4) + 4*reg][col = l&15]
+inline void mfma_f64_16x16x4(double a, double b, double* c) {
+    Runtime* r = rt();
+    int me = r->cur, base = me & ~63, l = me & 63;
+    r->exch[me] = a;
+    r->exch2[me] = b;
+    wave_barrier();
+    for (int reg = 0; reg < 4; ++reg) {
+        int row = (l >> 4) + 4 * reg, col = l & 15;
+        double acc = c[reg];
+        for (int k = 0; k < 4; ++k) acc += r->exch[base + 16 * k + row] * r->exch2[base + 16 * k + col];
+        c[reg] = acc;
+    }
+    wave_barrier();
+}
+
 inline void trampoline() {
     Runtime* r = rt();
     r->body();
@@ -105,6 +134,7 @@ inline long run_block(int nt, int order, std::function<void()> body) {
     R.wave_count.assign((nt + 63) / 64, 0);
     R.wave_gen.assign((nt + 63) / 64, 0);
     R.exch.assign(nt, 0.0);
+    R.exch2.assign(nt, 0.0);
     const size_t STK = 256 * 1024;
     for (int i = 0; i < nt; ++i) {
         R.stacks[i] = (char*)malloc(STK);

@@ -26,6 +26,9 @@ ctx.launch(); ctx.sync()
 ms = ctx.last_kernel_ms()
 st = ctx.stage_cycles()
 sweeps = st.pop("_jacobi_sweeps")
+sub = {k: st.pop(k) for k in ("_gj_panel", "_gj_update", "_gj_perm")}
+print("gauss-jordan split (cycles/solve): panel %.0f  update %.0f  permutation %.0f" % tuple(
+    sub[k] / batch.n_pairs for k in ("_gj_panel", "_gj_update", "_gj_perm")))
 print("jacobi sweeps per layer-problem: %.2f" % (sweeps / batch.n_pairs / bench.N_LAYERS))
 tot = sum(st.values())
 print("threads=%d pairs=%d kernel_ms=%.2f  solves/s=%.0f" % (threads, batch.n_pairs, ms, batch.n_pairs / ms * 1e3))
