@@ -120,6 +120,11 @@ double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_
 /* Tuning knob: threads per workgroup of the pair kernel (64..1024, multiple of 64). 0 = default. */
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 
+/* Pipeline shape on the LDS-resident path (N <= 64): 1 (default) = three kernels (prep per pair, Jacobi per
+ * pair x layer with four workgroups per CU, finish per pair) with the factors staged through HBM/L2;
+ * 0 = everything fused in one kernel, one workgroup per pair.  Call before smrt_dort_upload. */
+int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
+
 /* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
 double smrt_dort_sum_n3(smrt_dort_ctx* ctx);

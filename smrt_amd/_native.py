@@ -153,6 +153,8 @@ def load_library():
     lib.smrt_dort_total_kernel_ms.restype = C.c_double
     lib.smrt_dort_set_block_threads.argtypes = [C.c_void_p, C.c_int32]
     lib.smrt_dort_set_block_threads.restype = C.c_int32
+    lib.smrt_dort_set_pipeline.argtypes = [C.c_void_p, C.c_int32]
+    lib.smrt_dort_set_pipeline.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
     lib.smrt_dort_sum_n3.restype = C.c_double
     lib.smrt_dort_stage_cycles.argtypes = [C.c_void_p, P(C.c_double)]
@@ -168,7 +170,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
     "smrt_dort_upload", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
-    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
+    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version",
 ]
 
@@ -212,6 +214,9 @@ class DortContext:
 
     def set_block_threads(self, n):
         self._check(self._lib.smrt_dort_set_block_threads(self._h, int(n)), "smrt_dort_set_block_threads")
+
+    def set_pipeline(self, split=True):
+        self._check(self._lib.smrt_dort_set_pipeline(self._h, 1 if split else 0), "smrt_dort_set_pipeline")
 
     def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1) -> BatchOutput:
         if pair_count < 0:

@@ -53,6 +53,18 @@ struct DevBatch {
     double* stage_out;  // [pair_count][16] shader cycles per stage (only written by -DSMRT_STAGE_TIMING builds)
 };
 
+// Staging area of the three-kernel pipeline (prep -> jacobi -> finish): per (pair, layer) the Cholesky factor L+,
+// the matrix B = L+^T L- (replaced in place by B' = B V), the row scaling d, the singular values and N.
+struct DevStage {
+    double* L;
+    double* B;
+    double* d;
+    double* sigma;
+    int* n;
+    long long mat_stride;  // doubles per matrix slot (NMAX * LD)
+    int vec_stride;        // doubles per vector slot (NMAX)
+};
+
 constexpr double kCSpeed = 299792458.0;
 constexpr double kPlanck = 6.62607015e-34;
 constexpr double kBoltzmann = 1.380649e-23;
@@ -438,7 +450,7 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
     // N_max x LD buffer (never read by any other stage), loads from them are masked to zero with a select instead
     // of being predicated (per-element exec-mask branches were costing more than the arithmetic).
     double x[RPL], y[RPL];
-    double a = 0.0, bb = 0.0, gg = 0.0;
+    double a = 0.0, bb = 0.0, gg = 0.0, a2 = 0.0, bb2 = 0.0, gg2 = 0.0;  // two accumulators: half the FMA chain
     double* cp = Bm + p * LD;
     double* cq = Bm + q * LD;
 #pragma unroll
@@ -449,8 +461,10 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
         const double xv = cp[r], yv = cq[r];
         x[i] = in ? xv : 0.0;
         y[i] = in ? yv : 0.0;
-        a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i];
+        if (i & 1) { a2 += x[i] * x[i]; bb2 += y[i] * y[i]; gg2 += x[i] * y[i]; }
+        else { a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i]; }
     }
+    a += a2; bb += bb2; gg += gg2;
 #if !defined(SMRT_ABLATE) || SMRT_ABLATE < 2
     a = group_sum<GS>(a); bb = group_sum<GS>(bb); gg = group_sum<GS>(gg);
 #endif
@@ -466,8 +480,8 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
         const double tt = dd * 1e-300;
 #else
         const double hh = dd * dd + 4.0 * g2;
-        const double h = hh * fast_rsqrt(hh);
-        const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp(fabs(dd) + h);
+        const double h = hh * fast_rsqrt1(hh);
+        const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);  // angle only: 1 Newton step
 #endif
 #if defined(SMRT_ABLATE) && SMRT_ABLATE >= 1
         const double c = 0.8 + 1e-300 * tt * 0.0, sn = 0.6 + gg * 1e-300;
@@ -490,7 +504,8 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
 }
 
 template <int NT, int JW, int GS, int RPL>
-SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag, int* n_sweeps) {
+SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* rsig, int* flag, int* n_sweeps,
+                              double* sub_acc = nullptr) {
     // JW = wavefronts that take part (the others only meet the workgroup barriers): with few lanes per pair and many
     // rows per lane the fixed per-rotation cost (index math, reductions, rotation parameters) is amortised better
     // than by spreading every pair over more lanes of more wavefronts.
@@ -502,10 +517,17 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
     const int m = (N + NB - 1) / NB;         // columns per block
     const int me = m + (m & 1);              // even player count of the in-block tournament
     bool converged = false;
+#ifdef SMRT_STAGE_TIMING
+    long long tj0 = cycle_counter();
+#define SMRT_JSUB(k) do { const long long n_ = cycle_counter(); if (t == 0 && sub_acc) sub_acc[k] += (double)(n_ - tj0); tj0 = n_; } while (0)
+#else
+#define SMRT_JSUB(k) do {} while (0)
+#endif
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         block_sync();  // everyone has read the previous flag
         if (t == 0) *flag = 0;
         block_sync();
+        SMRT_JSUB(5);
         for (int s = 0; s < NB - 1; ++s) {
             if (wave >= JW) { block_sync(); continue; }
             int I, J;
@@ -533,8 +555,9 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
                         const bool valid = (ps < 2 * half) && (a < m) && (b < m) && (p < N) && (q < N);
                         rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, slot, flag);
                     }
-                    wave_sync();
+                    wave_sync_lds();
                 }
+                SMRT_JSUB(3);
             }
             for (int j = 0; j < m; ++j) {
                 for (int ps0 = 0; ps0 < m; ps0 += SLOTS) {  // uniform trip count over the wavefront
@@ -544,9 +567,11 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
                     const bool valid = (ps < m) && (p < N) && (q < N);
                     rotate_pair<GS, RPL>(Bm, LD, N, valid ? p : 0, valid ? q : 0, valid, sub, slot, flag);
                 }
-                wave_sync();
+                wave_sync_lds();
             }
+            SMRT_JSUB(3);
             block_sync();
+            SMRT_JSUB(4);
         }
         converged = (*flag == 0);
 #ifdef SMRT_ABLATE
@@ -1073,8 +1098,12 @@ enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_
 // rows-per-wavefront register blocking of the two "row times matrix" passes
 constexpr int RB = 2;
 
-template <int NT, int CH>
-SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr) {
+// MODE 0: the whole solve in one workgroup (fused).  MODE 1 ("prep"): per layer assemble X+-, factorise, form
+// B = L+^T L- and park L+, B, d in the staging area.  MODE 2 ("finish"): pick up L+, B' (rotated by the Jacobi
+// kernel) and the singular values, build the eigenvectors and run the layer recursion.
+template <int NT, int CH, int MODE = 0>
+SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr,
+                                const DevStage* stg = nullptr) {
     constexpr int P = 2;
     constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;  // wavefronts rotating columns (one per SIMD)
     constexpr int GS = 8;                                             // lanes per Jacobi column pair
@@ -1086,7 +1115,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
 #ifdef SMRT_STAGE_TIMING
-    double sub_acc_store[4] = {0.0, 0.0, 0.0, 0.0};
+    double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     s.sub_acc = sub_acc_store;
 #endif
     const int LD = plan.LD;
@@ -1112,6 +1141,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     // ---- stage 0: layer scalars, azimuth table, Gauss-Legendre sines -------------------------------------
     if (t < 8) s.ints[t] = 0;
     block_sync();
+    if (MODE == 2) {  // a failure recorded by the prep or Jacobi kernel
+        const int prev = b.status[p];
+        if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
+    }
     for (int l = t; l < L; l += NT) {
         cplx ee; double ks, ka, pa, pb; int bad = 0;
         layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
@@ -1165,7 +1198,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
     const int n_air = s.ints[5];
 
-    if (b.want_layer_out) {
+    if (MODE != 1 && b.want_layer_out) {
         double* lo = b.layer_out + p * (long long)b.Lmax * 5;
         for (int l = t; l < b.Lmax; l += NT) {
             const bool in = l < L;
@@ -1174,7 +1207,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
         }
     }
-    if (b.want_stream_out) {
+    if (MODE != 1 && b.want_stream_out) {
         double* so = b.stream_out + p * (long long)(1 + nmax);
         if (t == 0) so[0] = (double)n_air;
         for (int j = t; j < nmax; j += NT) so[1 + j] = (j < n_air) ? s.outmu[j] : 0.0;
@@ -1227,6 +1260,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             }
 
         SMRT_STAGE(SG_ASSEMBLE);
+        if (MODE != 2) {
         // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
         //    (lower triangle by stream blocks; the matrices are symmetric)
         {
@@ -1311,9 +1345,33 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_BTL);
         if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
+        }  // MODE != 2
+        if (MODE == 1) {  // park L+, B, d for the Jacobi and finish kernels
+            const long long item = p * (long long)b.Lmax + l;
+            double* gL = stg->L + item * stg->mat_stride;
+            double* gB = stg->B + item * stg->mat_stride;
+            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; gB[c * LD + r] = s.M2[c * LD + r]; });
+            for (int r = t; r < N; r += NT) stg->d[item * stg->vec_stride + r] = s.d[r];
+            if (t == 0) stg->n[item] = N;
+            block_sync();
+            continue;
+        }
         SMRT_STAGE(SG_JACOBI);
-        if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps)) {
-            fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+        if (MODE == 0) {
+            if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, s.sub_acc)) {
+                fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+            }
+        } else {  // MODE 2: pick up L+, B' = B V, d and the singular values
+            const long long item = p * (long long)b.Lmax + l;
+            const double* gL = stg->L + item * stg->mat_stride;
+            const double* gB = stg->B + item * stg->mat_stride;
+            for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gL[c * LD + r]; s.M2[c * LD + r] = gB[c * LD + r]; });
+            for (int r = t; r < N; r += NT) {
+                s.d[r] = stg->d[item * stg->vec_stride + r];
+                const double sg = stg->sigma[item * stg->vec_stride + r];
+                s.sigma[r] = sg; s.rsig[r] = 1.0 / sg;
+            }
+            block_sync();
         }
         SMRT_STAGE(SG_TRI);
         if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
@@ -1449,6 +1507,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
     }
 
+    if (MODE == 1) {
+        if (t == 0) b.status[p] = ST_OK;
+        return;
+    }
     SMRT_STAGE(SG_OUT);
     // ---- emerging brightness temperature at the air streams, then at the sensor angles ---------------------
     for (int i = t; i < n_air * P; i += NT) {
@@ -1479,8 +1541,55 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
         b.stage_out[p * 16 + 12] = (double)n_sweeps;
         for (int k = 0; k < 3; ++k) b.stage_out[p * 16 + 13 + k] = sub_acc_store[k];
+        b.stage_out[p * 16 + 0] = sub_acc_store[3]; b.stage_out[p * 16 + 1] = sub_acc_store[4]; b.stage_out[p * 16 + 2] = sub_acc_store[5];  // (overrides setup/assemble/cholesky slots in this debug build)
     }
 #endif
+}
+
+// ---- Jacobi kernel of the split pipeline: one (pair, layer) item per workgroup, ONE matrix in LDS, so that four
+// workgroups share a CU and hide each other's dependency latency (the rotation sequence of one matrix is strictly
+// sequential: N-1 steps per sweep).
+struct JacobiPlan { int NMAX, LD, o_sigma, o_rsig, o_int, total; };
+SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
+    JacobiPlan p;
+    p.NMAX = n_max_stream * P;
+    p.LD = p.NMAX | 1;
+    int o = p.NMAX * p.LD;
+    p.o_sigma = o; o += p.NMAX;
+    p.o_rsig = o; o += p.NMAX;
+    p.o_int = o; o += 4;
+    p.total = o;
+    return p;
+}
+
+template <int NT>
+SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
+    constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;
+    constexpr int GS = 8;
+    constexpr int RPL = 8;  // N <= 64
+    const int t = tid();
+    const long long p = item / b.Lmax;
+    const int l = (int)(item % b.Lmax);
+    const long long gp = b.pair_begin + p;
+    const int si = (int)(gp % b.S);
+    if (l >= b.n_layers[si]) return;          // uniform
+    if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
+    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, 2);
+    const int LD = plan.LD;
+    const int N = stg.n[item];
+    double* M = lds;
+    double* sigma = lds + plan.o_sigma;
+    double* rsig = lds + plan.o_rsig;
+    int* ints = (int*)(lds + plan.o_int);
+    double* gB = stg.B + item * stg.mat_stride;
+    for_2d<NT>(N, N, [&](int r, int c) { M[c * LD + r] = gB[c * LD + r]; });
+    if (t == 0) ints[0] = 0;
+    block_sync();
+    int n_sweeps = 0;
+    const bool ok = jacobi_onesided<NT, JW, GS, RPL>(M, N, LD, sigma, rsig, &ints[0], &n_sweeps);
+    if (!ok) { if (t == 0) gmem_max(&b.status[p], ST_EIGEN); return; }
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LD + r]; });
+    for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
 }
 
 }  // namespace smrt

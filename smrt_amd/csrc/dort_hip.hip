@@ -18,6 +18,23 @@ __global__ __launch_bounds__(NT) void dort_passive_kernel(DevBatch b) {
     dort_pair_passive<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
 }
 
+// ---- split pipeline (N <= 64): prep (per pair) -> Jacobi (per pair x layer, 4 workgroups per CU) -> finish (per pair)
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_prep_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_jacobi_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_jacobi_item<NT>(b, st, (long long)blockIdx.x, smrt_lds);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive<NT, 1, 2>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+}
+
 // N > 64 (n_max_stream up to 64 x CH/2): same device functions, work matrices in a per-workgroup global workspace
 // (L2 / Infinity-Cache resident), grid-stride over the pairs so the workspace stays bounded.
 template <int NT, int CH>
@@ -50,7 +67,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn;
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -61,6 +78,10 @@ struct smrt_dort_ctx {
     int64_t n_launch = 0;
     bool timing_pending = false;
     int max_lds = 0;
+    bool split = true;          // three-kernel pipeline on the LDS path (fused single kernel if false)
+    long long chunk_pairs = 0;  // pairs per pipeline pass (bounds the staging area)
+    size_t jacobi_lds = 0;
+    DevStage stage{};
     bool gmem_path = false;
     int gmem_grid = 0;
     long long ws_stride = 0;
@@ -93,7 +114,34 @@ static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
 }
 
 template <int NT>
+static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
+    auto kp = dort_prep_kernel<NT>;
+    auto kj = dort_jacobi_kernel<256>;
+    auto kf = dort_finish_kernel<NT>;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
+    const int out_stride = ctx->out_stride;
+    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
+        DevBatch c = d;
+        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
+        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
+        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
+        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
+        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
+        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
+        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int NT>
 static hipError_t launch_nt(smrt_dort_ctx* ctx, const DevBatch& d) {
+    if (ctx->split && ctx->chunk_pairs > 0) return launch_split<NT>(ctx, d);
     auto kern = dort_passive_kernel<NT, 1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
@@ -143,7 +191,8 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
-                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work};
+                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -152,6 +201,13 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
 }
 
 const char* smrt_dort_last_error(const smrt_dort_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
+    if (!ctx) return -1;
+    ctx->split = (split != 0);
+    ctx->uploaded = false;  // the staging area is sized at upload time
+    return 0;
+}
 
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
     if (!ctx) return -1;
@@ -186,6 +242,25 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * plan.mat_doubles));
     }
     ctx->nmax_rows = plan.NMAX;
+    if (!ctx->gmem_path && ctx->split) {
+        const size_t mat = (size_t)plan.NMAX * plan.LD;
+        const size_t per_pair = (size_t)b->n_layers_max * ((2 * mat + 2 * plan.NMAX) * sizeof(double) + sizeof(int));
+        long long chunk = (long long)(12.0e9 / (double)per_pair);
+        if (chunk < 1) chunk = 1;
+        if (chunk > pair_count) chunk = pair_count;
+        ctx->chunk_pairs = chunk;
+        const size_t items = (size_t)chunk * b->n_layers_max;
+        HIPCHK(ctx->d_stL.reserve(items * mat * sizeof(double)));
+        HIPCHK(ctx->d_stB.reserve(items * mat * sizeof(double)));
+        HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
+        HIPCHK(ctx->d_sts.reserve(items * plan.NMAX * sizeof(double)));
+        HIPCHK(ctx->d_stn.reserve(items * sizeof(int)));
+        ctx->stage.L = (double*)ctx->d_stL.p; ctx->stage.B = (double*)ctx->d_stB.p;
+        ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
+        ctx->stage.n = (int*)ctx->d_stn.p;
+        ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
+        ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, 2).total * sizeof(double);
+    }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
     if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;

@@ -21,6 +21,9 @@ namespace smrt {
 SMRT_DEV int tid() { return emu::tid(); }
 SMRT_DEV void block_sync() { emu::block_barrier(); }
 SMRT_DEV void wave_sync() { emu::wave_barrier(); }
+SMRT_DEV void wave_sync_lds() { emu::wave_barrier(); }
+SMRT_DEV double fast_rcp1(double x) { return 1.0 / x; }
+SMRT_DEV double fast_rsqrt1(double x) { return 1.0 / std::sqrt(x); }
 SMRT_DEV double shfl_xor(double v, int mask) { return emu::shfl_xor(v, mask); }
 SMRT_DEV int shfl_xor(int v, int mask) { return (int)emu::shfl_xor((double)v, mask); }
 SMRT_DEV long long cycle_counter() { return 0; }
@@ -46,6 +49,7 @@ SMRT_DEV double group_sum(double v) {
 }
 SMRT_DEV void lds_or(int* p, int v) { *p |= v; }
 SMRT_DEV void lds_max(int* p, int v) { if (v > *p) *p = v; }
+SMRT_DEV void gmem_max(int* p, int v) { if (v > *p) *p = v; }
 }  // namespace smrt
 
 #else
@@ -62,6 +66,21 @@ SMRT_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"
 SMRT_DEV double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 SMRT_DEV int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 SMRT_DEV long long cycle_counter() { return (long long)clock64(); }
+// Same-wavefront LDS hand-off: the LDS unit processes the DS instructions of one wavefront in issue order, so a
+// load issued after a store of the same wavefront sees it without draining lgkmcnt; only the compiler must not
+// move DS traffic across this point.
+SMRT_DEV void wave_sync_lds() { __builtin_amdgcn_wave_barrier(); }
+// one Newton step (about 1e-13 relative): enough wherever only a rotation ANGLE depends on the value
+SMRT_DEV double fast_rcp1(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+SMRT_DEV double fast_rsqrt1(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-0.5 * x * y, y, 0.5);
+    return __builtin_fma(y, e, y);
+}
 // v_rcp_f64 / v_rsq_f64 seeds refined by two Newton steps (full double accuracy for normal operands; no
 // denormal / inf fix-up, which the callers do not need).  Replaces the ~30-instruction IEEE division sequences
 // that sat on the critical path of every factorisation step.
@@ -149,6 +168,7 @@ SMRT_DEV double group_sum(double v) {
 }
 SMRT_DEV void lds_or(int* p, int v) { atomicOr(p, v); }
 SMRT_DEV void lds_max(int* p, int v) { atomicMax(p, v); }
+SMRT_DEV void gmem_max(int* p, int v) { atomicMax(p, v); }
 }  // namespace smrt
 
 #endif
