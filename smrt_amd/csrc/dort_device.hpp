@@ -89,7 +89,7 @@ struct LdsPlan {
     int o_phi;      // 3 vectors of nphi
     int o_tb;       // NMAX
     int o_int;      // 16 ints (8 doubles)
-    int o_gj;       // blocked Gauss-Jordan scratch: 12 * NMAX + 8 doubles, then (NMAX + 8) ints
+    int o_gj;       // scratch of the blocked solvers: max(12 * NMAX, 1024) + 8 doubles, then (NMAX + 8) ints
     int total;      // doubles
 };
 
@@ -118,7 +118,7 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_phi = o; o += 3 * nphi;
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
-    p.o_gj = o; o += 12 * p.NMAX + 8 + (p.NMAX + 8 + 1) / 2;
+    p.o_gj = o; o += ((12 * p.NMAX + 8 > 1024 + 8) ? 12 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
     p.total = o;
     return p;
 }
@@ -895,6 +895,191 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
     block_sync();
 }
 
+// ---- blocked Cholesky of two SPD matrices side by side on the matrix core (N <= 64) --------------------------
+// Right-looking with 16-column blocks: the 16x16 diagonal block is factorised (and its inverse formed) by one
+// wavefront per matrix with lane = row and the row in registers; the panel below (L_IJ = A_IJ inv(L_JJ)^T) and the
+// trailing update (A_IK -= L_IJ L_KJ^T) are MFMA tile GEMMs.  3 workgroup barriers per block column (12 for N = 64)
+// instead of one per column, and the O(N^3) part runs on the matrix core.
+template <int NT>
+SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int* fail, int N, int LD) {
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    constexpr int NW = NT / SMRT_LANES;
+    const int RT = (N + 15) >> 4;
+    if (t == 0) *fail = 0;
+    block_sync();
+    for (int J = 0; J < RT; ++J) {
+        const int b0 = J * 16;
+        // (a) diagonal block: L_JJ and its inverse
+        for (int mi = wave; mi < 2; mi += NW) {
+            double* A = mi ? A1 : A0;
+            double row[16];
+            const int gi = b0 + lr;                      // lanes 16..63 mirror lanes 0..15 (harmless duplicates)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int gj = b0 + j;
+                const int gic = gi < N ? gi : N - 1, gjc = gj < N ? gj : N - 1;
+                const double v = A[gjc * LD + gic];
+                row[j] = (gi < N && gj < N) ? v : ((lr == j) ? 1.0 : 0.0);   // identity padding
+            }
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double akk = wave_bcast(row[k], k);
+                if (!(akk > 0.0)) ok = false;
+                const double rk = fast_rsqrt(ok ? akk : 1.0);
+                const double lik = row[k] * rk;             // L[i][k] for i >= k (lane k: sqrt(akk))
+                row[k] = lik;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j > k) { const double ljk = wave_bcast(lik, j); row[j] -= lik * ljk; }
+            }
+            if (!ok && lane == 0) *fail = 1;
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int gj = b0 + j;
+                    if (gi < N && gj < N && j <= lr) A[gj * LD + gi] = row[j];
+                }
+            }
+            // inverse of L_JJ by forward substitution, lane = column of the inverse; L[i][k] = row[k] of lane i
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double acc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < i) { const double lik2 = wave_bcast(row[k], i); acc -= lik2 * ((k >= lr) ? x[k] : 0.0); }
+                const double dii = wave_bcast(row[i], i);
+                x[i] = (i >= lr) ? acc * fast_rcp(dii) : 0.0;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) inv[mi * 256 + lr * 16 + i] = x[i];   // (L^-1)[i][j = lr]
+            }
+        }
+        block_sync();
+        if (*fail) return false;  // uniform
+        // (b) panel below the diagonal block: L_IJ = A_IJ inv(L_JJ)^T
+        {
+            const int nt_ = 2 * (RT - 1 - J);
+            for (int tix = wave; tix < nt_; tix += NW) {
+                const int mi = tix & 1, I = J + 1 + (tix >> 1);
+                double* A = mi ? A1 : A0;
+                double c[4] = {0.0, 0.0, 0.0, 0.0};
+                const int i = I * 16 + lr, ic = i < N ? i : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + lk, gk = b0 + k, gkc = gk < N ? gk : N - 1;
+                    const double av = A[gkc * LD + ic];
+                    const double bv = inv[mi * 256 + k * 16 + lr];          // (L^-1)[lr][k] = invT[k][lr]
+                    mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, bv, c);
+                }
+                tile_foreach(I, J, N, [&](int reg, int row_, int col) { A[col * LD + row_] = c[reg]; });
+            }
+        }
+        block_sync();
+        // (c) trailing update A_IK -= L_IJ L_KJ^T, I >= K > J
+        {
+            const int nb = RT - 1 - J;
+            const int ntri = nb * (nb + 1) / 2;
+            for (int tix = wave; tix < 2 * ntri; tix += NW) {
+                const int mi = tix & 1;
+                int q = tix >> 1, Ir = 0;
+                while ((Ir + 1) * (Ir + 2) / 2 <= q) ++Ir;
+                const int Kr = q - Ir * (Ir + 1) / 2;
+                const int I = J + 1 + Ir, K = J + 1 + Kr;
+                double* A = mi ? A1 : A0;
+                double c[4] = {0.0, 0.0, 0.0, 0.0};
+                const int i = I * 16 + lr, ic = i < N ? i : N - 1;
+                const int j = K * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int gk = b0 + 4 * kk + lk, gkc = gk < N ? gk : N - 1;
+                    const double av = A[gkc * LD + ic], bv = A[gkc * LD + jc];
+                    mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, (j < N && gk < N) ? bv : 0.0, c);
+                }
+                tile_foreach(I, K, N, [&](int reg, int row_, int col) { A[col * LD + row_] -= c[reg]; });
+            }
+        }
+        block_sync();
+    }
+    return true;
+}
+
+// ---- blocked triangular solve on the matrix core: Bm <- Lp^-T Bm  (N <= 64) ---------------------------------
+// The (up to four) 16x16 diagonal blocks of Lp are inverted once (one wavefront per block, lane = column of the
+// inverse, forward substitution); then, block row by block row from the bottom,
+//   X_I = inv(L_II)^T (B_I - sum_{J>I} L_JI^T X_J)
+// is two MFMA GEMMs per 16x16 tile -- the accumulator layout of the first is exactly the B-operand layout of the
+// second (c[reg] = R[lk + 4 reg][lr] = B[k = 4 kk + lk][j = lr] for kk = reg), so nothing moves between them.
+template <int NT>
+SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*16] */, int N, int LD) {
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    constexpr int NW = NT / SMRT_LANES;
+    const int RT = (N + 15) >> 4;
+    // inverse of the diagonal blocks: inv[I][j*16 + i] = (L_II^-1)[i][j]  (identity padding beyond N).
+    // lane (mod 16) = row i of the block with the row in registers; entries of other rows come by wave_bcast
+    // (loading the block through broadcast LDS reads made the compiler hoist all 136 loads into registers).
+    for (int I = wave; I < RT; I += NW) {
+        const int b0 = I * 16, gi = b0 + lr;
+        double row[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int gk = b0 + k;
+            const int gic = gi < N ? gi : N - 1, gkc = gk < N ? gk : N - 1;
+            const double v = Lp[gkc * LD + gic];
+            row[k] = (gi < N && gk < N && k <= lr) ? v : ((k == lr) ? 1.0 : 0.0);
+        }
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double acc = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < i) { const double lik = wave_bcast(row[k], i); acc -= lik * ((k >= lr) ? x[k] : 0.0); }
+            const double dii = wave_bcast(row[i], i);
+            x[i] = (i >= lr) ? acc * fast_rcp(dii) : 0.0;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) inv[I * 256 + lr * 16 + i] = x[i];
+        }
+    }
+    block_sync();
+    for (int I = RT - 1; I >= 0; --I) {
+        for (int tj = wave; tj < RT; tj += NW) {
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
+            const int i = I * 16 + lr, j = tj * 16 + lr;
+            const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+            // acc = sum_{k in later blocks} L[k][i] X[k][j]
+            for (int k0 = (I + 1) * 16; k0 < N; k0 += 4) {
+                const int k = k0 + lk, kc = k < N ? k : N - 1;
+                const double av = Lp[ic * LD + kc], bv = Bm[jc * LD + kc];
+                mfma_f64_16x16x4((i < N && k < N) ? av : 0.0, (j < N && k < N) ? bv : 0.0, c);
+            }
+            // R = B_I - acc in accumulator layout
+            double r[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = I * 16 + lk + 4 * reg;
+                const int rowc = row < N ? row : N - 1;
+                const double bv = Bm[jc * LD + rowc];
+                r[reg] = ((row < N && j < N) ? bv : 0.0) - c[reg];
+            }
+            // X = inv(L_II)^T R : A[i][k] = inv[k][i]
+            double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + lk;                          // row of inv(L_II)
+                const double av = inv[I * 256 + lr * 16 + k];       // (L_II^-1)[k][lr]
+                mfma_f64_16x16x4(av, r[kk], x);
+            }
+            tile_foreach(I, tj, N, [&](int reg, int row, int col) { Bm[col * LD + row] = x[reg]; });
+        }
+        block_sync();
+    }
+}
+
 // Blocked Gauss-Jordan with implicit partial pivoting and rank-4 trailing updates on the FP64 matrix core
 // (N <= 64).  Per block of four columns:
 //   panel   (wavefront 0, lane = row, the four panel entries of the row in registers): four pivot rows by
@@ -1341,7 +1526,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         });
         block_sync();
         SMRT_STAGE(SG_CHOL);
-        if (!chol2<NT>(s.M0, s.M1, N, LD)) { fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return; }
+        if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD) : chol2<NT>(s.M0, s.M1, N, LD))) {
+            fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
+        }
         SMRT_STAGE(SG_BTL);
         if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
@@ -1376,7 +1563,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_TRI);
         if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
         else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
-        lt_solve<NT>(s.M0, s.M2, N, LD);                               // Ep' = L+^-T B'
+        if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
+        else lt_solve<NT>(s.M0, s.M2, N, LD);
         // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
         for_2d<NT>(N, N, [&](int i, int c) {
             const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];
