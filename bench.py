@@ -169,6 +169,14 @@ def main():
     kernel_ms = kernel_ms_total / max(n_launch, 1)
     achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):  # PMC counters cannot be collected from inside this process: measured with
+        with open(tpath) as fh:  # tools/pmc_passes.sh on the same command, summary committed under profiles/
+            tj = json.load(fh)
+        if tj.get("solves_per_launch") == n_pairs:
+            traffic = tj["traffic_bytes_per_launch"]
+
     if rank == 0:
         line = {
             "metric": "snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
@@ -197,13 +205,16 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_PEAK_TFLOPS,
-                "traffic": None,
-                "kernel": "dort_passive_kernel",
+                "traffic": traffic,
+                "traffic_unit": "bytes per pipeline launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_kernel (one launch each per "
+                          "step; kernel_ms is their summed HIP-event time on the launch stream)",
                 "kernel_ms": kernel_ms,
                 "flops_per_launch": flops_per_launch,
-                "note": "FP64 compute roofline (vector FMA rate = FP64 MFMA rate on gfx950); algorithmic flops = "
-                        "68 * sum over pairs and layers of N_l^3 with the actual stream counts (SURVEY 8d); "
-                        "algorithmic HBM bytes are ~1.6 KB per solve, i.e. the path is not HBM-bound",
+                "note": "FP64 compute roofline (vector FMA rate = FP64 MFMA rate on gfx950, 78.6 TFLOP/s); algorithmic "
+                        "flops = 68 * sum over pairs and layers of N_l^3 with the actual stream counts (SURVEY 8d); "
+                        "algorithmic HBM bytes are ~1.6 KB per solve; the pipeline additionally stages ~67 KB per "
+                        "(pair, layer) through HBM/L2 between its kernels (see DESIGN.md 4), still far from HBM-bound",
             },
         }
         if not args.no_cpu_baseline:
