@@ -1905,12 +1905,19 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
 // ---- Jacobi kernel of the split pipeline: one (pair, layer) item per workgroup, ONE matrix in LDS, so that four
 // workgroups share a CU and hide each other's dependency latency (the rotation sequence of one matrix is strictly
 // sequential: N-1 steps per sweep).
-struct JacobiPlan { int NMAX, LD, o_sigma, o_rsig, o_int, total; };
+// LDJ: leading dimension of the LDS matrix inside the Jacobi kernel, == 8 (mod 32) eight-byte slots: the column
+// pairs a 32-lane group rotates together are ADJACENT columns (8 lanes each), so consecutive columns must start 8
+// bank slots apart to be conflict-free (with the odd LD of the other kernels they overlapped: 41 % of the LDS cycles
+// of this kernel were bank conflicts, profiles/r1f_pmc_counters.txt).
+struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
 SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     JacobiPlan p;
     p.NMAX = n_max_stream * P;
-    p.LD = p.NMAX | 1;
-    int o = (p.NMAX + 9) * p.LD;   // up to NB*ceil(N/NB) + 1 <= NMAX + 8 padded columns
+    p.LD = p.NMAX | 1;                                  // layout of the staged matrices in global memory
+    const int rows = ((p.NMAX + 7) / 8) * 8;            // padded rows (RPL * GS)
+    p.LDJ = ((rows + 31) / 32) * 32 + 8;
+    p.NCOL = ((p.NMAX + 7) / 8) * 8 + 1;                // NB*ceil(N/NB) <= this - 1, plus the idle-slot column
+    int o = p.NCOL * p.LDJ;
     p.o_sigma = o; o += p.NMAX + 16;
     p.o_rsig = o; o += p.NMAX + 16; // tracked column norms (padded columns included)
     p.o_int = o; o += 4;
@@ -1931,7 +1938,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     if (l >= b.n_layers[si]) return;          // uniform
     if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
     const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, 2);
-    const int LD = plan.LD;
+    const int LD = plan.LD, LDJ = plan.LDJ;
     const int N = stg.n[item];
     double* M = lds;
     double* sigma = lds + plan.o_sigma;
@@ -1942,12 +1949,12 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     // slot column CP itself)
     const int m = (N + NB - 1) / NB;
     const int CP = NB * m;
-    for_2d<NT>(RPL * GS, CP + 1, [&](int r, int c) { M[c * LD + r] = (r < N && c < N) ? gB[c * LD + r] : 0.0; });
+    for_2d<NT>(RPL * GS, CP + 1, [&](int r, int c) { M[c * LDJ + r] = (r < N && c < N) ? gB[c * LD + r] : 0.0; });
     if (t == 0) ints[0] = 0;
     block_sync();
-    const bool ok = jacobi_padded<NT, JW, GS, RPL>(M, N, LD, sigma, nrm, &ints[0]);
+    const bool ok = jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0]);
     if (!ok) { if (t == 0) gmem_max(&b.status[p], ST_EIGEN); return; }
-    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LD + r]; });
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
     for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
 }
 
