@@ -1108,15 +1108,17 @@ SMRT_DEV bool gj_panel(double* A, int N, int LD, int k0, int lane, bool& used, d
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nbk) {
-            unsigned long long key = 0ull;
+            // pivot: arg-max over the unused rows of a 32-bit key = float magnitude bits with the row index in the
+            // 7 low mantissa bits (exactness of the choice is irrelevant; an all-zero column gives key < 128)
+            unsigned key = 0u;
             if (lane < N && !used) {
-                const double xr = fabs(a[j]);
-                memcpy(&key, &xr, 8);
-                key = (key & ~0x7Full) | (unsigned long long)(127 - lane);
+                const float xr = (float)fabs(a[j]);
+                memcpy(&key, &xr, 4);
+                key = (key & ~0x7Fu) | (unsigned)(127 - lane);
             }
-            key = wave_max_u64(key);
-            if (key < 128ull) ok = false;
-            const int p = ok ? 127 - (int)(key & 0x7Full) : 0;
+            key = wave_max_u32(key);
+            if (key < 128u) ok = false;
+            const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
             prow[j] = p;
             const bool isp = (lane == p);
             const double rpv = fast_rcp(ok ? wave_bcast(a[j], p) : 1.0);

@@ -37,6 +37,13 @@ SMRT_DEV unsigned long long wave_max_u64(unsigned long long k) {
     }
     return k;
 }
+SMRT_DEV unsigned wave_max_u32(unsigned k) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned o = (unsigned)emu::shfl_xor((double)k, m);
+        if (o > k) k = o;
+    }
+    return k;
+}
 SMRT_DEV double wave_bcast(double v, int src_lane) { return emu::wave_bcast(v, src_lane); }
 SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f64_16x16x4(a, b, c); }
 SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
@@ -152,6 +159,18 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
     smrt_v4d cv = {c[0], c[1], c[2], c[3]};
     cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cv, 0, 0, 0);
     c[0] = cv[0]; c[1] = cv[1]; c[2] = cv[2]; c[3] = cv[3];
+}
+// max of a 32-bit key over the wavefront (one v_max_u32 per DPP step, four readlanes for the 16-lane rows)
+SMRT_DEV unsigned wave_max_u32(unsigned k) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)k, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)k, 16),
+                   r2 = (unsigned)__builtin_amdgcn_readlane((int)k, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)k, 48);
+    const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
 }
 // Sum over aligned groups of GS consecutive lanes; every lane gets the group total.  quad_perm swaps inside a
 // quad, row_half_mirror / row_mirror reach the other quad / the other half of a 16-lane row (the source lane
