@@ -444,6 +444,12 @@ SMRT_DEV void lt_times_l(const double* Lp, const double* Lm, double* C, int N, i
 #ifndef SMRT_JACOBI_EXIT_COS2
 #define SMRT_JACOBI_EXIT_COS2 1e-15
 #endif
+// rotations between columns whose cosine is already below 1e-13 are skipped in the split-pipeline kernel: they
+// cannot change the result at the 1e-9 relative level of the parity requirement (1e-6 K), and in the last sweeps
+// most pairs are in that state (saves the update + store half of the step)
+#ifndef SMRT_JACOBI_SKIP_COS2
+#define SMRT_JACOBI_SKIP_COS2 1e-26
+#endif
 template <int GS, int RPL>
 SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, int sub, int slot, int* flag) {
     // Branch-free: every lane always loads and stores its RPL rows.  Rows >= N of a column are padding inside the
@@ -1761,7 +1767,7 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
     const double a = nrm[p], bb = nrm[q];
     gg = group_sum<GS>(gg + gg2);
     const double g2 = gg * gg, ab = a * bb;
-    if (g2 > 1e-30 * ab) {
+    if (g2 > SMRT_JACOBI_SKIP_COS2 * ab) {
         const double dd = bb - a;
         const double hh = dd * dd + 4.0 * g2;
         const double h = hh * fast_rsqrt1(hh);
@@ -1862,7 +1868,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                     const double bb = nrm[qc];
                     gg = group_sum<GS>(gg + gg2);
                     const double g2 = gg * gg, ab = a * bb;
-                    if (g2 > 1e-30 * ab) {
+                    if (g2 > SMRT_JACOBI_SKIP_COS2 * ab) {
                         const double dd = bb - a;
                         const double hh = dd * dd + 4.0 * g2;
                         const double h = hh * fast_rsqrt1(hh);
