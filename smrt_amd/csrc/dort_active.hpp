@@ -1,0 +1,427 @@
+// DORT hot path, ACTIVE mode (backscatter): device code (gfx950 / CDNA4), one workgroup per (snowpack, frequency).
+//
+// What is computed (paths relative to /root/reference):
+//   azimuth modes m = 0..m_max        smrt/rtsolver/dort.py:209-261 (mode loop, coherent subtraction, cos/sin(m phi))
+//   incident streams / intensity_0    smrt/rtsolver/dort.py:210-239 (two bracketing streams per incidence angle,
+//                                     power 1/(2 pi outweight), x2 for m > 0)
+//   phase matrix modes, 3 pols        smrt/emmodel/common.py:9-131 (IBA: discrete Fourier sums over 2^k azimuths),
+//                                     smrt/emmodel/rayleigh.py:52-127 (DMRT: closed forms m = 0, 1, 2)
+//   third Stokes component            smrt/rtsolver/dort.py:716-737 (U extinction / normalisation), :925-953 (half-rank
+//                                     reduction with the sign flip of the U columns of beta and the U rows of Ed),
+//                                     smrt/core/fresnel.py:417-474 (R_U, T_U)
+//   interpolation                     smrt/rtsolver/rtsolver_utils.py:199-239 (active branch)
+//
+// Design.  For m >= 1 the reduced matrices alpha -/+ beta D are NOT symmetrisable by the mode-0 scaling alone: the
+// (V|H, U) cross blocks of the phase matrix obey P_(U,x)(mu_i, mu_j) = 2 P_(x,U)(mu_j, mu_i).  Scaling the U
+// component by sqrt(2) on top of sqrt(norm w / mu) removes the factor: X+ and X- are then exactly symmetric and
+// (for albedo < 1) positive definite, so every mode runs through the same Cholesky x 2 -> one-sided Jacobi ->
+// triangular recovery pipeline as the passive solve -- no general non-symmetric eigensolver is needed.
+// There are no thermal sources in active mode: the layer recursion carries only the reflection matrix, and the
+// answer is read off the top-level reflection matrix K_0 at the incident streams (backscatter: scattered stream ==
+// incident stream).  The coherent (no-scattering) solution is diagonal and is a per-stream scalar recursion.
+#pragma once
+#include "dort_device.hpp"
+
+namespace smrt {
+
+// Flat interface, Maezawa & Miyauchi 2009 Fresnel (core/fresnel.py:99-146): power R and T for V, H and the
+// coherency term U (fresnel.py:417-474).
+SMRT_DEV void fresnel_RT3(cplx e1, cplx e2, double mu1, double* R3, double* T3) {
+    cplx n1 = csqrt_(e1);
+    double kz2 = n1.re * n1.re * (1.0 - mu1 * mu1);
+    cplx kyi = cscale(csqrt_(cmk(e1.re - kz2, e1.im)), -1.0);
+    cplx kyt = cscale(csqrt_(cmk(e2.re - kz2, e2.im)), -1.0);
+    cplx rh = cdiv(csub(kyi, kyt), cadd(cconj(kyi), kyt));
+    cplx num = cmul(cconj(n1), csub(cmul(e2, kyi), cmul(e1, kyt)));
+    cplx den = cmul(n1, cadd(cmul(e2, cconj(kyi)), cmul(cconj(e1), kyt)));
+    cplx rv = cdiv(num, den);
+    R3[0] = cabs2(rv);
+    R3[1] = cabs2(rh);
+    R3[2] = rv.re * rh.re + rv.im * rh.im;
+    T3[0] = 1.0 - R3[0];
+    T3[1] = 1.0 - R3[1];
+    const double mu2 = -kyt.re / csqrt_(e2).re;
+    T3[2] = mu2 / mu1 * ((1.0 + rv.re) * (1.0 + rh.re) + rv.im * rh.im);
+}
+
+template <int NT, int CH>
+SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr) {
+    constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;
+    constexpr int GS = 8;
+    constexpr int RPL = (64 * CH + GS - 1) / GS;
+    const int t = tid();
+    const int m_max = b.m_max;
+    const int nsamp = azimuth_samples(m_max);
+    const int nphi = nsamp / 2 + 1;
+    const int nmax = b.n_max_stream;
+    const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
+                                   active_doubles(nmax, b.Lmax, b.n_theta));
+    Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+    const int LD = plan.LD;
+    const int out_stride = 9 * b.n_theta;
+    const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
+    double* norm0 = s.act;                        // [Lmax][2 nmax]
+    double* total = norm0 + 2 * nmax * b.Lmax;    // [9][NI]
+    double* coh = total + 9 * NI;                 // [2][NI]
+    int* inc = (int*)(coh + 2 * NI);              // [NI], then the count
+    double* dsg = s.g;                            // row signs of the down-going eigenvectors
+    double* su = s.upb;                           // sqrt(2) on the U rows
+
+    const long long gp = b.pair_begin + p;
+    const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
+    const double frequency = b.frequency[fi];
+    const int L = b.n_layers[si];
+    const double* thickness = b.thickness + (long long)si * b.Lmax;
+    const double* fracvol = b.frac_volume + (long long)si * b.Lmax;
+    const double* temperature = b.temperature + (long long)si * b.Lmax;
+    const double* mp1 = b.p1 + (long long)si * b.Lmax;
+    const double* mp2 = b.p2 + (long long)si * b.Lmax;
+
+    if (t < 8) s.ints[t] = 0;
+    block_sync();
+    for (int k = t; k < nphi; k += NT) {
+        const double ph = kPi * (double)k / (double)(nphi - 1);
+        s.cphi[k] = cos(ph); s.sphi[k] = sin(ph);
+    }
+    {
+        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2);
+        if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
+    }
+    const int n_air = s.ints[5];
+    if (b.want_layer_out) {
+        double* lo = b.layer_out + p * (long long)b.Lmax * 5;
+        for (int l = t; l < b.Lmax; l += NT) {
+            const bool in = l < L;
+            lo[l * 5 + 0] = in ? s.eps_re[l] : 0.0; lo[l * 5 + 1] = in ? s.eps_im[l] : 0.0;
+            lo[l * 5 + 2] = in ? s.ks[l] : 0.0; lo[l * 5 + 3] = in ? s.ka[l] : 0.0;
+            lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
+        }
+    }
+    if (b.want_stream_out) {
+        double* so = b.stream_out + p * (long long)(1 + nmax);
+        if (t == 0) so[0] = (double)n_air;
+        for (int j = t; j < nmax; j += NT) so[1 + j] = (j < n_air) ? s.outmu[j] : 0.0;
+    }
+
+    // ---- incident streams: the two streams bracketing every incidence angle (dort.py:210-226), sorted, unique ----
+    if (t == 0) {
+        int cnt = 0;
+        for (int it = 0; it < b.n_theta; ++it) {
+            const double mi = cos(b.theta[it]);
+            int i0 = 0;
+            while (i0 < n_air && s.outmu[i0] > mi) ++i0;  // np.searchsorted(-outmu, -mu_inc)
+            int cand[2], nc = 0;
+            if (i0 == 0) cand[nc++] = 0;
+            else if (i0 == n_air) cand[nc++] = n_air - 1;
+            else { cand[nc++] = i0 - 1; cand[nc++] = i0; }
+            for (int q = 0; q < nc; ++q) {
+                int pos = 0;
+                while (pos < cnt && inc[pos] < cand[q]) ++pos;
+                if (pos < cnt && inc[pos] == cand[q]) continue;
+                for (int z = cnt; z > pos; --z) inc[z] = inc[z - 1];
+                inc[pos] = cand[q];
+                ++cnt;
+            }
+        }
+        inc[NI] = cnt;
+    }
+    for (int k = t; k < 9 * NI; k += NT) total[k] = 0.0;
+    block_sync();
+    const int ninc = inc[NI];
+
+    // ---- coherent (no scattering) mode-0 solution: diagonal, one thread per (incident stream, V|H) -------------
+    for (int idx = t; idx < 2 * ninc; idx += NT) {
+        const int jn = idx >> 1, pol = idx & 1;
+        const int j = inc[jn];
+        double Rt = 0.0, K = 0.0, Ttop0 = 0.0;
+        for (int l = L - 1; l >= 0; --l) {
+            const int n = (int)s.nl[l];
+            const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
+            const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
+            K = 0.0;
+            double Tt = 0.0;
+            if (j < n) {
+                const double rs = s.ri[l] * s.gsin[j];
+                const double mu = sqrt(1.0 - rs * rs);
+                double R3[3], T3[3];
+                fresnel_RT3(el, eup, mu, R3, T3);
+                const double tt = exp(-(s.ks[l] + s.ka[l]) * s.thick[l] / mu);
+                const double y = tt * tt * Rt;
+                K = y / (1.0 - R3[pol] * y);
+                Tt = T3[pol];
+            }
+            if (l > 0) {
+                const int nu = (int)s.nl[l - 1];
+                if (j < nu) {
+                    const double rs = s.ri[l - 1] * s.gsin[j];
+                    const double muu = sqrt(1.0 - rs * rs);
+                    double R3[3], T3[3];
+                    fresnel_RT3(eup, el, muu, R3, T3);
+                    Rt = R3[pol] + Tt * K * T3[pol];
+                } else Rt = 0.0;
+            } else Ttop0 = Tt;
+        }
+        double Ra[3], Ta[3];
+        fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta);
+        coh[pol * NI + jn] = Ra[pol] + Ttop0 * K * Ta[pol];
+    }
+    block_sync();
+
+    double n3 = 0.0;
+    int n_sweeps = 0;
+    for (int m = 0; m <= m_max; ++m) {
+        const int P = (m == 0) ? 2 : 3;
+        const double cc = (m == 0) ? 0.5 : 0.25;  // dort.py:716-721
+        // azimuth weights of this mode: cosine sums for the even entries, sine sums for the (V|H, U) cross entries
+        for (int k = t; k < nphi; k += NT) {
+            const double ph = kPi * (double)k / (double)(nphi - 1);
+            const bool end = (k == 0 || k == nphi - 1);
+            const double base = ((m == 0) ? 1.0 : 2.0) / (double)nsamp;
+            s.wphi[k] = base * (end ? 1.0 : 2.0) * cos((double)m * ph);
+            s.swphi[k] = end ? 0.0 : base * 2.0 * sin((double)m * ph);
+        }
+        block_sync();
+        for (int l = L - 1; l >= 0; --l) {
+            const int n = (int)s.nl[l];
+            const int N = n * P;
+            n3 += (double)N * N * N;
+            const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
+            const double ks = s.ks[l], ke = s.ks[l] + s.ka[l];
+            const int nu = (l > 0) ? (int)s.nl[l - 1] : 0;
+            const int Nu = nu * P;
+
+            for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
+            if (l > 0)
+                for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
+            if (l == L - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
+            for (int r = t; r < N; r += NT) { s.svec[r] = 0.0; s.tq[r] = 0.0; }
+            block_sync();
+            for (int j = t; j < n; j += NT) {
+                double w;
+                if (j == 0) w = 1.0 - 0.5 * (s.mu[0] + s.mu[1]);
+                else if (j == n - 1) w = fabs(0.5 * (s.mu[n - 2] + s.mu[n - 1]));
+                else w = fabs(0.5 * (s.mu[j - 1] - s.mu[j + 1]));
+                s.w[j] = w;
+                double R3[3], T3[3];
+                const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
+                fresnel_RT3(el, eup, s.mu[j], R3, T3);
+                for (int q = 0; q < P; ++q) {
+                    const int r = P * j + q;
+                    s.mrow[r] = s.mu[j]; s.wrow[r] = w;
+                    s.Rtop[r] = R3[q]; s.Ttop[r] = T3[q];
+                    dsg[r] = (q == 2) ? -1.0 : 1.0;
+                    su[r] = (q == 2) ? 1.4142135623730951 : 1.0;
+                }
+            }
+            if (l > 0)
+                for (int j = t; j < nu; j += NT) {
+                    double R3[3], T3[3];
+                    fresnel_RT3(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], R3, T3);
+                    for (int q = 0; q < P; ++q) { s.Rbu[P * j + q] = R3[q]; s.Tbu[P * j + q] = T3[q]; }
+                }
+
+            // -- phase matrix of mode m: S+ = P(mu,+mu') + P(mu,-mu') D -> M0, S- = P(+) - P(-) D -> M1, lower
+            //    triangle (rows = scattered stream/polarisation, columns = incident); D = -1 on the U columns
+            {
+                const int T = n * (n + 1) / 2;
+                const double pa = s.pa[l], pb = s.pb[l];
+                const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+                for (int idx = t; idx < T; idx += NT) {
+                    int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+                    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                    while (i * (i + 1) / 2 > idx) --i;
+                    const int j = idx - i * (i + 1) / 2;
+                    const double mi = s.mu[i], mj = s.mu[j];
+                    const double sis = sqrt(1.0 - mi * mi), sjs = sqrt(1.0 - mj * mj);
+                    double pp[3][3], pm[3][3];
+                    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pp[a][c] = 0.0; pm[a][c] = 0.0; }
+                    if (b.emmodel == EM_DMRT) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
+                        for (int sgn = 0; sgn < 2; ++sgn) {
+                            const double x = sgn ? -mj : mj;
+                            double (&q)[3][3] = sgn ? pm : pp;
+                            const double a2 = mi * mi, x2 = x * x;
+                            if (m == 0) {
+                                q[0][0] = pa * (0.5 * a2 * x2 + (1.0 - a2) * (1.0 - x2));
+                                q[0][1] = pa * 0.5 * a2; q[1][0] = pa * 0.5 * x2; q[1][1] = pa * 0.5;
+                            } else if (m == 1) {
+                                const double cs = mi * sis, ci = x * sjs;
+                                q[0][0] = pa * 2.0 * cs * ci;
+                                q[0][2] = -pa * cs * sjs;
+                                q[2][0] = -pa * 2.0 * sis * ci;
+                                q[2][2] = pa * sis * sjs;
+                            } else if (m == 2) {
+                                q[0][0] = pa * 0.5 * a2 * x2; q[0][1] = -pa * 0.5 * a2;
+                                q[1][0] = -pa * 0.5 * x2; q[1][1] = pa * 0.5;
+                                q[0][2] = -pa * 0.5 * a2 * x; q[1][2] = pa * 0.5 * x;
+                                q[2][0] = -pa * mi * x2; q[2][1] = pa * mi; q[2][2] = pa * mi * x;
+                            }
+                        }
+                    } else {
+                        const double sisj = sis * sjs, mm = mi * mj;
+                        for (int k = 0; k < nphi; ++k) {
+                            const double c = s.cphi[k], sn = s.sphi[k], cw = s.wphi[k], sw = s.swphi[k];
+                            for (int sgn = 0; sgn < 2; ++sgn) {
+                                const double x = sgn ? -mj : mj;
+                                double (&q)[3][3] = sgn ? pm : pp;
+                                double ct = (sgn ? -mm : mm) + sisj * c;  // cosine of the scattering angle
+                                ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
+                                double C;
+                                if (b.micro == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
+                                else C = pa * ft_corr(MS_SHS, pb * (1.0 - ct), fv, q1, q2);
+                                const double fvv = c * mi * x + sisj, fvh = sn * mi, fhv = -sn * x, fhh = c;
+                                const double Cc = C * cw, Cs = C * sw;
+                                q[0][0] += fvv * fvv * Cc; q[0][1] += fvh * fvh * Cc;
+                                q[1][0] += fhv * fhv * Cc; q[1][1] += fhh * fhh * Cc;
+                                if (P == 3) {
+                                    q[2][2] += (fvv * fhh + fvh * fhv) * Cc;
+                                    q[0][2] -= fvh * fvv * Cs; q[1][2] -= fhh * fhv * Cs;
+                                    q[2][0] += 2.0 * fvv * fhv * Cs; q[2][1] += 2.0 * fvh * fhh * Cs;
+                                }
+                            }
+                        }
+                    }
+                    for (int a = 0; a < P; ++a)
+                        for (int c = 0; c < P; ++c) {
+                            if (i == j && a < c) continue;  // above the diagonal
+                            const double dm = (c == 2) ? -pm[a][c] : pm[a][c];
+                            s.M0[(P * j + c) * LD + P * i + a] = pp[a][c] + dm;
+                            s.M1[(P * j + c) * LD + P * i + a] = pp[a][c] - dm;
+                        }
+                }
+            }
+            block_sync();
+            // -- renormalisation (dort.py:782-819): mode 0 fixes norm_r = ks / (c sum_c S+[r,c] w_c); the higher modes
+            //    reuse it, with sqrt(norm_V norm_H) on the U rows (dort.py:728-737)
+            for (int r = t; r < N; r += NT) {
+                double nr = 1.0;
+                if (m == 0) {
+                    double rs = 0.0;
+                    for (int c = 0; c <= r; ++c) rs += s.M0[c * LD + r] * s.wrow[c];
+                    for (int c = r + 1; c < N; ++c) rs += s.M0[r * LD + c] * s.wrow[c];
+                    if (b.normalization != 0 && ks != 0.0) {
+                        nr = ks / (0.5 * rs);
+                        if (b.normalization == 1 && !(fabs(nr - 1.0) <= 0.3)) lds_max(&s.ints[0], ST_NORM);
+                    }
+                    norm0[l * 2 * nmax + r] = nr;
+                } else {
+                    const int j = r / 3, q = r - 3 * j;
+                    const double nv = norm0[l * 2 * nmax + 2 * j], nh = norm0[l * 2 * nmax + 2 * j + 1];
+                    nr = (q == 0) ? nv : ((q == 1) ? nh : sqrt(nv * nh));
+                }
+                const double uu = sqrt(nr * s.wrow[r] / s.mrow[r]);
+                s.u[r] = uu;
+                s.d[r] = su[r] * uu / s.wrow[r];
+            }
+            block_sync();
+            if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+            // -- X+- (lower triangles), symmetric positive definite thanks to the sqrt(2) scaling of U
+            for_2d<NT>(N, N, [&](int r, int c) {
+                if (r >= c) {
+                    const double uu = cc * (s.u[r] / su[r]) * (s.u[c] * su[c]);
+                    const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
+                    s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
+                    s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
+                }
+            });
+            block_sync();
+            if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD) : chol2<NT>(s.M0, s.M1, N, LD))) {
+                fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
+            }
+            if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
+            else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
+            if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, nullptr)) {
+                fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+            }
+            if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
+            else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
+            if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
+            else lt_solve<NT>(s.M0, s.M2, N, LD);
+            for_2d<NT>(N, N, [&](int i, int c) {
+                const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];
+                const double hd = 0.5 * s.d[i];
+                s.M2[c * LD + i] = hd * (ep + em);   // F = (Ep - Em)/2 with Em = -d Em'/sigma
+                s.M1[c * LD + i] = hd * (ep - em);   // G = (Ep + Em)/2
+                s.M3[c * LD + i] *= dsg[c];          // reflection matrix seen from this layer times D
+            });
+            for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
+            block_sync();
+            double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+            // -- Q = (F - R~ D G)^-1 (R~ D F - G)
+            if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            if (!(CH == 1 ? gj_solve_mfma<NT, false>(Wk, Rt, nullptr, s, N, LD) : lu_solve<NT, false>(Wk, Rt, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            double* Q = Rt;
+            for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
+            block_sync();
+            // -- Y = F tQt + G ; W = (D G - Rtop F) tQt + (D F - Rtop G) ; K = Y W^-1
+            if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            if (!(CH == 1 ? gj_solve_mfma<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            double* K = Wk;
+            if (l > 0) {
+                const int nc = (N < Nu) ? N : Nu;
+                for_2d<NT>(Nu, Nu, [&](int i, int j) {
+                    double v = (i == j) ? s.Rbu[i] : 0.0;
+                    if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
+                    s.M3[j * LD + i] = v;
+                });
+                block_sync();
+            } else {
+                // -- read the backscatter of this mode off the reflection matrix of the whole snowpack
+                //    (dort.py:228-259): I0up = [Rbot_air + Ttop_0 K_0 Tbot_air] intensity_0 at the incident streams
+                const double cm = cos((double)m * b.phi), sm = sin((double)m * b.phi);
+                for (int idx = t; idx < ninc * P * P; idx += NT) {
+                    const int jn = idx / (P * P), rem = idx - jn * P * P, po = rem / P, pi = rem - po * P;
+                    const int j = inc[jn];
+                    double Ra[3], Ta[3];
+                    fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta);
+                    double w;  // outweight (streams.py:324-330 on outmu)
+                    if (n_air == 1) w = 1.0;
+                    else if (j == 0) w = 1.0 - 0.5 * (s.outmu[0] + s.outmu[1]);
+                    else if (j == n_air - 1) w = fabs(0.5 * (s.outmu[n_air - 2] + s.outmu[n_air - 1]));
+                    else w = fabs(0.5 * (s.outmu[j - 1] - s.outmu[j + 1]));
+                    const double power = ((m == 0) ? 1.0 : 2.0) / (2.0 * kPi * w);
+                    const int r = P * j + po, c = P * j + pi;
+                    double v = ((po == pi) ? Ra[po] : 0.0) + s.Ttop[r] * K[c * LD + r] * Ta[pi];
+                    v *= power;
+                    if (po < 2 && pi < 2 && po == pi) v -= coh[po * NI + jn] * ((m == 0) ? 1.0 : 2.0) / (2.0 * kPi * w);
+                    if (m > 0) v *= (po < 2) ? cm : sm;
+                    total[(po * 3 + pi) * NI + jn] += v;
+                }
+                block_sync();
+            }
+        }
+    }
+
+    // ---- interpolation to the incidence angles (rtsolver_utils.py:199-239, active branch) -------------------------
+    for (int idx = t; idx < 9 * b.n_theta; idx += NT) {
+        const int a = idx / b.n_theta, it = idx - a * b.n_theta;
+        const int po = a / 3, pi = a - 3 * po;
+        const double um = cos(b.theta[it]);
+        const double xtop = s.outmu[inc[0]];
+        bool any_above = false;
+        for (int q = 0; q < b.n_theta; ++q) any_above = any_above || (cos(b.theta[q]) > xtop);
+        // virtual node mu = 1: co = mean(VV, HH), cross = mean(HV, VH) of the steepest incident stream
+        double ytop;
+        if (po < 2 && pi < 2) {
+            if (po == pi) ytop = 0.5 * (total[0 * NI] + total[4 * NI]);
+            else ytop = 0.5 * (total[3 * NI] + total[1 * NI]);
+        } else ytop = total[a * NI];
+        const double* y = total + a * NI;
+        double res;
+        if (um > xtop || (ninc == 1 && any_above)) {
+            res = ytop + (y[0] - ytop) * ((um - 1.0) / (xtop - 1.0));
+        } else if (ninc == 1) {
+            res = y[0];
+        } else {
+            int k = 0;
+            while (k < ninc - 2 && um < s.outmu[inc[k + 1]]) ++k;
+            const double x0 = s.outmu[inc[k]], x1 = s.outmu[inc[k + 1]];
+            res = y[k] + (y[k + 1] - y[k]) * ((um - x0) / (x1 - x0));
+        }
+        b.out[p * out_stride + idx] = res;
+    }
+    if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+}
+
+}  // namespace smrt

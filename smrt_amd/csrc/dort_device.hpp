@@ -86,10 +86,11 @@ struct LdsPlan {
     int o_rowvec;   // 17 vectors of NMAX
     int o_strvec;   // 6 vectors of nmax
     int o_layvec;   // 11 vectors of Lmax
-    int o_phi;      // 3 vectors of nphi
+    int o_phi;      // 5 vectors of nphi
     int o_tb;       // NMAX
     int o_int;      // 16 ints (8 doubles)
     int o_gj;       // scratch of the blocked solvers: max(16 * NMAX, 1024) + 8 doubles, then (NMAX + 8) ints
+    int o_act;      // active mode only: per-layer mode-0 normalisation, mode totals, incident stream list
     int total;      // doubles
 };
 
@@ -99,11 +100,23 @@ struct LdsPlan {
 #define SMRT_HD __host__ __device__ inline
 #endif
 
-SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1) {
+// doubles of the active-mode region: norm0[Lmax][2 nmax], total[9][2 ntheta], coherent[2][2 ntheta], incident list
+SMRT_HD int active_doubles(int n_max_stream, int Lmax, int ntheta) {
+    return 2 * n_max_stream * Lmax + 9 * 2 * ntheta + 2 * 2 * ntheta + (2 * ntheta + 2) / 2 + 1;
+}
+// azimuth samples of the discrete Fourier decomposition of the phase function (emmodel/common.py:401-414)
+SMRT_HD int azimuth_samples(int m_max) {
+    int e = 4, v = 1;
+    while (v < m_max + 1) { v *= 2; ++e; }
+    return 1 << e;
+}
+
+SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1,
+                          int act_doubles = 0) {
     LdsPlan p;
     p.nmax = n_max_stream;
     p.NMAX = n_max_stream * P;
-    p.LD = p.NMAX | 1;
+    p.LD = (p.NMAX + 1) | 1;  // odd (bank-conflict free rows and columns) and at least one padding row
     p.Lmax = Lmax;
     p.nphi = nphi;
     p.ntheta = ntheta;
@@ -115,10 +128,11 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_rowvec = o; o += 17 * p.NMAX;
     p.o_strvec = o; o += 6 * p.nmax;
     p.o_layvec = o; o += 11 * Lmax;
-    p.o_phi = o; o += 3 * nphi;
+    p.o_phi = o; o += 5 * nphi;
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
     p.o_gj = o; o += ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    p.o_act = o; o += act_doubles;
     p.total = o;
     return p;
 }
@@ -128,8 +142,9 @@ struct Lds {
     double *mrow, *wrow, *u, *d, *sigma, *rsig, *t, *Rtop, *Ttop, *Rbu, *Tbu, *cvec, *tq, *svec, *g, *upb, *up;
     double *gmu, *gsin, *outmu, *mu, *w, *muu;
     double *eps_re, *eps_im, *ks, *ka, *pa, *pb, *pc, *BT, *thick, *ri, *nl;
-    double *cphi, *s2phi, *wphi;
+    double *cphi, *s2phi, *wphi, *sphi, *swphi;
     double* tb;
+    double* act;  // active-mode region (see active_doubles)
     int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air
     double* gj;  // blocked Gauss-Jordan scratch
     int gj_nmax;
@@ -153,7 +168,8 @@ SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
     s.eps_re = v; s.eps_im = v + L; s.ks = v + 2 * L; s.ka = v + 3 * L; s.pa = v + 4 * L; s.pb = v + 5 * L;
     s.pc = v + 6 * L; s.BT = v + 7 * L; s.thick = v + 8 * L; s.ri = v + 9 * L; s.nl = v + 10 * L;
     v = base + p.o_phi;
-    s.cphi = v; s.s2phi = v + p.nphi; s.wphi = v + 2 * p.nphi;
+    s.cphi = v; s.s2phi = v + p.nphi; s.wphi = v + 2 * p.nphi; s.sphi = v + 3 * p.nphi; s.swphi = v + 4 * p.nphi;
+    s.act = base + p.o_act;
     s.tb = base + p.o_tb;
     s.ints = (int*)(base + p.o_int);
     s.gj = base + p.o_gj;
@@ -647,18 +663,18 @@ SMRT_DEV bool lu_solve(double* A, double* Bm, double* v, double* udiag, int N, i
     const int nv = (v != nullptr) ? 1 : 0;
     for (int k = 0; k < N; ++k) {
         // pivot row: every wavefront finds it on its own (one LDS load per lane, DPP arg-max on a key made of the
-        // magnitude bits with the row index in the 7 low mantissa bits: exactness of the choice is irrelevant)
+        // magnitude bits with the row index in the 8 low mantissa bits: exactness of the choice is irrelevant)
         unsigned long long key = 0ull;
         for (int r = k + lane; r < N; r += SMRT_LANES) {
             const double xr = fabs(at<TR>(A, r, k, LD));
             unsigned long long bits;
             memcpy(&bits, &xr, 8);
-            bits = (bits & ~0x7Full) | (unsigned long long)(127 - (r - k < 127 ? r - k : 127));
+            bits = (bits & ~0xFFull) | (unsigned long long)(255 - (r - k < 255 ? r - k : 255));
             if (bits > key) key = bits;
         }
         key = wave_max_u64(key);
-        if (key < 128ull) return false;  // zero column: singular, uniform exit
-        const int p = k + 127 - (int)(key & 0x7Full);
+        if (key < 256ull) return false;  // zero column: singular, uniform exit
+        const int p = k + 255 - (int)(key & 0xFFull);
         const double pv = at<TR>(A, p, k, LD);
         const double akk = at<TR>(A, k, k, LD);
         if (!(fabs(pv) > 0.0 && fabs(pv) < 1e300)) return false;  // uniform
@@ -842,9 +858,11 @@ SMRT_DEV void r1_mfma(const double* F, const double* G, double* Rt, double* Wk, 
 
 // Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (in place)
 // upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
-template <int NT>
+// SIGNED (azimuth modes m >= 1, three polarisations): the down-going eigenvectors carry the row signs
+// dsg = (+1, +1, -1) per (V, H, U) (dort.py:951-953), i.e. W = (D G - Rtop F) tQt + (D F - Rtop G).
+template <int NT, bool SIGNED = false>
 SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
-                       double* upb, double* gvec, double Bl, int N, int LD) {
+                       double* upb, double* gvec, double Bl, int N, int LD, const double* dsg = nullptr) {
     using RTc = RowTiles<NT>;
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
@@ -856,6 +874,7 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
         tis[o] = ti;
         const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
         const double rt = Rtop[ic];
+        const double sg = SIGNED ? dsg[ic] : 1.0;
         double vy = 0.0, vg = 0.0;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
@@ -863,7 +882,7 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
             const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
             const bool in = (ti < RT && i < N && k < N);
             af[o][kk] = in ? fv : 0.0;
-            aw[o][kk] = in ? gv - rt * fv : 0.0;
+            aw[o][kk] = in ? (SIGNED ? sg * gv : gv) - rt * fv : 0.0;
             vy += af[o][kk] * tk;
             vg += aw[o][kk] * tk;
         }
@@ -894,8 +913,102 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
             tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
                 const double fic = F[col * LD + row], gic = G[col * LD + row];
                 Wk[col * LD + row] = cy[reg] + gic;
-                F[col * LD + row] = cw[reg] + fic - Rtop[row] * gic;
+                F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
             });
+        }
+    }
+    block_sync();
+}
+
+// ---- the same two passes without the matrix core (N > 64: CH column chunks of 64 per lane) --------------------
+// rows-per-wavefront register blocking
+constexpr int RB = 2;
+
+// Wk = F - Rt G ; Rt <- Rt F - G (row-wise in place) ; cvec = (Rt 1) B - B + svec
+template <int NT, int CH>
+SMRT_DEV void r1_rows(const double* F, const double* G, double* Rt, double* Wk, double* cvec, const double* svec,
+                      double Bl, int N, int LD) {
+    const int t = tid(), lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
+        double a1[RB][CH], a2[RB][CH], rsum[RB];
+        for (int bb = 0; bb < RB; ++bb) { rsum[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] = 0.0; a2[bb][ch] = 0.0; } }
+        for (int k = 0; k < N; ++k) {
+            double fk[CH], gk[CH];
+            for (int ch = 0; ch < CH; ++ch) {
+                const int c = ch * SMRT_LANES + lane;
+                fk[ch] = (c < N) ? F[c * LD + k] : 0.0;
+                gk[ch] = (c < N) ? G[c * LD + k] : 0.0;
+            }
+            for (int bb = 0; bb < RB; ++bb) {
+                const int i = i0 + bb;
+                const double r = (i < N) ? Rt[k * LD + i] : 0.0;
+                rsum[bb] += r;
+                for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] += r * gk[ch]; a2[bb][ch] += r * fk[ch]; }
+            }
+        }
+        wave_sync();  // every lane has read rows i0.. of Rt before they are overwritten
+        for (int bb = 0; bb < RB; ++bb) {
+            const int i = i0 + bb;
+            if (i < N) {
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int c = ch * SMRT_LANES + lane;
+                    if (c < N) {
+                        Wk[c * LD + i] = F[c * LD + i] - a1[bb][ch];
+                        Rt[c * LD + i] = a2[bb][ch] - G[c * LD + i];
+                    }
+                }
+                if (lane == 0) cvec[i] = rsum[bb] * Bl - Bl + svec[i];
+            }
+        }
+    }
+    block_sync();
+}
+
+// Y = F tQt + G -> Wk ; W = (D G - Rtop F) tQt + (D F - Rtop G) -> over F (row-wise in place; D = 1 unless SIGNED)
+// upb = F tq + B ; g = (D G - Rtop F) tq + (1 - Rtop) B
+template <int NT, int CH, bool SIGNED>
+SMRT_DEV void r45_rows(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
+                       double* upb, double* gvec, double Bl, int N, int LD, const double* dsg) {
+    const int t = tid(), lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
+        double ay[RB][CH], aw[RB][CH], vy[RB], vg[RB];
+        for (int bb = 0; bb < RB; ++bb) { vy[bb] = 0.0; vg[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] = 0.0; aw[bb][ch] = 0.0; } }
+        for (int k = 0; k < N; ++k) {
+            double tk[CH];
+            for (int ch = 0; ch < CH; ++ch) {
+                const int c = ch * SMRT_LANES + lane;
+                tk[ch] = (c < N) ? Q[c * LD + k] : 0.0;
+            }
+            const double tqk = tq[k];
+            for (int bb = 0; bb < RB; ++bb) {
+                const int i = i0 + bb;
+                double fik = 0.0, wik = 0.0;
+                if (i < N) {
+                    fik = F[k * LD + i];
+                    const double gik = G[k * LD + i];
+                    wik = (SIGNED ? dsg[i] * gik : gik) - Rtop[i] * fik;
+                }
+                vy[bb] += fik * tqk; vg[bb] += wik * tqk;
+                for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] += fik * tk[ch]; aw[bb][ch] += wik * tk[ch]; }
+            }
+        }
+        wave_sync();  // every lane has read rows i0.. of F before they are overwritten
+        for (int bb = 0; bb < RB; ++bb) {
+            const int i = i0 + bb;
+            if (i < N) {
+                const double rt = Rtop[i];
+                for (int ch = 0; ch < CH; ++ch) {
+                    const int c = ch * SMRT_LANES + lane;
+                    if (c < N) {
+                        const double fic = F[c * LD + i], gic = G[c * LD + i];
+                        Wk[c * LD + i] = ay[bb][ch] + gic;
+                        F[c * LD + i] = aw[bb][ch] + (SIGNED ? dsg[i] * fic : fic) - rt * gic;
+                    }
+                }
+                if (lane == 0) { upb[i] = vy[bb] + Bl; gvec[i] = vg[bb] + (1.0 - rt) * Bl; }
+            }
         }
     }
     block_sync();
@@ -1279,6 +1392,60 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 }
 
 
+// ---- stages 0 and 1 of a pair, shared by the passive and the active drivers ---------------------------------------
+// Layer scalars (one thread per layer), Gauss-Legendre sines, number of streams per layer and the air streams
+// (streams.py:136-223).  s.ints[0..7] must be zero on entry.  Returns the status, uniform over the workgroup; on
+// ST_OK s.ints[4] = most refringent layer, s.ints[5] = n_air.
+template <int NT>
+SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L, const double* thickness,
+                        const double* fracvol, const double* temperature, const double* mp1, const double* mp2) {
+    const int t = tid();
+    const int nmax = b.n_max_stream;
+    for (int l = t; l < L; l += NT) {
+        cplx ee; double ks, ka, pa, pb; int bad = 0;
+        layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
+        s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
+        s.thick[l] = thickness[l];
+        s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
+        if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
+    }
+    for (int j = t; j < nmax; j += NT) {
+        const double m = b.gl_mu[j];
+        s.gmu[j] = m; s.gsin[j] = sqrt(1.0 - m * m);
+    }
+    block_sync();
+    if (s.ints[0] != ST_OK) return s.ints[0];
+    if (t == 0) {
+        int ks_ = 0;
+        for (int l = 1; l < L; ++l)  // np.argmax on complex: lexicographic, first maximum
+            if (s.eps_re[l] > s.eps_re[ks_] || (s.eps_re[l] == s.eps_re[ks_] && s.eps_im[l] > s.eps_im[ks_])) ks_ = l;
+        s.ints[4] = ks_;
+    }
+    block_sync();
+    {
+        const cplx estar = cmk(s.eps_re[s.ints[4]], s.eps_im[s.ints[4]]);
+        for (int l = t; l < L; l += NT) {
+            const double ri = csqrt_(cdiv(estar, cmk(s.eps_re[l], s.eps_im[l]))).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) n += (ri * s.gsin[j] < 1.0) ? 1 : 0;
+            s.ri[l] = ri; s.nl[l] = (double)n;
+            if (n < 2) lds_max(&s.ints[0], ST_INPUT);
+        }
+        if (t == NT - 1) {
+            const double ria = csqrt_(estar).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) {
+                const double rs = ria * s.gsin[j];
+                if (rs < 1.0) { s.outmu[n] = sqrt(1.0 - rs * rs); ++n; }
+            }
+            s.ints[5] = n;
+            if (n < 1) lds_max(&s.ints[0], ST_INPUT);
+        }
+    }
+    block_sync();
+    return s.ints[0];
+}
+
 #ifdef SMRT_EMU_DEBUG
 #include <cstdio>
 #define SMRT_DUMP(tag, M, NN) do { block_sync(); if (t == 0) { char fn[128]; snprintf(fn, 128, "/tmp/dump_l%d_%s.bin", l, tag); FILE* f = fopen(fn, "wb"); for (int c_ = 0; c_ < (NN); ++c_) fwrite((M) + c_ * LD, 8, (NN), f); fclose(f);} block_sync(); } while (0)
@@ -1292,9 +1459,6 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 #define SMRT_STAGE(k) do {} while (0)
 #endif
 enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_LU1, SG_R45, SG_LU2, SG_R78, SG_OUT, SG_COUNT };
-
-// rows-per-wavefront register blocking of the two "row times matrix" passes
-constexpr int RB = 2;
 
 // MODE 0: the whole solve in one workgroup (fused).  MODE 1 ("prep"): per layer assemble X+-, factorise, form
 // B = L+^T L- and park L+, B, d in the staging area.  MODE 2 ("finish"): pick up L+, B' (rotated by the Jacobi
@@ -1343,57 +1507,16 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         const int prev = b.status[p];
         if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
     }
-    for (int l = t; l < L; l += NT) {
-        cplx ee; double ks, ka, pa, pb; int bad = 0;
-        layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
-        s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
-        s.thick[l] = thickness[l];
-        s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
-        if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
-    }
     for (int k = t; k < nphi; k += NT) {
         const double ph = kPi * (double)k / (double)(nphi - 1);
         const double c = cos(ph), sn = sin(ph);
         s.cphi[k] = c; s.s2phi[k] = sn * sn;
         s.wphi[k] = ((k == 0 || k == nphi - 1) ? 1.0 : 2.0) / (double)(2 * (nphi - 1));
     }
-    for (int j = t; j < nmax; j += NT) {
-        const double m = b.gl_mu[j];
-        s.gmu[j] = m; s.gsin[j] = sqrt(1.0 - m * m);
-    }
-    block_sync();
-    if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
-
-    // ---- stage 1: streams (streams.py:136-223) -----------------------------------------------------------
-    if (t == 0) {
-        int ks_ = 0;
-        for (int l = 1; l < L; ++l)  // np.argmax on complex: lexicographic, first maximum
-            if (s.eps_re[l] > s.eps_re[ks_] || (s.eps_re[l] == s.eps_re[ks_] && s.eps_im[l] > s.eps_im[ks_])) ks_ = l;
-        s.ints[4] = ks_;
-    }
-    block_sync();
     {
-        const cplx estar = cmk(s.eps_re[s.ints[4]], s.eps_im[s.ints[4]]);
-        for (int l = t; l < L; l += NT) {
-            const double ri = csqrt_(cdiv(estar, cmk(s.eps_re[l], s.eps_im[l]))).re;
-            int n = 0;
-            for (int j = 0; j < nmax; ++j) n += (ri * s.gsin[j] < 1.0) ? 1 : 0;
-            s.ri[l] = ri; s.nl[l] = (double)n;
-            if (n < 2) lds_max(&s.ints[0], ST_INPUT);
-        }
-        if (t == NT - 1) {
-            const double ria = csqrt_(estar).re;
-            int n = 0;
-            for (int j = 0; j < nmax; ++j) {
-                const double rs = ria * s.gsin[j];
-                if (rs < 1.0) { s.outmu[n] = sqrt(1.0 - rs * rs); ++n; }
-            }
-            s.ints[5] = n;
-            if (n < 1) lds_max(&s.ints[0], ST_INPUT);
-        }
+        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2);
+        if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
-    block_sync();
-    if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
     const int n_air = s.ints[5];
 
     if (MODE != 1 && b.want_layer_out) {
@@ -1594,40 +1717,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (CH == 1) {
             r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         } else {
-        // -- R1: Wk = F - Rt G ; Rt <- Rt F - G (row-wise in place) ; cvec = (Rt 1) B - B + svec
-        for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
-            double a1[RB][CH], a2[RB][CH], rsum[RB];
-            for (int bb = 0; bb < RB; ++bb) { rsum[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] = 0.0; a2[bb][ch] = 0.0; } }
-            for (int k = 0; k < N; ++k) {
-                double fk[CH], gk[CH];
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int c = ch * SMRT_LANES + lane;
-                    fk[ch] = (c < N) ? F[c * LD + k] : 0.0;
-                    gk[ch] = (c < N) ? G[c * LD + k] : 0.0;
-                }
-                for (int bb = 0; bb < RB; ++bb) {
-                    const int i = i0 + bb;
-                    const double r = (i < N) ? Rt[k * LD + i] : 0.0;
-                    rsum[bb] += r;
-                    for (int ch = 0; ch < CH; ++ch) { a1[bb][ch] += r * gk[ch]; a2[bb][ch] += r * fk[ch]; }
-                }
-            }
-            wave_sync();  // every lane has read rows i0.. of Rt before they are overwritten
-            for (int bb = 0; bb < RB; ++bb) {
-                const int i = i0 + bb;
-                if (i < N) {
-                    for (int ch = 0; ch < CH; ++ch) {
-                        const int c = ch * SMRT_LANES + lane;
-                        if (c < N) {
-                            Wk[c * LD + i] = F[c * LD + i] - a1[bb][ch];
-                            Rt[c * LD + i] = a2[bb][ch] - G[c * LD + i];
-                        }
-                    }
-                    if (lane == 0) s.cvec[i] = rsum[bb] * Bl - Bl + s.svec[i];
-                }
-            }
-        }
-        block_sync();
+            r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         }
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
         SMRT_STAGE(SG_LU1);
@@ -1642,44 +1732,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
         } else {
-        // -- R4/R5: Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (row-wise in place)
-        //    upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
-        for (int i0 = wave * RB; i0 < N; i0 += NW * RB) {
-            double ay[RB][CH], aw[RB][CH], vy[RB], vg[RB];
-            for (int bb = 0; bb < RB; ++bb) { vy[bb] = 0.0; vg[bb] = 0.0; for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] = 0.0; aw[bb][ch] = 0.0; } }
-            for (int k = 0; k < N; ++k) {
-                double tk[CH];
-                for (int ch = 0; ch < CH; ++ch) {
-                    const int c = ch * SMRT_LANES + lane;
-                    tk[ch] = (c < N) ? Q[c * LD + k] : 0.0;
-                }
-                const double tqk = s.tq[k];
-                for (int bb = 0; bb < RB; ++bb) {
-                    const int i = i0 + bb;
-                    double fik = 0.0, wik = 0.0;
-                    if (i < N) { fik = F[k * LD + i]; wik = G[k * LD + i] - s.Rtop[i] * fik; }
-                    vy[bb] += fik * tqk; vg[bb] += wik * tqk;
-                    for (int ch = 0; ch < CH; ++ch) { ay[bb][ch] += fik * tk[ch]; aw[bb][ch] += wik * tk[ch]; }
-                }
-            }
-            wave_sync();  // every lane has read rows i0.. of F before they are overwritten
-            for (int bb = 0; bb < RB; ++bb) {
-                const int i = i0 + bb;
-                if (i < N) {
-                    const double rt = s.Rtop[i];
-                    for (int ch = 0; ch < CH; ++ch) {
-                        const int c = ch * SMRT_LANES + lane;
-                        if (c < N) {
-                            const double fic = F[c * LD + i], gic = G[c * LD + i];
-                            Wk[c * LD + i] = ay[bb][ch] + gic;
-                            F[c * LD + i] = aw[bb][ch] + fic - rt * gic;
-                        }
-                    }
-                    if (lane == 0) { s.upb[i] = vy[bb] + Bl; s.g[i] = vg[bb] + (1.0 - rt) * Bl; }
-                }
-            }
-        }
-        block_sync();
+            r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         }
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);

@@ -7,7 +7,7 @@
 #include <string>
 #include <vector>
 
-#include "dort_device.hpp"
+#include "dort_active.hpp"
 #include "dort_host_common.hpp"
 
 using namespace smrt;
@@ -43,6 +43,22 @@ __global__ __launch_bounds__(NT) void dort_passive_kernel_gmem(DevBatch b, doubl
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
         dort_pair_passive<NT, CH>(b, p, smrt_lds, mat);
+        __syncthreads();
+    }
+}
+
+// ---- active mode (backscatter): one fused kernel per pair, azimuth modes 0..m_max inside ---------------------------
+template <int NT, int CH>
+__global__ __launch_bounds__(NT) void dort_active_kernel(DevBatch b) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_active<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
+}
+template <int NT, int CH>
+__global__ __launch_bounds__(NT) void dort_active_kernel_gmem(DevBatch b, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, CH>(b, p, smrt_lds, mat);
         __syncthreads();
     }
 }
@@ -83,6 +99,7 @@ struct smrt_dort_ctx {
     size_t jacobi_lds = 0;
     DevStage stage{};
     bool gmem_path = false;
+    bool active = false;
     int gmem_grid = 0;
     long long ws_stride = 0;
     int nmax_rows = 0;
@@ -105,7 +122,7 @@ static int upload_array(smrt_dort_ctx* ctx, DevBuf& buf, const void* src, size_t
 
 template <int NT, int CH>
 static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
-    auto kern = dort_passive_kernel_gmem<NT, CH>;
+    auto kern = ctx->active ? dort_active_kernel_gmem<NT, CH> : dort_passive_kernel_gmem<NT, CH>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)ctx->gmem_grid), dim3(NT), ctx->lds_bytes, ctx->stream, d,
@@ -141,8 +158,8 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
 
 template <int NT>
 static hipError_t launch_nt(smrt_dort_ctx* ctx, const DevBatch& d) {
-    if (ctx->split && ctx->chunk_pairs > 0) return launch_split<NT>(ctx, d);
-    auto kern = dort_passive_kernel<NT, 1>;
+    if (!ctx->active && ctx->split && ctx->chunk_pairs > 0) return launch_split<NT>(ctx, d);
+    auto kern = ctx->active ? dort_active_kernel<NT, 1> : dort_passive_kernel<NT, 1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)d.pair_count), dim3(NT), ctx->lds_bytes, ctx->stream, d);
@@ -224,17 +241,23 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     if (!ctx) return -1;
     const char* why = smrt_host::validate(b);
     if (why) { ctx->err = why; return -1; }
-    if (b->mode != SMRT_MODE_PASSIVE) { ctx->err = "active mode is not available in this build"; return -1; }
+    ctx->active = (b->mode == SMRT_MODE_ACTIVE);
+    if (ctx->active && (b->m_max < 0 || b->m_max > 15)) { ctx->err = "m_max must be in 0..15"; return -1; }
     const int64_t npairs = (int64_t)b->n_snowpacks * b->n_frequencies;
     if (pair_count < 0) pair_count = npairs - pair_begin;
     if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
-    const int P = 2;
-    LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9, 1);
+    const int P = ctx->active ? 3 : 2;
+    const int nphi = ctx->active ? azimuth_samples(b->m_max) / 2 + 1 : 9;
+    const int actd = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta) : 0;
+    LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd);
     size_t lds = (size_t)plan.total * sizeof(double);
     ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds);
     if (ctx->gmem_path) {
-        if (plan.NMAX > 256) { ctx->err = "n_max_stream above 128 is not supported by this build"; return -1; }
-        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, 9, 0);
+        if (plan.NMAX > 256) {
+            ctx->err = "streams x polarisations above 256 (n_max_stream > 128 passive, > 85 active) is not supported by this build";
+            return -1;
+        }
+        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd);
         lds = (size_t)plan.total * sizeof(double);
         if (lds > (size_t)ctx->max_lds) { ctx->err = "too many layers for the LDS-resident per-layer tables"; return -1; }
         ctx->gmem_grid = (int)std::min<int64_t>(pair_count, 1024);
@@ -242,7 +265,8 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * plan.mat_doubles));
     }
     ctx->nmax_rows = plan.NMAX;
-    if (!ctx->gmem_path && ctx->split) {
+    ctx->chunk_pairs = 0;
+    if (!ctx->gmem_path && ctx->split && !ctx->active) {
         const size_t mat = (size_t)plan.NMAX * plan.LD;
         const size_t per_pair = (size_t)b->n_layers_max * ((2 * mat + 2 * plan.NMAX) * sizeof(double) + sizeof(int));
         long long chunk = (long long)(12.0e9 / (double)per_pair);

@@ -148,11 +148,17 @@ class DORT(object):
             pola = ["V", "H", "U"]
             coords = [("polarization_inc", pola), ("polarization", pola), ("theta_inc", sensor.theta_inc_deg)]
         n_air = int(out.streams[p, 0])
+        outmu = out.streams[p, 1:1 + n_air]
+        if sensor.mode == "A":  # only the incident streams are reported (rtsolver_utils.py:307-316, dort.py:210-226)
+            keep = set()
+            for mu_inc in np.cos(np.atleast_1d(sensor.theta_inc)):
+                i0 = int(np.searchsorted(-outmu, -mu_inc))
+                keep.update((0,) if i0 == 0 else ((n_air - 1,) if i0 == n_air else (i0, i0 - 1)))
+            outmu = outmu[sorted(keep)]
         layer_idx = ("layer", np.arange(L))
         lay = out.layers[p, :L]
         other = {
-            "stream_angles": LabeledArray(np.rad2deg(np.arccos(out.streams[p, 1:1 + n_air])),
-                                          [("dim_0", np.arange(n_air))]),
+            "stream_angles": LabeledArray(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
             "effective_permittivity": LabeledArray(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
             "ks": LabeledArray(lay[:, 2].copy(), [layer_idx], name="ks"),
             "ke": LabeledArray(lay[:, 2] + lay[:, 3], [layer_idx], name="ke"),

@@ -150,7 +150,16 @@ def dump_stages(out, tag, m, se, spk, rtsolver_options, stage_layers):
         out[tag + "beta_sorted_m%d" % mode] = betas
 
 
+ONLY = set(sys.argv[1:])  # optional: regenerate only the named fixtures
+
+
+def wanted(name):
+    return not ONLY or name in ONLY
+
+
 def save(name, d):
+    if not wanted(name):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
     print("wrote", os.path.relpath(path), "%.1f KB" % (os.path.getsize(path) / 1024))
@@ -226,6 +235,21 @@ def main():
     spx = random_snowpack(rng, 4, "exponential", 0.02, 0.10, 1000.0)
     save("iba_active_L4_n32_ku", run_case("iba", active(13.4e9, [30, 40]), spx,
                                           rtsolver_options=dict(n_max_stream=32, m_max=2)))
+
+    # active, other branches: DMRT (closed-form Rayleigh modes), sticky hard spheres under IBA, m_max = 1, and an
+    # incidence angle steeper than every stream (mu = 1 node of the active interpolation)
+    rng = np.random.default_rng(5)
+    spx = random_snowpack(rng, 3, "sticky_hard_spheres", 0.05, 0.20, 1000.0)
+    if wanted("dmrt_active_L3_n12"):
+        save("dmrt_active_L3_n12", run_case("dmrt_qca_shortrange", active(10e9, [35, 50]), spx,
+                                            rtsolver_options=dict(n_max_stream=12, m_max=2)))
+    if wanted("iba_shs_active_L3_n8"):
+        save("iba_shs_active_L3_n8", run_case("iba", active(17.2e9, [25, 45]), spx,
+                                              rtsolver_options=dict(n_max_stream=8, m_max=2)))
+    spx = random_snowpack(rng, 3, "exponential", 0.05, 0.20, 1000.0)
+    if wanted("iba_active_L3_n10_m1_steep"):
+        save("iba_active_L3_n10_m1_steep", run_case("iba", active(9.6e9, [2, 30, 55]), spx,
+                                                    rtsolver_options=dict(n_max_stream=10, m_max=1)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../../smrt_amd/csrc/dort_device.hpp"
+#include "../../smrt_amd/csrc/dort_active.hpp"
 #include "../../smrt_amd/csrc/dort_host_common.hpp"
 
 using namespace smrt;
@@ -19,6 +19,19 @@ static long run_pairs(DevBatch& d, int order, size_t lds_doubles, size_t mat_dou
         for (auto& x : mat) x = NAN;
         double* gm = mat_doubles ? mat.data() : nullptr;
         nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, CH>(d, p, lds.data(), gm); });
+    }
+    return nb;
+}
+
+template <int NT, int CH>
+static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_doubles) {
+    long nb = 0;
+    std::vector<double> lds(lds_doubles), mat(mat_doubles);
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        for (auto& x : mat) x = NAN;
+        double* gm = mat_doubles ? mat.data() : nullptr;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, CH>(d, p, lds.data(), gm); });
     }
     return nb;
 }
@@ -57,9 +70,12 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
                             long* n_barriers) {
     const char* why = smrt_host::validate(b);
     if (why) { fprintf(stderr, "smrt_emu_run: %s\n", why); return -1; }
-    if (b->mode != SMRT_MODE_PASSIVE) return -1;
-    const bool gmem = b->n_max_stream * 2 > 64;
-    const LdsPlan plan = make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1);
+    const bool active = (b->mode == SMRT_MODE_ACTIVE);
+    const int P = active ? 3 : 2;
+    const bool gmem = b->n_max_stream * P > 64;
+    const LdsPlan plan = active ? make_plan(b->n_max_stream, 3, b->n_layers_max, b->n_theta, azimuth_samples(b->m_max) / 2 + 1,
+                                            gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta))
+                                : make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1);
     if (plan.NMAX > 128) return -2;
     const size_t matd = gmem ? (size_t)plan.mat_doubles : 0;
     std::vector<double> gl(b->n_max_stream);
@@ -75,7 +91,22 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    if (gmem) {
+    if (active) {
+        if (gmem) {
+            switch (nt) {
+                case 64: nb = run_active<64, 2>(d, order, plan.total, matd); break;
+                case 256: nb = run_active<256, 2>(d, order, plan.total, matd); break;
+                default: return -3;
+            }
+        } else {
+            switch (nt) {
+                case 64: nb = run_active<64, 1>(d, order, plan.total, 0); break;
+                case 128: nb = run_active<128, 1>(d, order, plan.total, 0); break;
+                case 256: nb = run_active<256, 1>(d, order, plan.total, 0); break;
+                default: return -3;
+            }
+        }
+    } else if (gmem) {
         switch (nt) {
             case 64: nb = run_pairs<64, 2>(d, order, plan.total, matd); break;
             case 256: nb = run_pairs<256, 2>(d, order, plan.total, matd); break;

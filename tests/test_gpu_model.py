@@ -25,6 +25,36 @@ def test_iba_dort_oneconfig_passive():
         np.testing.assert_allclose(res.TbH(), 237.3487270223389, atol=1e-4)
 
 
+def test_iba_dort_oneconfig_active():
+    """smrt/test/test_integration_iba.py:55-69: the reference's own known answer for the radar case."""
+    from smrt_amd import make_model, sensor_list
+
+    res = make_model("iba", "dort").run(sensor_list.active(frequency=19e9, theta_inc=55), two_layer())
+    np.testing.assert_allclose(res.sigmaVV_dB(), -24.044882546524693, atol=1e-4)
+    np.testing.assert_allclose(res.sigmaHH_dB(), -24.416295329469907, atol=1e-4)
+    np.testing.assert_allclose(res.sigmaHV_dB(), -51.544272924876886, atol=1e-4)
+    d = load_golden("iba_2layer_active19")
+    np.testing.assert_allclose(res.other_data["stream_angles"].values, d["f0_stream_angles"], rtol=1e-11)
+
+
+def test_active_model_run_sentinel1_batch():
+    """Model.run in active mode over several snowpacks: dims, labels and values of the cfg4-like fixture."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    d = load_golden("cfg4_iba_active_L5_n16")
+    sp = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                       corr_length=d["corr_length"])
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16, m_max=2))
+    res = m.run(sensor_list.sentinel1(), [sp, sp, sp])
+    assert "snowpack" in res.data.dims
+    r0 = d["result"][0]
+    th = d["theta_inc_deg"]
+    want_vv = 10 * np.log10(4 * np.pi * np.cos(np.deg2rad(th)) * r0[0, 0, :])
+    got = np.asarray(res.sigmaVV_dB().values if hasattr(res.sigmaVV_dB(), "values") else res.sigmaVV_dB())
+    assert got.shape == (3, len(th))
+    np.testing.assert_allclose(got, np.tile(want_vv, (3, 1)), atol=1e-7)
+
+
 def test_onelayer_example():
     """examples/iba_onelayer_example.py."""
     from smrt_amd import make_model, make_snowpack, sensor_list

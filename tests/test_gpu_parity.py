@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from conftest import PASSIVE_FIXTURES, fixture_options, load_golden, snowpack_dict
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, assert_backscatter_close, fixture_options, load_golden,
+                      snowpack_dict)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,9 +28,10 @@ def batch_from_fixture(d, freqs=None):
     p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
     fr = d["frequency"] if freqs is None else d["frequency"][freqs]
     o = fixture_options(d)
+    active = str(d["mode"]) == "A"
     return PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2, fr,
-                       np.deg2rad(d["theta_deg"]), emmodel=str(d["emmodel"]), microstructure=ms,
-                       n_max_stream=o["n_max_stream"])
+                       np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]), emmodel=str(d["emmodel"]),
+                       microstructure=ms, mode="A" if active else "P", n_max_stream=o["n_max_stream"], m_max=o["m_max"])
 
 
 @pytest.mark.parametrize("name", PASSIVE_FIXTURES)
@@ -172,3 +174,79 @@ def test_full_size_batch_properties(ctx):
     cv = c.values.reshape(5, S, 2, 1)
     assert np.array_equal(cv, av[:, perm])
     assert (a.values > 50).all() and (a.values < temp.max()).all()
+
+
+# ---- active mode (backscatter) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ACTIVE_FIXTURES)
+@pytest.mark.parametrize("threads", [64, 512])
+def test_active_golden(ctx, name, threads):
+    """Backscatter I[pol, pol_inc, theta_inc] against the reference (smrt/test/test_integration_iba.py:55-69 is the
+    first fixture); the 32-stream fixtures have N = 96 rows and run the global-workspace variant of the kernel."""
+    d = load_golden(name)
+    if fixture_options(d)["n_max_stream"] * 3 > 64 and threads != 512:
+        pytest.skip("the global-workspace kernel has a fixed workgroup size")
+    ctx.set_block_threads(threads)
+    out = ctx.run(batch_from_fixture(d))
+    ctx.set_block_threads(0)
+    assert (out.status == 0).all(), out.status
+    assert_backscatter_close(out.values, d["result"])
+    L = len(d["thickness"])
+    for i in range(len(d["frequency"])):
+        tag = "f%d_" % i
+        np.testing.assert_allclose(out.layers[i, :L, 2], d[tag + "ks"], rtol=1e-11)
+        np.testing.assert_allclose(out.layers[i, :L, 3], d[tag + "ka"], rtol=1e-10)
+
+
+def test_active_random_batch_against_oracle(ctx):
+    """cfg4 laws at reduced size (thin layers over a deep one, C and Ku band, three incidence angles): every pair
+    against the CPU oracle run with the reference's default diagonalisation."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(11)
+    S, L = 5, 6
+    thick = np.concatenate([rng.uniform(0.02, 0.10, (S, L - 1)), np.full((S, 1), 1000.0)], axis=1)
+    dens = rng.uniform(150, 450, (S, L))
+    temp = rng.uniform(230, 270, (S, L))
+    lc = rng.uniform(5e-5, 3e-4, (S, L))
+    freqs = np.array([5.405e9, 13.4e9])
+    theta = np.array([25.0, 40.0, 55.0])
+    nl = np.array([6, 6, 4, 6, 2], np.int32)
+    b = PackedBatch(nl, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad(theta), emmodel="iba",
+                    microstructure="exponential", mode="A", n_max_stream=16, m_max=2)
+    out = ctx.run(b)
+    assert (out.status == 0).all(), out.status
+    for f in range(len(freqs)):
+        for s_ in range(S):
+            n = nl[s_]
+            sp = dict(thickness=thick[s_, :n], density=dens[s_, :n], temperature=temp[s_, :n],
+                      microstructure="exponential", corr_length=lc[s_, :n])
+            ref = O.solve(sp, freqs[f], theta, mode="A", theta_inc_deg=theta, n_max_stream=16, m_max=2,
+                          method="schur_forcedtriu")
+            assert_backscatter_close(out.values[f * S + s_], ref)
+
+
+def test_active_properties(ctx):
+    """Size-independent properties on a batch the oracle is not asked about: near-reciprocity of the cross-polarised
+    backscatter (sigma_HV ~ sigma_VH: exact in the continuum, within a few per cent in the discretised reference
+    too), co-pol above cross-pol, sub-range == full range, repeatability."""
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(12)
+    S, L = 48, 8
+    thick = np.concatenate([rng.uniform(0.02, 0.10, (S, L - 1)), np.full((S, 1), 1000.0)], axis=1)
+    dens = rng.uniform(150, 450, (S, L))
+    temp = rng.uniform(230, 270, (S, L))
+    lc = rng.uniform(5e-5, 3e-4, (S, L))
+    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, [9.6e9, 17.2e9], np.deg2rad([30.0, 45.0]),
+                    emmodel="iba", microstructure="exponential", mode="A", n_max_stream=16, m_max=2)
+    out = ctx.run(b)
+    assert (out.status == 0).all()
+    v = out.values
+    assert np.isfinite(v).all() and (v[:, 0, 0] > 0).all() and (v[:, 1, 1] > 0).all()
+    np.testing.assert_allclose(v[:, 0, 1], v[:, 1, 0], rtol=0.1)
+    assert (v[:, 0, 1] < v[:, 0, 0]).all()
+    again = ctx.run(b)
+    assert np.array_equal(again.values, v)
+    part = ctx.run(b, pair_begin=10, pair_count=30)
+    assert np.array_equal(part.values, v[10:40])

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, fixture_options, load_golden, snowpack_dict
+from conftest import ROOT, assert_backscatter_close, fixture_options, load_golden, snowpack_dict
 from smrt_amd._native import PackedBatch, SmrtBatch
 
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
@@ -18,7 +18,8 @@ EMU_LIB = os.path.join(EMU_DIR, "libsmrt_emu.so")
 @pytest.fixture(scope="module")
 def emu():
     srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp"),
-            os.path.join(ROOT, "smrt_amd", "csrc", "dort_device.hpp"), os.path.join(ROOT, "smrt_amd", "csrc", "spmd.hpp")]
+            os.path.join(ROOT, "smrt_amd", "csrc", "dort_device.hpp"), os.path.join(ROOT, "smrt_amd", "csrc", "spmd.hpp"),
+            os.path.join(ROOT, "smrt_amd", "csrc", "dort_active.hpp")]
     if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR, "-o", EMU_LIB, srcs[0]])
     lib = C.CDLL(EMU_LIB)
@@ -35,9 +36,11 @@ def run_fixture(lib, name, nt=64, order=0, freqs=None):
     p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
     p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
     fr = d["frequency"] if freqs is None else d["frequency"][freqs]
+    active = str(d["mode"]) == "A"
+    o = fixture_options(d)
     b = PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2, fr,
-                    np.deg2rad(d["theta_deg"]), emmodel=str(d["emmodel"]), microstructure=ms,
-                    n_max_stream=fixture_options(d)["n_max_stream"])
+                    np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]), emmodel=str(d["emmodel"]),
+                    microstructure=ms, mode="A" if active else "P", n_max_stream=o["n_max_stream"], m_max=o["m_max"])
     n = b.n_pairs
     out = np.empty((n,) + b.out_shape())
     st = np.empty(n, np.int32)
@@ -69,6 +72,17 @@ def test_emulated_kernel_full_size_pair(emu):
     """One 20-layer, 32-stream pair of the headline configuration at 89 GHz (strongest scattering)."""
     out, st, ref = run_fixture(emu, "cfg2_iba_L20_n32_sp1", nt=64, order=1, freqs=[5])
     assert (st == 0).all() and np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,nt,order", [("cfg4_iba_active_L5_n16", 64, 0), ("dmrt_active_L3_n12", 128, 1),
+                                           ("iba_shs_active_L3_n8", 64, 2), ("iba_active_L3_n10_m1_steep", 256, 1),
+                                           ("iba_2layer_active19", 64, 0)])
+def test_emulated_active_kernel_matches_reference(emu, name, nt, order):
+    """Active mode (three polarisations, azimuth modes 0..m_max, coherent subtraction, backscatter read-out);
+    the last case has N = 3 x 32 = 96 rows, i.e. the global-workspace variant of the kernel."""
+    out, st, ref = run_fixture(emu, name, nt=nt, order=order)
+    assert (st == 0).all()
+    assert_backscatter_close(out, ref)
 
 
 def test_emulated_kernel_flags_albedo_above_one(emu):

@@ -38,6 +38,14 @@ def test_passive_tb(name, method):
 @pytest.mark.parametrize("method", ["half_rank_eig", "schur_forcedtriu"])
 def test_active_backscatter(name, method):
     d = load_golden(name)
+    if name.startswith("dmrt_active") and method == "half_rank_eig":
+        # the Rayleigh modes m = 1, 2 are low-rank: the reduced matrix has (numerically) degenerate eigenvalues and
+        # the non-symmetric eigensolver of this method returns complex pairs, which the reference rejects too
+        # (dort.py:1068-1085); its default method (forced-triangular Schur) and the device algorithm do not care
+        with pytest.raises(O.OracleError):
+            O.solve(snowpack_dict(d), float(d["frequency"][0]), d["theta_deg"], emmodel=str(d["emmodel"]), mode="A",
+                    theta_inc_deg=d["theta_inc_deg"], method=method, **fixture_options(d))
+        return
     sp = snowpack_dict(d)
     for i, f in enumerate(d["frequency"]):
         r = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), mode="A",
@@ -49,6 +57,19 @@ def test_active_backscatter(name, method):
         # cross-pol on its own scale (40-50 dB below co-pol)
         assert np.allclose(r[0, 1], ref[0, 1], rtol=1e-6, atol=0)
         assert np.allclose(r[1, 0], ref[1, 0], rtol=1e-6, atol=0)
+
+
+def test_active_cross_pol_conditioning():
+    """Why the cross-polarised backscatter is held to 1e-6 on its own scale (conftest.assert_backscatter_close): for
+    a weakly scattering 2-layer pack the reference's own diagonalisation methods agree to 1e-10 on co-pol but only
+    to ~1e-7 on cross-pol."""
+    sp = dict(thickness=np.array([0.05, 0.08]), density=np.array([250.0, 380.0]), temperature=np.array([255.0, 262.0]),
+              microstructure="exponential", corr_length=np.array([1.2e-4, 2.1e-4]))
+    th = np.array([25.0, 40.0, 55.0])
+    a = O.solve(sp, 5.405e9, th, mode="A", theta_inc_deg=th, n_max_stream=16, method="schur_forcedtriu")
+    b = O.solve(sp, 5.405e9, th, mode="A", theta_inc_deg=th, n_max_stream=16, method="half_rank_eig")
+    assert np.abs(b[0, 0] / a[0, 0] - 1).max() < 1e-9
+    assert np.abs(b[0, 1] / a[0, 1] - 1).max() < 1e-6
 
 
 @pytest.mark.parametrize("name", ["cfg1_iba_onelayer", "iba_2layer_passive37", "cfg2_iba_L20_n32_sp0",
