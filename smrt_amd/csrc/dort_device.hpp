@@ -1381,6 +1381,235 @@ SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int 
     return true;
 }
 
+// ---- 16-wide blocked Gauss-Jordan (N <= 64): ONE workgroup barrier per 16 columns ---------------------------------
+// Same elimination as gj_solve_mfma (implicit partial pivoting, tracked transformation columns u_j, permutation undone
+// at the end) with three changes that take the sequential part off the critical path of every block:
+//   * block width 16 = one MFMA tile column = four chained v_mfma_f64_16x16x4 per tile (the C tile is loaded and
+//     stored once per 16 eliminated columns instead of once per 4);
+//   * the multipliers u_j are written into the panel's own, now dead, columns of A -- no side buffer;
+//   * the pivot rows of the running block are NOT touched by the tile updates (stores to them are masked), so they
+//     can be read in place as the B operand by every wavefront; their own new values R_P + U_P R_P are computed as
+//     one extra "virtual" tile per column tile, kept in registers across the block barrier and stored after it.
+// Every wavefront owns fixed absolute column tiles of [A | B] for the whole solve, so the only cross-wavefront
+// traffic per block is the panel (u columns, permutation, row states), published by the one barrier.  The panel of
+// block k+1 is factorised by the owner of that column tile right after it has updated the tile (look-ahead).
+template <bool TR>
+SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+    const int k0 = 16 * k;
+    const int nbk = (N - k0 < 16) ? N - k0 : 16;
+    double a[16], u[16];
+    const int rc = lane < N ? lane : N - 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int cc = (k0 + j < N) ? k0 + j : N - 1;
+        const double x = at<TR>(A, rc, cc, LD);
+        a[j] = (lane < N && j < nbk) ? x : 0.0;
+        u[j] = 0.0;
+    }
+    bool used = (lane < N) ? (rowblk[lane] >= 0) : true;
+    bool mine = false, ok = true;
+    int pj_store = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < nbk) {
+            unsigned key = 0u;
+            if (!used) {
+                const float xr = (float)fabs(a[j]);
+                memcpy(&key, &xr, 4);
+                key = (key & ~0x7Fu) | (unsigned)(127 - lane);
+            }
+            key = wave_max_u32(key);
+            if (key < 128u) ok = false;
+            const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
+            if (lane == j) pj_store = p;
+            const bool isp = (lane == p);
+            const double rpv = fast_rcp(ok ? wave_bcast(a[j], p) : 1.0);
+            if (isp) { used = true; mine = true; }
+            // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as every
+            // other row with the multiplier 1 - 1/pv (one select per column instead of one per entry)
+            const double uj = isp ? rpv - 1.0 : -(a[j] * rpv);
+            // all the broadcasts of the pivot row first, then all the updates (the readlane -> FMA pairs otherwise
+            // serialise on the SGPR hand-off)
+            double pr[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if (jj > j) pr[jj] = wave_bcast(a[jj], p);
+                if (jj < j) pr[jj] = wave_bcast(u[jj], p);
+            }
+#if !defined(SMRT_HOST_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if (jj > j) a[jj] = __builtin_fma(uj, pr[jj], a[jj]);
+                if (jj < j) u[jj] = __builtin_fma(uj, pr[jj], u[jj]);
+            }
+            u[j] = uj;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (lane < N && j < nbk) at<TR>(A, lane, k0 + j, LD) = ok ? u[j] : 0.0;
+    if (lane < nbk) perm[k0 + lane] = pj_store;
+    if (mine && ok) rowblk[lane] = k;
+    return ok;
+}
+
+template <int NT, bool TR>
+SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
+    const int t = tid();
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    constexpr int MAXOWN = (8 + NW - 1) / NW;   // column tiles of [A | B] per wavefront (2 RT <= 8)
+    const int NMX = s.gj_nmax;
+    int* perm = (int*)s.gj;                     // [NMX + 16] pivot row of every column
+    int* rowblk = perm + NMX + 16;              // [NMX] block in which the row was a pivot row, -1 before
+    int* fail = rowblk + NMX;
+    const bool has_v = (v != nullptr);
+    const int RT = (N + 15) >> 4;
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int r = t; r < NMX; r += NT) rowblk[r] = -1;
+    if (t == 0) *fail = 0;
+    block_sync();
+#ifdef SMRT_STAGE_TIMING
+    long long tg0 = cycle_counter();
+#define SMRT_GSUB(k) do { const long long n_ = cycle_counter(); if (t == 0 && s.sub_acc) s.sub_acc[k] += (double)(n_ - tg0); tg0 = n_; } while (0)
+#else
+#define SMRT_GSUB(k) do {} while (0)
+#endif
+    if (wave == 0) { if (!gj_panel16<TR>(A, N, LD, 0, lane, perm, rowblk) && lane == 0) *fail = 1; }
+    SMRT_GSUB(0);
+    block_sync();
+    if (*fail) return false;  // uniform
+
+    for (int k = 0; k < RT; ++k) {
+        const int k0 = 16 * k;
+        const int nbk = (N - k0 < 16) ? N - k0 : 16;
+        // one absolute column tile g of [A | B]: all row tiles (pivot rows masked) + the virtual pivot-row tile -> pvt
+        auto do_tile = [&](int g, double (&pvt)[4]) {
+            double* Mat = (g < RT) ? A : Bm;
+            const int col = ((g < RT) ? g : g - RT) * 16 + lr;
+            const bool cin = col < N;
+            const int colc = cin ? col : 0;
+            double bop[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk;
+                const int pr = (j < nbk) ? perm[k0 + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                bop[kk] = (cin && j < nbk) ? x : 0.0;
+            }
+            for (int ti = 0; ti < RT; ++ti) {
+                double c[4];
+                bool keep[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    const int rowc = row < N ? row : 0;
+                    const double x = at<TR>(Mat, rowc, colc, LD);
+                    keep[reg] = cin && row < N && rowblk[rowc] != k;
+                    c[reg] = keep[reg] ? x : 0.0;
+                }
+                const int arow = ti * 16 + lr;
+                const int arowc = arow < N ? arow : 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int j = 4 * kk + lk;
+                    const int jc = (j < nbk) ? j : 0;
+                    const double x = at<TR>(A, arowc, k0 + jc, LD);
+                    mfma_f64_16x16x4((arow < N && j < nbk) ? x : 0.0, bop[kk], c);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    if (keep[reg]) at<TR>(Mat, row, col, LD) = c[reg];
+                }
+            }
+            // new pivot rows: R_P + U_P R_P with U_P[j][i] = u_i[p_j]
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                const int pr = (j < nbk) ? perm[k0 + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                pvt[reg] = (cin && j < nbk) ? x : 0.0;
+            }
+            const int prl = (lr < nbk) ? perm[k0 + lr] : 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk;
+                const int jc = (j < nbk) ? j : 0;
+                const double x = at<TR>(A, prl, k0 + jc, LD);
+                mfma_f64_16x16x4((lr < nbk && j < nbk) ? x : 0.0, bop[kk], pvt);
+            }
+        };
+        auto store_pivot_rows = [&](int g, const double (&pvt)[4]) {
+            double* Mat = (g < RT) ? A : Bm;
+            const int col = ((g < RT) ? g : g - RT) * 16 + lr;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                if (col < N && j < nbk) at<TR>(Mat, perm[k0 + j], col, LD) = pvt[reg];
+            }
+        };
+
+        double pv[MAXOWN][4];
+        const int gnext = k + 1;  // the column tile of the next panel
+        if (gnext < RT && (gnext % NW) == wave) {
+            double tmp[4];
+            do_tile(gnext, tmp);
+            wave_sync_lds();
+            store_pivot_rows(gnext, tmp);
+            wave_sync_lds();
+            if (!gj_panel16<TR>(A, N, LD, k + 1, lane, perm, rowblk) && lane == 0) *fail = 1;
+        }
+#pragma unroll
+        for (int slot = 0; slot < MAXOWN; ++slot) {
+            const int g = wave + slot * NW;
+            const bool live = (g < 2 * RT) && !(g < RT && g <= k) && (g != gnext || gnext >= RT);
+            if (live) do_tile(g, pv[slot]);
+        }
+        if (has_v && wave == (RT % NW) && lane < N) {  // extra right-hand side: same transformation, lane = row
+            double acc = v[lane];
+            for (int j = 0; j < nbk; ++j) acc += at<TR>(A, lane, k0 + j, LD) * v[perm[k0 + j]];
+            wave_sync_lds();
+            v[lane] = acc;
+        } else if (has_v && wave == (RT % NW)) {
+            wave_sync_lds();
+        }
+        block_sync();
+        if (*fail) return false;  // uniform
+#pragma unroll
+        for (int slot = 0; slot < MAXOWN; ++slot) {
+            const int g = wave + slot * NW;
+            const bool live = (g < 2 * RT) && !(g < RT && g <= k) && (g != gnext || gnext >= RT);
+            if (live) store_pivot_rows(g, pv[slot]);
+        }
+        wave_sync_lds();
+    }
+    block_sync();
+    SMRT_GSUB(1);
+    // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
+    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
+    double vk = 0.0;
+    if (has_v && t < N) vk = v[perm[t]];
+    block_sync();
+    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
+    if (has_v && t < N) v[t] = vk;
+    block_sync();
+    SMRT_GSUB(2);
+    return true;
+}
+
+// the Gauss-Jordan variant used by the drivers (-DSMRT_GJ_BLOCK4 selects the older 4-wide one for A/B timing)
+template <int NT, bool TR>
+SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
+#ifdef SMRT_GJ_BLOCK4
+    return gj_solve_mfma<NT, TR>(A, Bm, v, s, N, LD);
+#else
+    return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // the per-pair solve (passive mode, azimuth mode 0, 2 polarisations)
 // ------------------------------------------------------------------------------------------------------------
@@ -1722,7 +1951,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
-        if (!(CH == 1 ? gj_solve_mfma<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH == 1 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = Rt;
         SMRT_DUMP("Q", Q, N);
@@ -1737,7 +1966,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
-        if (!(CH == 1 ? gj_solve_mfma<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH == 1 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);

@@ -16,6 +16,7 @@
 #include <cstring>
 #include "emu_runtime.hpp"
 #define SMRT_DEV inline
+#define SMRT_DEV_NOINLINE inline
 #define SMRT_LANES 64
 namespace smrt {
 SMRT_DEV int tid() { return emu::tid(); }
@@ -63,6 +64,7 @@ SMRT_DEV void gmem_max(int* p, int v) { if (v > *p) *p = v; }
 
 #include <hip/hip_runtime.h>
 #define SMRT_DEV __device__ __forceinline__
+#define SMRT_DEV_NOINLINE __device__ __noinline__
 #define SMRT_LANES 64
 namespace smrt {
 SMRT_DEV int tid() { return threadIdx.x; }
@@ -160,8 +162,19 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
     cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cv, 0, 0, 0);
     c[0] = cv[0]; c[1] = cv[1]; c[2] = cv[2]; c[3] = cv[3];
 }
-// max of a 32-bit key over the wavefront (one v_max_u32 per DPP step, four readlanes for the 16-lane rows)
+// max of a 32-bit key over the wavefront with DPP only: four steps inside the 16-lane rows, then row_bcast15 /
+// row_bcast31 carry the row maxima across (lane 63 ends up with the maximum of all 64), one readlane
 SMRT_DEV unsigned wave_max_u32(unsigned k) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x142, 0xA, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x143, 0xC, 0xF, false); k = o > k ? o : k;
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+SMRT_DEV unsigned wave_max_u32_rl(unsigned k) {
     unsigned o;
     o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
     o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
