@@ -111,8 +111,10 @@ SMRT_HD int azimuth_samples(int m_max) {
     return 1 << e;
 }
 
+// slim = 1: the "prep" kernel of the split pipeline -- two work matrices (X+- -> L+-), four row vectors and the
+// Cholesky scratch only, so that TWO workgroups fit in the 160 KB of a CU.
 SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1,
-                          int act_doubles = 0) {
+                          int act_doubles = 0, int slim = 0) {
     LdsPlan p;
     p.nmax = n_max_stream;
     p.NMAX = n_max_stream * P;
@@ -121,17 +123,18 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.nphi = nphi;
     p.ntheta = ntheta;
     p.matrices_in_lds = matrices_in_lds;
-    p.mat_doubles = 4 * p.NMAX * p.LD;
+    const int nmat = slim ? 2 : 4;
+    p.mat_doubles = nmat * p.NMAX * p.LD;
     int o = 0;
-    for (int i = 0; i < 4; ++i) { p.o_M[i] = i * p.NMAX * p.LD; }
+    for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * p.NMAX * p.LD; }
     if (matrices_in_lds) o = p.mat_doubles;
-    p.o_rowvec = o; o += 17 * p.NMAX;
+    p.o_rowvec = o; o += (slim ? 4 : 17) * p.NMAX;
     p.o_strvec = o; o += 6 * p.nmax;
     p.o_layvec = o; o += 11 * Lmax;
     p.o_phi = o; o += 5 * nphi;
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
-    p.o_gj = o; o += ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    p.o_gj = o; o += slim ? 520 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
     p.o_act = o; o += act_doubles;
     p.total = o;
     return p;
@@ -1703,7 +1706,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
-    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0);
+    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
+                                   MODE == 1 ? 1 : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1781,7 +1785,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
         if (l > 0)
             for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
-        if (l == L - 1) {  // nothing below the last layer (rtsolver_utils.py:548-551,601-603)
+        if (MODE != 1 && l == L - 1) {  // nothing below the last layer (rtsolver_utils.py:548-551,601-603)
             for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
             for (int r = t; r < N; r += NT) s.svec[r] = 0.0;
         }
@@ -1795,13 +1799,14 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             s.w[j] = w;
             s.mrow[2 * j] = s.mu[j]; s.mrow[2 * j + 1] = s.mu[j];
             s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
+            if (MODE == 1) continue;  // the interfaces belong to the finish kernel
             double Rv, Rh;
             const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
             fresnel_RvRh(el, eup, s.mu[j], &Rv, &Rh);
             s.Rtop[2 * j] = Rv; s.Rtop[2 * j + 1] = Rh;
             s.Ttop[2 * j] = 1.0 - Rv; s.Ttop[2 * j + 1] = 1.0 - Rh;
         }
-        if (l > 0)
+        if (MODE != 1 && l > 0)
             for (int j = t; j < nu; j += NT) {
                 double Rv, Rh;
                 fresnel_RvRh(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], &Rv, &Rh);
@@ -1895,14 +1900,17 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
         }
         SMRT_STAGE(SG_BTL);
+        if (MODE == 1) {  // B = L+^T L- straight from the accumulators into the staging area
+            lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD);
+        } else {
         if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
+        }
         }  // MODE != 2
-        if (MODE == 1) {  // park L+, B, d for the Jacobi and finish kernels
+        if (MODE == 1) {  // park L+ and d for the finish kernel (B is already there)
             const long long item = p * (long long)b.Lmax + l;
             double* gL = stg->L + item * stg->mat_stride;
-            double* gB = stg->B + item * stg->mat_stride;
-            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; gB[c * LD + r] = s.M2[c * LD + r]; });
+            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; });
             for (int r = t; r < N; r += NT) stg->d[item * stg->vec_stride + r] = s.d[r];
             if (t == 0) stg->n[item] = N;
             block_sync();

@@ -89,6 +89,7 @@ struct smrt_dort_ctx {
     int out_stride = 0;
     int nt = 512;
     size_t lds_bytes = 0;
+    size_t prep_lds_bytes = 0;
     float last_ms = 0.f;
     double total_ms = 0.0;
     int64_t n_launch = 0;
@@ -130,13 +131,17 @@ static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
     return hipGetLastError();
 }
 
+#ifndef SMRT_PREP_THREADS
+#define SMRT_PREP_THREADS 256  // two 256-thread prep workgroups per CU (77 KB of LDS each) beat one of 512
+#endif
 template <int NT>
 static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
-    auto kp = dort_prep_kernel<NT>;
+    constexpr int PNT = (NT >= 256) ? SMRT_PREP_THREADS : NT;
+    auto kp = dort_prep_kernel<PNT>;
     auto kj = dort_jacobi_kernel<256>;
     auto kf = dort_finish_kernel<NT>;
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
     const int out_stride = ctx->out_stride;
@@ -148,7 +153,7 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
         c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
-        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -284,6 +289,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         ctx->stage.n = (int*)ctx->d_stn.p;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, 2).total * sizeof(double);
+        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 1).total * sizeof(double);
     }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
