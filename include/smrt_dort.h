@@ -121,8 +121,9 @@ double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 
 /* Pipeline shape on the LDS-resident path (N <= 64): 1 (default) = three kernels (prep per pair, Jacobi per
- * pair x layer with four workgroups per CU, finish per pair) with the factors staged through HBM/L2;
- * 0 = everything fused in one kernel, one workgroup per pair.  Call before smrt_dort_upload. */
+ * pair x layer with four workgroups per CU, finish per pair with two LDS-resident matrices and two workgroups per CU)
+ * with the factors staged through HBM/L2; 2 = the same with the previous finish kernel (four LDS-resident matrices,
+ * one workgroup per CU); 0 = everything fused in one kernel, one workgroup per pair.  Call before smrt_dort_upload. */
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
 
 /* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3

@@ -215,8 +215,10 @@ class DortContext:
     def set_block_threads(self, n):
         self._check(self._lib.smrt_dort_set_block_threads(self._h, int(n)), "smrt_dort_set_block_threads")
 
-    def set_pipeline(self, split=True):
-        self._check(self._lib.smrt_dort_set_pipeline(self._h, 1 if split else 0), "smrt_dort_set_pipeline")
+    def set_pipeline(self, split=1):
+        """1 (default): prep / Jacobi / two-slot finish kernels; 2: the same with the LDS-resident finish kernel;
+        0: one fused kernel per pair."""
+        self._check(self._lib.smrt_dort_set_pipeline(self._h, int(split)), "smrt_dort_set_pipeline")
 
     def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1) -> BatchOutput:
         if pair_count < 0:

@@ -63,6 +63,7 @@ struct DevStage {
     int* n;
     long long mat_stride;  // doubles per matrix slot (NMAX * LD)
     int vec_stride;        // doubles per vector slot (NMAX)
+    double* Linv;          // [item][4][256] inverses of the 16x16 diagonal blocks of L+ (written by the prep kernel)
 };
 
 constexpr double kCSpeed = 299792458.0;
@@ -80,6 +81,7 @@ enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_
 // ------------------------------------------------------------------------------------------------------------
 struct LdsPlan {
     int NMAX, LD, nmax, Lmax, nphi, ntheta;
+    int slim;             // 0: full layout, 1: prep kernel, 2: two-slot finish kernel (see make_plan)
     int matrices_in_lds;  // 1: the four N x N work matrices are LDS-resident; 0: they live in a global workspace
     int mat_doubles;      // doubles of matrix workspace per workgroup (4 * NMAX * LD)
     int o_M[4];
@@ -113,6 +115,7 @@ SMRT_HD int azimuth_samples(int m_max) {
 
 // slim = 1: the "prep" kernel of the split pipeline -- two work matrices (X+- -> L+-), four row vectors and the
 // Cholesky scratch only, so that TWO workgroups fit in the 160 KB of a CU.
+// slim = 2: the two-slot "finish" kernel -- two work matrices (X, R), all row vectors, Gauss-Jordan bookkeeping only.
 SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1,
                           int act_doubles = 0, int slim = 0) {
     LdsPlan p;
@@ -127,14 +130,16 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.mat_doubles = nmat * p.NMAX * p.LD;
     int o = 0;
     for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * p.NMAX * p.LD; }
+    if (slim == 2) p.o_M[3] = p.NMAX * p.LD;  // the two-slot finish kernel: M0 = X, M3 = R (M1, M2 live in global memory)
     if (matrices_in_lds) o = p.mat_doubles;
-    p.o_rowvec = o; o += (slim ? 4 : 17) * p.NMAX;
+    p.slim = slim;
+    p.o_rowvec = o; o += (slim == 1 ? 4 : slim == 2 ? 14 : 17) * p.NMAX;  // slim 2: no mrow / wrow / u
     p.o_strvec = o; o += 6 * p.nmax;
     p.o_layvec = o; o += 11 * Lmax;
-    p.o_phi = o; o += 5 * nphi;
+    p.o_phi = o; o += (slim == 2 ? 0 : 5 * nphi);
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
-    p.o_gj = o; o += slim ? 520 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? 88 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
     p.o_act = o; o += act_doubles;
     p.total = o;
     return p;
@@ -157,8 +162,8 @@ struct Lds {
 SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
     Lds s;
     s.M0 = mat_base + p.o_M[0]; s.M1 = mat_base + p.o_M[1]; s.M2 = mat_base + p.o_M[2]; s.M3 = mat_base + p.o_M[3];
-    double* v = base + p.o_rowvec;
     const int n = p.NMAX;
+    double* v = base + p.o_rowvec - (p.slim == 2 ? 3 * n : 0);  // slim 2: mrow / wrow / u do not exist (never touched)
     s.mrow = v; s.wrow = v + n; s.u = v + 2 * n; s.d = v + 3 * n; s.sigma = v + 4 * n; s.rsig = v + 5 * n;
     s.t = v + 6 * n; s.Rtop = v + 7 * n; s.Ttop = v + 8 * n; s.Rbu = v + 9 * n; s.Tbu = v + 10 * n;
     s.cvec = v + 11 * n; s.tq = v + 12 * n; s.svec = v + 13 * n; s.g = v + 14 * n; s.upb = v + 15 * n;
@@ -923,6 +928,82 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
     block_sync();
 }
 
+// Two-slot variant for the finish kernel whose F and G live in global memory: Y and W are held in registers until
+// every wavefront has finished reading Q, then Y goes to Yout and W OVER Q (Wout == Q is allowed).
+template <int NT>
+SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, double* Yout, double* Wout,
+                        const double* Rtop, const double* tq, double* upb, double* gvec, double Bl, int N, int LD) {
+    using RTc = RowTiles<NT>;
+    constexpr int MAXTJ = (4 + RTc::CS - 1) / RTc::CS;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    double ys[RTc::RPW][MAXTJ][4], ws[RTc::RPW][MAXTJ][4];
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        const double rt = Rtop[ic];
+        double af[16], aw[16];
+        double vy = 0.0, vg = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
+            const bool in = (ti < RT && i < N && k < N);
+            af[kk] = in ? fv : 0.0;
+            aw[kk] = in ? gv - rt * fv : 0.0;
+            vy += af[kk] * tk;
+            vg += aw[kk] * tk;
+        }
+        vy += shfl_xor(vy, 16); vy += shfl_xor(vy, 32);
+        vg += shfl_xor(vg, 16); vg += shfl_xor(vg, 32);
+        const bool owner = (RTc::NW >= 4) ? (wave < 4) : true;
+        if (owner && ti < RT && lk == 0 && i < N) { upb[i] = vy + Bl; gvec[i] = vg + (1.0 - rt) * Bl; }
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+#pragma unroll
+        for (int q = 0; q < MAXTJ; ++q) {
+            const int tj = cs + q * RTc::CS;
+            double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ti < RT && tj < RT) {
+                const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    if (4 * kk < N) {
+                        const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                        const double qv = Q[jc * LD + kc];
+                        const double bop = (j < N && k < N) ? qv : 0.0;
+                        mfma_f64_16x16x4(af[kk], bop, cy);
+                        mfma_f64_16x16x4(aw[kk], bop, cw);
+                    }
+                }
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    const double fic = F[col * LD + row], gic = G[col * LD + row];
+                    cy[reg] += gic;
+                    cw[reg] += fic - Rtop[row] * gic;
+                });
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { ys[o][q][reg] = cy[reg]; ws[o][q][reg] = cw[reg]; }
+        }
+    }
+    block_sync();  // every wavefront has read Q
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+#pragma unroll
+        for (int q = 0; q < MAXTJ; ++q) {
+            const int tj = cs + q * RTc::CS;
+            if (ti < RT && tj < RT)
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    Yout[col * LD + row] = ys[o][q][reg];
+                    Wout[col * LD + row] = ws[o][q][reg];
+                });
+        }
+    }
+    block_sync();
+}
+
 // ---- the same two passes without the matrix core (N > 64: CH column chunks of 64 per lane) --------------------
 // rows-per-wavefront register blocking
 constexpr int RB = 2;
@@ -1023,7 +1104,8 @@ SMRT_DEV void r45_rows(double* F, const double* G, const double* Q, double* Wk, 
 // trailing update (A_IK -= L_IJ L_KJ^T) are MFMA tile GEMMs.  3 workgroup barriers per block column (12 for N = 64)
 // instead of one per column, and the O(N^3) part runs on the matrix core.
 template <int NT>
-SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int* fail, int N, int LD) {
+SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int* fail, int N, int LD,
+                         double* inv_out = nullptr /* [4][256]: inverses of the diagonal blocks of the first factor */) {
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     constexpr int NW = NT / SMRT_LANES;
     const int RT = (N + 15) >> 4;
@@ -1077,6 +1159,10 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
             if (lane < 16) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) inv[mi * 256 + lr * 16 + i] = x[i];   // (L^-1)[i][j = lr]
+                if (mi == 0 && inv_out) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) inv_out[J * 256 + lr * 16 + i] = x[i];
+                }
             }
         }
         block_sync();
@@ -1135,14 +1221,15 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
 // is two MFMA GEMMs per 16x16 tile -- the accumulator layout of the first is exactly the B-operand layout of the
 // second (c[reg] = R[lk + 4 reg][lr] = B[k = 4 kk + lk][j = lr] for kk = reg), so nothing moves between them.
 template <int NT>
-SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*16] */, int N, int LD) {
+SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*16] */, int N, int LD,
+                            bool have_inv = false /* inv already holds the block inverses (from chol2_mfma) */) {
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     constexpr int NW = NT / SMRT_LANES;
     const int RT = (N + 15) >> 4;
     // inverse of the diagonal blocks: inv[I][j*16 + i] = (L_II^-1)[i][j]  (identity padding beyond N).
     // lane (mod 16) = row i of the block with the row in registers; entries of other rows come by wave_bcast
     // (loading the block through broadcast LDS reads made the compiler hoist all 136 loads into registers).
-    for (int I = wave; I < RT; I += NW) {
+    for (int I = wave; I < RT && !have_inv; I += NW) {
         const int b0 = I * 16, gi = b0 + lr;
         double row[16];
 #pragma unroll
@@ -1167,7 +1254,7 @@ SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*
             for (int i = 0; i < 16; ++i) inv[I * 256 + lr * 16 + i] = x[i];
         }
     }
-    block_sync();
+    if (!have_inv) block_sync();
     for (int I = RT - 1; I >= 0; --I) {
         for (int tj = wave; tj < RT; tj += NW) {
             double c[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1398,61 +1485,71 @@ SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int 
 // block k+1 is factorised by the owner of that column tile right after it has updated the tile (look-ahead).
 template <bool TR>
 SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+    // x[s] holds panel column s of this lane's row until the column has been a pivot column, its multiplier u_s
+    // afterwards: both kinds of slot receive the same update x[s] += u_j * x[s][pivot row], so a step treats all
+    // slots but the pivot one alike.  The loop is unrolled by four only, with the slots rotated by four after every
+    // group (the pivot slot index stays a compile-time constant): a fully unrolled panel is ~18 KB of straight-line
+    // code that is executed once per call and does not live in the instruction cache next to the rest of the kernel.
     const int k0 = 16 * k;
     const int nbk = (N - k0 < 16) ? N - k0 : 16;
-    double a[16], u[16];
+    double x[16];
     const int rc = lane < N ? lane : N - 1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int cc = (k0 + j < N) ? k0 + j : N - 1;
-        const double x = at<TR>(A, rc, cc, LD);
-        a[j] = (lane < N && j < nbk) ? x : 0.0;
-        u[j] = 0.0;
+        const double v = at<TR>(A, rc, cc, LD);
+        x[j] = (lane < N && j < nbk) ? v : 0.0;
     }
     bool used = (lane < N) ? (rowblk[lane] >= 0) : true;
     bool mine = false, ok = true;
     int pj_store = 0;
+    int grp = 0;
+    for (; grp * 4 < nbk; ++grp) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (j < nbk) {
-            unsigned key = 0u;
-            if (!used) {
-                const float xr = (float)fabs(a[j]);
-                memcpy(&key, &xr, 4);
-                key = (key & ~0x7Fu) | (unsigned)(127 - lane);
-            }
-            key = wave_max_u32(key);
-            if (key < 128u) ok = false;
-            const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
-            if (lane == j) pj_store = p;
-            const bool isp = (lane == p);
-            const double rpv = fast_rcp(ok ? wave_bcast(a[j], p) : 1.0);
-            if (isp) { used = true; mine = true; }
-            // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as every
-            // other row with the multiplier 1 - 1/pv (one select per column instead of one per entry)
-            const double uj = isp ? rpv - 1.0 : -(a[j] * rpv);
-            // all the broadcasts of the pivot row first, then all the updates (the readlane -> FMA pairs otherwise
-            // serialise on the SGPR hand-off)
-            double pr[16];
+        for (int q = 0; q < 4; ++q) {
+            const int j = grp * 4 + q;
+            if (j < nbk) {   // uniform
+                unsigned key = 0u;
+                if (!used) {
+                    const float xr = (float)fabs(x[q]);
+                    memcpy(&key, &xr, 4);
+                    key = (key & ~0x7Fu) | (unsigned)(127 - lane);
+                }
+                key = wave_max_u32(key);
+                if (key < 128u) ok = false;
+                const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
+                if (lane == j) pj_store = p;
+                const bool isp = (lane == p);
+                const double rpv = fast_rcp(ok ? wave_bcast(x[q], p) : 1.0);
+                if (isp) { used = true; mine = true; }
+                // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as every
+                // other row with the multiplier 1 - 1/pv
+                const double uj = isp ? rpv - 1.0 : -(x[q] * rpv);
+                double pr[16];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                if (jj > j) pr[jj] = wave_bcast(a[jj], p);
-                if (jj < j) pr[jj] = wave_bcast(u[jj], p);
-            }
+                for (int s2 = 0; s2 < 16; ++s2)
+                    if (s2 != q) pr[s2] = wave_bcast(x[s2], p);
 #if !defined(SMRT_HOST_EMU)
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                if (jj > j) a[jj] = __builtin_fma(uj, pr[jj], a[jj]);
-                if (jj < j) u[jj] = __builtin_fma(uj, pr[jj], u[jj]);
+                for (int s2 = 0; s2 < 16; ++s2)
+                    if (s2 != q) x[s2] = __builtin_fma(uj, pr[s2], x[s2]);
+                x[q] = uj;
             }
-            u[j] = uj;
         }
-    }
+        // rotate the slots left by four: slot s now holds what slot s + 4 held
+        double t0 = x[0], t1 = x[1], t2 = x[2], t3 = x[3];
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (lane < N && j < nbk) at<TR>(A, lane, k0 + j, LD) = ok ? u[j] : 0.0;
+        for (int s2 = 0; s2 < 12; ++s2) x[s2] = x[s2 + 4];
+        x[12] = t0; x[13] = t1; x[14] = t2; x[15] = t3;
+    }
+    // after grp rotations slot s holds column (s + 4 grp) mod 16
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int j = (s2 + 4 * grp) & 15;
+        if (lane < N && j < nbk) at<TR>(A, lane, k0 + j, LD) = ok ? x[s2] : 0.0;
+    }
     if (lane < nbk) perm[k0 + lane] = pj_store;
     if (mine && ok) rowblk[lane] = k;
     return ok;
@@ -1695,6 +1792,11 @@ enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_
 // MODE 0: the whole solve in one workgroup (fused).  MODE 1 ("prep"): per layer assemble X+-, factorise, form
 // B = L+^T L- and park L+, B, d in the staging area.  MODE 2 ("finish"): pick up L+, B' (rotated by the Jacobi
 // kernel) and the singular values, build the eigenvectors and run the layer recursion.
+// MODE 3 ("finish", two LDS slots): the same recursion with only two N x N matrices in LDS, so that TWO workgroups
+// share a CU (the Gauss-Jordan panels are wavefront-serial: a second resident workgroup fills the idle SIMDs).
+//   slot X: B' -> Ep' -> Wk (LU1 matrix) -> Y -> K         slot R: R~ (carried between layers) -> Q -> W
+//   global: L+ is used where it lies in the staging area; Em' -> G overwrites the item's B slot, F the item's L
+//   slot (both dead by then); the 16x16 diagonal-block inverses of L+ come from the prep kernel.
 template <int NT, int CH, int MODE = 0>
 SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr,
                                 const DevStage* stg = nullptr) {
@@ -1707,7 +1809,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
-                                   MODE == 1 ? 1 : 0);
+                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0));
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1736,11 +1838,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     // ---- stage 0: layer scalars, azimuth table, Gauss-Legendre sines -------------------------------------
     if (t < 8) s.ints[t] = 0;
     block_sync();
-    if (MODE == 2) {  // a failure recorded by the prep or Jacobi kernel
+    if (MODE >= 2) {  // a failure recorded by the prep or Jacobi kernel
         const int prev = b.status[p];
         if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
     }
-    for (int k = t; k < nphi; k += NT) {
+    for (int k = t; k < nphi && MODE < 2; k += NT) {  // azimuth table of the phase-matrix assembly
         const double ph = kPi * (double)k / (double)(nphi - 1);
         const double c = cos(ph), sn = sin(ph);
         s.cphi[k] = c; s.s2phi[k] = sn * sn;
@@ -1797,8 +1899,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             else if (j == n - 1) w = fabs(0.5 * (s.mu[n - 2] + s.mu[n - 1]));
             else w = fabs(0.5 * (s.mu[j - 1] - s.mu[j + 1]));
             s.w[j] = w;
-            s.mrow[2 * j] = s.mu[j]; s.mrow[2 * j + 1] = s.mu[j];
-            s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
+            if (MODE < 2) {
+                s.mrow[2 * j] = s.mu[j]; s.mrow[2 * j + 1] = s.mu[j];
+                s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
+            }
             if (MODE == 1) continue;  // the interfaces belong to the finish kernel
             double Rv, Rh;
             const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
@@ -1815,7 +1919,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             }
 
         SMRT_STAGE(SG_ASSEMBLE);
-        if (MODE != 2) {
+        if (MODE < 2) {
         // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
         //    (lower triangle by stream blocks; the matrices are symmetric)
         {
@@ -1896,7 +2000,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         });
         block_sync();
         SMRT_STAGE(SG_CHOL);
-        if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD) : chol2<NT>(s.M0, s.M1, N, LD))) {
+        if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD,
+                                       MODE == 1 ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
+                      : chol2<NT>(s.M0, s.M1, N, LD))) {
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
         }
         SMRT_STAGE(SG_BTL);
@@ -1906,7 +2012,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
         }
-        }  // MODE != 2
+        }  // MODE < 2
         if (MODE == 1) {  // park L+ and d for the finish kernel (B is already there)
             const long long item = p * (long long)b.Lmax + l;
             double* gL = stg->L + item * stg->mat_stride;
@@ -1921,11 +2027,12 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, s.sub_acc)) {
                 fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
             }
-        } else {  // MODE 2: pick up L+, B' = B V, d and the singular values
+        } else {  // MODE 2 / 3: pick up L+, B' = B V, d and the singular values
             const long long item = p * (long long)b.Lmax + l;
             const double* gL = stg->L + item * stg->mat_stride;
             const double* gB = stg->B + item * stg->mat_stride;
-            for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gL[c * LD + r]; s.M2[c * LD + r] = gB[c * LD + r]; });
+            if (MODE == 3) for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gB[c * LD + r]; });   // B' -> slot X
+            else for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gL[c * LD + r]; s.M2[c * LD + r] = gB[c * LD + r]; });
             for (int r = t; r < N; r += NT) {
                 s.d[r] = stg->d[item * stg->vec_stride + r];
                 const double sg = stg->sigma[item * stg->vec_stride + r];
@@ -1934,6 +2041,21 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             block_sync();
         }
         SMRT_STAGE(SG_TRI);
+        double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+        if (MODE == 3) {
+            const long long item = p * (long long)b.Lmax + l;
+            double* gL = stg->L + item * stg->mat_stride;   // L+, later F
+            double* gB = stg->B + item * stg->mat_stride;   // (B' is in slot X by now) Em', later G
+            l_times_m_mfma<NT>(gL, s.M0, gB, N, LD);                                            // Em' = L+ B'
+            lt_solve_mfma<NT>(gL, s.M0, stg->Linv + item * 1024, N, LD, true);                  // Ep' = L+^-T B'
+            for_2d<NT>(N, N, [&](int i, int c) {
+                const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
+                const double hd = 0.5 * s.d[i];
+                gL[c * LD + i] = hd * (ep + em);
+                gB[c * LD + i] = hd * (ep - em);
+            });
+            F = gL; G = gB;
+        } else {
         if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
         else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
         if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
@@ -1945,9 +2067,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             s.M2[c * LD + i] = hd * (ep + em);
             s.M1[c * LD + i] = hd * (ep - em);
         });
+        }
         for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
         block_sync();
-        double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
         SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
 
         SMRT_STAGE(SG_R1);
@@ -1966,7 +2088,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
         for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
         block_sync();
-        if (CH == 1) {
+        if (MODE == 3) {
+            r45_mfma2<NT>(F, G, Q, Wk, Rt, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot X, W -> slot R (over Q)
+        } else if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
         } else {
             r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
@@ -1974,7 +2098,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
-        if (!(CH == 1 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH == 1 ? gj_solve<NT, true>(MODE == 3 ? Rt : F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +34,13 @@ template <int NT>
 __global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, 1, 2>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+}
+// two LDS slots + F, G in the (dead) staging slots of the item: two workgroups per CU
+// (second launch-bound argument on HIP = wavefronts per SIMD the compiler must leave room for: 2 -> <= 256 VGPRs)
+template <int NT>
+__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_finish2_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
 }
 
 // N > 64 (n_max_stream up to 64 x CH/2): same device functions, work matrices in a per-workgroup global workspace
@@ -83,13 +91,15 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti;
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
     int nt = 512;
     size_t lds_bytes = 0;
     size_t prep_lds_bytes = 0;
+    size_t finish2_lds_bytes = 0;
+    bool finish2 = true;        // two-slot finish kernel (set_pipeline(2) selects the LDS-resident one)
     float last_ms = 0.f;
     double total_ms = 0.0;
     int64_t n_launch = 0;
@@ -134,17 +144,33 @@ static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
 #ifndef SMRT_PREP_THREADS
 #define SMRT_PREP_THREADS 256  // two 256-thread prep workgroups per CU (77 KB of LDS each) beat one of 512
 #endif
+#ifndef SMRT_FINISH_THREADS
+#define SMRT_FINISH_THREADS 256  // likewise for the two-slot finish kernel (80 KB of LDS each)
+#endif
 template <int NT>
 static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
     constexpr int PNT = (NT >= 256) ? SMRT_PREP_THREADS : NT;
+    constexpr int FNT = (NT >= 256) ? SMRT_FINISH_THREADS : NT;
     auto kp = dort_prep_kernel<PNT>;
     auto kj = dort_jacobi_kernel<256>;
     auto kf = dort_finish_kernel<NT>;
+    auto kf2 = dort_finish2_kernel<FNT>;
     hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
     const int out_stride = ctx->out_stride;
+    if (getenv("SMRT_DORT_DEBUG_OCCUPANCY")) {  // resident workgroups per CU as the runtime sees them
+        int op = 0, oj = 0, of2 = 0, of = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&op, kp, PNT, ctx->prep_lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oj, kj, 256, ctx->jacobi_lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of2, kf2, FNT, ctx->finish2_lds_bytes);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, kf, NT, ctx->lds_bytes);
+        fprintf(stderr, "occupancy (workgroups/CU): prep<%d> lds=%zu -> %d | jacobi<256> lds=%zu -> %d | finish2<%d> lds=%zu -> %d | "
+                        "finish<%d> lds=%zu -> %d\n", PNT, ctx->prep_lds_bytes, op, ctx->jacobi_lds, oj, FNT,
+                ctx->finish2_lds_bytes, of2, NT, ctx->lds_bytes, of);
+    }
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
         DevBatch c = d;
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
@@ -155,7 +181,8 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
         hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
+        if (ctx->finish2) hipLaunchKernelGGL(kf2, dim3((unsigned)cn), dim3(FNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -214,7 +241,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
-                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn};
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -227,6 +254,7 @@ const char* smrt_dort_last_error(const smrt_dort_ctx* ctx) { return ctx ? ctx->e
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
     if (!ctx) return -1;
     ctx->split = (split != 0);
+    ctx->finish2 = (split != 2);
     ctx->uploaded = false;  // the staging area is sized at upload time
     return 0;
 }
@@ -273,7 +301,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     ctx->chunk_pairs = 0;
     if (!ctx->gmem_path && ctx->split && !ctx->active) {
         const size_t mat = (size_t)plan.NMAX * plan.LD;
-        const size_t per_pair = (size_t)b->n_layers_max * ((2 * mat + 2 * plan.NMAX) * sizeof(double) + sizeof(int));
+        const size_t per_pair = (size_t)b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
         long long chunk = (long long)(12.0e9 / (double)per_pair);
         if (chunk < 1) chunk = 1;
         if (chunk > pair_count) chunk = pair_count;
@@ -284,12 +312,14 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
         HIPCHK(ctx->d_sts.reserve(items * plan.NMAX * sizeof(double)));
         HIPCHK(ctx->d_stn.reserve(items * sizeof(int)));
+        HIPCHK(ctx->d_sti.reserve(items * 1024 * sizeof(double)));
         ctx->stage.L = (double*)ctx->d_stL.p; ctx->stage.B = (double*)ctx->d_stB.p;
         ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
-        ctx->stage.n = (int*)ctx->d_stn.p;
+        ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, 2).total * sizeof(double);
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 1).total * sizeof(double);
+        ctx->finish2_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 2).total * sizeof(double);
     }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;

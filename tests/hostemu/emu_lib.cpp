@@ -10,6 +10,10 @@
 
 using namespace smrt;
 
+// 1: three-kernel pipeline with the two-slot finish kernel (default, like the library), 2: three-kernel pipeline with
+// the LDS-resident finish kernel, 0: fused kernel
+extern "C" { int smrt_emu_pipeline = 1; }
+
 template <int NT, int CH>
 static long run_pairs(DevBatch& d, int order, size_t lds_doubles, size_t mat_doubles) {
     long nb = 0;
@@ -44,7 +48,8 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
     const size_t mat = (size_t)plan.NMAX * plan.LD;
     std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
     std::vector<int> stn(items, -1);
-    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX};
+    std::vector<double> stinv(items * 1024, NAN);
+    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
     std::vector<double> lds(lds_doubles);
     for (long long p = 0; p < d.pair_count; ++p) {
         for (auto& x : lds) x = NAN;
@@ -58,12 +63,12 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
     }
     for (long long p = 0; p < d.pair_count; ++p) {
         for (auto& x : lds) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &st); });
+        if (smrt_emu_pipeline == 2) nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &st); });
+        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 3>(d, p, lds.data(), nullptr, &st); });
     }
     return nb;
 }
 
-extern "C" int smrt_emu_pipeline = 1;  // 1: three-kernel pipeline (default, like the library), 0: fused kernel
 
 extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long pair_count, int nt, int order,
                             double* out, int32_t* status, double* layer_out, double* stream_out, double* n3_out,

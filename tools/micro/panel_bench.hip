@@ -2,6 +2,7 @@
 // of it switched off, to see where the cycles go.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I smrt_amd/csrc
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "dort_device.hpp"
 using namespace smrt;
 
@@ -82,26 +83,59 @@ __global__ __launch_bounds__(64) void k(const double* src, double* out, long lon
         __syncthreads();
         tot += clock64() - t0;
     }
-    for (int j = 0; j < 16; ++j) out[j * 64 + lane] = A[j * 65 + lane];
-    if (lane == 0) cyc[0] = tot / reps;
+    if (blockIdx.x == 0) for (int j = 0; j < 16; ++j) out[j * 64 + lane] = A[j * 65 + lane];
+    if (lane == 0 && blockIdx.x == 0) cyc[0] = tot / reps;
 }
 
+// the product's own panel routine (noinline device function, generic pointers)
+template <bool TR>
+__global__ __launch_bounds__(64) void kreal(const double* src, double* out, long long* cyc, int reps) {
+    __shared__ double A[64 * 65];
+    __shared__ int perm[96];
+    __shared__ int rowblk[64];
+    const int lane = threadIdx.x;
+    long long tot = 0;
+    for (int r = 0; r < reps; ++r) {
+        for (int j = 0; j < 16; ++j) { if (TR) A[lane * 65 + j] = src[j * 64 + lane] + 1e-3 * r; else A[j * 65 + lane] = src[j * 64 + lane] + 1e-3 * r; }
+        rowblk[lane] = -1;
+        __syncthreads();
+        const long long t0 = clock64();
+        gj_panel16<TR>(A, 64, 65, 0, lane, perm, rowblk);
+        __syncthreads();
+        tot += clock64() - t0;
+    }
+    if (blockIdx.x == 0) for (int j = 0; j < 16; ++j) out[j * 64 + lane] = A[j * 65 + lane];
+    if (lane == 0 && blockIdx.x == 0) cyc[0] = tot / reps;
+}
+static int g_grid = 1;
+template <bool TR>
+void run_real(const char* name, const double* dsrc, double* dout, long long* dcyc) {
+    hipLaunchKernelGGL(kreal<TR>, dim3(g_grid), dim3(64), 0, 0, dsrc, dout, dcyc, 50);
+    hipDeviceSynchronize();
+    long long c;
+    hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost);
+    printf("%-46s %6lld cycles / panel  = %5.0f / column\n", name, c, c / 16.0);
+}
 template <int VAR>
 void run(const char* name, const double* dsrc, double* dout, long long* dcyc) {
-    hipLaunchKernelGGL(k<VAR>, dim3(1), dim3(64), 0, 0, dsrc, dout, dcyc, 50);
+    hipLaunchKernelGGL(k<VAR>, dim3(g_grid), dim3(64), 0, 0, dsrc, dout, dcyc, 50);
     hipDeviceSynchronize();
     long long c;
     hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost);
     printf("%-46s %6lld cycles / panel  = %5.0f / column\n", name, c, c / 16.0);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_grid = atoi(argv[1]);
+    printf("grid = %d workgroups of one wavefront\n", g_grid);
     double h[16 * 64];
     for (int j = 0; j < 16; ++j)
         for (int i = 0; i < 64; ++i) h[j * 64 + i] = (i == j ? 4.0 : 0.0) + sin(1.0 + i * 0.37 + j * 1.91);
     double *dsrc, *dout; long long* dcyc;
     hipMalloc(&dsrc, sizeof(h)); hipMalloc(&dout, sizeof(h)); hipMalloc(&dcyc, 8);
     hipMemcpy(dsrc, h, sizeof(h), hipMemcpyHostToDevice);
+    run_real<false>("product gj_panel16<TR=false>", dsrc, dout, dcyc);
+    run_real<true>("product gj_panel16<TR=true>", dsrc, dout, dcyc);
     run<15>("full (search + a-updates + u-tracking + NR rcp)", dsrc, dout, dcyc);
     run<31>("full, DPP-only wavefront max", dsrc, dout, dcyc);
     run<47>("full, broadcasts batched before the FMAs", dsrc, dout, dcyc);
