@@ -207,14 +207,15 @@ def main():
                 "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per pipeline launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
-                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_kernel (one launch each per "
+                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish2_kernel (one launch each per "
                           "step; kernel_ms is their summed HIP-event time on the launch stream)",
                 "kernel_ms": kernel_ms,
                 "flops_per_launch": flops_per_launch,
                 "note": "FP64 compute roofline (vector FMA rate = FP64 MFMA rate on gfx950, 78.6 TFLOP/s); algorithmic "
                         "flops = 68 * sum over pairs and layers of N_l^3 with the actual stream counts (SURVEY 8d); "
-                        "algorithmic HBM bytes are ~1.6 KB per solve; the pipeline additionally stages ~67 KB per "
-                        "(pair, layer) through HBM/L2 between its kernels (see DESIGN.md 4), still far from HBM-bound",
+                        "algorithmic HBM bytes are ~1.6 KB per solve; the pipeline additionally stages ~75 KB per "
+                        "(pair, layer) through HBM/L2 between its kernels and keeps F, G of the running layer there "
+                        "(see DESIGN.md 4), still far from HBM-bound",
             },
         }
         if not args.no_cpu_baseline:
