@@ -275,7 +275,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     const char* why = smrt_host::validate(b);
     if (why) { ctx->err = why; return -1; }
     ctx->active = (b->mode == SMRT_MODE_ACTIVE);
-    if (ctx->active && (b->m_max < 0 || b->m_max > 15)) { ctx->err = "m_max must be in 0..15"; return -1; }
+    if (ctx->active && (b->m_max < 0 || b->m_max > 64)) { ctx->err = "m_max must be in 0..64"; return -1; }
     const int64_t npairs = (int64_t)b->n_snowpacks * b->n_frequencies;
     if (pair_count < 0) pair_count = npairs - pair_begin;
     if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }

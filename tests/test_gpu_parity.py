@@ -226,6 +226,23 @@ def test_active_random_batch_against_oracle(ctx):
             assert_backscatter_close(out.values[f * S + s_], ref)
 
 
+def test_active_reference_schur_case_m16(ctx):
+    """smrt/rtsolver/test_dort.py:13-38: IBA, one deep layer, 32 streams, m_max = 16 (the case the reference's `eig`
+    method cannot do); N = 96 rows, 17 azimuth modes, 512 azimuth samples.  Against the oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    sp = dict(thickness=np.array([1000.0]), density=np.array([280.0]), temperature=np.array([265.0]),
+              microstructure="exponential", corr_length=np.array([0.05e-3]))
+    th = np.array([50.0])
+    ref = O.solve(sp, 10e9, th, mode="A", theta_inc_deg=th, n_max_stream=32, m_max=16, method="schur_forcedtriu")
+    b = PackedBatch([1], sp["thickness"], sp["density"] / 916.7, sp["temperature"], sp["corr_length"], None, [10e9],
+                    np.deg2rad(th), emmodel="iba", microstructure="exponential", mode="A", n_max_stream=32, m_max=16)
+    out = ctx.run(b)
+    assert out.status[0] == 0
+    assert_backscatter_close(out.values[0], ref)
+
+
 def test_active_properties(ctx):
     """Size-independent properties on a batch the oracle is not asked about: near-reciprocity of the cross-polarised
     backscatter (sigma_HV ~ sigma_VH: exact in the continuum, within a few per cent in the discretised reference

@@ -85,6 +85,25 @@ def test_emulated_active_kernel_matches_reference(emu, name, nt, order):
     assert_backscatter_close(out, ref)
 
 
+def test_emulated_active_kernel_high_azimuth_order(emu):
+    """m_max = 16 (512 azimuth samples) as in smrt/rtsolver/test_dort.py:13-38, at 8 streams, against the oracle."""
+    from oracle import dort_oracle as O
+
+    sp = dict(thickness=np.array([1000.0]), density=np.array([280.0]), temperature=np.array([265.0]),
+              microstructure="exponential", corr_length=np.array([0.05e-3]))
+    th = np.array([50.0])
+    ref = O.solve(sp, 10e9, th, mode="A", theta_inc_deg=th, n_max_stream=8, m_max=16, method="schur_forcedtriu")
+    b = PackedBatch([1], sp["thickness"], sp["density"] / 916.7, sp["temperature"], sp["corr_length"], None, [10e9],
+                    np.deg2rad(th), emmodel="iba", microstructure="exponential", mode="A", n_max_stream=8, m_max=16)
+    out = np.empty((1,) + b.out_shape())
+    st = np.empty(1, np.int32)
+    nb = C.c_long()
+    rc = emu.smrt_emu_run(C.byref(b.struct), 0, 1, 64, 1, out.ctypes.data_as(C.POINTER(C.c_double)),
+                          st.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, C.byref(nb))
+    assert rc == 0 and st[0] == 0
+    assert_backscatter_close(out[0], ref)
+
+
 def test_emulated_kernel_flags_albedo_above_one(emu):
     out, st, _ = run_fixture(emu, "dmrt_2layer_passive37")
     assert st[0] == 3 and np.isnan(out).all()
