@@ -43,6 +43,11 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_NORM_ON 1
 #define SMRT_NORM_FORCED 2
 
+/* substrate under the last layer */
+#define SMRT_SUBSTRATE_NONE 0       /* semi-infinite / transparent (rtsolver_utils.py:548-551,601-603) */
+#define SMRT_SUBSTRATE_FLAT 1       /* Fresnel against a given permittivity (substrate/flat.py) */
+#define SMRT_SUBSTRATE_REFLECTOR 2  /* prescribed specular reflection, emissivity 1 - R (substrate/reflector.py), passive only */
+
 /* per-pair status word */
 #define SMRT_OK 0
 #define SMRT_ERR_EIGEN 1           /* eigen iteration did not converge (dort.py:1068-1085)                */
@@ -67,7 +72,7 @@ typedef struct smrt_batch {
     int32_t m_max;            /* DORT m_max, used in active mode only (dort.py:151,209) */
     int32_t phase_normalization; /* SMRT_NORM_* */
     int32_t rayleigh_jeans;   /* DORT rayleigh_jeans_approximation (dort.py:160) */
-    int32_t reserved;
+    int32_t substrate_kind;   /* SMRT_SUBSTRATE_*: what lies under the last layer (Snowpack.substrate) */
     const int32_t* n_layers;  /* [S] */
     const double* thickness;  /* [S][Lmax] m */
     const double* frac_volume;/* [S][Lmax] ice volume fraction (SnowLayer.compute_frac_volumes, make_medium.py:390-434) */
@@ -77,6 +82,16 @@ typedef struct smrt_batch {
     const double* frequency;  /* [F] Hz */
     const double* theta;      /* [n_theta] rad: Sensor.theta (== theta_inc in active/backscatter mode) */
     double phi;               /* active: azimuth (rad), pi for backscatter (sensor.py:179-180) */
+    /* substrate (smrt/substrate/flat.py, reflector.py; rtsolver_utils.py:544-605, dort.py:429-441), per pair because
+     * permittivity / reflection models may depend on the frequency.  Unused (may be NULL) for SMRT_SUBSTRATE_NONE. */
+    const double* substrate_p1;          /* [F][S] flat: Re eps_substrate | reflector: specular reflection, V */
+    const double* substrate_p2;          /* [F][S] flat: Im eps_substrate | reflector: specular reflection, H */
+    const double* substrate_temperature; /* [S] K; <= 0: the substrate does not emit (temperature=None) */
+    /* SimpleIsotropicAtmosphere (smrt/atmosphere/simple_isotropic_atmosphere.py; rtsolver_utils.py:251-260,302-305),
+     * passive mode only; all three NULL = no atmosphere */
+    const double* atm_tb_down;           /* [F] K */
+    const double* atm_tb_up;             /* [F] K */
+    const double* atm_transmittance;     /* [F] */
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

@@ -393,8 +393,11 @@ def _flatten_pol(d, mode):
     return d.T.reshape(-1)
 
 
-def interface_diagonals(eps, st, npol):
-    """Flat interfaces, no substrate: smrt/rtsolver/rtsolver_utils.py:473-644 (coherent terms only)."""
+def interface_diagonals(eps, st, npol, substrate=None):
+    """Flat interfaces: smrt/rtsolver/rtsolver_utils.py:473-644 (coherent terms only).  substrate: None, or a dict
+    {"kind": "flat", "eps": complex} (smrt/substrate/flat.py via core/interface.py:169-240: Fresnel reflection /
+    transmission against the substrate permittivity) or {"kind": "reflector", "R": (R_V, R_H)}
+    (smrt/substrate/reflector.py: prescribed specular reflection, emissivity 1 - R; two polarisations only)."""
     L = len(eps)
     itf = dict(Rtop=[], Ttop=[], Rbot=[], Tbot=[])
     for l in range(L):
@@ -404,6 +407,15 @@ def interface_diagonals(eps, st, npol):
         if l < L - 1:
             itf["Rbot"].append(flat_reflection(eps[l], eps[l + 1], st.mu[l], npol))
             itf["Tbot"].append(flat_transmission(eps[l], eps[l + 1], st.mu[l], npol))
+        elif substrate is not None and substrate["kind"] == "flat":  # rtsolver_utils.py:544-547,579-584
+            itf["Rbot"].append(flat_reflection(eps[l], substrate["eps"], st.mu[l], npol))
+            itf["Tbot"].append(flat_transmission(eps[l], substrate["eps"], st.mu[l], npol))
+        elif substrate is not None and substrate["kind"] == "reflector":
+            if npol > 2:
+                raise NotImplementedError("reflector substrate in active mode (reflector.py: not implemented)")
+            R = np.repeat(np.asarray(substrate["R"], float)[:, None], st.n[l], axis=1)
+            itf["Rbot"].append(R)
+            itf["Tbot"].append(1.0 - R)
         else:  # nothing below (rtsolver_utils.py:548-551,601-603)
             itf["Rbot"].append(np.zeros((npol, st.n[l])))
             itf["Tbot"].append(np.zeros((npol, st.n[l])))
@@ -545,7 +557,7 @@ def _put_block(ab, u, i0, j0, blk):
 
 
 def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coherent_only=False,
-              return_x0=False):
+              return_x0=False, planck_substrate=None):
     """Assemble and solve the block-tridiagonal boundary system for mode m: smrt/rtsolver/dort.py:263-488.
 
     planck_T: per-layer black-body radiance B(T_l) (None in active mode).  intensity_down: (n_air*P, R).
@@ -598,6 +610,8 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
             b[row_bot[l] : row_bot[l] + N[l]] -= ((1.0 - Rbot) * planck_T[l])[:, None]
             if l > 0:
                 b[row_bot[l - 1] : row_bot[l - 1] + nc] += (Ttop * planck_T[l])[:nc, None]
+            if l == L - 1 and planck_substrate is not None:  # emission of the substrate, dort.py:429-441
+                b[row_bot[l] : row_bot[l] + N[l]] += (Tbot * planck_substrate)[:, None]
     x = scipy.linalg.solve_banded((nband, nband), ab, b)  # dort.py:469
     x0 = x[: 2 * N[0]]
     I1 = Eu0 @ (tt0[:, None] * x0)  # dort.py:476
@@ -613,8 +627,15 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
 # full solve for one (snowpack, frequency)
 # ----------------------------------------------------------------------------------------------------------------
 def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None, phi=np.pi, n_max_stream=32,
-          m_max=2, method="half_rank_eig", phase_normalization=True, rayleigh_jeans=False, details=None):
-    """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces, no substrate, no atmosphere.
+          m_max=2, method="half_rank_eig", phase_normalization=True, rayleigh_jeans=False, details=None,
+          substrate=None, atmosphere=None):
+    """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces.
+
+    substrate: None or a dict, see interface_diagonals, plus "temperature" (None: no emission).
+    atmosphere: None or a dict {"tb_down", "tb_up", "transmittance"} (K, K, -) of a SimpleIsotropicAtmosphere at this
+    frequency (smrt/atmosphere/simple_isotropic_atmosphere.py, core/atmosphere.py:131-160): its downwelling radiation
+    illuminates the snowpack and the result is tb_up + transmittance * (...) (rtsolver_utils.py:251-260,302-305);
+    ignored in active mode like in the reference.
 
     Passive: returns Tb[(V,H), theta].  Active: returns intensity[(pol V,H,U), (pol_inc V,H,U), theta_inc]
     (the layout of the reference's Result.data; sigma = 4 pi cos(theta) I, smrt/core/result.py:484-486).
@@ -626,7 +647,7 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
     active = mode == "A"
     npol = 3 if active else 2
     mm = m_max if active else 0
-    itf = interface_diagonals(eps, st, npol)
+    itf = interface_diagonals(eps, st, npol, substrate)
     leig = [LayerEigen(ems[l], st.mu[l], st.weight[l], mm, npol, method, phase_normalization)
             for l in range(len(ems))]
     if details is not None:
@@ -636,7 +657,16 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
             BT = [float(t) for t in sp["temperature"]]
         else:
             BT = [planck(frequency, float(t)) for t in sp["temperature"]]
-        I0 = dort_mode(0, leig, st, itf, thickness, BT, np.zeros((2 * st.n_air, 1)))[:, 0]
+        to_I = (lambda t: float(t)) if rayleigh_jeans else (lambda t: planck(frequency, float(t)))
+        Bsub = None
+        if substrate is not None and substrate.get("temperature") is not None:
+            Bsub = to_I(substrate["temperature"])
+        I_down = np.zeros((2 * st.n_air, 1))
+        if atmosphere is not None:
+            I_down[:] = to_I(atmosphere["tb_down"])
+        I0 = dort_mode(0, leig, st, itf, thickness, BT, I_down, planck_substrate=Bsub)[:, 0]
+        if atmosphere is not None:
+            I0 = to_I(atmosphere["tb_up"]) + atmosphere["transmittance"] * I0
         tb = I0 if rayleigh_jeans else inverse_planck(frequency, I0)
         tb = tb.reshape(st.n_air, 2).T  # (pol, stream), dort.py:503-505
         if details is not None:

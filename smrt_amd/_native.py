@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
 EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1}
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
+SUBSTRATE_CODES = {"flat": 1, "reflector": 2}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}
 STATUS_MESSAGES = {
     1: "The eigen-decomposition did not converge in DORT.",
@@ -44,7 +45,7 @@ class SmrtBatch(C.Structure):
         ("m_max", C.c_int32),
         ("phase_normalization", C.c_int32),
         ("rayleigh_jeans", C.c_int32),
-        ("reserved", C.c_int32),
+        ("substrate_kind", C.c_int32),
         ("n_layers", C.POINTER(C.c_int32)),
         ("thickness", C.POINTER(C.c_double)),
         ("frac_volume", C.POINTER(C.c_double)),
@@ -54,6 +55,12 @@ class SmrtBatch(C.Structure):
         ("frequency", C.POINTER(C.c_double)),
         ("theta", C.POINTER(C.c_double)),
         ("phi", C.c_double),
+        ("substrate_p1", C.POINTER(C.c_double)),
+        ("substrate_p2", C.POINTER(C.c_double)),
+        ("substrate_temperature", C.POINTER(C.c_double)),
+        ("atm_tb_down", C.POINTER(C.c_double)),
+        ("atm_tb_up", C.POINTER(C.c_double)),
+        ("atm_transmittance", C.POINTER(C.c_double)),
     ]
 
 
@@ -67,7 +74,10 @@ class PackedBatch:
 
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
-                 phase_normalization="auto", rayleigh_jeans=False, phi=np.pi):
+                 phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None):
+        """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
+        "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
+        atmosphere: None or (tb_down[F], tb_up[F], transmittance[F])."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
         S = len(self.n_layers)
         two_d = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(S, -1))  # noqa: E731
@@ -99,6 +109,19 @@ class PackedBatch:
         s.micro_p1, s.micro_p2 = _dptr(self.micro_p1), _dptr(self.micro_p2)
         s.frequency, s.theta = _dptr(self.frequency), _dptr(self.theta)
         s.phi = float(phi)
+        s.substrate_kind = 0
+        if substrate is not None:
+            kind, q1, q2, ts = substrate
+            F = len(self.frequency)
+            self.sub_p1 = np.ascontiguousarray(np.broadcast_to(np.asarray(q1, np.float64), (F, S)))
+            self.sub_p2 = np.ascontiguousarray(np.broadcast_to(np.asarray(q2, np.float64), (F, S)))
+            self.sub_T = np.ascontiguousarray(np.nan_to_num(np.broadcast_to(np.asarray(ts, np.float64), (S,)), nan=0.0))
+            s.substrate_kind = SUBSTRATE_CODES[kind]
+            s.substrate_p1, s.substrate_p2, s.substrate_temperature = _dptr(self.sub_p1), _dptr(self.sub_p2), _dptr(self.sub_T)
+        if atmosphere is not None:
+            F = len(self.frequency)
+            self.atm = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (F,))) for a in atmosphere]
+            s.atm_tb_down, s.atm_tb_up, s.atm_transmittance = (_dptr(a) for a in self.atm)
         self.struct = s
 
     @property

@@ -1,4 +1,5 @@
-"""Snowpack container (counterpart of smrt/core/snowpack.py:34-260 for Flat interfaces without substrate)."""
+"""Snowpack container (counterpart of smrt/core/snowpack.py:34-260 for Flat interfaces; optional Flat / Reflector
+substrate and SimpleIsotropicAtmosphere)."""
 import numpy as np
 
 from ..interface.flat import Flat
@@ -7,14 +8,20 @@ from .error import SMRTError
 
 class Snowpack:
     def __init__(self, layers=None, interfaces=None, substrate=None, atmosphere=None):
-        if substrate is not None:
-            raise SMRTError("substrates are outside the scope of smrt_amd (semi-infinite bottom layer, SURVEY 8f)")
-        if atmosphere is not None:
-            raise SMRTError("atmospheres are outside the scope of smrt_amd (SURVEY 8f)")
+        if substrate is not None and getattr(substrate, "device_kind", None) is None:
+            raise SMRTError("smrt_amd implements the Flat and Reflector substrates (smrt_amd.substrate)")
+        if atmosphere is not None and not hasattr(atmosphere, "device_params"):
+            raise SMRTError("smrt_amd implements the SimpleIsotropicAtmosphere (smrt_amd.atmosphere)")
         self.layers = list(layers) if layers is not None else []
         self.interfaces = list(interfaces) if interfaces is not None else [Flat() for _ in self.layers]
-        self.substrate = None
-        self.atmosphere = None
+        self.substrate = substrate
+        self.atmosphere = atmosphere
+
+    def __add__(self, other):
+        """snowpack + substrate (smrt/core/snowpack.py:__add__)."""
+        if getattr(other, "device_kind", None) is not None:
+            return Snowpack(layers=self.layers, interfaces=self.interfaces, substrate=other, atmosphere=self.atmosphere)
+        raise SMRTError("only a substrate can be added to a snowpack in smrt_amd")
 
     @property
     def nlayer(self):

@@ -134,6 +134,12 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         const int jn = idx >> 1, pol = idx & 1;
         const int j = inc[jn];
         double Rt = 0.0, K = 0.0, Ttop0 = 0.0;
+        if (b.sub_kind == SUB_FLAT && j < (int)s.nl[L - 1]) {  // specular reflection of the substrate
+            const double rs = s.ri[L - 1] * s.gsin[j];
+            double R3[3], T3[3];
+            fresnel_RT3(cmk(s.eps_re[L - 1], s.eps_im[L - 1]), cmk(b.sub_p1[gp], b.sub_p2[gp]), sqrt(1.0 - rs * rs), R3, T3);
+            Rt = R3[pol];
+        }
         for (int l = L - 1; l >= 0; --l) {
             const int n = (int)s.nl[l];
             const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
@@ -196,6 +202,13 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (l == L - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
             for (int r = t; r < N; r += NT) { s.svec[r] = 0.0; s.tq[r] = 0.0; }
             block_sync();
+            if (l == L - 1 && b.sub_kind == SUB_FLAT) {  // substrate: R_sub (V, H, U) on the diagonal
+                for (int j = t; j < n; j += NT) {
+                    double R3[3], T3[3];
+                    fresnel_RT3(el, cmk(b.sub_p1[gp], b.sub_p2[gp]), s.mu[j], R3, T3);
+                    for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
+                }
+            }
             for (int j = t; j < n; j += NT) {
                 double w;
                 if (j == 0) w = 1.0 - 0.5 * (s.mu[0] + s.mu[1]);

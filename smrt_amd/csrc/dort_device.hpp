@@ -44,6 +44,10 @@ struct DevBatch {
     const double* frequency;
     const double* theta;
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
+    int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
+    const double *sub_p1, *sub_p2;        // [F][S]
+    const double* sub_T;                  // [S], <= 0: no emission
+    const double *atm_down, *atm_up, *atm_trans;  // [F] or null
     double phi;
     double* out;
     int* status;
@@ -75,6 +79,7 @@ constexpr double kPi = 3.14159265358979323846;
 enum { EM_IBA = 0, EM_DMRT = 1 };
 enum { MS_EXP = 0, MS_SHS = 1 };
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5 };
+enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
 // LDS layout (shared by host sizing code and the kernel)
@@ -753,8 +758,11 @@ SMRT_DEV void tile_foreach(int ti, int tj, int N, F f) {
 }
 
 // C = Lp^T Lm (both lower triangular; whatever sits above their diagonals is ignored)
+// reverse_cols: column c of the product is stored as column N-1-c.  The column norms of B = L+^T L- grow with the
+// column index (beta ~ ke / mu, mu descending); the one-sided Jacobi converges in fewer sweeps when the large
+// columns come first (de Rijk), and nothing downstream depends on the order of the eigenpairs.
 template <int NT>
-SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int N, int LD) {
+SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int N, int LD, bool reverse_cols = false) {
     const int wave = tid() / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
     const int RT = (N + 15) >> 4;
@@ -770,7 +778,7 @@ SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int
             const double av = Lp[ic * LD + kc], bv = Lm[jc * LD + kc];
             mfma_f64_16x16x4((i < N && k < N && k >= i) ? av : 0.0, (j < N && k < N && k >= j) ? bv : 0.0, c);
         }
-        tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[col * LD + row] = c[reg]; });
+        tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[(reverse_cols ? N - 1 - col : col) * LD + row] = c[reg]; });
     }
     block_sync();
 }
@@ -1887,9 +1895,29 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
         if (l > 0)
             for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
-        if (MODE != 1 && l == L - 1) {  // nothing below the last layer (rtsolver_utils.py:548-551,601-603)
+        if (MODE != 1 && l == L - 1) {
+            // what the last layer sees below: nothing (rtsolver_utils.py:548-551,601-603), or a substrate: specular
+            // reflection R_sub on the diagonal and its emission (1 - R_sub) B(T_sub) (rtsolver_utils.py:544-547,
+            // 579-584; dort.py:429-441)
             for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
-            for (int r = t; r < N; r += NT) s.svec[r] = 0.0;
+            block_sync();
+            for (int r = t; r < N; r += NT) {
+                double Rs = 0.0, src = 0.0;
+                if (b.sub_kind != SUB_NONE) {
+                    const long long gpi = b.pair_begin + p;
+                    const double q1 = b.sub_p1[gpi], q2 = b.sub_p2[gpi];
+                    if (b.sub_kind == SUB_FLAT) {
+                        const double rs = s.ri[l] * s.gsin[r >> 1];
+                        double Rv, Rh;
+                        fresnel_RvRh(el, cmk(q1, q2), sqrt(1.0 - rs * rs), &Rv, &Rh);
+                        Rs = (r & 1) ? Rh : Rv;
+                    } else Rs = (r & 1) ? q2 : q1;
+                    const double Ts = b.sub_T[si];
+                    if (Ts > 0.0) src = (1.0 - Rs) * (b.rayleigh_jeans ? Ts : planck_radiance(frequency, Ts));
+                }
+                s.M3[r * LD + r] = Rs;
+                s.svec[r] = src;
+            }
         }
         block_sync();
         // -- weights (streams.py:324-330), per-row copies, interface diagonals
@@ -2007,7 +2035,12 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         SMRT_STAGE(SG_BTL);
         if (MODE == 1) {  // B = L+^T L- straight from the accumulators into the staging area
-            lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD);
+            lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD,
+#ifdef SMRT_NO_COLUMN_REVERSAL
+                                false);
+#else
+                                true);
+#endif
         } else {
         if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
@@ -2128,9 +2161,32 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     }
     SMRT_STAGE(SG_OUT);
     // ---- emerging brightness temperature at the air streams, then at the sensor angles ---------------------
-    for (int i = t; i < n_air * P; i += NT) {
-        const double I0 = s.Ttop[i] * s.up[i];  // dort.py:484 with no downwelling sky radiation
-        s.tb[i] = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
+    {
+        // atmosphere (rtsolver_utils.py:251-260,302-305): isotropic downwelling radiation I_dn enters through the
+        // surface (dort.py:391-395), is reflected by it (dort.py:484) and by the snowpack (K_0 of the top layer is
+        // still in the work matrix), and the result is tb_up + transmittance * (...)
+        const bool atm = (b.atm_down != nullptr);
+        const double Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
+        const double Iup = atm ? (b.rayleigh_jeans ? b.atm_up[fi] : planck_radiance(frequency, b.atm_up[fi])) : 0.0;
+        const double trans = atm ? b.atm_trans[fi] : 1.0;
+        const double* K0 = s.M0;
+        const cplx e0 = cmk(s.eps_re[0], s.eps_im[0]);
+        for (int i = t; i < n_air * P; i += NT) {
+            double I0 = s.Ttop[i] * s.up[i];  // dort.py:484
+            if (atm && Idn != 0.0) {
+                double acc = 0.0;
+                for (int j = 0; j < n_air; ++j) {
+                    double Rv, Rh;
+                    fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[j], &Rv, &Rh);
+                    acc += K0[(2 * j) * LD + i] * (1.0 - Rv) + K0[(2 * j + 1) * LD + i] * (1.0 - Rh);
+                }
+                double Rv, Rh;
+                fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[i >> 1], &Rv, &Rh);
+                I0 += ((i & 1) ? Rh : Rv) * Idn + s.Ttop[i] * acc * Idn;
+            }
+            if (atm) I0 = Iup + trans * I0;
+            s.tb[i] = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
+        }
     }
     block_sync();
     for (int idx = t; idx < P * b.n_theta; idx += NT) {

@@ -91,7 +91,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm;
     DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -241,7 +241,8 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
-                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti};
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -331,6 +332,19 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     if (upload_array(ctx, ctx->d_p2, b->micro_p2 ? b->micro_p2 : b->micro_p1, sizeof(double) * SL)) return -1;
     if (upload_array(ctx, ctx->d_freq, b->frequency, sizeof(double) * b->n_frequencies)) return -1;
     if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
+    const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
+    if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
+        if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;
+        if (upload_array(ctx, ctx->d_sub2, b->substrate_p2, sizeof(double) * FS)) return -1;
+        if (upload_array(ctx, ctx->d_subT, b->substrate_temperature, sizeof(double) * b->n_snowpacks)) return -1;
+    }
+    std::vector<double> atm;
+    if (b->atm_tb_down) {
+        atm.insert(atm.end(), b->atm_tb_down, b->atm_tb_down + b->n_frequencies);
+        atm.insert(atm.end(), b->atm_tb_up, b->atm_tb_up + b->n_frequencies);
+        atm.insert(atm.end(), b->atm_transmittance, b->atm_transmittance + b->n_frequencies);
+        if (upload_array(ctx, ctx->d_atm, atm.data(), sizeof(double) * atm.size())) return -1;
+    }
     std::vector<double> gl(b->n_max_stream);
     smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
     if (upload_array(ctx, ctx->d_gl, gl.data(), sizeof(double) * gl.size())) return -1;
@@ -353,6 +367,12 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     d.p1 = (const double*)ctx->d_p1.p; d.p2 = (const double*)ctx->d_p2.p;
     d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
     d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
+    d.sub_kind = b->substrate_kind;
+    d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
+    const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
+    d.atm_down = has_atm ? (const double*)ctx->d_atm.p : nullptr;
+    d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
+    d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
     d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
     ctx->lds_bytes = lds;

@@ -58,6 +58,13 @@ inline const char* validate(const smrt_batch* b) {
         !b->theta)
         return "null input array";
     if (b->microstructure == SMRT_MS_STICKY_HARD_SPHERES && !b->micro_p2) return "stickiness array missing";
+    if (b->substrate_kind < SMRT_SUBSTRATE_NONE || b->substrate_kind > SMRT_SUBSTRATE_REFLECTOR) return "unknown substrate kind";
+    if (b->substrate_kind != SMRT_SUBSTRATE_NONE && (!b->substrate_p1 || !b->substrate_p2 || !b->substrate_temperature))
+        return "substrate arrays missing";
+    if (b->substrate_kind == SMRT_SUBSTRATE_REFLECTOR && b->mode == SMRT_MODE_ACTIVE)
+        return "the reflector substrate has no third Stokes component: passive mode only (smrt/substrate/reflector.py)";
+    if ((b->atm_tb_down != nullptr) != (b->atm_tb_up != nullptr) || (b->atm_tb_down != nullptr) != (b->atm_transmittance != nullptr))
+        return "atmosphere arrays must be given together";
     return nullptr;
 }
 

@@ -12,6 +12,7 @@ import numpy as np
 from .._native import STATUS_MESSAGES, DortContext, PackedBatch
 from ..core.error import SMRTError, smrt_warn
 from ..core.result import LabeledArray, make_result
+from ..core.snowpack import Snowpack
 from ..emmodel.dmrt_qca_shortrange import DMRT_QCA_ShortRange
 from ..emmodel.iba import IBA
 
@@ -55,8 +56,9 @@ class DORT(object):
     def solve(self, snowpack, emmodels, sensor, atmosphere=None, parallel_computation=None):
         """Solve one (snowpack, sensor-configuration); `emmodels` are the per-layer instances made by
         Model.prepare_emmodels (only their class and layer are used: the device recomputes their numbers)."""
-        if atmosphere is not None:
-            raise SMRTError("atmospheres are outside the scope of smrt_amd's DORT")
+        if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
+            snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
+                                atmosphere=atmosphere)
         emmodel_cls = type(emmodels[0]) if emmodels else IBA
         if any(type(e) is not emmodel_cls for e in emmodels):
             raise SMRTError("smrt_amd's DORT needs the same emmodel in all the layers")
@@ -81,9 +83,10 @@ class DORT(object):
             if len(micro) != 1:
                 raise SMRTError("smrt_amd's DORT needs the same microstructure model in all the layers")
             angles = sensor.theta_inc_deg if sensor.mode == "A" else sensor.theta_deg
-            key = (sensor.mode, micro.pop(), tuple(np.round(angles, 12)), float(np.ravel(sensor.phi)[0]))
+            key = (sensor.mode, micro.pop(), tuple(np.round(angles, 12)), float(np.ravel(sensor.phi)[0]),
+                   getattr(sp.substrate, "device_kind", None), id(sp.atmosphere) if sp.atmosphere is not None else None)
             groups.setdefault(key, []).append(i)
-        for (mode, micro, _, phi), idx in groups.items():
+        for (mode, micro, _, phi, _sub, _atm), idx in groups.items():
             self._run_group(simulations, idx, device_name, mode, micro, phi, results)
         return results
 
@@ -125,10 +128,21 @@ class DORT(object):
             p2[s, :n] = [b for _, b in pp]
         sensor0 = simulations[idx[0]][0]
         angles = sensor0.theta_inc if mode == "A" else sensor0.theta
+        substrate = atmosphere = None
+        sub0 = sps[0].substrate
+        if sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
+            q = np.array([[sp.substrate.device_params(f) for sp in sps] for f in freqs])  # (F, S, 2)
+            ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
+            substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
+        atm0 = sps[0].atmosphere
+        if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)
+            a = np.array([atm0.device_params(f) for f in freqs])  # (F, 3)
+            atmosphere = (a[:, 0], a[:, 1], a[:, 2])
         batch = PackedBatch(nl, thick, fv, temp, p1, p2, freqs, angles, emmodel=device_name, microstructure=micro,
                             mode=mode, n_max_stream=self.n_max_stream, m_max=self.m_max,
                             phase_normalization=self.phase_normalization,
-                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=phi)
+                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=phi, substrate=substrate,
+                            atmosphere=atmosphere)
         wanted = np.array([f_index[float(simulations[i][0].frequency)] * S + sp_index[id(simulations[i][1])]
                            for i in idx])
         out = run_on_devices(batch, self.devices, self.block_threads, needed=np.unique(wanted))

@@ -34,6 +34,54 @@ def fixture_options(d):
     return dict(n_max_stream=int(d.get("opt_n_max_stream", 32)), m_max=int(d.get("opt_m_max", 2)))
 
 
+def fixture_substrate(d, i):
+    """Substrate description of frequency index i of a fixture, in the oracle's form (None if there is none)."""
+    if "substrate_kind" not in d:
+        return None
+    T = float(d["substrate_temperature"])
+    sub = dict(kind=str(d["substrate_kind"]), temperature=None if np.isnan(T) else T)
+    if sub["kind"] == "flat":
+        sub["eps"] = complex(d["substrate_eps"][i])
+    else:
+        sub["R"] = tuple(d["substrate_R"][i])
+    return sub
+
+
+def fixture_atmosphere(d, i):
+    if "atm_tb_down" not in d:
+        return None
+    return dict(tb_down=float(d["atm_tb_down"][i]), tb_up=float(d["atm_tb_up"][i]),
+                transmittance=float(d["atm_trans"][i]))
+
+
+def packed_batch_from_fixture(d, freqs=None):
+    """The one-snowpack PackedBatch (C-ABI input) of a fixture: all its frequencies, or the listed ones."""
+    from smrt_amd._native import PackedBatch
+
+    sp = snowpack_dict(d)
+    ms = sp["microstructure"]
+    p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
+    p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
+    sel = slice(None) if freqs is None else freqs
+    o = fixture_options(d)
+    active = str(d["mode"]) == "A"
+    substrate = atmosphere = None
+    if "substrate_kind" in d:
+        kind = str(d["substrate_kind"])
+        q = d["substrate_eps"][sel] if kind == "flat" else None
+        q1 = q.real if kind == "flat" else d["substrate_R"][sel][:, 0]
+        q2 = q.imag if kind == "flat" else d["substrate_R"][sel][:, 1]
+        substrate = (kind, np.asarray(q1)[:, None], np.asarray(q2)[:, None], [float(d["substrate_temperature"])])
+    if "atm_tb_down" in d:
+        atmosphere = (d["atm_tb_down"][sel], d["atm_tb_up"][sel], d["atm_trans"][sel])
+    return PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2,
+                       d["frequency"][sel], np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]),
+                       emmodel=str(d["emmodel"]), microstructure=ms, mode="A" if active else "P",
+                       n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere)
+
+
+SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",
+                      "iba_L2_n10_mirror_atmosphere_only"]
 PASSIVE_FIXTURES = [
     "cfg1_iba_onelayer",
     "iba_2layer_passive37",
@@ -45,7 +93,7 @@ PASSIVE_FIXTURES = [
     "cfg3_dmrt_L50_n64_sp0",
 ]
 ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_L4_n32_ku", "dmrt_active_L3_n12",
-                   "iba_shs_active_L3_n8", "iba_active_L3_n10_m1_steep"]
+                   "iba_shs_active_L3_n8", "iba_active_L3_n10_m1_steep", "iba_active_L3_n12_flat_substrate"]
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)
 
 

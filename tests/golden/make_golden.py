@@ -54,6 +54,8 @@ def snowpack_arrays(sp):
 
 def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_layers=(0,)):
     """Run the reference for every (frequency) configuration of `sensor` on snowpack `sp`."""
+    if ONLY and SKIP_OLD[0]:
+        return {}
     rtsolver_options = dict(rtsolver_options or {})
     m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options)
     sims, dims = m.prepare_simulations(sensor, sp, None, "snowpack")
@@ -79,6 +81,22 @@ def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_lay
         out["theta_inc_deg"] = np.asarray(sensor.theta_inc_deg, float)
     for k, v in rtsolver_options.items():
         out["opt_" + k] = np.asarray(v)
+    sub = sp.substrate
+    if sub is not None:  # what our boundary needs of it: kind, permittivity or reflection per frequency, temperature
+        kind = type(sub).__name__.lower()
+        out["substrate_kind"] = "flat" if kind == "flat" else "reflector"
+        out["substrate_temperature"] = np.nan if sub.temperature is None else float(sub.temperature)
+        if kind == "flat":
+            out["substrate_eps"] = np.array([complex(sub.permittivity(f)) for f in freqs])
+        else:
+            one = np.array([1.0])
+            out["substrate_R"] = np.array([[float(sub._get_refl(f, pol, one)[0]) for pol in "VH"] for f in freqs])
+    atm = sp.atmosphere
+    if atm is not None:
+        pick = lambda x, f: float(x[f]) if isinstance(x, dict) else float(x)  # noqa: E731
+        out["atm_tb_down"] = np.array([pick(atm.constant_tbdown, f) for f in freqs])
+        out["atm_tb_up"] = np.array([pick(atm.constant_tbup, f) for f in freqs])
+        out["atm_trans"] = np.array([pick(atm.constant_trans, f) for f in freqs])
     return out
 
 
@@ -151,6 +169,7 @@ def dump_stages(out, tag, m, se, spk, rtsolver_options, stage_layers):
 
 
 ONLY = set(sys.argv[1:])  # optional: regenerate only the named fixtures
+SKIP_OLD = [False]  # set while main() walks through cases that are not wanted (their run is skipped)
 
 
 def wanted(name):
@@ -158,7 +177,7 @@ def wanted(name):
 
 
 def save(name, d):
-    if not wanted(name):
+    if not wanted(name) or not d:
         return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
@@ -179,7 +198,17 @@ def random_snowpack(rng, L, micro, thick_lo=0.05, thick_hi=0.30, last=100.0):
     )
 
 
+def run_new(*args, **kwargs):
+    """run_case for the cases that are guarded by wanted(): always runs."""
+    SKIP_OLD[0] = False
+    try:
+        return run_case(*args, **kwargs)
+    finally:
+        SKIP_OLD[0] = bool(ONLY)
+
+
 def main():
+    SKIP_OLD[0] = bool(ONLY)  # with fixture names on the command line the unguarded (older) cases are not re-run
     # (i) config 1: examples/iba_onelayer_example.py:6-27
     sp = make_snowpack([100], "exponential", density=[320], temperature=[270], corr_length=[5e-5])
     d = run_case("iba", sensor_list.amsre("37V"), sp, stages=True)
@@ -241,15 +270,58 @@ def main():
     rng = np.random.default_rng(5)
     spx = random_snowpack(rng, 3, "sticky_hard_spheres", 0.05, 0.20, 1000.0)
     if wanted("dmrt_active_L3_n12"):
-        save("dmrt_active_L3_n12", run_case("dmrt_qca_shortrange", active(10e9, [35, 50]), spx,
+        save("dmrt_active_L3_n12", run_new("dmrt_qca_shortrange", active(10e9, [35, 50]), spx,
                                             rtsolver_options=dict(n_max_stream=12, m_max=2)))
     if wanted("iba_shs_active_L3_n8"):
-        save("iba_shs_active_L3_n8", run_case("iba", active(17.2e9, [25, 45]), spx,
+        save("iba_shs_active_L3_n8", run_new("iba", active(17.2e9, [25, 45]), spx,
                                               rtsolver_options=dict(n_max_stream=8, m_max=2)))
     spx = random_snowpack(rng, 3, "exponential", 0.05, 0.20, 1000.0)
     if wanted("iba_active_L3_n10_m1_steep"):
-        save("iba_active_L3_n10_m1_steep", run_case("iba", active(9.6e9, [2, 30, 55]), spx,
+        save("iba_active_L3_n10_m1_steep", run_new("iba", active(9.6e9, [2, 30, 55]), spx,
                                                     rtsolver_options=dict(n_max_stream=10, m_max=1)))
+
+    # substrates (Flat with a constant permittivity, Reflector) and a SimpleIsotropicAtmosphere
+    # (smrt/substrate/flat.py, reflector.py, atmosphere/simple_isotropic_atmosphere.py; physics of
+    # smrt/test/test_physics_law.py)
+    from smrt.atmosphere.simple_isotropic_atmosphere import SimpleIsotropicAtmosphere
+    from smrt.substrate.flat import Flat
+    from smrt.substrate.reflector import Reflector
+
+    def snow(rng, L, micro, last, **kw):
+        base = random_snowpack(rng, L, micro, 0.05, 0.30, last)
+        return make_snowpack([lay.thickness for lay in base.layers], micro,
+                             density=[lay.density for lay in base.layers],
+                             temperature=[lay.temperature for lay in base.layers],
+                             **({"corr_length": [lay.microstructure.corr_length for lay in base.layers]}
+                                if micro == "exponential" else
+                                {"radius": [lay.microstructure.radius for lay in base.layers], "stickiness": 0.2}), **kw)
+
+    rng = np.random.default_rng(6)
+    if wanted("iba_L3_n16_flat_substrate"):
+        spx = snow(rng, 3, "exponential", 0.4, substrate=Flat(temperature=270.0, permittivity_model=3.5 + 0.3j))
+        save("iba_L3_n16_flat_substrate", run_new("iba", passive([18.7e9, 36.5e9], [40, 55]), spx,
+                                                   rtsolver_options=dict(n_max_stream=16)))
+    if wanted("iba_L3_n16_substrate_atmosphere"):
+        spx = snow(rng, 3, "exponential", 0.3, substrate=Flat(temperature=268.0, permittivity_model=6.0 + 0.8j),
+                   atmosphere=SimpleIsotropicAtmosphere(tb_down={18.7e9: 20.0, 36.5e9: 32.0},
+                                                        tb_up={18.7e9: 6.0, 36.5e9: 11.0},
+                                                        transmittance={18.7e9: 0.95, 36.5e9: 0.9}))
+        save("iba_L3_n16_substrate_atmosphere", run_new("iba", passive([18.7e9, 36.5e9], [30, 55]), spx,
+                                                         rtsolver_options=dict(n_max_stream=16)))
+    if wanted("dmrt_L4_n12_reflector"):
+        spx = snow(rng, 4, "sticky_hard_spheres", 0.25,
+                   substrate=Reflector(temperature=265.0, specular_reflection={"V": 0.2, "H": 0.35}))
+        save("dmrt_L4_n12_reflector", run_new("dmrt_qca_shortrange", passive([10.65e9, 36.5e9], [55]), spx,
+                                               rtsolver_options=dict(n_max_stream=12)))
+    if wanted("iba_L2_n10_mirror_atmosphere_only"):
+        spx = snow(rng, 2, "exponential", 0.2, substrate=Reflector(specular_reflection=1.0),
+                   atmosphere=SimpleIsotropicAtmosphere(tb_down=25.0, tb_up=8.0, transmittance=0.92))
+        save("iba_L2_n10_mirror_atmosphere_only", run_new("iba", passive([23.8e9], [0, 50]), spx,
+                                                           rtsolver_options=dict(n_max_stream=10)))
+    if wanted("iba_active_L3_n12_flat_substrate"):
+        spx = snow(rng, 3, "exponential", 0.15, substrate=Flat(temperature=270.0, permittivity_model=4.0 + 0.5j))
+        save("iba_active_L3_n12_flat_substrate", run_new("iba", active(13.4e9, [25, 45]), spx,
+                                                          rtsolver_options=dict(n_max_stream=12, m_max=2)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

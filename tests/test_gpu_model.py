@@ -55,6 +55,37 @@ def test_active_model_run_sentinel1_batch():
     np.testing.assert_allclose(got, np.tile(want_vv, (3, 1)), atol=1e-7)
 
 
+def test_substrate_and_atmosphere_through_the_model():
+    """make_snowpack(substrate=, atmosphere=) / snowpack + substrate / atmosphere + snowpack, against the reference
+    fixture; Kirchhoff check: a non-scattering isothermal pack over an isothermal substrate under a black sky at the
+    same temperature radiates that temperature."""
+    from smrt_amd import make_atmosphere, make_model, make_snowpack, sensor_list
+    from smrt_amd.substrate.flat import Flat
+
+    d = load_golden("iba_L3_n16_substrate_atmosphere")
+    sub = Flat(temperature=float(d["substrate_temperature"]), permittivity_model=complex(d["substrate_eps"][0]))
+    atm = make_atmosphere("simple_isotropic_atmosphere", tb_down=dict(zip(d["frequency"], d["atm_tb_down"])),
+                          tb_up=dict(zip(d["frequency"], d["atm_tb_up"])),
+                          transmittance=dict(zip(d["frequency"], d["atm_trans"])))
+    kw = dict(density=d["density"], temperature=d["temperature"], corr_length=d["corr_length"])
+    sp1 = make_snowpack(d["thickness"], "exponential", substrate=sub, atmosphere=atm, **kw)
+    sp2 = atm + (make_snowpack(d["thickness"], "exponential", **kw) + sub)
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16))
+    sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+    for sp in (sp1, sp2):
+        res = m.run(sensor, sp)
+        for i, f in enumerate(d["frequency"]):
+            np.testing.assert_allclose(res.TbV(frequency=f), d["result"][i, 0], atol=1e-6)
+            np.testing.assert_allclose(res.TbH(frequency=f), d["result"][i, 1], atol=1e-6)
+    T = 265.0
+    iso = make_snowpack([0.3, 0.5], "exponential", density=[250, 350], temperature=T, corr_length=1e-7,
+                        substrate=Flat(temperature=T, permittivity_model=5 + 0.5j),
+                        atmosphere=make_atmosphere(tb_down=T, tb_up=0.0, transmittance=1.0))
+    res = m.run(sensor_list.passive(18.7e9, [30, 55]), iso)
+    np.testing.assert_allclose(np.ravel(res.TbV()), T, atol=1e-3)
+    np.testing.assert_allclose(np.ravel(res.TbH()), T, atol=1e-3)
+
+
 def test_onelayer_example():
     """examples/iba_onelayer_example.py."""
     from smrt_amd import make_model, make_snowpack, sensor_list

@@ -2,8 +2,8 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, assert_backscatter_close, fixture_options, load_golden,
-                      snowpack_dict)
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options,
+                      load_golden, packed_batch_from_fixture, snowpack_dict)
 
 pytestmark = pytest.mark.gpu
 
@@ -20,18 +20,19 @@ def ctx():
 
 
 def batch_from_fixture(d, freqs=None):
-    from smrt_amd._native import PackedBatch
+    return packed_batch_from_fixture(d, freqs)
 
-    sp = snowpack_dict(d)
-    ms = sp["microstructure"]
-    p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
-    p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
-    fr = d["frequency"] if freqs is None else d["frequency"][freqs]
-    o = fixture_options(d)
-    active = str(d["mode"]) == "A"
-    return PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2, fr,
-                       np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]), emmodel=str(d["emmodel"]),
-                       microstructure=ms, mode="A" if active else "P", n_max_stream=o["n_max_stream"], m_max=o["m_max"])
+
+@pytest.mark.parametrize("name", SUBSTRATE_FIXTURES)
+@pytest.mark.parametrize("pipeline", [1, 2, 0])
+def test_substrate_atmosphere_golden(ctx, name, pipeline):
+    """Flat / Reflector substrates (emitting or not) and the SimpleIsotropicAtmosphere, every pipeline shape."""
+    d = load_golden(name)
+    ctx.set_pipeline(pipeline)
+    out = ctx.run(batch_from_fixture(d))
+    ctx.set_pipeline(1)
+    assert (out.status == 0).all(), out.status
+    assert np.abs(out.values - d["result"]).max() < TB_TOL
 
 
 @pytest.mark.parametrize("name", PASSIVE_FIXTURES)

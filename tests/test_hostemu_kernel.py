@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_backscatter_close, fixture_options, load_golden, snowpack_dict
+from conftest import (ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, packed_batch_from_fixture)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
@@ -31,16 +31,7 @@ def emu():
 
 def run_fixture(lib, name, nt=64, order=0, freqs=None):
     d = load_golden(name)
-    sp = snowpack_dict(d)
-    ms = sp["microstructure"]
-    p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
-    p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
-    fr = d["frequency"] if freqs is None else d["frequency"][freqs]
-    active = str(d["mode"]) == "A"
-    o = fixture_options(d)
-    b = PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2, fr,
-                    np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]), emmodel=str(d["emmodel"]),
-                    microstructure=ms, mode="A" if active else "P", n_max_stream=o["n_max_stream"], m_max=o["m_max"])
+    b = packed_batch_from_fixture(d, freqs)
     n = b.n_pairs
     out = np.empty((n,) + b.out_shape())
     st = np.empty(n, np.int32)
@@ -61,6 +52,14 @@ def test_emulated_kernel_matches_reference(emu, name):
     assert np.abs(out - ref).max() < 1e-6
 
 
+@pytest.mark.parametrize("name,nt,order", [(n, (64, 128, 256, 64)[i], i % 3) for i, n in enumerate(SUBSTRATE_FIXTURES)])
+def test_emulated_kernel_substrate_atmosphere(emu, name, nt, order):
+    """Flat / Reflector substrates (emitting or not) and the isotropic atmosphere on the device code."""
+    out, st, ref = run_fixture(emu, name, nt=nt, order=order)
+    assert (st == 0).all()
+    assert np.abs(out - ref).max() < 1e-6
+
+
 def test_emulated_kernel_is_schedule_independent(emu):
     base, _, _ = run_fixture(emu, "iba_L6_n8_angles", nt=128, order=0)
     for order in (1, 2):
@@ -76,7 +75,7 @@ def test_emulated_kernel_full_size_pair(emu):
 
 @pytest.mark.parametrize("name,nt,order", [("cfg4_iba_active_L5_n16", 64, 0), ("dmrt_active_L3_n12", 128, 1),
                                            ("iba_shs_active_L3_n8", 64, 2), ("iba_active_L3_n10_m1_steep", 256, 1),
-                                           ("iba_2layer_active19", 64, 0)])
+                                           ("iba_2layer_active19", 64, 0), ("iba_active_L3_n12_flat_substrate", 128, 2)])
 def test_emulated_active_kernel_matches_reference(emu, name, nt, order):
     """Active mode (three polarisations, azimuth modes 0..m_max, coherent subtraction, backscatter read-out);
     the last case has N = 3 x 32 = 96 rows, i.e. the global-workspace variant of the kernel."""

@@ -3,7 +3,8 @@
 import numpy as np
 import pytest
 
-from conftest import ACTIVE_FIXTURES, PASSIVE_FIXTURES, fixture_options, load_golden, snowpack_dict
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, SUBSTRATE_FIXTURES, fixture_atmosphere, fixture_options,
+                      fixture_substrate, load_golden, snowpack_dict)
 from oracle import dort_oracle as O
 
 TB_TOL = 1e-6  # K      (BASELINE.json north_star)
@@ -34,6 +35,17 @@ def test_passive_tb(name, method):
         assert np.abs(tb - d["result"][i]).max() < TB_TOL
 
 
+@pytest.mark.parametrize("name", SUBSTRATE_FIXTURES)
+def test_passive_tb_substrate_atmosphere(name):
+    """Flat / Reflector substrates (with and without emission) and a SimpleIsotropicAtmosphere."""
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    for i, f in enumerate(d["frequency"]):
+        tb = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), substrate=fixture_substrate(d, i),
+                     atmosphere=fixture_atmosphere(d, i), **fixture_options(d))
+        assert np.abs(tb - d["result"][i]).max() < TB_TOL
+
+
 @pytest.mark.parametrize("name", ACTIVE_FIXTURES)
 @pytest.mark.parametrize("method", ["half_rank_eig", "schur_forcedtriu"])
 def test_active_backscatter(name, method):
@@ -49,7 +61,8 @@ def test_active_backscatter(name, method):
     sp = snowpack_dict(d)
     for i, f in enumerate(d["frequency"]):
         r = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), mode="A",
-                    theta_inc_deg=d["theta_inc_deg"], method=method, **fixture_options(d))
+                    theta_inc_deg=d["theta_inc_deg"], method=method, substrate=fixture_substrate(d, i),
+                    **fixture_options(d))
         ref = d["result"][i]
         # co- and cross-polarised intensities (V,H x V,H): relative to the co-pol level
         scale = np.abs(ref[:2, :2]).max(axis=(0, 1))
