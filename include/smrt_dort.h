@@ -29,9 +29,11 @@ extern "C" {
 
 typedef struct smrt_dort_ctx smrt_dort_ctx;
 
-/* emmodel (smrt/emmodel/iba.py, smrt/emmodel/dmrt_qca_shortrange.py) */
+/* emmodel (smrt/emmodel/iba.py, dmrt_qca_shortrange.py, dmrt_qcacp_shortrange.py, nonscattering.py) */
 #define SMRT_EM_IBA 0
 #define SMRT_EM_DMRT_QCA_SHORTRANGE 1
+#define SMRT_EM_DMRT_QCACP_SHORTRANGE 2
+#define SMRT_EM_NONSCATTERING 3
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1

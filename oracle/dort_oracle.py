@@ -199,6 +199,60 @@ class DMRTQCAShortRangeLayer(LayerEM):
         return rayleigh_ft_even_phase(self.ks, mu_s, mu_i, m_max, npol)
 
 
+class DMRTQCACPShortRangeLayer(LayerEM):
+    """DMRT QCA-CP short range as in DMRT-ML, smrt/emmodel/dmrt_qcacp_shortrange.py:63-125; Rayleigh phase."""
+
+    kind = "dmrt_qcacp_shortrange"
+
+    def __init__(self, frequency, frac_volume, temperature, microstructure, **mp):
+        if microstructure != "sticky_hard_spheres":
+            raise ValueError("DMRT_QCACP_ShortRange needs sticky_hard_spheres")
+        f = frac_volume
+        radius = mp["radius"]
+        e0 = 1.0
+        es = ice_permittivity_maetzler06(frequency, temperature)
+        if f > 0.5:  # dense_snow_correction="auto": inverted medium
+            f, e0, es = 1.0 - f, es, e0
+        t = shs_t_parameter(f, mp["stickiness"])
+        lmda = C_SPEED / frequency
+        b = (es - e0) * (1.0 - 4.0 * f) / 3.0 - e0
+        c = -e0 * (es - e0) * (1.0 - f) / 3.0
+        disc = np.sqrt(complex(b * b - 4.0 * c))
+        e_eff0 = 0.5 * (-b + disc)
+        if e_eff0.real < 1:
+            e_eff0 = 0.5 * (-b - disc)
+        x3 = (2.0 * np.pi * radius / lmda) ** 3
+        shape = (1.0 - f) ** 4 / (1.0 + 2.0 * f - t * f * (1.0 - f)) ** 2
+        corr = (es - e0) / (1.0 + (es - e0) / (3.0 * e_eff0) * (1.0 - f))
+        e_eff = e0 + (e_eff0 - e0) * (1.0 + 2j / 9.0 * x3 * np.sqrt(complex(e_eff0)) * corr * shape)
+        sq_im = np.sqrt(complex(e_eff)).imag
+        albedo = 2.0 / 9.0 * x3 * f / (2.0 * sq_im) * abs(corr) ** 2 * shape
+        beta = 2.0 * np.pi / lmda * 2.0 * sq_im
+        self.f = f
+        self.eps_eff = complex(e_eff)
+        self.ks = float(albedo * beta)
+        self.ka = float(beta - self.ks)
+
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol):
+        return rayleigh_ft_even_phase(self.ks, mu_s, mu_i, m_max, npol)
+
+
+class NonScatteringLayer(LayerEM):
+    """smrt/emmodel/nonscattering.py: Polder-van Santen permittivity, absorption only, null phase matrix."""
+
+    kind = "nonscattering"
+
+    def __init__(self, frequency, frac_volume, temperature, microstructure, **mp):
+        eps = ice_permittivity_maetzler06(frequency, temperature)
+        self.f = frac_volume
+        self.eps_eff = polder_van_santen_spheres(frac_volume, 1.0, eps)
+        self.ka = float(2.0 * (2.0 * np.pi * frequency / C_SPEED) * np.sqrt(self.eps_eff).imag)
+        self.ks = 0.0
+
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol):
+        return np.zeros((npol, npol, m_max + 1, len(mu_s), len(mu_i)))
+
+
 def romberg65(y, dx):
     """Romberg extrapolation of the trapezoid rule on 2**6+1 equally spaced samples (scipy.integrate.romb, called at
     smrt/emmodel/iba.py:179)."""
@@ -305,7 +359,8 @@ def rayleigh_ft_even_phase(ks, mu_s, mu_i, m_max, npol):
 def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
-    cls = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer}[emmodel]
+    cls = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
+           "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer}[emmodel]
     L = len(sp["thickness"])
     fv = sp["frac_volume"] if "frac_volume" in sp else np.asarray(sp["density"]) / DENSITY_OF_ICE
     micro = str(sp["microstructure"])

@@ -15,7 +15,7 @@ from .core.error import SMRTError
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
-EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1}
+EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3}
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
 SUBSTRATE_CODES = {"flat": 1, "reflector": 2}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}

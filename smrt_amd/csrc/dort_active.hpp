@@ -248,7 +248,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double sis = sqrt(1.0 - mi * mi), sjs = sqrt(1.0 - mj * mj);
                     double pp[3][3], pm[3][3];
                     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pp[a][c] = 0.0; pm[a][c] = 0.0; }
-                    if (b.emmodel == EM_DMRT) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
+                    if (b.emmodel != EM_IBA) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
                         for (int sgn = 0; sgn < 2; ++sgn) {
                             const double x = sgn ? -mj : mj;
                             double (&q)[3][3] = sgn ? pm : pp;

@@ -76,7 +76,7 @@ constexpr double kBoltzmann = 1.380649e-23;
 constexpr double kFreezing = 273.15;
 constexpr double kPi = 3.14159265358979323846;
 
-enum { EM_IBA = 0, EM_DMRT = 1 };
+enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3 };  // every emmodel but IBA has a Rayleigh phase matrix
 enum { MS_EXP = 0, MS_SHS = 1 };
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5 };
 enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2 };
@@ -337,6 +337,43 @@ SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T,
             *pa = coeff;
             *pb = 0.5 * kfac * kfac;
         }
+    } else if (b.emmodel == EM_NONSCAT) {
+        // non-scattering medium (nonscattering.py): Polder-van Santen permittivity, absorption only
+        cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
+        cplx ee = cscale(csub(csqrt_(cadd(cmul(bq, bq), cscale(es, 8.0))), bq), 0.25);
+        *eps_eff = ee;
+        *ka = 2.0 * k0 * csqrt_(ee).im;
+        *ks = 0.0; *pa = 0.0; *pb = 0.0;
+    } else if (b.emmodel == EM_QCACP) {
+        // DMRT QCA-CP short range as in DMRT-ML (dmrt_qcacp_shortrange.py:63-125), dense_snow_correction="auto"
+        double f = fv;
+        cplx e0 = cmk(1.0, 0.0), e1 = es;
+        if (f > 0.5) { f = 1.0 - f; e0 = es; e1 = cmk(1.0, 0.0); }
+        int tb = 0;
+        const double tt = shs_t(f, p2, &tb);
+        if (tb) *bad = 1;
+        const cplx de = csub(e1, e0);
+        const cplx bq = csub(cscale(de, (1.0 - 4.0 * f) / 3.0), e0);
+        const cplx cq = cscale(cmul(e0, de), -(1.0 - f) / 3.0);
+        const cplx disc = csqrt_(csub(cmul(bq, bq), cscale(cq, 4.0)));
+        cplx ee0 = cscale(csub(disc, bq), 0.5);
+        if (ee0.re < 1.0) ee0 = cscale(cadd(disc, bq), -0.5);
+        const double x = k0 * p1;  // 2 pi radius / lambda (vacuum wavelength)
+        const double x3 = x * x * x;
+        const double den = 1.0 + 2.0 * f - tt * f * (1.0 - f);
+        const double omf4 = (1.0 - f) * (1.0 - f) * (1.0 - f) * (1.0 - f);
+        const double shape = omf4 / (den * den);
+        const cplx corr = cdiv(de, cadd(cmk(1.0, 0.0), cscale(cdiv(de, cscale(ee0, 3.0)), 1.0 - f)));
+        const cplx fac = cadd(cmk(1.0, 0.0), cscale(cmul(cmul(cmk(0.0, 2.0 / 9.0 * x3), csqrt_(ee0)), corr), shape));
+        const cplx ee = cadd(e0, cmul(csub(ee0, e0), fac));
+        *eps_eff = ee;
+        const double sqim = csqrt_(ee).im;
+        const double albedo = 2.0 / 9.0 * x3 * f / (2.0 * sqim) * cabs2(corr) * shape;
+        const double beta = 2.0 * k0 * sqim;
+        *ks = albedo * beta;
+        *ka = beta - albedo * beta;
+        *pa = 1.5 * albedo * beta;
+        *pb = 0.0;
     } else {
         // DMRT QCA short range (dmrt_qca_shortrange.py:65-112), dense_snow_correction="auto"
         double f = fv;
@@ -1961,7 +1998,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 const int j = idx - i * (i + 1) / 2;
                 const double mi = s.mu[i], mj = s.mu[j];
                 double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
-                if (b.emmodel == EM_DMRT) {  // closed form, rayleigh.py:70-76; even in mu'
+                if (b.emmodel != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
                     const double a2 = mi * mi, b2 = mj * mj;
                     pvv_p = pa * (0.5 * a2 * b2 + (1.0 - a2) * (1.0 - b2));
                     pvh_p = pa * 0.5 * a2; phv_p = pa * 0.5 * b2; phh_p = pa * 0.5;

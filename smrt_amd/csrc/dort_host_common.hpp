@@ -48,11 +48,12 @@ inline const char* validate(const smrt_batch* b) {
     if (b->n_snowpacks <= 0 || b->n_frequencies <= 0 || b->n_layers_max <= 0) return "empty batch";
     if (b->n_theta <= 0) return "n_theta must be positive";
     if (b->n_max_stream < 2) return "n_max_stream must be >= 2";
-    if (b->emmodel != SMRT_EM_IBA && b->emmodel != SMRT_EM_DMRT_QCA_SHORTRANGE) return "unknown emmodel";
+    if (b->emmodel < SMRT_EM_IBA || b->emmodel > SMRT_EM_NONSCATTERING) return "unknown emmodel";
     if (b->microstructure != SMRT_MS_EXPONENTIAL && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
         return "unknown microstructure";
-    if (b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
-        return "dmrt_qca_shortrange is only compatible with sticky_hard_spheres";
+    if ((b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE || b->emmodel == SMRT_EM_DMRT_QCACP_SHORTRANGE) &&
+        b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
+        return "the dmrt short-range emmodels are only compatible with sticky_hard_spheres";
     if (b->mode != SMRT_MODE_PASSIVE && b->mode != SMRT_MODE_ACTIVE) return "unknown mode";
     if (!b->n_layers || !b->thickness || !b->frac_volume || !b->temperature || !b->micro_p1 || !b->frequency ||
         !b->theta)

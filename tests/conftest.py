@@ -81,7 +81,7 @@ def packed_batch_from_fixture(d, freqs=None):
 
 
 SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",
-                      "iba_L2_n10_mirror_atmosphere_only"]
+                      "iba_L2_n10_mirror_atmosphere_only", "nonscattering_L3_n10_substrate"]
 PASSIVE_FIXTURES = [
     "cfg1_iba_onelayer",
     "iba_2layer_passive37",
@@ -91,6 +91,8 @@ PASSIVE_FIXTURES = [
     "iba_L3_n16_shallow",
     "dmrt_L8_n16",
     "cfg3_dmrt_L50_n64_sp0",
+    "dmrtcp_2layer_passive37",
+    "dmrtcp_L5_n12",
 ]
 ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_L4_n32_ku", "dmrt_active_L3_n12",
                    "iba_shs_active_L3_n8", "iba_active_L3_n10_m1_steep", "iba_active_L3_n12_flat_substrate"]

@@ -323,6 +323,20 @@ def main():
         save("iba_active_L3_n12_flat_substrate", run_new("iba", active(13.4e9, [25, 45]), spx,
                                                           rtsolver_options=dict(n_max_stream=12, m_max=2)))
 
+    # other emmodels feeding the same solver: DMRT QCA-CP short range (smrt/test/test_dmrtdort.py:20-37 known answer
+    # 201.83572222 / 187.29558162 K) and the non-scattering medium over a substrate
+    if wanted("dmrtcp_2layer_passive37"):
+        save("dmrtcp_2layer_passive37", run_new("dmrt_qcacp_shortrange", sensor_list.amsre("37V"), sp3))
+    rng = np.random.default_rng(7)
+    if wanted("dmrtcp_L5_n12"):
+        spx = random_snowpack(rng, 5, "sticky_hard_spheres")
+        save("dmrtcp_L5_n12", run_new("dmrt_qcacp_shortrange", passive([10.65e9, 36.5e9], [35, 55]), spx,
+                                      rtsolver_options=dict(n_max_stream=12)))
+    if wanted("nonscattering_L3_n10_substrate"):
+        spx = snow(rng, 3, "exponential", 0.5, substrate=Flat(temperature=271.0, permittivity_model=5.0 + 0.6j))
+        save("nonscattering_L3_n10_substrate", run_new("nonscattering", passive([6.925e9, 36.5e9], [20, 55]), spx,
+                                                       rtsolver_options=dict(n_max_stream=10)))
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

@@ -86,6 +86,28 @@ def test_substrate_and_atmosphere_through_the_model():
     np.testing.assert_allclose(np.ravel(res.TbH()), T, atol=1e-3)
 
 
+def test_other_emmodels_through_the_model():
+    """dmrt_qcacp_shortrange (the reference's known answer, smrt/test/test_dmrtdort.py:20-37) and nonscattering over a
+    Flat substrate through make_model()/Model.run()."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.substrate.flat import Flat
+
+    sp = make_snowpack([0.1, 1000], "sticky_hard_spheres", density=[200, 400], temperature=[250.0, 250.0],
+                       radius=[2e-4, 2e-4], stickiness=[0.1, 0.1])
+    res = make_model("dmrt_qcacp_shortrange", "dort").run(sensor_list.amsre("37V"), sp)
+    assert abs(res.TbV() - 201.83572222) < 1e-6 and abs(res.TbH() - 187.29558162) < 1e-6
+    d = load_golden("nonscattering_L3_n10_substrate")
+    sp = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                       corr_length=d["corr_length"],
+                       substrate=Flat(temperature=float(d["substrate_temperature"]),
+                                      permittivity_model=complex(d["substrate_eps"][0])))
+    res = make_model("nonscattering", "dort", rtsolver_options=dict(n_max_stream=10)).run(
+        sensor_list.passive(list(d["frequency"]), list(d["theta_deg"])), sp)
+    for i, f in enumerate(d["frequency"]):
+        np.testing.assert_allclose(res.TbV(frequency=f), d["result"][i, 0], atol=1e-6)
+        np.testing.assert_allclose(res.TbH(frequency=f), d["result"][i, 1], atol=1e-6)
+
+
 def test_onelayer_example():
     """examples/iba_onelayer_example.py."""
     from smrt_amd import make_model, make_snowpack, sensor_list

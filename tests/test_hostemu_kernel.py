@@ -45,14 +45,14 @@ def run_fixture(lib, name, nt=64, order=0, freqs=None):
 
 
 @pytest.mark.parametrize("name", ["cfg1_iba_onelayer", "iba_2layer_passive37", "iba_L6_n8_angles",
-                                  "iba_L3_n16_shallow", "dmrt_L8_n16"])
+                                  "iba_L3_n16_shallow", "dmrt_L8_n16", "dmrtcp_L5_n12", "dmrtcp_2layer_passive37"])
 def test_emulated_kernel_matches_reference(emu, name):
     out, st, ref = run_fixture(emu, name)
     assert (st == 0).all()
     assert np.abs(out - ref).max() < 1e-6
 
 
-@pytest.mark.parametrize("name,nt,order", [(n, (64, 128, 256, 64)[i], i % 3) for i, n in enumerate(SUBSTRATE_FIXTURES)])
+@pytest.mark.parametrize("name,nt,order", [(n, (64, 128, 256, 64, 128)[i], i % 3) for i, n in enumerate(SUBSTRATE_FIXTURES)])
 def test_emulated_kernel_substrate_atmosphere(emu, name, nt, order):
     """Flat / Reflector substrates (emitting or not) and the isotropic atmosphere on the device code."""
     out, st, ref = run_fixture(emu, name, nt=nt, order=order)
