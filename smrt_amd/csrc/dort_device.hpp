@@ -1605,7 +1605,6 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
-    constexpr int MAXOWN = (8 + NW - 1) / NW;   // column tiles of [A | B] per wavefront (2 RT <= 8)
     const int NMX = s.gj_nmax;
     int* perm = (int*)s.gj;                     // [NMX + 16] pivot row of every column
     int* rowblk = perm + NMX + 16;              // [NMX] block in which the row was a pivot row, -1 before
@@ -1697,9 +1696,15 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             }
         };
 
-        double pv[MAXOWN][4];
-        const int gnext = k + 1;  // the column tile of the next panel
-        if (gnext < RT && (gnext % NW) == wave) {
+        // Work distribution of block k: the owner of the next panel (wavefront gnext mod NW) takes only that column
+        // tile and then factorises the panel; the other live column tiles ([A | B] minus the dead A tiles) go round
+        // robin to the remaining wavefronts.  A column tile is read and written by exactly one wavefront per block
+        // (pivot rows included: only the tile's own pivot-row entries serve as its B operand), so the new pivot rows
+        // are stored right away and the block barrier is the only synchronisation.
+        const int gnext = k + 1;
+        const bool has_next = gnext < RT;
+        const int owner = has_next ? (gnext % NW) : -1;
+        if (has_next && wave == owner) {
             double tmp[4];
             do_tile(gnext, tmp);
             wave_sync_lds();
@@ -1707,29 +1712,31 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             wave_sync_lds();
             if (!gj_panel16<TR>(A, N, LD, k + 1, lane, perm, rowblk) && lane == 0) *fail = 1;
         }
-#pragma unroll
-        for (int slot = 0; slot < MAXOWN; ++slot) {
-            const int g = wave + slot * NW;
-            const bool live = (g < 2 * RT) && !(g < RT && g <= k) && (g != gnext || gnext >= RT);
-            if (live) do_tile(g, pv[slot]);
-        }
-        if (has_v && wave == (RT % NW) && lane < N) {  // extra right-hand side: same transformation, lane = row
-            double acc = v[lane];
-            for (int j = 0; j < nbk; ++j) acc += at<TR>(A, lane, k0 + j, LD) * v[perm[k0 + j]];
-            wave_sync_lds();
-            v[lane] = acc;
-        } else if (has_v && wave == (RT % NW)) {
-            wave_sync_lds();
+        const bool worker = (NW == 1) || !has_next || wave != owner;
+        const int nworkers = (NW == 1 || !has_next) ? NW : NW - 1;
+        const int widx = (NW == 1 || !has_next) ? wave : (wave - owner - 1 + NW) % NW;
+        if (worker) {
+            int idx = 0;
+            for (int g = (has_next ? gnext + 1 : RT); g < 2 * RT; ++g, ++idx) {
+                if (idx % nworkers != widx) continue;
+                double tmp[4];
+                do_tile(g, tmp);
+                wave_sync_lds();
+                store_pivot_rows(g, tmp);
+                wave_sync_lds();
+            }
+            if (has_v && widx == 0) {  // extra right-hand side: same transformation, lane = row
+                double acc = 0.0;
+                if (lane < N) {
+                    acc = v[lane];
+                    for (int j = 0; j < nbk; ++j) acc += at<TR>(A, lane, k0 + j, LD) * v[perm[k0 + j]];
+                }
+                wave_sync_lds();
+                if (lane < N) v[lane] = acc;
+            }
         }
         block_sync();
         if (*fail) return false;  // uniform
-#pragma unroll
-        for (int slot = 0; slot < MAXOWN; ++slot) {
-            const int g = wave + slot * NW;
-            const bool live = (g < 2 * RT) && !(g < RT && g <= k) && (g != gnext || gnext >= RT);
-            if (live) store_pivot_rows(g, pv[slot]);
-        }
-        wave_sync_lds();
     }
     block_sync();
     SMRT_GSUB(1);
