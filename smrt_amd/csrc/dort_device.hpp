@@ -1021,11 +1021,20 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
                         mfma_f64_16x16x4(aw[kk], bop, cw);
                     }
                 }
-                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
-                    const double fic = F[col * LD + row], gic = G[col * LD + row];
-                    cy[reg] += gic;
-                    cw[reg] += fic - Rtop[row] * gic;
-                });
+                // the elementwise terms + G (for Y) and + F - Rtop G (for W) of this tile: the row block of F and G is
+                // already in registers in A-operand layout, so they are added as four more k-steps against an identity
+                // B operand instead of being re-read from global memory in accumulator layout (uncoalesced)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int kk = 4 * tj + q4;                      // k = 4 kk + lk runs over the columns of tile tj
+                    const double idb = (4 * q4 + lk == lr) ? 1.0 : 0.0;
+                    double gk = 0.0, fk = 0.0;
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2)
+                        if (k2 == kk) { fk = af[k2]; gk = aw[k2] + rt * af[k2]; }
+                    mfma_f64_16x16x4(gk, idb, cy);
+                    mfma_f64_16x16x4(fk - rt * gk, idb, cw);
+                }
             }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) { ys[o][q][reg] = cy[reg]; ws[o][q][reg] = cw[reg]; }
@@ -1600,8 +1609,11 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
     return ok;
 }
 
+// result_in_A: leave the solution in A (one pass and one barrier less than copying it back over Bm), optionally scaled
+// X[k][c] * rs[k] * cs[c] on the way (the t Q t scaling of the recursion).
 template <int NT, bool TR>
-SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
+SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
+                           const double* rs = nullptr, const double* cs = nullptr) {
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
@@ -1741,11 +1753,12 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     block_sync();
     SMRT_GSUB(1);
     // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
-    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
+    if (rs) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD) * (rs[k] * cs[c]); });
+    else for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
     double vk = 0.0;
     if (has_v && t < N) vk = v[perm[t]];
     block_sync();
-    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
+    if (!result_in_A) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
     if (has_v && t < N) v[t] = vk;
     block_sync();
     SMRT_GSUB(2);
@@ -1846,7 +1859,8 @@ enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_
 // kernel) and the singular values, build the eigenvectors and run the layer recursion.
 // MODE 3 ("finish", two LDS slots): the same recursion with only two N x N matrices in LDS, so that TWO workgroups
 // share a CU (the Gauss-Jordan panels are wavefront-serial: a second resident workgroup fills the idle SIMDs).
-//   slot X: B' -> Ep' -> Wk (LU1 matrix) -> Y -> K         slot R: R~ (carried between layers) -> Q -> W
+//   slot X: B' -> Ep' -> Wk (matrix of solve 1) -> t Q t -> W (matrix of solve 2) -> K
+//   slot R: R~ (carried between layers) -> right-hand side of solve 1 -> Y (right-hand side of solve 2) -> next R~
 //   global: L+ is used where it lies in the staging area; Em' -> G overwrites the item's B slot, F the item's L
 //   slot (both dead by then); the 16x16 diagonal-block inverses of L+ come from the prep kernel.
 template <int NT, int CH, int MODE = 0>
@@ -2158,15 +2172,18 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
+        if (MODE == 3) {  // the solution t Q t stays in slot X (one pass over the matrix instead of three)
+            if (!gj_solve_b16<NT, false>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        } else
         if (!(CH == 1 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
-        double* Q = Rt;
+        double* Q = (MODE == 3) ? Wk : Rt;
         SMRT_DUMP("Q", Q, N);
-        for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
+        if (MODE != 3) for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
         for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
         block_sync();
         if (MODE == 3) {
-            r45_mfma2<NT>(F, G, Q, Wk, Rt, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot X, W -> slot R (over Q)
+            r45_mfma2<NT>(F, G, Q, Rt, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot R, W -> slot X (over Q)
         } else if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
         } else {
@@ -2175,7 +2192,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
-        if (!(CH == 1 ? gj_solve<NT, true>(MODE == 3 ? Rt : F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (MODE == 3) {  // A = W (slot X), B = Y (slot R); K is left in slot X
+            if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        } else
+        if (!(CH == 1 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);
