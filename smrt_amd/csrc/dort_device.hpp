@@ -2038,7 +2038,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                         double Cp, Cm;
                         if (b.micro == MS_EXP) {
                             const double dp = 1.0 + pb * (1.0 - ct_p), dm = 1.0 + pb * (1.0 - ct_m);
-                            Cp = pa / (dp * dp); Cm = pa / (dm * dm);
+                            Cp = pa * fast_rcp(dp * dp); Cm = pa * fast_rcp(dm * dm);   // 1 / (dp dm)^2 without the IEEE division
                         } else {
                             Cp = pa * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
                             Cm = pa * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
