@@ -44,8 +44,12 @@ SMRT_DEV void fresnel_RT3(cplx e1, cplx e2, double mu1, double* R3, double* T3) 
     T3[2] = mu2 / mu1 * ((1.0 + rv.re) * (1.0 + rh.re) + rv.im * rh.im);
 }
 
-template <int NT, int CH>
-SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr) {
+// MODE 0: everything in one workgroup.  MODE 1 / 3: the "prep" and "finish" halves of the three-kernel pipeline (see
+// dort_pair_passive): staging items are (pair, mode, layer) -> item = (p (m_max + 1) + m) Lmax + l; the Jacobi kernel
+// in between is the passive one.
+template <int NT, int CH, int MODE = 0>
+SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr,
+                               const DevStage* stg = nullptr) {
     constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;
     constexpr int GS = 8;
     constexpr int RPL = (64 * CH + GS - 1) / GS;
@@ -55,7 +59,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int nphi = nsamp / 2 + 1;
     const int nmax = b.n_max_stream;
     const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
-                                   active_doubles(nmax, b.Lmax, b.n_theta));
+                                   active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0));
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
@@ -64,8 +68,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     double* total = norm0 + 2 * nmax * b.Lmax;    // [9][NI]
     double* coh = total + 9 * NI;                 // [2][NI]
     int* inc = (int*)(coh + 2 * NI);              // [NI], then the count
-    double* dsg = s.g;                            // row signs of the down-going eigenvectors
-    double* su = s.upb;                           // sqrt(2) on the U rows
+    double* dsg = s.g;                            // row signs of the down-going eigenvectors (not in the prep kernel)
+    auto su_of = [](int r, int P) { return (P == 3 && r % 3 == 2) ? 1.4142135623730951 : 1.0; };  // sqrt(2) on U rows
 
     const long long gp = b.pair_begin + p;
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
@@ -79,7 +83,11 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
 
     if (t < 8) s.ints[t] = 0;
     block_sync();
-    for (int k = t; k < nphi; k += NT) {
+    if (MODE == 3) {  // a failure recorded by the prep or Jacobi kernel
+        const int prev = b.status[p];
+        if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
+    }
+    for (int k = t; k < nphi && MODE != 3; k += NT) {
         const double ph = kPi * (double)k / (double)(nphi - 1);
         s.cphi[k] = cos(ph); s.sphi[k] = sin(ph);
     }
@@ -88,7 +96,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
     const int n_air = s.ints[5];
-    if (b.want_layer_out) {
+    if (MODE != 1 && b.want_layer_out) {
         double* lo = b.layer_out + p * (long long)b.Lmax * 5;
         for (int l = t; l < b.Lmax; l += NT) {
             const bool in = l < L;
@@ -97,14 +105,14 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
         }
     }
-    if (b.want_stream_out) {
+    if (MODE != 1 && b.want_stream_out) {
         double* so = b.stream_out + p * (long long)(1 + nmax);
         if (t == 0) so[0] = (double)n_air;
         for (int j = t; j < nmax; j += NT) so[1 + j] = (j < n_air) ? s.outmu[j] : 0.0;
     }
 
     // ---- incident streams: the two streams bracketing every incidence angle (dort.py:210-226), sorted, unique ----
-    if (t == 0) {
+    if (t == 0 && MODE != 1) {
         int cnt = 0;
         for (int it = 0; it < b.n_theta; ++it) {
             const double mi = cos(b.theta[it]);
@@ -125,9 +133,9 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         }
         inc[NI] = cnt;
     }
-    for (int k = t; k < 9 * NI; k += NT) total[k] = 0.0;
+    for (int k = t; k < 9 * NI && MODE != 1; k += NT) total[k] = 0.0;
     block_sync();
-    const int ninc = inc[NI];
+    const int ninc = (MODE != 1) ? inc[NI] : 0;
 
     // ---- coherent (no scattering) mode-0 solution: diagonal, one thread per (incident stream, V|H) -------------
     for (int idx = t; idx < 2 * ninc; idx += NT) {
@@ -179,7 +187,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         const int P = (m == 0) ? 2 : 3;
         const double cc = (m == 0) ? 0.5 : 0.25;  // dort.py:716-721
         // azimuth weights of this mode: cosine sums for the even entries, sine sums for the (V|H, U) cross entries
-        for (int k = t; k < nphi; k += NT) {
+        for (int k = t; k < nphi && MODE != 3; k += NT) {
             const double ph = kPi * (double)k / (double)(nphi - 1);
             const bool end = (k == 0 || k == nphi - 1);
             const double base = ((m == 0) ? 1.0 : 2.0) / (double)nsamp;
@@ -199,10 +207,11 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
             if (l > 0)
                 for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
-            if (l == L - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
-            for (int r = t; r < N; r += NT) { s.svec[r] = 0.0; s.tq[r] = 0.0; }
+            const long long item = (p * (long long)(m_max + 1) + m) * b.Lmax + l;   // staging slot (MODE 1 / 3)
+            if (MODE != 1 && l == L - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
+            if (MODE != 1) for (int r = t; r < N; r += NT) { s.svec[r] = 0.0; s.tq[r] = 0.0; }
             block_sync();
-            if (l == L - 1 && b.sub_kind == SUB_FLAT) {  // substrate: R_sub (V, H, U) on the diagonal
+            if (MODE != 1 && l == L - 1 && b.sub_kind == SUB_FLAT) {  // substrate: R_sub (V, H, U) on the diagonal
                 for (int j = t; j < n; j += NT) {
                     double R3[3], T3[3];
                     fresnel_RT3(el, cmk(b.sub_p1[gp], b.sub_p2[gp]), s.mu[j], R3, T3);
@@ -220,19 +229,21 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 fresnel_RT3(el, eup, s.mu[j], R3, T3);
                 for (int q = 0; q < P; ++q) {
                     const int r = P * j + q;
-                    s.mrow[r] = s.mu[j]; s.wrow[r] = w;
-                    s.Rtop[r] = R3[q]; s.Ttop[r] = T3[q];
-                    dsg[r] = (q == 2) ? -1.0 : 1.0;
-                    su[r] = (q == 2) ? 1.4142135623730951 : 1.0;
+                    if (MODE != 3) { s.mrow[r] = s.mu[j]; s.wrow[r] = w; }
+                    if (MODE != 1) {
+                        s.Rtop[r] = R3[q]; s.Ttop[r] = T3[q];
+                        dsg[r] = (q == 2) ? -1.0 : 1.0;
+                    }
                 }
             }
-            if (l > 0)
+            if (MODE != 1 && l > 0)
                 for (int j = t; j < nu; j += NT) {
                     double R3[3], T3[3];
                     fresnel_RT3(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], R3, T3);
                     for (int q = 0; q < P; ++q) { s.Rbu[P * j + q] = R3[q]; s.Tbu[P * j + q] = T3[q]; }
                 }
 
+            if (MODE != 3) {
             // -- phase matrix of mode m: S+ = P(mu,+mu') + P(mu,-mu') D -> M0, S- = P(+) - P(-) D -> M1, lower
             //    triangle (rows = scattered stream/polarisation, columns = incident); D = -1 on the U columns
             {
@@ -323,28 +334,61 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 }
                 const double uu = sqrt(nr * s.wrow[r] / s.mrow[r]);
                 s.u[r] = uu;
-                s.d[r] = su[r] * uu / s.wrow[r];
+                s.d[r] = su_of(r, P) * uu / s.wrow[r];
             }
             block_sync();
             if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
             // -- X+- (lower triangles), symmetric positive definite thanks to the sqrt(2) scaling of U
             for_2d<NT>(N, N, [&](int r, int c) {
                 if (r >= c) {
-                    const double uu = cc * (s.u[r] / su[r]) * (s.u[c] * su[c]);
+                    const double uu = cc * (s.u[r] / su_of(r, P)) * (s.u[c] * su_of(c, P));
                     const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
                     s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
                     s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
                 }
             });
             block_sync();
-            if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD) : chol2<NT>(s.M0, s.M1, N, LD))) {
+            if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD, MODE == 1 ? stg->Linv + item * 1024 : nullptr)
+                          : chol2<NT>(s.M0, s.M1, N, LD))) {
                 fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
+            }
+            if (MODE == 1) {  // B = L+^T L- (columns reversed), L+ and d to the staging area; the Jacobi kernel is next
+                lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + item * stg->mat_stride, N, LD, true);
+                double* gL = stg->L + item * stg->mat_stride;
+                for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; });
+                for (int r = t; r < N; r += NT) stg->d[item * stg->vec_stride + r] = s.d[r];
+                if (t == 0) stg->n[item] = N;
+                block_sync();
+                continue;
             }
             if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
             else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
             if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, nullptr)) {
                 fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
             }
+            }  // MODE != 3
+            double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+            if (MODE == 3) {  // two LDS slots (X = M0, R = M3), F and G in the item's dead staging slots
+                double* gL = stg->L + item * stg->mat_stride;   // L+, later F
+                double* gB = stg->B + item * stg->mat_stride;   // B', later Em' and G
+                for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gB[c * LD + r]; });
+                for (int r = t; r < N; r += NT) {
+                    s.d[r] = stg->d[item * stg->vec_stride + r];
+                    const double sg = stg->sigma[item * stg->vec_stride + r];
+                    s.sigma[r] = sg; s.rsig[r] = 1.0 / sg;
+                }
+                block_sync();
+                l_times_m_mfma<NT>(gL, s.M0, gB, N, LD);                                  // Em' = L+ B'
+                lt_solve_mfma<NT>(gL, s.M0, stg->Linv + item * 1024, N, LD, true);        // Ep' = L+^-T B'
+                for_2d<NT>(N, N, [&](int i, int c) {
+                    const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
+                    const double hd = 0.5 * s.d[i];
+                    gL[c * LD + i] = hd * (ep + em);
+                    gB[c * LD + i] = hd * (ep - em);
+                    s.M3[c * LD + i] *= dsg[c];
+                });
+                F = gL; G = gB;
+            } else {
             if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
             else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
             if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
@@ -356,12 +400,19 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 s.M1[c * LD + i] = hd * (ep - em);   // G = (Ep + Em)/2
                 s.M3[c * LD + i] *= dsg[c];          // reflection matrix seen from this layer times D
             });
+            }
             for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
             block_sync();
-            double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
             if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            double* K = Wk;
+            if (MODE == 3) {
+                if (!gj_solve_b16<NT, false>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                // -- Y = F tQt + G -> slot R ; W = (D G - Rtop F) tQt + (D F - Rtop G) -> slot X (over tQt) ; K = Y W^-1
+                r45_mfma2<NT, true>(F, G, Wk, Rt, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+                if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            } else {
             if (!(CH == 1 ? gj_solve<NT, false>(Wk, Rt, nullptr, s, N, LD) : lu_solve<NT, false>(Wk, Rt, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             double* Q = Rt;
             for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
@@ -370,7 +421,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             if (!(CH == 1 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
-            double* K = Wk;
+            }
             if (l > 0) {
                 const int nc = (N < Nu) ? N : Nu;
                 for_2d<NT>(Nu, Nu, [&](int i, int j) {
@@ -406,6 +457,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         }
     }
 
+    if (MODE == 1) {
+        if (t == 0) b.status[p] = ST_OK;
+        return;
+    }
     // ---- interpolation to the incidence angles (rtsolver_utils.py:199-239, active branch) -------------------------
     for (int idx = t; idx < 9 * b.n_theta; idx += NT) {
         const int a = idx / b.n_theta, it = idx - a * b.n_theta;

@@ -975,9 +975,10 @@ SMRT_DEV void r45_mfma(double* F, const double* G, const double* Q, double* Wk, 
 
 // Two-slot variant for the finish kernel whose F and G live in global memory: Y and W are held in registers until
 // every wavefront has finished reading Q, then Y goes to Yout and W OVER Q (Wout == Q is allowed).
-template <int NT>
+template <int NT, bool SIGNED = false>
 SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, double* Yout, double* Wout,
-                        const double* Rtop, const double* tq, double* upb, double* gvec, double Bl, int N, int LD) {
+                        const double* Rtop, const double* tq, double* upb, double* gvec, double Bl, int N, int LD,
+                        const double* dsg = nullptr) {
     using RTc = RowTiles<NT>;
     constexpr int MAXTJ = (4 + RTc::CS - 1) / RTc::CS;
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
@@ -988,6 +989,7 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
         const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
         const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
         const double rt = Rtop[ic];
+        const double sg = SIGNED ? dsg[ic] : 1.0;   // row sign of the down-going eigenvectors (+-1)
         double af[16], aw[16];
         double vy = 0.0, vg = 0.0;
 #pragma unroll
@@ -996,7 +998,7 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
             const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
             const bool in = (ti < RT && i < N && k < N);
             af[kk] = in ? fv : 0.0;
-            aw[kk] = in ? gv - rt * fv : 0.0;
+            aw[kk] = in ? (SIGNED ? sg * gv : gv) - rt * fv : 0.0;
             vy += af[kk] * tk;
             vg += aw[kk] * tk;
         }
@@ -1031,9 +1033,9 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
                     double gk = 0.0, fk = 0.0;
 #pragma unroll
                     for (int k2 = 0; k2 < 16; ++k2)
-                        if (k2 == kk) { fk = af[k2]; gk = aw[k2] + rt * af[k2]; }
+                        if (k2 == kk) { fk = af[k2]; gk = (SIGNED ? sg : 1.0) * (aw[k2] + rt * af[k2]); }
                     mfma_f64_16x16x4(gk, idb, cy);
-                    mfma_f64_16x16x4(fk - rt * gk, idb, cw);
+                    mfma_f64_16x16x4((SIGNED ? sg * fk : fk) - rt * gk, idb, cw);
                 }
             }
 #pragma unroll
@@ -2455,7 +2457,7 @@ struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
 SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     JacobiPlan p;
     p.NMAX = n_max_stream * P;
-    p.LD = p.NMAX | 1;                                  // layout of the staged matrices in global memory
+    p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
     const int rows = ((p.NMAX + 7) / 8) * 8;            // padded rows (RPL * GS)
     p.LDJ = ((rows + 31) / 32) * 32 + 8;
     p.NCOL = ((p.NMAX + 7) / 8) * 8 + 1;                // NB*ceil(N/NB) <= this - 1, plus the idle-slot column
@@ -2473,13 +2475,14 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     constexpr int GS = 8;
     constexpr int NB = 2 * JW;
     const int t = tid();
-    const long long p = item / b.Lmax;
+    const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
+    const long long p = item / ((long long)b.Lmax * nmodes);
     const int l = (int)(item % b.Lmax);
     const long long gp = b.pair_begin + p;
     const int si = (int)(gp % b.S);
     if (l >= b.n_layers[si]) return;          // uniform
     if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
-    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, 2);
+    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2);
     const int LD = plan.LD, LDJ = plan.LDJ;
     const int N = stg.n[item];
     double* M = lds;
@@ -2502,7 +2505,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 
 template <int NT>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
-    const int NMAX = b.n_max_stream * 2;   // rows per lane = ceil(NMAX / 8), so that RPL * 8 <= NMAX (< LD)
+    const int NMAX = b.n_max_stream * (b.mode == 1 ? 3 : 2);   // rows per lane = ceil(NMAX / 8): RPL * 8 <= NMAX (< LD)
     if (NMAX > 32) dort_jacobi_item_impl<NT, 8>(b, stg, item, lds);
     else if (NMAX > 16) dort_jacobi_item_impl<NT, 4>(b, stg, item, lds);
     else if (NMAX > 8) dort_jacobi_item_impl<NT, 2>(b, stg, item, lds);

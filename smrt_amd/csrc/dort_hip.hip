@@ -71,6 +71,18 @@ __global__ __launch_bounds__(NT) void dort_active_kernel_gmem(DevBatch b, double
     }
 }
 
+// active mode through the three-kernel pipeline (prep and two-slot finish; the Jacobi kernel is shared)
+template <int NT>
+__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_prep_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_active<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+}
+template <int NT>
+__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_finish_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_active<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -189,7 +201,36 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
 }
 
 template <int NT>
+static hipError_t launch_split_active(smrt_dort_ctx* ctx, const DevBatch& d) {
+    constexpr int PNT = (NT >= 256) ? 256 : NT;
+    auto kp = dort_active_prep_kernel<PNT>;
+    auto kj = dort_jacobi_kernel<256>;
+    auto kf = dort_active_finish_kernel<PNT>;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
+    const int out_stride = ctx->out_stride;
+    const long long items_per_pair = (long long)(d.m_max + 1) * d.Lmax;
+    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
+        DevBatch c = d;
+        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
+        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
+        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
+        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
+        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
+        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
+        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(PNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int NT>
 static hipError_t launch_nt(smrt_dort_ctx* ctx, const DevBatch& d) {
+    if (ctx->active && ctx->split && ctx->finish2 && ctx->chunk_pairs > 0) return launch_split_active<NT>(ctx, d);
     if (!ctx->active && ctx->split && ctx->chunk_pairs > 0) return launch_split<NT>(ctx, d);
     auto kern = ctx->active ? dort_active_kernel<NT, 1> : dort_passive_kernel<NT, 1>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
@@ -300,14 +341,15 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
-    if (!ctx->gmem_path && ctx->split && !ctx->active) {
+    if (!ctx->gmem_path && ctx->split) {
+        const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer
         const size_t mat = (size_t)plan.NMAX * plan.LD;
-        const size_t per_pair = (size_t)b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
+        const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
         long long chunk = (long long)(12.0e9 / (double)per_pair);
         if (chunk < 1) chunk = 1;
         if (chunk > pair_count) chunk = pair_count;
         ctx->chunk_pairs = chunk;
-        const size_t items = (size_t)chunk * b->n_layers_max;
+        const size_t items = (size_t)chunk * b->n_layers_max * nmodes;
         HIPCHK(ctx->d_stL.reserve(items * mat * sizeof(double)));
         HIPCHK(ctx->d_stB.reserve(items * mat * sizeof(double)));
         HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
@@ -318,9 +360,9 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
         ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
-        ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, 2).total * sizeof(double);
-        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 1).total * sizeof(double);
-        ctx->finish2_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 2).total * sizeof(double);
+        ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
+        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 1).total * sizeof(double);
+        ctx->finish2_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
     }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;

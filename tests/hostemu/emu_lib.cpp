@@ -40,6 +40,35 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
     return nb;
 }
 
+// active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
+template <int NT>
+static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
+    long nb = 0;
+    const size_t items = (size_t)d.pair_count * (d.m_max + 1) * d.Lmax;
+    const size_t mat = (size_t)plan.NMAX * plan.LD;
+    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
+    std::vector<int> stn(items, -1);
+    std::vector<double> stinv(items * 1024, NAN);
+    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    std::vector<double> lds(lds_doubles);
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 1>(d, p, lds.data(), nullptr, &st); });
+    }
+    const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 3);
+    std::vector<double> jl(jp.total);
+    for (long long it = 0; it < (long long)items; ++it) {
+        if (stn[it] < 0) continue;   // unused slot (layer beyond the snowpack, or a pair the prep kernel rejected)
+        for (auto& x : jl) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, st, it, jl.data()); });
+    }
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 3>(d, p, lds.data(), nullptr, &st); });
+    }
+    return nb;
+}
+
 // three-kernel pipeline under emulation: prep for every pair, Jacobi for every (pair, layer), finish for every pair
 template <int NT>
 static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
@@ -105,6 +134,13 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
             switch (nt) {
                 case 64: nb = run_active<64, 2>(d, order, plan.total, matd); break;
                 case 256: nb = run_active<256, 2>(d, order, plan.total, matd); break;
+                default: return -3;
+            }
+        } else if (smrt_emu_pipeline) {
+            switch (nt) {
+                case 64: nb = run_split_active<64>(d, order, plan.total, plan); break;
+                case 128: nb = run_split_active<128>(d, order, plan.total, plan); break;
+                case 256: nb = run_split_active<256>(d, order, plan.total, plan); break;
                 default: return -3;
             }
         } else {
