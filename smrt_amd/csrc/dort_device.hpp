@@ -1527,7 +1527,7 @@ SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int 
     return true;
 }
 
-// ---- 16-wide blocked Gauss-Jordan (N <= 64): ONE workgroup barrier per 16 columns ---------------------------------
+// ---- 16-wide blocked Gauss-Jordan (N <= 128): ONE workgroup barrier per 16 columns ---------------------------------
 // Same elimination as gj_solve_mfma (implicit partial pivoting, tracked transformation columns u_j, permutation undone
 // at the end) with three changes that take the sequential part off the critical path of every block:
 //   * block width 16 = one MFMA tile column = four chained v_mfma_f64_16x16x4 per tile (the C tile is loaded and
@@ -1539,25 +1539,32 @@ SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int 
 // Every wavefront owns fixed absolute column tiles of [A | B] for the whole solve, so the only cross-wavefront
 // traffic per block is the panel (u columns, permutation, row states), published by the one barrier.  The panel of
 // block k+1 is factorised by the owner of that column tile right after it has updated the tile (look-ahead).
-template <bool TR>
+// RPLN = rows per lane: 1 for N <= 64 (lane = row), 2 for N <= 128 (lane holds rows lane and lane + 64).
+template <bool TR, int RPLN>
 SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
-    // x[s] holds panel column s of this lane's row until the column has been a pivot column, its multiplier u_s
+    // x[r][s] holds panel column s of row (lane + 64 r) until the column has been a pivot column, its multiplier u_s
     // afterwards: both kinds of slot receive the same update x[s] += u_j * x[s][pivot row], so a step treats all
     // slots but the pivot one alike.  The loop is unrolled by four only, with the slots rotated by four after every
     // group (the pivot slot index stays a compile-time constant): a fully unrolled panel is ~18 KB of straight-line
     // code that is executed once per call and does not live in the instruction cache next to the rest of the kernel.
     const int k0 = 16 * k;
     const int nbk = (N - k0 < 16) ? N - k0 : 16;
-    double x[16];
-    const int rc = lane < N ? lane : N - 1;
+    double x[RPLN][16];
+    bool used[RPLN], mine[RPLN];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int cc = (k0 + j < N) ? k0 + j : N - 1;
-        const double v = at<TR>(A, rc, cc, LD);
-        x[j] = (lane < N && j < nbk) ? v : 0.0;
+    for (int r = 0; r < RPLN; ++r) {
+        const int row = lane + 64 * r;
+        const int rc = row < N ? row : N - 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int cc = (k0 + j < N) ? k0 + j : N - 1;
+            const double v = at<TR>(A, rc, cc, LD);
+            x[r][j] = (row < N && j < nbk) ? v : 0.0;
+        }
+        used[r] = (row < N) ? (rowblk[rc] >= 0) : true;
+        mine[r] = false;
     }
-    bool used = (lane < N) ? (rowblk[lane] >= 0) : true;
-    bool mine = false, ok = true;
+    bool ok = true;
     int pj_store = 0;
     int grp = 0;
     for (; grp * 4 < nbk; ++grp) {
@@ -1565,49 +1572,73 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
         for (int q = 0; q < 4; ++q) {
             const int j = grp * 4 + q;
             if (j < nbk) {   // uniform
+                // arg-max over the unused rows: float magnitude bits with (255 - row) in the 8 low mantissa bits
                 unsigned key = 0u;
-                if (!used) {
-                    const float xr = (float)fabs(x[q]);
-                    memcpy(&key, &xr, 4);
-                    key = (key & ~0x7Fu) | (unsigned)(127 - lane);
+#pragma unroll
+                for (int r = 0; r < RPLN; ++r) {
+                    if (!used[r]) {
+                        const float xr = (float)fabs(x[r][q]);
+                        unsigned kr;
+                        memcpy(&kr, &xr, 4);
+                        kr = (kr & ~0xFFu) | (unsigned)(255 - (lane + 64 * r));
+                        key = kr > key ? kr : key;
+                    }
                 }
                 key = wave_max_u32(key);
-                if (key < 128u) ok = false;
-                const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
+                if (key < 256u) ok = false;
+                const int p = ok ? 255 - (int)(key & 0xFFu) : 0;
                 if (lane == j) pj_store = p;
-                const bool isp = (lane == p);
-                const double rpv = fast_rcp(ok ? wave_bcast(x[q], p) : 1.0);
-                if (isp) { used = true; mine = true; }
-                // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as every
-                // other row with the multiplier 1 - 1/pv
-                const double uj = isp ? rpv - 1.0 : -(x[q] * rpv);
+                const int pl = p & 63, ps = p >> 6;   // lane and slot of the pivot row (uniform)
+                double pvq = x[0][q];
+                if (RPLN > 1) pvq = ps ? x[RPLN - 1][q] : x[0][q];
+                const double rpv = fast_rcp(ok ? wave_bcast(pvq, pl) : 1.0);
                 double pr[16];
 #pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2)
-                    if (s2 != q) pr[s2] = wave_bcast(x[s2], p);
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    if (s2 != q) {
+                        double src = x[0][s2];
+                        if (RPLN > 1) src = ps ? x[RPLN - 1][s2] : x[0][s2];
+                        pr[s2] = wave_bcast(src, pl);
+                    }
+                }
 #if !defined(SMRT_HOST_EMU)
                 __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2)
-                    if (s2 != q) x[s2] = __builtin_fma(uj, pr[s2], x[s2]);
-                x[q] = uj;
+                for (int r = 0; r < RPLN; ++r) {
+                    const bool isp = (lane == pl) && (r == ps);
+                    if (isp) { used[r] = true; mine[r] = true; }
+                    // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as
+                    // every other row with the multiplier 1 - 1/pv
+                    const double uj = isp ? rpv - 1.0 : -(x[r][q] * rpv);
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2)
+                        if (s2 != q) x[r][s2] = __builtin_fma(uj, pr[s2], x[r][s2]);
+                    x[r][q] = uj;
+                }
             }
         }
         // rotate the slots left by four: slot s now holds what slot s + 4 held
-        double t0 = x[0], t1 = x[1], t2 = x[2], t3 = x[3];
 #pragma unroll
-        for (int s2 = 0; s2 < 12; ++s2) x[s2] = x[s2 + 4];
-        x[12] = t0; x[13] = t1; x[14] = t2; x[15] = t3;
+        for (int r = 0; r < RPLN; ++r) {
+            const double t0 = x[r][0], t1 = x[r][1], t2 = x[r][2], t3 = x[r][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 12; ++s2) x[r][s2] = x[r][s2 + 4];
+            x[r][12] = t0; x[r][13] = t1; x[r][14] = t2; x[r][15] = t3;
+        }
     }
     // after grp rotations slot s holds column (s + 4 grp) mod 16
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-        const int j = (s2 + 4 * grp) & 15;
-        if (lane < N && j < nbk) at<TR>(A, lane, k0 + j, LD) = ok ? x[s2] : 0.0;
+    for (int r = 0; r < RPLN; ++r) {
+        const int row = lane + 64 * r;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int j = (s2 + 4 * grp) & 15;
+            if (row < N && j < nbk) at<TR>(A, row, k0 + j, LD) = ok ? x[r][s2] : 0.0;
+        }
+        if (mine[r] && ok) rowblk[row] = k;
     }
     if (lane < nbk) perm[k0 + lane] = pj_store;
-    if (mine && ok) rowblk[lane] = k;
     return ok;
 }
 
@@ -1635,7 +1666,8 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 #else
 #define SMRT_GSUB(k) do {} while (0)
 #endif
-    if (wave == 0) { if (!gj_panel16<TR>(A, N, LD, 0, lane, perm, rowblk) && lane == 0) *fail = 1; }
+    auto panel = [&](int kb) { return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk); };
+    if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
     SMRT_GSUB(0);
     block_sync();
     if (*fail) return false;  // uniform
@@ -1724,7 +1756,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             wave_sync_lds();
             store_pivot_rows(gnext, tmp);
             wave_sync_lds();
-            if (!gj_panel16<TR>(A, N, LD, k + 1, lane, perm, rowblk) && lane == 0) *fail = 1;
+            if (!panel(k + 1) && lane == 0) *fail = 1;
         }
         const bool worker = (NW == 1) || !has_next || wave != owner;
         const int nworkers = (NW == 1 || !has_next) ? NW : NW - 1;
@@ -1739,14 +1771,20 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
                 store_pivot_rows(g, tmp);
                 wave_sync_lds();
             }
-            if (has_v && widx == 0) {  // extra right-hand side: same transformation, lane = row
-                double acc = 0.0;
-                if (lane < N) {
-                    acc = v[lane];
-                    for (int j = 0; j < nbk; ++j) acc += at<TR>(A, lane, k0 + j, LD) * v[perm[k0 + j]];
+            if (has_v && widx == 0) {  // extra right-hand side: same transformation, rows lane and lane + 64
+                double acc[2] = {0.0, 0.0};
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const int row = lane + 64 * r2;
+                    if (row < N) {
+                        acc[r2] = v[row];
+                        for (int j = 0; j < nbk; ++j) acc[r2] += at<TR>(A, row, k0 + j, LD) * v[perm[k0 + j]];
+                    }
                 }
                 wave_sync_lds();
-                if (lane < N) v[lane] = acc;
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+                    if (lane + 64 * r2 < N) v[lane + 64 * r2] = acc[r2];
             }
         }
         block_sync();
@@ -1757,11 +1795,17 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
     if (rs) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD) * (rs[k] * cs[c]); });
     else for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
-    double vk = 0.0;
-    if (has_v && t < N) vk = v[perm[t]];
+    double vk[2] = {0.0, 0.0};   // N <= 128 <= 2 NT
+    if (has_v) {
+        if (t < N) vk[0] = v[perm[t]];
+        if (t + NT < N) vk[1] = v[perm[t + NT]];
+    }
     block_sync();
     if (!result_in_A) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
-    if (has_v && t < N) v[t] = vk;
+    if (has_v) {
+        if (t < N) v[t] = vk[0];
+        if (t + NT < N) v[t + NT] = vk[1];
+    }
     block_sync();
     SMRT_GSUB(2);
     return true;
@@ -2177,7 +2221,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (MODE == 3) {  // the solution t Q t stays in slot X (one pass over the matrix instead of three)
             if (!gj_solve_b16<NT, false>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH == 1 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH <= 2 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = (MODE == 3) ? Wk : Rt;
         SMRT_DUMP("Q", Q, N);
@@ -2197,7 +2241,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (MODE == 3) {  // A = W (slot X), B = Y (slot R); K is left in slot X
             if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH == 1 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH <= 2 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void kreal(const double* src, double* out, long
         rowblk[lane] = -1;
         __syncthreads();
         const long long t0 = clock64();
-        gj_panel16<TR>(A, 64, 65, 0, lane, perm, rowblk);
+        gj_panel16<TR, 1>(A, 64, 65, 0, lane, perm, rowblk);
         __syncthreads();
         tot += clock64() - t0;
     }
