@@ -59,7 +59,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int nphi = nsamp / 2 + 1;
     const int nmax = b.n_max_stream;
     const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
-                                   active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0));
+                                   active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
+                                   gmem_mat != nullptr ? b.jac_in_lds : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
@@ -363,8 +364,13 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             }
             if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
             else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
-            if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, nullptr)) {
-                fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+            {
+                double* Jm = (plan.o_jac >= 0) ? lds_base + plan.o_jac : s.M2;
+                if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { Jm[c * LD + r] = s.M2[c * LD + r]; }); block_sync(); }
+                if (!jacobi_onesided<NT, JW, GS, RPL>(Jm, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, nullptr)) {
+                    fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+                }
+                if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { s.M2[c * LD + r] = Jm[c * LD + r]; }); block_sync(); }
             }
             }  // MODE != 3
             double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;

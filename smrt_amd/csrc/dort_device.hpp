@@ -34,6 +34,7 @@ struct DevBatch {
     int S, Lmax, F, n_theta;
     int emmodel, micro, mode, n_max_stream, m_max, normalization, rayleigh_jeans;
     int want_layer_out, want_stream_out;
+    int jac_in_lds;  // global-workspace kernels: the Jacobi stage runs on an LDS copy of B (host: it fits)
     long long pair_begin, pair_count;
     const int* n_layers;
     const double* thickness;
@@ -98,6 +99,7 @@ struct LdsPlan {
     int o_int;      // 16 ints (8 doubles)
     int o_gj;       // scratch of the blocked solvers: max(16 * NMAX, 1024) + 8 doubles, then (NMAX + 8) ints
     int o_act;      // active mode only: per-layer mode-0 normalisation, mode totals, incident stream list
+    int o_jac;      // global-workspace kernels: an NMAX x LD LDS buffer for the Jacobi stage, or -1 if it does not fit
     int total;      // doubles
 };
 
@@ -121,8 +123,9 @@ SMRT_HD int azimuth_samples(int m_max) {
 // slim = 1: the "prep" kernel of the split pipeline -- two work matrices (X+- -> L+-), four row vectors and the
 // Cholesky scratch only, so that TWO workgroups fit in the 160 KB of a CU.
 // slim = 2: the two-slot "finish" kernel -- two work matrices (X, R), all row vectors, Gauss-Jordan bookkeeping only.
+// jac_in_lds (global-workspace kernels only): reserve one LDS matrix for the Jacobi stage.
 SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nphi, int matrices_in_lds = 1,
-                          int act_doubles = 0, int slim = 0) {
+                          int act_doubles = 0, int slim = 0, int jac_in_lds = 0) {
     LdsPlan p;
     p.nmax = n_max_stream;
     p.NMAX = n_max_stream * P;
@@ -144,8 +147,10 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_phi = o; o += (slim == 2 ? 0 : 5 * nphi);
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
-    p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? 88 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? 88 : !matrices_in_lds ? 2 * p.NMAX / 2 + p.NMAX / 2 + 32 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
     p.o_act = o; o += act_doubles;
+    p.o_jac = -1;
+    if (jac_in_lds && !matrices_in_lds) { p.o_jac = o; o += p.NMAX * p.LD; }
     p.total = o;
     return p;
 }
@@ -1921,7 +1926,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
-                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0));
+                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0), gmem_mat != nullptr ? b.jac_in_lds : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2161,9 +2166,13 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         SMRT_STAGE(SG_JACOBI);
         if (MODE == 0) {
-            if (!jacobi_onesided<NT, JW, GS, RPL>(s.M2, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, s.sub_acc)) {
+            // global-workspace kernels: the rotations run on an LDS copy of B when one fits next to the vectors
+            double* Jm = (plan.o_jac >= 0) ? lds_base + plan.o_jac : s.M2;
+            if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { Jm[c * LD + r] = s.M2[c * LD + r]; }); block_sync(); }
+            if (!jacobi_onesided<NT, JW, GS, RPL>(Jm, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, s.sub_acc)) {
                 fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
             }
+            if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { s.M2[c * LD + r] = Jm[c * LD + r]; }); block_sync(); }
         } else {  // MODE 2 / 3: pick up L+, B' = B V, d and the singular values
             const long long item = p * (long long)b.Lmax + l;
             const double* gL = stg->L + item * stg->mat_stride;

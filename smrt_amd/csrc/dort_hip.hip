@@ -122,6 +122,7 @@ struct smrt_dort_ctx {
     size_t jacobi_lds = 0;
     DevStage stage{};
     bool gmem_path = false;
+    int jac_in_lds = 0;
     bool active = false;
     int gmem_grid = 0;
     long long ws_stride = 0;
@@ -332,7 +333,12 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
             ctx->err = "streams x polarisations above 256 (n_max_stream > 128 passive, > 85 active) is not supported by this build";
             return -1;
         }
-        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd);
+        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 1);   // with an LDS Jacobi matrix
+        ctx->jac_in_lds = 1;
+        if ((size_t)plan.total * sizeof(double) > (size_t)ctx->max_lds) {
+            plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd);
+            ctx->jac_in_lds = 0;
+        }
         lds = (size_t)plan.total * sizeof(double);
         if (lds > (size_t)ctx->max_lds) { ctx->err = "too many layers for the LDS-resident per-layer tables"; return -1; }
         ctx->gmem_grid = (int)std::min<int64_t>(pair_count, 1024);
@@ -403,6 +409,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
     d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
     d.want_layer_out = 1; d.want_stream_out = 1;
+    d.jac_in_lds = ctx->gmem_path ? ctx->jac_in_lds : 0;
     d.pair_begin = pair_begin; d.pair_count = pair_count;
     d.n_layers = (const int*)ctx->d_nl.p; d.thickness = (const double*)ctx->d_thick.p;
     d.frac_volume = (const double*)ctx->d_fv.p; d.temperature = (const double*)ctx->d_temp.p;

@@ -108,8 +108,8 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     const int P = active ? 3 : 2;
     const bool gmem = b->n_max_stream * P > 64;
     const LdsPlan plan = active ? make_plan(b->n_max_stream, 3, b->n_layers_max, b->n_theta, azimuth_samples(b->m_max) / 2 + 1,
-                                            gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta))
-                                : make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1);
+                                            gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta), 0, gmem ? 1 : 0)
+                                : make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1, 0, 0, gmem ? 1 : 0);
     if (plan.NMAX > 128) return -2;
     const size_t matd = gmem ? (size_t)plan.mat_doubles : 0;
     std::vector<double> gl(b->n_max_stream);
@@ -119,6 +119,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
     d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
     d.want_layer_out = layer_out ? 1 : 0; d.want_stream_out = stream_out ? 1 : 0;
+    d.jac_in_lds = gmem ? 1 : 0;
     d.pair_begin = pair_begin; d.pair_count = pair_count;
     d.n_layers = b->n_layers; d.thickness = b->thickness; d.frac_volume = b->frac_volume;
     d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
