@@ -62,6 +62,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                                    active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
                                    gmem_mat != nullptr ? b.jac_in_lds : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+    // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
+    // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
+    const bool dense_mfma = (CH == 1) || (CH == 2 && plan.o_jac >= 0);
+    double* dense_scratch = (CH == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
     const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
@@ -349,7 +353,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 }
             });
             block_sync();
-            if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD, MODE == 1 ? stg->Linv + item * 1024 : nullptr)
+            if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, MODE == 1 ? stg->Linv + item * 1024 : nullptr)
                           : chol2<NT>(s.M0, s.M1, N, LD))) {
                 fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
             }
@@ -362,7 +366,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 block_sync();
                 continue;
             }
-            if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
+            if (dense_mfma) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
             else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
             {
                 double* Jm = (plan.o_jac >= 0) ? lds_base + plan.o_jac : s.M2;
@@ -395,9 +399,9 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 });
                 F = gL; G = gB;
             } else {
-            if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
+            if (dense_mfma) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
             else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
-            if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
+            if (dense_mfma) lt_solve_mfma<NT>(s.M0, s.M2, dense_scratch, N, LD);       // Ep' = L+^-T B'
             else lt_solve<NT>(s.M0, s.M2, N, LD);
             for_2d<NT>(N, N, [&](int i, int c) {
                 const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];

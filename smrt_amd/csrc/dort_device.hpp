@@ -1928,6 +1928,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
                                    MODE == 1 ? 1 : (MODE == 3 ? 2 : 0), gmem_mat != nullptr ? b.jac_in_lds : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+    // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
+    // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
+    const bool dense_mfma = (CH == 1) || (CH == 2 && plan.o_jac >= 0);
+    double* dense_scratch = (CH == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     s.sub_acc = sub_acc_store;
@@ -2137,7 +2141,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         });
         block_sync();
         SMRT_STAGE(SG_CHOL);
-        if (!(CH == 1 ? chol2_mfma<NT>(s.M0, s.M1, s.gj, &s.ints[2], N, LD,
+        if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
                                        MODE == 1 ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
                       : chol2<NT>(s.M0, s.M1, N, LD))) {
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
@@ -2151,7 +2155,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                                 true);
 #endif
         } else {
-        if (CH == 1) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
+        if (dense_mfma) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
         else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
         }
         }  // MODE < 2
@@ -2202,9 +2206,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             });
             F = gL; G = gB;
         } else {
-        if (CH == 1) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
+        if (dense_mfma) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
         else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
-        if (CH == 1) lt_solve_mfma<NT>(s.M0, s.M2, s.gj, N, LD);       // Ep' = L+^-T B'
+        if (dense_mfma) lt_solve_mfma<NT>(s.M0, s.M2, dense_scratch, N, LD);       // Ep' = L+^-T B'
         else lt_solve<NT>(s.M0, s.M2, N, LD);
         // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
         for_2d<NT>(N, N, [&](int i, int c) {
