@@ -415,6 +415,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             block_sync();
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
             if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            else if (CH == 2 && dense_mfma) r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;
             if (MODE == 3) {
@@ -429,6 +430,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             block_sync();
             // -- Y = F tQt + G ; W = (D G - Rtop F) tQt + (D F - Rtop G) ; K = Y W^-1
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            else if (CH == 2 && dense_mfma) r45_mfma_big<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             if (!(CH <= 2 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }

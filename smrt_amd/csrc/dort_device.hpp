@@ -1065,6 +1065,113 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
     block_sync();
 }
 
+// ---- the two row-block passes for 64 < N <= 128 (global-workspace kernels): same algorithm, 32 k-groups per row,
+// up to eight row tiles, one row tile per wavefront at a time (its A operands in registers), operands from wherever
+// the matrices live (all pointers are generic).
+template <int NT>
+SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* Wk, double* cvec, const double* svec,
+                          double Bl, int N, int LD) {
+    constexpr int NW = NT / SMRT_LANES;
+    constexpr int RPW = (NW >= 8) ? 1 : (8 + NW - 1) / NW;
+    constexpr int CS = (NW > 8) ? NW / 8 : 1;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    for (int o = 0; o < RPW; ++o) {
+        const int ti = (NW >= 8) ? (wave & 7) : (wave + o * NW);
+        const int cs = (NW >= 8) ? (wave >> 3) : 0;
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        double a[32];
+        double rs = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double x = Rt[kc * LD + ic];
+            a[kk] = (ti < RT && i < N && k < N) ? x : 0.0;
+            rs += a[kk];
+        }
+        rs += shfl_xor(rs, 16);
+        rs += shfl_xor(rs, 32);
+        if (cs == 0 && ti < RT && lk == 0 && i < N) cvec[i] = rs * Bl - Bl + svec[i];
+        block_sync();  // column-split wavefronts share a row tile: everybody has its A operands before anybody writes
+        if (ti < RT) {
+            for (int tj = cs; tj < RT; tj += CS) {
+                double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+                const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    if (4 * kk < N) {
+                        const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                        const bool in = (j < N && k < N);
+                        const double gv = G[jc * LD + kc], fv = F[jc * LD + kc];
+                        mfma_f64_16x16x4(a[kk], in ? gv : 0.0, c1);
+                        mfma_f64_16x16x4(a[kk], in ? fv : 0.0, c2);
+                    }
+                }
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    Wk[col * LD + row] = F[col * LD + row] - c1[reg];
+                    Rt[col * LD + row] = c2[reg] - G[col * LD + row];
+                });
+            }
+        }
+    }
+    block_sync();
+}
+
+template <int NT, bool SIGNED>
+SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
+                           double* upb, double* gvec, double Bl, int N, int LD, const double* dsg) {
+    constexpr int NW = NT / SMRT_LANES;
+    constexpr int RPW = (NW >= 8) ? 1 : (8 + NW - 1) / NW;
+    constexpr int CS = (NW > 8) ? NW / 8 : 1;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    for (int o = 0; o < RPW; ++o) {
+        const int ti = (NW >= 8) ? (wave & 7) : (wave + o * NW);
+        const int cs = (NW >= 8) ? (wave >> 3) : 0;
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        const double rt = Rtop[ic];
+        const double sg = SIGNED ? dsg[ic] : 1.0;
+        double af[32], aw[32];
+        double vy = 0.0, vg = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
+            const bool in = (ti < RT && i < N && k < N);
+            af[kk] = in ? fv : 0.0;
+            aw[kk] = in ? (SIGNED ? sg * gv : gv) - rt * fv : 0.0;
+            vy += af[kk] * tk;
+            vg += aw[kk] * tk;
+        }
+        vy += shfl_xor(vy, 16); vy += shfl_xor(vy, 32);
+        vg += shfl_xor(vg, 16); vg += shfl_xor(vg, 32);
+        if (cs == 0 && ti < RT && lk == 0 && i < N) { upb[i] = vy + Bl; gvec[i] = vg + (1.0 - rt) * Bl; }
+        block_sync();
+        if (ti < RT) {
+            for (int tj = cs; tj < RT; tj += CS) {
+                double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
+                const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    if (4 * kk < N) {
+                        const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                        const double qv = Q[jc * LD + kc];
+                        const double bop = (j < N && k < N) ? qv : 0.0;
+                        mfma_f64_16x16x4(af[kk], bop, cy);
+                        mfma_f64_16x16x4(aw[kk], bop, cw);
+                    }
+                }
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    const double fic = F[col * LD + row], gic = G[col * LD + row];
+                    Wk[col * LD + row] = cy[reg] + gic;
+                    F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
+                });
+            }
+        }
+    }
+    block_sync();
+}
+
 // ---- the same two passes without the matrix core (N > 64: CH column chunks of 64 per lane) --------------------
 // rows-per-wavefront register blocking
 constexpr int RB = 2;
@@ -2225,6 +2332,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_R1);
         if (CH == 1) {
             r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        } else if (CH == 2 && dense_mfma) {
+            r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         } else {
             r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         }
@@ -2245,6 +2354,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             r45_mfma2<NT>(F, G, Q, Rt, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot R, W -> slot X (over Q)
         } else if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
+        } else if (CH == 2 && dense_mfma) {
+            r45_mfma_big<NT, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         } else {
             r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         }
