@@ -2033,12 +2033,14 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
-                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0), gmem_mat != nullptr ? b.jac_in_lds : 0);
+                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
+                                   (gmem_mat != nullptr && MODE != 1) ? b.jac_in_lds : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
-    const bool dense_mfma = (CH == 1) || (CH == 2 && plan.o_jac >= 0);
-    double* dense_scratch = (CH == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
+    // (the prep half only needs the 512-double Cholesky scratch, which its slim plan has)
+    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1));
+    double* dense_scratch = (CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     s.sub_acc = sub_acc_store;
@@ -2249,7 +2251,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         block_sync();
         SMRT_STAGE(SG_CHOL);
         if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
-                                       MODE == 1 ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
+                                       (MODE == 1 && CH == 1) ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
                       : chol2<NT>(s.M0, s.M1, N, LD))) {
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
         }
@@ -2674,7 +2676,8 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 template <int NT>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     const int NMAX = b.n_max_stream * (b.mode == 1 ? 3 : 2);   // rows per lane = ceil(NMAX / 8): RPL * 8 <= NMAX (< LD)
-    if (NMAX > 32) dort_jacobi_item_impl<NT, 8>(b, stg, item, lds);
+    if (NMAX > 64) dort_jacobi_item_impl<NT, 16>(b, stg, item, lds);
+    else if (NMAX > 32) dort_jacobi_item_impl<NT, 8>(b, stg, item, lds);
     else if (NMAX > 16) dort_jacobi_item_impl<NT, 4>(b, stg, item, lds);
     else if (NMAX > 8) dort_jacobi_item_impl<NT, 2>(b, stg, item, lds);
     else dort_jacobi_item_impl<NT, 1>(b, stg, item, lds);

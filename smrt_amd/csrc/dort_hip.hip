@@ -55,6 +55,27 @@ __global__ __launch_bounds__(NT) void dort_passive_kernel_gmem(DevBatch b, doubl
     }
 }
 
+// ---- three-kernel pipeline for 64 < N <= 128 (passive): prep and the four-matrix finish on the per-workgroup global
+// workspace (grid-stride over the pairs), the shared Jacobi kernel with its 128-column LDS matrix in between
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+
 // ---- active mode (backscatter): one fused kernel per pair, azimuth modes 0..m_max inside ---------------------------
 template <int NT, int CH>
 __global__ __launch_bounds__(NT) void dort_active_kernel(DevBatch b) {
@@ -122,6 +143,7 @@ struct smrt_dort_ctx {
     size_t jacobi_lds = 0;
     DevStage stage{};
     bool gmem_path = false;
+    bool gmem_split = false;    // 64 < N <= 128 passive: three-kernel pipeline on the global workspace
     int jac_in_lds = 0;
     bool active = false;
     int gmem_grid = 0;
@@ -196,6 +218,33 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
         hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         if (ctx->finish2) hipLaunchKernelGGL(kf2, dim3((unsigned)cn), dim3(FNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
         else hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
+    constexpr int NT = 256;
+    auto kp = dort_prep_kernel_gmem<NT>;
+    auto kj = dort_jacobi_kernel<256>;
+    auto kf = dort_finish_kernel_gmem<NT>;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
+    const int out_stride = ctx->out_stride;
+    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
+        DevBatch c = d;
+        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
+        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
+        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
+        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
+        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
+        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
+        const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -347,7 +396,9 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
-    if (!ctx->gmem_path && ctx->split) {
+    ctx->gmem_split = ctx->gmem_path && ctx->split && !ctx->active && plan.NMAX <= 128 && ctx->jac_in_lds &&
+                      (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
+    if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
         const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer
         const size_t mat = (size_t)plan.NMAX * plan.LD;
         const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
@@ -367,7 +418,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
-        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 1).total * sizeof(double);
+        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd, 1).total * sizeof(double);
         ctx->finish2_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -447,7 +498,8 @@ int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
     if (ctx->gmem_path) {
-        if (ctx->nmax_rows <= 128) e = launch_gmem<256, 2>(ctx, d);
+        if (ctx->gmem_split) e = launch_split_gmem(ctx, d);
+        else if (ctx->nmax_rows <= 128) e = launch_gmem<256, 2>(ctx, d);
         else e = launch_gmem<256, 4>(ctx, d);
         HIPCHK(e);
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

@@ -40,6 +40,38 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
     return nb;
 }
 
+// 64 < N <= 128, passive: three-kernel pipeline with prep / finish on a global workspace
+template <int NT>
+static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
+    long nb = 0;
+    const size_t items = (size_t)d.pair_count * d.Lmax;
+    const size_t mat = (size_t)plan.NMAX * plan.LD;
+    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
+    std::vector<int> stn(items, -1);
+    std::vector<double> stinv(items * 1024, NAN);
+    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    const LdsPlan pp = make_plan(d.n_max_stream, 2, d.Lmax, d.n_theta, 9, 0, 0, 1, 0);
+    std::vector<double> lds(plan.total > pp.total ? plan.total : pp.total), ws(plan.mat_doubles);
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        for (auto& x : ws) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
+    }
+    const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
+    std::vector<double> jl(jp.total);
+    for (long long it = 0; it < (long long)items; ++it) {
+        if (stn[it] < 0) continue;
+        for (auto& x : jl) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, st, it, jl.data()); });
+    }
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        for (auto& x : ws) x = NAN;
+        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
+    }
+    return nb;
+}
+
 // active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
 template <int NT>
 static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
@@ -130,7 +162,9 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    if (active) {
+    if (!active && gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
+        nb = run_split_gmem<256>(d, order, plan);
+    } else if (active) {
         if (gmem) {
             switch (nt) {
                 case 64: nb = run_active<64, 2>(d, order, plan.total, matd); break;
