@@ -150,7 +150,9 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? 88 : !matrices_in_lds ? 2 * p.NMAX / 2 + p.NMAX / 2 + 32 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
     p.o_act = o; o += act_doubles;
     p.o_jac = -1;
-    if (jac_in_lds && !matrices_in_lds) { p.o_jac = o; o += p.NMAX * p.LD; }
+    // 1: a whole matrix (Jacobi stage of the fused kernel); 2: only the 16 NMAX doubles of scratch that the blocked
+    // triangular solve needs (finish half of the global-workspace pipeline: small LDS, several workgroups per CU)
+    if (jac_in_lds && !matrices_in_lds) { p.o_jac = o; o += (jac_in_lds == 2) ? 16 * p.NMAX : p.NMAX * p.LD; }
     p.total = o;
     return p;
 }
@@ -2034,7 +2036,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
                                    MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
-                                   (gmem_mat != nullptr && MODE != 1) ? b.jac_in_lds : 0);
+                                   (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)

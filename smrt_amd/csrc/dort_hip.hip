@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage
     }
 }
 template <int NT>
-__global__ __launch_bounds__(NT) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, 2) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
@@ -230,7 +230,7 @@ static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
     auto kf = dort_finish_kernel_gmem<NT>;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
     const int out_stride = ctx->out_stride;
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
@@ -244,7 +244,7 @@ static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
         const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
         hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -419,7 +419,9 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd, 1).total * sizeof(double);
-        ctx->finish2_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
+        ctx->finish2_lds_bytes = ctx->gmem_split
+            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 2).total * sizeof(double)
+            : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
     }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
