@@ -60,12 +60,12 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int nmax = b.n_max_stream;
     const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
                                    active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
-                                   gmem_mat != nullptr ? b.jac_in_lds : 0);
+                                   (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
-    const bool dense_mfma = (CH == 1) || (CH == 2 && plan.o_jac >= 0);
-    double* dense_scratch = (CH == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
+    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1));
+    double* dense_scratch = (CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
     const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
@@ -88,11 +88,11 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
 
     if (t < 8) s.ints[t] = 0;
     block_sync();
-    if (MODE == 3) {  // a failure recorded by the prep or Jacobi kernel
+    if (MODE >= 2) {  // a failure recorded by the prep or Jacobi kernel
         const int prev = b.status[p];
         if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
     }
-    for (int k = t; k < nphi && MODE != 3; k += NT) {
+    for (int k = t; k < nphi && MODE < 2; k += NT) {
         const double ph = kPi * (double)k / (double)(nphi - 1);
         s.cphi[k] = cos(ph); s.sphi[k] = sin(ph);
     }
@@ -192,7 +192,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         const int P = (m == 0) ? 2 : 3;
         const double cc = (m == 0) ? 0.5 : 0.25;  // dort.py:716-721
         // azimuth weights of this mode: cosine sums for the even entries, sine sums for the (V|H, U) cross entries
-        for (int k = t; k < nphi && MODE != 3; k += NT) {
+        for (int k = t; k < nphi && MODE < 2; k += NT) {
             const double ph = kPi * (double)k / (double)(nphi - 1);
             const bool end = (k == 0 || k == nphi - 1);
             const double base = ((m == 0) ? 1.0 : 2.0) / (double)nsamp;
@@ -234,7 +234,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 fresnel_RT3(el, eup, s.mu[j], R3, T3);
                 for (int q = 0; q < P; ++q) {
                     const int r = P * j + q;
-                    if (MODE != 3) { s.mrow[r] = s.mu[j]; s.wrow[r] = w; }
+                    if (MODE < 2) { s.mrow[r] = s.mu[j]; s.wrow[r] = w; }
                     if (MODE != 1) {
                         s.Rtop[r] = R3[q]; s.Ttop[r] = T3[q];
                         dsg[r] = (q == 2) ? -1.0 : 1.0;
@@ -248,7 +248,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     for (int q = 0; q < P; ++q) { s.Rbu[P * j + q] = R3[q]; s.Tbu[P * j + q] = T3[q]; }
                 }
 
-            if (MODE != 3) {
+            if (MODE < 2) {
             // -- phase matrix of mode m: S+ = P(mu,+mu') + P(mu,-mu') D -> M0, S- = P(+) - P(-) D -> M1, lower
             //    triangle (rows = scattered stream/polarisation, columns = incident); D = -1 on the U columns
             {
@@ -353,7 +353,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 }
             });
             block_sync();
-            if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, MODE == 1 ? stg->Linv + item * 1024 : nullptr)
+            if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, (MODE == 1 && CH == 1) ? stg->Linv + item * 1024 : nullptr)
                           : chol2<NT>(s.M0, s.M1, N, LD))) {
                 fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
             }
@@ -376,8 +376,19 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 }
                 if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { s.M2[c * LD + r] = Jm[c * LD + r]; }); block_sync(); }
             }
-            }  // MODE != 3
+            }  // MODE < 2
             double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+            if (MODE == 2) {  // four-matrix finish (global workspace): pick up L+, B' = B V, d and the singular values
+                const double* gL = stg->L + item * stg->mat_stride;
+                const double* gB = stg->B + item * stg->mat_stride;
+                for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gL[c * LD + r]; s.M2[c * LD + r] = gB[c * LD + r]; });
+                for (int r = t; r < N; r += NT) {
+                    s.d[r] = stg->d[item * stg->vec_stride + r];
+                    const double sg = stg->sigma[item * stg->vec_stride + r];
+                    s.sigma[r] = sg; s.rsig[r] = 1.0 / sg;
+                }
+                block_sync();
+            }
             if (MODE == 3) {  // two LDS slots (X = M0, R = M3), F and G in the item's dead staging slots
                 double* gL = stg->L + item * stg->mat_stride;   // L+, later F
                 double* gB = stg->B + item * stg->mat_stride;   // B', later Em' and G

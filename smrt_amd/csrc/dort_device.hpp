@@ -2460,7 +2460,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
 // validity test or a masked load (a zero column never rotates: g = 0).  Column norms are tracked in LDS (a rotation
 // changes them by -/+ t g exactly) and refreshed once per sweep, so a step needs ONE dot product and ONE group sum.
 template <int GS, int RPL>
-SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, double* nrm, int* flag) {
+SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, double* nrm, int* flag, double skip2,
+                                 double exit2) {
     double x[RPL], y[RPL];
     double gg = 0.0, gg2 = 0.0;
     double* cp = Bm + p * LD;
@@ -2475,7 +2476,7 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
     const double a = nrm[p], bb = nrm[q];
     gg = group_sum<GS>(gg + gg2);
     const double g2 = gg * gg, ab = a * bb;
-    if (g2 > SMRT_JACOBI_SKIP_COS2 * ab) {
+    if (g2 > skip2 * ab) {
         const double dd = bb - a;
         const double hh = dd * dd + 4.0 * g2;
         const double h = hh * fast_rsqrt1(hh);
@@ -2490,14 +2491,19 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
         if (sub == 0) {
             nrm[p] = a - tt * gg;
             nrm[q] = bb + tt * gg;
-            if (g2 > SMRT_JACOBI_EXIT_COS2 * ab) lds_or(flag, 1);
+            if (g2 > exit2 * ab) lds_or(flag, 1);
         }
     }
 }
 
 // Two-level ordering as jacobi_onesided, on a zero-padded LDS matrix (rows < RPL*GS <= LD, columns < NB*m).
+// skip2 / exit2: squared-cosine thresholds below which a rotation is skipped / does not count against convergence.
+// Passive brightness temperatures (1e-6 K of ~250 K) tolerate 1e-26 / 1e-15; the backscatter is a small difference
+// of intensities (coherent part subtracted, azimuth modes cancelling in cross-pol), so active mode uses 1e-30 / 1e-22
+// (5e-10 -> 2e-11 relative error on the fixtures, about a third of a sweep more).
 template <int NT, int JW, int GS, int RPL>
-SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nrm, int* flag) {
+SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nrm, int* flag,
+                            double skip2 = SMRT_JACOBI_SKIP_COS2, double exit2 = SMRT_JACOBI_EXIT_COS2) {
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
     constexpr int NB = 2 * JW;
@@ -2546,7 +2552,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                         }
                         const bool valid = (ps < 2 * half) && (a < m) && (b < m);
                         // an idle slot rotates the (all-zero) last padding column with itself: a no-op
-                        rotate_pair_padded<GS, RPL>(Bm, LD, valid ? base + a : CP, valid ? base + b : CP, sub, nrm, flag);
+                        rotate_pair_padded<GS, RPL>(Bm, LD, valid ? base + a : CP, valid ? base + b : CP, sub, nrm, flag, skip2, exit2);
                     }
                     wave_sync_lds();
                 }
@@ -2576,7 +2582,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                     const double bb = nrm[qc];
                     gg = group_sum<GS>(gg + gg2);
                     const double g2 = gg * gg, ab = a * bb;
-                    if (g2 > SMRT_JACOBI_SKIP_COS2 * ab) {
+                    if (g2 > skip2 * ab) {
                         const double dd = bb - a;
                         const double hh = dd * dd + 4.0 * g2;
                         const double h = hh * fast_rsqrt1(hh);
@@ -2590,7 +2596,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                         }
                         if (sub == 0) {
                             nrm[qc] = bb + tt * gg;
-                            if (g2 > SMRT_JACOBI_EXIT_COS2 * ab) lds_or(flag, 1);
+                            if (g2 > exit2 * ab) lds_or(flag, 1);
                         }
                         a -= tt * gg;
                     }
@@ -2630,7 +2636,8 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     JacobiPlan p;
     p.NMAX = n_max_stream * P;
     p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
-    const int rows = ((p.NMAX + 7) / 8) * 8;            // padded rows (RPL * GS)
+    // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
+    const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
     p.LDJ = ((rows + 31) / 32) * 32 + 8;
     p.NCOL = ((p.NMAX + 7) / 8) * 8 + 1;                // NB*ceil(N/NB) <= this - 1, plus the idle-slot column
     int o = p.NCOL * p.LDJ;
@@ -2669,7 +2676,8 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     for_2d<NT>(RPL * GS, CP + 1, [&](int r, int c) { M[c * LDJ + r] = (r < N && c < N) ? gB[c * LD + r] : 0.0; });
     if (t == 0) ints[0] = 0;
     block_sync();
-    const bool ok = jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0]);
+    const bool ok = (b.mode == 1) ? jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], 1e-30, 1e-22)
+                                  : jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0]);
     if (!ok) { if (t == 0) gmem_max(&b.status[p], ST_EIGEN); return; }
     for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
     for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];

@@ -76,6 +76,25 @@ __global__ __launch_bounds__(NT, 2) void dort_finish_kernel_gmem(DevBatch b, Dev
     }
 }
 
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_active_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT, 2) void dort_active_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+
 // ---- active mode (backscatter): one fused kernel per pair, azimuth modes 0..m_max inside ---------------------------
 template <int NT, int CH>
 __global__ __launch_bounds__(NT) void dort_active_kernel(DevBatch b) {
@@ -225,9 +244,10 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
 
 static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
     constexpr int NT = 256;
-    auto kp = dort_prep_kernel_gmem<NT>;
+    auto kp = ctx->active ? dort_active_prep_kernel_gmem<NT> : dort_prep_kernel_gmem<NT>;
     auto kj = dort_jacobi_kernel<256>;
-    auto kf = dort_finish_kernel_gmem<NT>;
+    auto kf = ctx->active ? dort_active_finish_kernel_gmem<NT> : dort_finish_kernel_gmem<NT>;
+    const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
@@ -243,7 +263,7 @@ static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
         const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
@@ -396,7 +416,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
-    ctx->gmem_split = ctx->gmem_path && ctx->split && !ctx->active && plan.NMAX <= 128 && ctx->jac_in_lds &&
+    ctx->gmem_split = ctx->gmem_path && ctx->split && plan.NMAX <= 128 && ctx->jac_in_lds &&
                       (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
     if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
         const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer

@@ -41,23 +41,23 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
 }
 
 // 64 < N <= 128, passive: three-kernel pipeline with prep / finish on a global workspace
-template <int NT>
+template <int NT, bool ACTIVE>
 static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     long nb = 0;
-    const size_t items = (size_t)d.pair_count * d.Lmax;
+    const size_t items = (size_t)d.pair_count * d.Lmax * (ACTIVE ? d.m_max + 1 : 1);
     const size_t mat = (size_t)plan.NMAX * plan.LD;
     std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
     std::vector<int> stn(items, -1);
     std::vector<double> stinv(items * 1024, NAN);
     DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
-    const LdsPlan pp = make_plan(d.n_max_stream, 2, d.Lmax, d.n_theta, 9, 0, 0, 1, 0);
-    std::vector<double> lds(plan.total > pp.total ? plan.total : pp.total), ws(plan.mat_doubles);
+    std::vector<double> lds(2 * plan.total), ws(plan.mat_doubles);   // generous: the three kernels lay out LDS differently
     for (long long p = 0; p < d.pair_count; ++p) {
         for (auto& x : lds) x = NAN;
         for (auto& x : ws) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
+        if (ACTIVE) nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
+        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
     }
-    const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
+    const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, ACTIVE ? 3 : 2);
     std::vector<double> jl(jp.total);
     for (long long it = 0; it < (long long)items; ++it) {
         if (stn[it] < 0) continue;
@@ -67,7 +67,8 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     for (long long p = 0; p < d.pair_count; ++p) {
         for (auto& x : lds) x = NAN;
         for (auto& x : ws) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
+        if (ACTIVE) nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
+        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
     }
     return nb;
 }
@@ -162,8 +163,8 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    if (!active && gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
-        nb = run_split_gmem<256>(d, order, plan);
+    if (gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
+        nb = active ? run_split_gmem<256, true>(d, order, plan) : run_split_gmem<256, false>(d, order, plan);
     } else if (active) {
         if (gmem) {
             switch (nt) {
