@@ -268,3 +268,36 @@ def test_active_properties(ctx):
     assert np.array_equal(again.values, v)
     part = ctx.run(b, pair_begin=10, pair_count=30)
     assert np.array_equal(part.values, v[10:40])
+
+
+def test_pipeline_shapes_agree(ctx):
+    """Every way the library can run a batch -- three kernels with the two-slot finish (1, default), with the four-slot
+    finish (2), one fused kernel (0) -- on the LDS-resident path (N <= 64) and on the global-workspace path
+    (64 < N <= 128), passive and active: same answers to rounding."""
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(31)
+    S, L = 4, 7
+    thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 100.0)], axis=1)
+    dens, temp = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L))
+    lc = rng.uniform(5e-5, 3e-4, (S, L))
+    cases = [
+        dict(freq=[18.7e9, 89e9], theta=[55.0], mode="P", n_max_stream=32, rtol=1e-9),
+        dict(freq=[36.5e9], theta=[40.0], mode="P", n_max_stream=64, rtol=1e-9),
+        dict(freq=[13.4e9], theta=[30.0, 45.0], mode="A", n_max_stream=16, rtol=1e-7),
+        dict(freq=[13.4e9], theta=[30.0, 45.0], mode="A", n_max_stream=32, rtol=1e-7),
+    ]
+    for c in cases:
+        b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, c["freq"], np.deg2rad(c["theta"]), emmodel="iba",
+                        microstructure="exponential", mode=c["mode"], n_max_stream=c["n_max_stream"], m_max=2)
+        outs = []
+        for pipe in (1, 2, 0):
+            ctx.set_pipeline(pipe)
+            outs.append(ctx.run(b))
+        ctx.set_pipeline(1)
+        for o in outs:
+            assert (o.status == 0).all()
+        ref = outs[0].values
+        sel = (slice(None), slice(0, 2), slice(0, 2)) if c["mode"] == "A" else slice(None)
+        for o in outs[1:]:
+            np.testing.assert_allclose(o.values[sel], ref[sel], rtol=c["rtol"], atol=0)
