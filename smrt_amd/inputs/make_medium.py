@@ -1,5 +1,5 @@
 """make_snowpack / make_snow_layer with the reference's signature (smrt/inputs/make_medium.py:158-314) for dry snow,
-Flat interfaces, no substrate."""
+Flat interfaces, optional Flat / Reflector substrate and SimpleIsotropicAtmosphere."""
 import collections.abc
 
 import numpy as np

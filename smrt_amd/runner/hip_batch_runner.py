@@ -24,8 +24,9 @@ class HipBatchRunner(object):
         if model is None or not hasattr(model, "rtsolver"):
             raise SMRTError("HipBatchRunner must be given the bound Model.run_single_simulation method")
         for _, atmosphere, _ in args:
-            if atmosphere is not None:
-                raise SMRTError("atmospheres are outside the scope of smrt_amd")
+            if atmosphere is not None:  # Model.run's deprecated argument (model.py:345-349): use snowpack.atmosphere
+                raise SMRTError("give the atmosphere to the snowpack (make_snowpack(..., atmosphere=...) or "
+                                "atmosphere + snowpack), not to Model.run")
         rtsolver = model.rtsolver
         if inspect.isclass(rtsolver):
             options = dict(model.rtsolver_options)
