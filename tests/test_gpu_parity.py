@@ -270,6 +270,31 @@ def test_active_properties(ctx):
     assert np.array_equal(part.values, v[10:40])
 
 
+def test_error_statuses_through_every_path(ctx):
+    """Single-scattering albedo > 1 (status 3) and an invalid layer (T above the melting point, status 5) must come out
+    as statuses + NaN rows -- never as numbers -- on the passive and active pipelines, LDS-resident and
+    global-workspace, without disturbing the healthy pairs of the same batch."""
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden("dmrt_2layer_passive37")   # albedo 1.09 in the top layer
+    sp = snowpack_dict(d)
+    S = 3
+    thick = np.tile(sp["thickness"], (S, 1))
+    fv = np.tile(sp["frac_volume"], (S, 1))
+    temp = np.tile(sp["temperature"], (S, 1))
+    rad = np.tile(sp["radius"], (S, 1))
+    stick = np.tile(np.broadcast_to(sp["stickiness"], sp["radius"].shape), (S, 1))
+    rad[1] *= 0.25          # healthy pair in the middle
+    temp[2, 0] = 280.0      # melting
+    for mode, n in (("P", 16), ("P", 40), ("A", 12), ("A", 30)):
+        b = PackedBatch([2] * S, thick, fv, temp, rad, stick, [37e9], np.deg2rad([55.0]), emmodel="dmrt_qca_shortrange",
+                        microstructure="sticky_hard_spheres", mode=mode, n_max_stream=n, m_max=2)
+        out = ctx.run(b)
+        assert list(out.status) == [3, 0, 5], (mode, n, out.status)
+        assert np.isnan(out.values[0]).all() and np.isnan(out.values[2]).all()
+        assert np.isfinite(out.values[1][:2, :2] if mode == "A" else out.values[1]).all()
+
+
 def test_pipeline_shapes_agree(ctx):
     """Every way the library can run a batch -- three kernels with the two-slot finish (1, default), with the four-slot
     finish (2), one fused kernel (0) -- on the LDS-resident path (N <= 64) and on the global-workspace path
