@@ -97,7 +97,7 @@ struct LdsPlan {
     int o_phi;      // 5 vectors of nphi
     int o_tb;       // NMAX
     int o_int;      // 16 ints (8 doubles)
-    int o_gj;       // scratch of the blocked solvers: max(16 * NMAX, 1024) + 8 doubles, then (NMAX + 8) ints
+    int o_gj;       // scratch of the blocked solvers (block inverses of Cholesky / triangular solve, Gauss-Jordan bookkeeping)
     int o_act;      // active mode only: per-layer mode-0 normalisation, mode totals, incident stream list
     int o_jac;      // global-workspace kernels: an NMAX x LD LDS buffer for the Jacobi stage, or -1 if it does not fit
     int total;      // doubles
@@ -1459,191 +1459,13 @@ SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*
     }
 }
 
-// Blocked Gauss-Jordan with implicit partial pivoting, rank-4 trailing updates on the FP64 matrix core and
-// look-ahead (N <= 64).  Per block of four columns:
-//   panel   (wavefront 0, lane = row, the four panel entries of the row in registers): four pivot rows by
-//           wavefront arg-max among the rows not used yet (rows are never swapped: the permutation is applied once
-//           at the end).  The accumulated row transformation T of the four normalised elimination steps differs from
-//           I only in the pivot columns; its columns u_j = T[:,p_j] - e_pj are tracked per lane, so that the whole
-//           block update is C <- C + U R_P with the ORIGINAL pivot rows R_P (no 4x4 inverse to form);
-//   update  (all wavefronts): one v_mfma_f64_16x16x4_f64 per 16x16 tile of [A(rest) | B] (K = 4 = block width); the
-//           pivot rows come out normalised, so after the last block row perm[k] of B IS row k of the solution.
-// Look-ahead: during update k wavefront 0 takes the column tile that holds the next panel first and factorises
-// panel k+1 while the other wavefronts finish the update; the pivot rows of block k+1 are copied aside after the
-// barrier.  Two workgroup barriers per block.
-template <bool TR>
-SMRT_DEV bool gj_panel(double* A, int N, int LD, int k0, int lane, bool& used, double* Mp, int NMX, int* perm) {
-    const int nbk = (N - k0 < 4) ? N - k0 : 4;
-    double a[4], u[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rc = lane < N ? lane : N - 1, cc = (k0 + j < N) ? k0 + j : N - 1;
-        const double v = at<TR>(A, rc, cc, LD);
-        a[j] = (lane < N && j < nbk) ? v : 0.0;
-        u[j] = 0.0;
-    }
-    bool ok = true;
-    int prow[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < nbk) {
-            // pivot: arg-max over the unused rows of a 32-bit key = float magnitude bits with the row index in the
-            // 7 low mantissa bits (exactness of the choice is irrelevant; an all-zero column gives key < 128)
-            unsigned key = 0u;
-            if (lane < N && !used) {
-                const float xr = (float)fabs(a[j]);
-                memcpy(&key, &xr, 4);
-                key = (key & ~0x7Fu) | (unsigned)(127 - lane);
-            }
-            key = wave_max_u32(key);
-            if (key < 128u) ok = false;
-            const int p = ok ? 127 - (int)(key & 0x7Fu) : 0;
-            prow[j] = p;
-            const bool isp = (lane == p);
-            const double rpv = fast_rcp(ok ? wave_bcast(a[j], p) : 1.0);
-            if (isp) used = true;
-            const double l = a[j] * rpv;                       // multiplier of this row (pivot row: a/pv = 1)
-            const double uj = isp ? rpv - 1.0 : -l;            // new column of T - I
-            // remaining panel columns: normalised elimination
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj > j) { const double pa = wave_bcast(a[jj], p); a[jj] = isp ? pa * rpv : a[jj] - l * pa; }
-            // columns tracked so far pick up the new elementary transformation: u_i += u_j * u_i[p]
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < j) { const double ti = wave_bcast(u[i], p); u[i] += uj * ti; }
-            u[j] = uj;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (lane < NMX) Mp[j * NMX + lane] = (lane < N && j < nbk && ok) ? u[j] : 0.0;
-    if (lane < 4 && lane < nbk) perm[k0 + lane] = prow[lane];
-    return ok;
-}
-
-template <int NT, bool TR>
-SMRT_DEV bool gj_solve_mfma(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
-    const int t = tid();
-    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
-    constexpr int NW = NT / SMRT_LANES;
-    const int NMX = s.gj_nmax;            // 64 on this path
-    double* Mp0 = s.gj;                   // [2][4][NMX] multipliers U (double buffered for the look-ahead)
-    double* Rp = s.gj + 8 * NMX;          // [4][2*NMX] pivot rows of [A(rest) | B]
-    double* vp = s.gj + 16 * NMX;         // [4] pivot entries of the extra right-hand side
-    int* perm = (int*)(s.gj + 16 * NMX + 8);  // [NMX] pivot row of every column; perm[NMX] = failure flag
-    const int RW = 2 * NMX;
-    const bool has_v = (v != nullptr);
-    const int RT = (N + 15) >> 4;
-    const int lr = lane & 15, lk = lane >> 4;
-    bool used = false;                    // wavefront 0: this lane's row has been a pivot row
-    if (t == 0) perm[NMX] = 0;
-    block_sync();
-
-    // copy of the pivot rows of block k0 (all threads): Rp[j][ci], ci over [A cols after the block | B cols]
-    auto copy_pivot_rows = [&](int k0) {
-        const int nbk = (N - k0 < 4) ? N - k0 : 4;
-        const int ma = N - k0 - nbk;
-        for (int idx = t; idx < 4 * (ma + N); idx += NT) {
-            const int j = idx & 3, ci = idx >> 2;
-            double val = 0.0;
-            if (j < nbk) {
-                const int pr = perm[k0 + j];
-                val = (ci < ma) ? at<TR>(A, pr, k0 + nbk + ci, LD) : at<TR>(Bm, pr, ci - ma, LD);
-            }
-            Rp[j * RW + ci] = val;
-        }
-        if (t < 4) vp[t] = (has_v && t < nbk) ? v[perm[k0 + t]] : 0.0;
-    };
-    // rank-4 update of one 16x16 tile (tile row ti, concatenated tile column tj) with multipliers Mp
-    auto update_tile = [&](int k0, const double* Mp, int ti, int tj) {
-        const int nbk = (N - k0 < 4) ? N - k0 : 4;
-        const int ma = N - k0 - nbk;
-        const int ci = tj * 16 + lr;
-        const bool cin = ci < ma + N;
-        double* Mat = (ci < ma) ? A : Bm;
-        const int col = (ci < ma) ? (k0 + nbk + ci) : (ci - ma);
-        const int colc = cin ? col : 0;
-        double c[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = ti * 16 + lk + 4 * reg;
-            const int rowc = row < N ? row : 0;
-            const double x = at<TR>(Mat, rowc, colc, LD);
-            c[reg] = (cin && row < N) ? x : 0.0;
-        }
-        const int arow = ti * 16 + lr;
-        const double aop = (arow < NMX) ? Mp[lk * NMX + arow] : 0.0;
-        const double bop = cin ? Rp[lk * RW + ci] : 0.0;
-        mfma_f64_16x16x4(aop, bop, c);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = ti * 16 + lk + 4 * reg;
-            if (cin && row < N) at<TR>(Mat, row, col, LD) = c[reg];
-        }
-    };
-
-    if (wave == 0) { if (!gj_panel<TR>(A, N, LD, 0, lane, used, Mp0, NMX, perm) && lane == 0) perm[NMX] = 1; }
-    block_sync();
-    if (perm[NMX]) return false;  // uniform
-    copy_pivot_rows(0);
-    block_sync();
-    int buf = 0;
-    for (int k0 = 0; k0 < N; k0 += 4) {
-        const int nbk = (N - k0 < 4) ? N - k0 : 4;
-        const int ma = N - k0 - nbk;
-        const int CT = (ma + N + 15) >> 4;
-        const double* Mp = Mp0 + buf * 4 * NMX;
-        const bool next = (k0 + 4 < N);
-        if (NW >= 2 && next) {
-            if (wave == 0) {
-                // the column tile holding the next panel first, then the next panel itself
-                for (int ti = 0; ti < RT; ++ti) update_tile(k0, Mp, ti, 0);
-                wave_sync_lds();
-                if (!gj_panel<TR>(A, N, LD, k0 + 4, lane, used, Mp0 + (buf ^ 1) * 4 * NMX, NMX, perm) && lane == 0)
-                    perm[NMX] = 1;
-            } else {
-                for (int tix = wave - 1; tix < RT * (CT - 1); tix += NW - 1) update_tile(k0, Mp, tix % RT, 1 + tix / RT);
-                if (has_v && wave == 1 && lane < N) {
-                    double acc = v[lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc += Mp[j * NMX + lane] * vp[j];
-                    v[lane] = acc;
-                }
-            }
-        } else {
-            for (int tix = wave; tix < RT * CT; tix += NW) update_tile(k0, Mp, tix % RT, tix / RT);
-            if (has_v && t < N) {
-                double acc = v[t];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc += Mp[j * NMX + t] * vp[j];
-                v[t] = acc;
-            }
-            if (next) {  // single-wavefront workgroups: no look-ahead, panel after the update
-                wave_sync_lds();
-                if (wave == 0 && !gj_panel<TR>(A, N, LD, k0 + 4, lane, used, Mp0 + (buf ^ 1) * 4 * NMX, NMX, perm) && lane == 0)
-                    perm[NMX] = 1;
-            }
-        }
-        block_sync();
-        if (perm[NMX]) return false;  // uniform
-        if (next) { copy_pivot_rows(k0 + 4); block_sync(); }
-        buf ^= 1;
-    }
-    // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
-    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
-    double vk = 0.0;
-    if (has_v && t < N) vk = v[perm[t]];
-    block_sync();
-    for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
-    if (has_v && t < N) v[t] = vk;
-    block_sync();
-    return true;
-}
-
 // ---- 16-wide blocked Gauss-Jordan (N <= 128): ONE workgroup barrier per 16 columns ---------------------------------
-// Same elimination as gj_solve_mfma (implicit partial pivoting, tracked transformation columns u_j, permutation undone
-// at the end) with three changes that take the sequential part off the critical path of every block:
+// Gauss-Jordan with implicit partial pivoting: per block one wavefront factorises the panel (lane = row, arg-max over
+// the rows not used yet by DPP on a 32-bit key; rows are never swapped, the permutation is undone once at the end) and
+// tracks the columns u_j = T[:, p_j] - e_pj of the accumulated row transformation T, so that the whole block update is
+// C <- C + U R_P with the ORIGINAL pivot rows R_P (no inverse to form); the pivot rows come out normalised, so after
+// the last block row perm[k] of B is row k of the solution.  (An earlier version used 4-column blocks with a side
+// buffer for U and a copy of the pivot rows, two barriers per block.)  Design points of this one:
 //   * block width 16 = one MFMA tile column = four chained v_mfma_f64_16x16x4 per tile (the C tile is loaded and
 //     stored once per 16 eliminated columns instead of once per 4);
 //   * the multipliers u_j are written into the panel's own, now dead, columns of A -- no side buffer;
@@ -1925,14 +1747,10 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     return true;
 }
 
-// the Gauss-Jordan variant used by the drivers (-DSMRT_GJ_BLOCK4 selects the older 4-wide one for A/B timing)
+// the Gauss-Jordan entry point of the drivers (solution copied back over Bm)
 template <int NT, bool TR>
 SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
-#ifdef SMRT_GJ_BLOCK4
-    return gj_solve_mfma<NT, TR>(A, Bm, v, s, N, LD);
-#else
     return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
