@@ -137,10 +137,12 @@ double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_
 /* Tuning knob: threads per workgroup of the pair kernel (64..1024, multiple of 64). 0 = default. */
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 
-/* Pipeline shape on the LDS-resident path (N <= 64): 1 (default) = three kernels (prep per pair, Jacobi per
- * pair x layer with four workgroups per CU, finish per pair with two LDS-resident matrices and two workgroups per CU)
- * with the factors staged through HBM/L2; 2 = the same with the previous finish kernel (four LDS-resident matrices,
- * one workgroup per CU); 0 = everything fused in one kernel, one workgroup per pair.  Call before smrt_dort_upload. */
+/* Pipeline shape.  1 (default) = three kernels -- prep per pair, Jacobi per (pair, layer[, azimuth mode]), finish per
+ * pair -- with the factors staged through HBM/L2: on the LDS-resident path (streams x polarisations N <= 64) with the
+ * two-slot finish kernel, two workgroups per CU; for 64 < N <= 128 on a per-workgroup global workspace.
+ * 2 = the same with the four-matrix LDS finish kernel (one workgroup per CU; N <= 64 passive only, otherwise like 0).
+ * 0 = everything fused in one kernel, one workgroup per pair (also what N > 128 always uses; N <= 256 is the limit:
+ * n_max_stream <= 128 passive, <= 85 active).  Call before smrt_dort_upload. */
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
 
 /* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3
