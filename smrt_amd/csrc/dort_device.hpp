@@ -2449,6 +2449,12 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
 // pairs a 32-lane group rotates together are ADJACENT columns (8 lanes each), so consecutive columns must start 8
 // bank slots apart to be conflict-free (with the odd LD of the other kernels they overlapped: 41 % of the LDS cycles
 // of this kernel were bank conflicts, profiles/r1f_pmc_counters.txt).
+#ifndef SMRT_JACOBI_GS
+#define SMRT_JACOBI_GS 8     // lanes per column pair in the Jacobi kernel
+#endif
+#ifndef SMRT_JACOBI_NT
+#define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
+#endif
 struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
 SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     JacobiPlan p;
@@ -2456,7 +2462,7 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
     // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
     const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
-    p.LDJ = ((rows + 31) / 32) * 32 + 8;
+    p.LDJ = ((rows + 31) / 32) * 32 + SMRT_JACOBI_GS;
     p.NCOL = ((p.NMAX + 7) / 8) * 8 + 1;                // NB*ceil(N/NB) <= this - 1, plus the idle-slot column
     int o = p.NCOL * p.LDJ;
     p.o_sigma = o; o += p.NMAX + 16;
@@ -2469,7 +2475,7 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
 template <int NT, int RPL>
 SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;
-    constexpr int GS = 8;
+    constexpr int GS = SMRT_JACOBI_GS;
     constexpr int NB = 2 * JW;
     const int t = tid();
     const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
@@ -2504,11 +2510,12 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 template <int NT>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     const int NMAX = b.n_max_stream * (b.mode == 1 ? 3 : 2);   // rows per lane = ceil(NMAX / 8): RPL * 8 <= NMAX (< LD)
-    if (NMAX > 64) dort_jacobi_item_impl<NT, 16>(b, stg, item, lds);
-    else if (NMAX > 32) dort_jacobi_item_impl<NT, 8>(b, stg, item, lds);
-    else if (NMAX > 16) dort_jacobi_item_impl<NT, 4>(b, stg, item, lds);
-    else if (NMAX > 8) dort_jacobi_item_impl<NT, 2>(b, stg, item, lds);
-    else dort_jacobi_item_impl<NT, 1>(b, stg, item, lds);
+    constexpr int G = SMRT_JACOBI_GS;   // rows per lane = padded rows / lanes per column pair
+    if (NMAX > 64) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
+    else if (NMAX > 32) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
+    else if (NMAX > 16) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
+    else if (NMAX > 8) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
+    else dort_jacobi_item_impl<NT, 8 / G>(b, stg, item, lds);
 }
 
 }  // namespace smrt

@@ -206,7 +206,7 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
     constexpr int PNT = (NT >= 256) ? SMRT_PREP_THREADS : NT;
     constexpr int FNT = (NT >= 256) ? SMRT_FINISH_THREADS : NT;
     auto kp = dort_prep_kernel<PNT>;
-    auto kj = dort_jacobi_kernel<256>;
+    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
     auto kf = dort_finish_kernel<NT>;
     auto kf2 = dort_finish2_kernel<FNT>;
     hipError_t e;
@@ -218,7 +218,7 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
     if (getenv("SMRT_DORT_DEBUG_OCCUPANCY")) {  // resident workgroups per CU as the runtime sees them
         int op = 0, oj = 0, of2 = 0, of = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&op, kp, PNT, ctx->prep_lds_bytes);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oj, kj, 256, ctx->jacobi_lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oj, kj, SMRT_JACOBI_NT, ctx->jacobi_lds);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of2, kf2, FNT, ctx->finish2_lds_bytes);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, kf, NT, ctx->lds_bytes);
         fprintf(stderr, "occupancy (workgroups/CU): prep<%d> lds=%zu -> %d | jacobi<256> lds=%zu -> %d | finish2<%d> lds=%zu -> %d | "
@@ -234,7 +234,7 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
         hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         if (ctx->finish2) hipLaunchKernelGGL(kf2, dim3((unsigned)cn), dim3(FNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
         else hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -245,7 +245,7 @@ static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
 static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
     constexpr int NT = 256;
     auto kp = ctx->active ? dort_active_prep_kernel_gmem<NT> : dort_prep_kernel_gmem<NT>;
-    auto kj = dort_jacobi_kernel<256>;
+    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
     auto kf = ctx->active ? dort_active_finish_kernel_gmem<NT> : dort_finish_kernel_gmem<NT>;
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
     hipError_t e;
@@ -263,7 +263,7 @@ static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
         const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
@@ -274,7 +274,7 @@ template <int NT>
 static hipError_t launch_split_active(smrt_dort_ctx* ctx, const DevBatch& d) {
     constexpr int PNT = (NT >= 256) ? 256 : NT;
     auto kp = dort_active_prep_kernel<PNT>;
-    auto kj = dort_jacobi_kernel<256>;
+    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
     auto kf = dort_active_finish_kernel<PNT>;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
@@ -291,7 +291,7 @@ static hipError_t launch_split_active(smrt_dort_ctx* ctx, const DevBatch& d) {
         c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
         c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
         hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(256), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
+        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
         hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(PNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
