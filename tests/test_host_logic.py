@@ -57,11 +57,44 @@ def test_snowpack_builder_scope():
     assert np.isclose(sp.layers[0].frac_volume, 250 / 916.7)
     assert sp.layers[1].microstructure.device_params == (2e-4, 0.2)
     with pytest.raises(SMRTError):
-        make_snowpack([1], "exponential", density=300, corr_length=1e-4, substrate="soil")
+        make_snowpack([1], "exponential", density=300, corr_length=1e-4, substrate="soil")  # not a substrate object
     with pytest.raises(SMRTError):
         make_snowpack([1], "gaussian_random_field", density=300, corr_length=1e-4)
     with pytest.raises(SMRTError):
         make_snowpack([1], "exponential", density=300, corr_length=1e-4, liquid_water=0.1)
+
+
+def test_substrate_atmosphere_and_emmodel_descriptors():
+    """Host-side counterparts of smrt/substrate/{flat,reflector}.py, atmosphere/simple_isotropic_atmosphere.py and the
+    extra emmodels: what they hand to the device batch (no GPU needed)."""
+    from smrt_amd import make_atmosphere
+    from smrt_amd._native import PackedBatch
+    from smrt_amd.substrate.flat import Flat
+    from smrt_amd.substrate.reflector import Reflector, make_reflector
+
+    flat = Flat(temperature=270.0, permittivity_model=lambda f, t: 3.0 + 1e-10 * f * 1j)
+    assert flat.device_kind == "flat" and np.allclose(flat.device_params(18.7e9), (3.0, 1.87))
+    with pytest.raises(SMRTError):
+        Flat(temperature=270.0).device_params(10e9)  # no permittivity model (core/interface.py:185-189)
+    refl = Reflector(specular_reflection={(21e9, "H"): 0.5, "V": 0.6, 36e9: 0.7})
+    assert refl.device_params(21e9) == (0.6, 0.5) and refl.device_params(36e9) == (0.7, 0.7)  # frequency key wins over polarisation (reflector.py)
+    assert make_reflector(temperature=260).device_params(10e9) == (1.0, 1.0)
+    with pytest.raises(SMRTError):
+        Reflector(specular_reflection=np.cos).device_params(10e9)
+    atm = make_atmosphere("simple_isotropic_atmosphere", tb_down={10e9: 15.0, 21e9: 23.5}, tb_up=6.0, transmittance=0.9)
+    assert atm.device_params(21e9) == (23.5, 6.0, 0.9)
+    with pytest.raises(SMRTError):
+        atm.device_params(37e9)
+    sp = atm + (two_layer() + flat)
+    assert sp.substrate is flat and sp.atmosphere is atm and sp.nlayer == 2
+    with pytest.raises(SMRTError):
+        two_layer() + 3
+    b = PackedBatch([2], [[0.1, 100]], [[0.2, 0.4]], [[250, 250]], [[5e-5, 5e-5]], None, [10e9, 21e9], np.deg2rad([55.0]),
+                    substrate=("flat", [[3.0], [3.1]], [[0.1], [0.2]], [270.0]), atmosphere=([15.0, 23.5], 6.0, 0.9))
+    assert b.struct.substrate_kind == 1 and b.sub_p1.shape == (2, 1) and b.atm[1].shape == (2,)
+    assert bool(b.struct.atm_tb_down) and bool(b.struct.substrate_temperature)
+    for name, cls in (("dmrt_qcacp_shortrange", "DMRT_QCACP_ShortRange"), ("nonscattering", "NonScattering")):
+        assert make_model(name, "dort").emmodel.__name__ == cls
 
 
 def test_result_accessors_passive():
