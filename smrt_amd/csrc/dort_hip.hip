@@ -35,10 +35,13 @@ __global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, 1, 2>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
 }
+#ifndef SMRT_FINISH_WAVES_BIG
+#define SMRT_FINISH_WAVES_BIG 1   // wavefronts per SIMD the 512-thread variant must leave room for (experiments)
+#endif
 // two LDS slots + F, G in the (dead) staging slots of the item: two workgroups per CU
 // (second launch-bound argument on HIP = wavefronts per SIMD the compiler must leave room for: 2 -> <= 256 VGPRs)
 template <int NT>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_finish2_kernel(DevBatch b, DevStage st) {
+__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : SMRT_FINISH_WAVES_BIG)) void dort_finish2_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
 }
