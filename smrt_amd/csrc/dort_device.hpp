@@ -544,32 +544,15 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
         else { a += x[i] * x[i]; bb += y[i] * y[i]; gg += x[i] * y[i]; }
     }
     a += a2; bb += bb2; gg += gg2;
-#if !defined(SMRT_ABLATE) || SMRT_ABLATE < 2
     a = group_sum<GS>(a); bb = group_sum<GS>(bb); gg = group_sum<GS>(gg);
-#endif
     const double g2 = gg * gg, ab = a * bb;
-#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 4
-    if (g2 == 12345.678) lds_or(flag, 1);  // keep the dot products alive
-    return;
-#endif
     if (valid && g2 > 1e-30 * ab) {
         // tan of the rotation angle: t = 2 g sign(d) / (|d| + sqrt(d^2 + 4 g^2)), d = b - a
         const double dd = bb - a;
-#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 1
-        const double tt = dd * 1e-300;
-#else
         const double hh = dd * dd + 4.0 * g2;
         const double h = hh * fast_rsqrt1(hh);
         const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);  // angle only: 1 Newton step
-#endif
-#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 1
-        const double c = 0.8 + 1e-300 * tt * 0.0, sn = 0.6 + gg * 1e-300;
-#else
         const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
-#endif
-#if defined(SMRT_ABLATE) && SMRT_ABLATE >= 3
-        if (c * x[0] - sn * y[0] + sn * x[RPL - 1] + c * y[RPL - 1] == 12345.678) lds_or(flag, 1);
-#else
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int r0 = sub + i * GS;
@@ -577,7 +560,6 @@ SMRT_DEV void rotate_pair(double* Bm, int LD, int N, int p, int q, bool valid, i
             cp[r] = c * x[i] - sn * y[i];
             cq[r] = sn * x[i] + c * y[i];
         }
-#endif
         if (sub == 0 && g2 > SMRT_JACOBI_EXIT_COS2 * ab) lds_or(flag, 1);
     }
 }
@@ -653,9 +635,6 @@ SMRT_DEV bool jacobi_onesided(double* Bm, int N, int LD, double* sigma, double* 
             SMRT_JSUB(4);
         }
         converged = (*flag == 0);
-#ifdef SMRT_ABLATE
-        converged = (sweep >= 5);  // fixed six sweeps for timing ablations (results are meaningless)
-#endif
         ++*n_sweeps;
     }
     block_sync();
