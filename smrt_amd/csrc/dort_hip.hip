@@ -399,7 +399,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     const int actd = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta) : 0;
     LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd);
     size_t lds = (size_t)plan.total * sizeof(double);
-    ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds);
+    ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds || getenv("SMRT_DORT_FORCE_GLOBAL_WORKSPACE") != nullptr);
     if (ctx->gmem_path) {
         if (plan.NMAX > 256) {
             ctx->err = "streams x polarisations above 256 (n_max_stream > 128 passive, > 85 active) is not supported by this build";
