@@ -378,6 +378,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             }
             }  // MODE < 2
             double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+            double r1a[RowTiles<NT>::RPW][16];   // MODE 3: rows of R~ D of this wavefront's row tile
             if (MODE == 2) {  // four-matrix finish (global workspace): pick up L+, B' = B V, d and the singular values
                 const double* gL = stg->L + item * stg->mat_stride;
                 const double* gB = stg->B + item * stg->mat_stride;
@@ -399,14 +400,19 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     s.sigma[r] = sg; s.rsig[r] = 1.0 / sg;
                 }
                 block_sync();
-                l_times_m_mfma<NT>(gL, s.M0, gB, N, LD);                                  // Em' = L+ B'
-                lt_solve_mfma<NT>(gL, s.M0, stg->Linv + item * 1024, N, LD, true);        // Ep' = L+^-T B'
+                // R~ D into registers, L+ into the freed slot R for the triangular stage, then F / G into slots R / X
+                // (see dort_pair_passive, MODE 3)
+                r1_load<NT>(s.M3, r1a, s.cvec, s.svec, 0.0, N, LD, dsg);
+                for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = gL[c * LD + r]; });
+                block_sync();
+                l_times_m_mfma<NT>(s.M3, s.M0, gB, N, LD);                                // Em' = L+ B'
+                lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * 1024, N, LD, true);      // Ep' = L+^-T B'
                 for_2d<NT>(N, N, [&](int i, int c) {
                     const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
                     const double hd = 0.5 * s.d[i];
-                    gL[c * LD + i] = hd * (ep + em);
-                    gB[c * LD + i] = hd * (ep - em);
-                    s.M3[c * LD + i] *= dsg[c];
+                    const double fv = hd * (ep + em), gv = hd * (ep - em);
+                    gL[c * LD + i] = fv; s.M3[c * LD + i] = fv;
+                    gB[c * LD + i] = gv; s.M0[c * LD + i] = gv;
                 });
                 F = gL; G = gB;
             } else {
@@ -425,7 +431,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
             block_sync();
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
-            if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            if (MODE == 3) r1_compute<NT>(s.M3, s.M0, r1a, N, LD);
+            else if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else if (CH == 2 && dense_mfma) r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;

@@ -897,6 +897,91 @@ SMRT_DEV void r1_mfma(const double* F, const double* G, double* Rt, double* Wk, 
 
 // Y = F tQt + G -> Wk ; W = (G - Rtop F) tQt + (F - Rtop G) -> over F (in place)
 // upb = F tq + B ; g = (G - Rtop F) tq + (1 - Rtop) B
+// r1_mfma in two halves for the two-slot finish kernel.  r1_load pulls the A operands (the rows of R~ of this
+// wavefront's row tile) into registers and writes cvec -- after it slot R is free.  r1_compute runs the MFMA loops
+// with both B operands in LDS (Gl in slot X, Fl in slot R: staged there by the F/G formation), keeps the results in
+// registers until every wavefront is done reading, and then writes Wk = F - R~ G over Gl and R~ F - G over Fl.
+template <int NT>
+SMRT_DEV void r1_load(const double* Rt, double (&a)[RowTiles<NT>::RPW][16], double* cvec, const double* svec, double Bl,
+                      int N, int LD, const double* colsign = nullptr /* active mode: R~ D, D = +-1 per column */) {
+    using RTc = RowTiles<NT>;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
+        double rs = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double x = Rt[kc * LD + ic] * (colsign ? colsign[kc] : 1.0);
+            a[o][kk] = (ti < RT && i < N && k < N) ? x : 0.0;
+            rs += a[o][kk];
+        }
+        rs += shfl_xor(rs, 16);
+        rs += shfl_xor(rs, 32);
+        const bool owner = (RTc::NW >= 4) ? (wave < 4) : true;
+        if (owner && ti < RT && lk == 0 && i < N) cvec[i] = rs * Bl - Bl + svec[i];
+    }
+    block_sync();
+}
+
+template <int NT>
+SMRT_DEV void r1_compute(double* Fl /* slot R */, double* Gl /* slot X */, const double (&a)[RowTiles<NT>::RPW][16],
+                         int N, int LD) {
+    using RTc = RowTiles<NT>;
+    constexpr int MAXTJ = (4 + RTc::CS - 1) / RTc::CS;
+    const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
+    const int RT = (N + 15) >> 4;
+    double r1[RTc::RPW][MAXTJ][4], r2[RTc::RPW][MAXTJ][4];
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+#pragma unroll
+        for (int q = 0; q < MAXTJ; ++q) {
+            const int tj = cs + q * RTc::CS;
+            double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ti < RT && tj < RT) {
+                const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    if (4 * kk < N) {
+                        const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+                        const bool in = (j < N && k < N);
+                        const double gv = Gl[jc * LD + kc], fv = Fl[jc * LD + kc];
+                        mfma_f64_16x16x4(a[o][kk], in ? gv : 0.0, c1);
+                        mfma_f64_16x16x4(a[o][kk], in ? fv : 0.0, c2);
+                    }
+                }
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    c1[reg] = Fl[col * LD + row] - c1[reg];   // Wk
+                    c2[reg] = c2[reg] - Gl[col * LD + row];   // R~ F - G
+                });
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { r1[o][q][reg] = c1[reg]; r2[o][q][reg] = c2[reg]; }
+        }
+    }
+    block_sync();  // every wavefront has finished reading F and G
+#pragma unroll
+    for (int o = 0; o < RTc::RPW; ++o) {
+        const int ti = (RTc::NW >= 4) ? (wave & 3) : (wave + o * RTc::NW);
+        const int cs = (RTc::NW >= 4) ? (wave >> 2) : 0;
+#pragma unroll
+        for (int q = 0; q < MAXTJ; ++q) {
+            const int tj = cs + q * RTc::CS;
+            if (ti < RT && tj < RT)
+                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                    Gl[col * LD + row] = r1[o][q][reg];
+                    Fl[col * LD + row] = r2[o][q][reg];
+                });
+        }
+    }
+    block_sync();
+}
+
 // SIGNED (azimuth modes m >= 1, three polarisations): the down-going eigenvectors carry the row signs
 // dsg = (+1, +1, -1) per (V, H, U) (dort.py:951-953), i.e. W = (D G - Rtop F) tQt + (D F - Rtop G).
 template <int NT, bool SIGNED = false>
@@ -2100,17 +2185,26 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         SMRT_STAGE(SG_TRI);
         double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+        double r1a[RowTiles<NT>::RPW][16];   // MODE 3: rows of R~ of this wavefront's row tile (A operands of R1)
         if (MODE == 3) {
             const long long item = p * (long long)b.Lmax + l;
             double* gL = stg->L + item * stg->mat_stride;   // L+, later F
             double* gB = stg->B + item * stg->mat_stride;   // (B' is in slot X by now) Em', later G
-            l_times_m_mfma<NT>(gL, s.M0, gB, N, LD);                                            // Em' = L+ B'
-            lt_solve_mfma<NT>(gL, s.M0, stg->Linv + item * 1024, N, LD, true);                  // Ep' = L+^-T B'
+            // R~ goes into registers now, which frees slot R for L+ during the triangular stage (its transposed walk in
+            // the solve is uncoalesced in global memory) and, after that, for the LDS copy of F
+            r1_load<NT>(s.M3, r1a, s.cvec, s.svec, Bl, N, LD);
+            for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = gL[c * LD + r]; });
+            block_sync();
+            l_times_m_mfma<NT>(s.M3, s.M0, gB, N, LD);                                          // Em' = L+ B'
+            lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * 1024, N, LD, true);                // Ep' = L+^-T B'
+            // F, G to global memory (A operands and elementwise terms of the second GEMM pass) and to slots R, X
+            // (B operands of the first one)
             for_2d<NT>(N, N, [&](int i, int c) {
                 const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
                 const double hd = 0.5 * s.d[i];
-                gL[c * LD + i] = hd * (ep + em);
-                gB[c * LD + i] = hd * (ep - em);
+                const double fv = hd * (ep + em), gv = hd * (ep - em);
+                gL[c * LD + i] = fv; s.M3[c * LD + i] = fv;
+                gB[c * LD + i] = gv; s.M0[c * LD + i] = gv;
             });
             F = gL; G = gB;
         } else {
@@ -2131,7 +2225,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
 
         SMRT_STAGE(SG_R1);
-        if (CH == 1) {
+        if (MODE == 3) {
+            r1_compute<NT>(s.M3, s.M0, r1a, N, LD);   // Wk -> slot X, R~ F - G -> slot R
+        } else if (CH == 1) {
             r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         } else if (CH == 2 && dense_mfma) {
             r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
