@@ -197,7 +197,7 @@ def main():
                 "solves_per_step_per_gpu": n_pairs,
                 "parallelism": "%d independent rank(s), results gathered to rank 0" % world,
                 "failed_solves": n_fail,
-                "block_threads": args.threads or 512,
+                "block_threads": 256,  # workgroup size of the three pipeline kernels (--threads only sizes the fused kernel)
             },
             "roofline": {
                 "bound": "mfma",
@@ -218,7 +218,7 @@ def main():
                         "(see DESIGN.md 4), still far from HBM-bound",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             cb, err = cpu_baseline(thick, dens, temp, lc, res.values)
             line["cpu_baseline"] = cb
             line["config"]["max_abs_dTb_vs_oracle_K"] = err

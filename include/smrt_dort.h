@@ -94,6 +94,12 @@ typedef struct smrt_batch {
     const double* atm_tb_down;           /* [F] K */
     const double* atm_tb_up;             /* [F] K */
     const double* atm_transmittance;     /* [F] */
+    /* DORT option prune_deep_snowpack (dort.py:117-124,176-178,443-452): optical depth (sum over the layers, from the
+     * top, of min|beta_l| * thickness_l) beyond which the deeper layers are left out of the solve; the layer in which
+     * the threshold is passed keeps its bottom reflection and receives nothing from below.  <= 0 (or NaN): off.
+     * Needs the three-kernel pipeline (the eigenvalues of all the layers are known before the boundary recursion
+     * starts): smrt_dort_upload fails for streams x polarisations > 128 or after smrt_dort_set_pipeline(ctx, 0). */
+    double prune_optical_depth;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

@@ -612,11 +612,16 @@ def _put_block(ab, u, i0, j0, blk):
 
 
 def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coherent_only=False,
-              return_x0=False, planck_substrate=None):
+              return_x0=False, planck_substrate=None, prune_deep_snowpack=None, pruned_at=None):
     """Assemble and solve the block-tridiagonal boundary system for mode m: smrt/rtsolver/dort.py:263-488.
 
     planck_T: per-layer black-body radiance B(T_l) (None in active mode).  intensity_down: (n_air*P, R).
     Returns the upwelling intensity above the surface, (n_air*P, R).
+
+    prune_deep_snowpack: optical depth (sum over the layers of min|beta| * thickness) beyond which the deeper layers
+    are dropped from the system (dort.py:443-452): the boundary rows and the unknowns below the bottom of the layer in
+    which the threshold is passed are cut away, i.e. that layer keeps its bottom reflection and sees nothing coming
+    up from below.  pruned_at (a list) receives the number of layers kept.
     """
     P = 2 if m == 0 else 3
     L = len(layers_eig)
@@ -632,6 +637,7 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
     ab = np.zeros((2 * nband + 1, ntot))
     R = intensity_down.shape[1]
     b = np.zeros((ntot, R))
+    optical_depth = 0.0
     for l in range(L):
         beta, Eu, Ed = layers_eig[l].solve(m, coherent_only)
         tt = np.exp(-np.maximum(beta, 0.0) * thickness[l])  # reference at the bottom (dort.py:339)
@@ -667,6 +673,14 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
                 b[row_bot[l - 1] : row_bot[l - 1] + nc] += (Ttop * planck_T[l])[:nc, None]
             if l == L - 1 and planck_substrate is not None:  # emission of the substrate, dort.py:429-441
                 b[row_bot[l] : row_bot[l] + N[l]] += (Tbot * planck_substrate)[:, None]
+        optical_depth += np.min(np.abs(beta)) * thickness[l]  # dort.py:444
+        if prune_deep_snowpack is not None and optical_depth > prune_deep_snowpack:  # dort.py:446-452
+            nkeep = int(2 * N[: l + 1].sum())
+            ab = ab[:, :nkeep]
+            b = b[:nkeep]
+            if pruned_at is not None:
+                pruned_at.append(l + 1)
+            break
     x = scipy.linalg.solve_banded((nband, nband), ab, b)  # dort.py:469
     x0 = x[: 2 * N[0]]
     I1 = Eu0 @ (tt0[:, None] * x0)  # dort.py:476
@@ -683,7 +697,7 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
 # ----------------------------------------------------------------------------------------------------------------
 def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None, phi=np.pi, n_max_stream=32,
           m_max=2, method="half_rank_eig", phase_normalization=True, rayleigh_jeans=False, details=None,
-          substrate=None, atmosphere=None):
+          substrate=None, atmosphere=None, prune_deep_snowpack=None):
     """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces.
 
     substrate: None or a dict, see interface_diagonals, plus "temperature" (None: no emission).
@@ -691,10 +705,18 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
     frequency (smrt/atmosphere/simple_isotropic_atmosphere.py, core/atmosphere.py:131-160): its downwelling radiation
     illuminates the snowpack and the result is tb_up + transmittance * (...) (rtsolver_utils.py:251-260,302-305);
     ignored in active mode like in the reference.
+    prune_deep_snowpack: None, True (= 6, dort.py:176-177) or the optical depth beyond which layers are dropped.
 
     Passive: returns Tb[(V,H), theta].  Active: returns intensity[(pol V,H,U), (pol_inc V,H,U), theta_inc]
     (the layout of the reference's Result.data; sigma = 4 pi cos(theta) I, smrt/core/result.py:484-486).
     """
+    if prune_deep_snowpack is True:
+        prune_deep_snowpack = 6.0
+    elif prune_deep_snowpack is False:
+        prune_deep_snowpack = None
+    prune = dict(prune_deep_snowpack=prune_deep_snowpack)
+    if details is not None:
+        details["pruned_at"] = prune["pruned_at"] = []
     ems = make_layers(emmodel, frequency, sp)
     eps = np.array([e.eps_eff for e in ems])
     st = compute_streams(n_max_stream, eps)
@@ -719,7 +741,7 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
         I_down = np.zeros((2 * st.n_air, 1))
         if atmosphere is not None:
             I_down[:] = to_I(atmosphere["tb_down"])
-        I0 = dort_mode(0, leig, st, itf, thickness, BT, I_down, planck_substrate=Bsub)[:, 0]
+        I0 = dort_mode(0, leig, st, itf, thickness, BT, I_down, planck_substrate=Bsub, **prune)[:, 0]
         if atmosphere is not None:
             I0 = to_I(atmosphere["tb_up"]) + atmosphere["transmittance"] * I0
         tb = I0 if rayleigh_jeans else inverse_planck(frequency, I0)
@@ -753,10 +775,10 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
     def reshape(I, P):  # dort.py:506-508
         return I.reshape(I.shape[0] // P, P, I.shape[1] // P, P).transpose(1, 0, 3, 2)
 
-    coh = reshape(dort_mode(0, leig, st, itf, thickness, None, I_0, coherent_only=True), 2)
+    coh = reshape(dort_mode(0, leig, st, itf, thickness, None, I_0, coherent_only=True, **prune), 2)
     for m in range(mm + 1):
         P = 2 if m == 0 else 3
-        Im = reshape(dort_mode(m, leig, st, itf, thickness, None, I_0 if m == 0 else I_h), P)
+        Im = reshape(dort_mode(m, leig, st, itf, thickness, None, I_0 if m == 0 else I_h, **prune), P)
         Im[0:2, :, 0:2, :] -= coh * (1.0 + float(m > 0))
         if m == 0:
             total[0:2, :, 0:2] += Im[0:2, :, 0:2]

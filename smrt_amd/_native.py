@@ -61,6 +61,7 @@ class SmrtBatch(C.Structure):
         ("atm_tb_down", C.POINTER(C.c_double)),
         ("atm_tb_up", C.POINTER(C.c_double)),
         ("atm_transmittance", C.POINTER(C.c_double)),
+        ("prune_optical_depth", C.c_double),
     ]
 
 
@@ -74,10 +75,12 @@ class PackedBatch:
 
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
-                 phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None):
+                 phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
+                 prune_deep_snowpack=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
-        atmosphere: None or (tb_down[F], tb_up[F], transmittance[F])."""
+        atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
+        prune_deep_snowpack: None / False, True (= 6, smrt/rtsolver/dort.py:176-177) or the optical depth itself."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
         S = len(self.n_layers)
         two_d = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(S, -1))  # noqa: E731
@@ -109,6 +112,9 @@ class PackedBatch:
         s.micro_p1, s.micro_p2 = _dptr(self.micro_p1), _dptr(self.micro_p2)
         s.frequency, s.theta = _dptr(self.frequency), _dptr(self.theta)
         s.phi = float(phi)
+        if prune_deep_snowpack is True:
+            prune_deep_snowpack = 6.0
+        s.prune_optical_depth = float(prune_deep_snowpack) if prune_deep_snowpack else 0.0
         s.substrate_kind = 0
         if substrate is not None:
             kind, q1, q2, ts = substrate

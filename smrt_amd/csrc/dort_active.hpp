@@ -147,13 +147,32 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         const int jn = idx >> 1, pol = idx & 1;
         const int j = inc[jn];
         double Rt = 0.0, K = 0.0, Ttop0 = 0.0;
+        // prune_deep_snowpack (dort.py:443-452) acts on this solve with ITS eigenvalues beta = ke / mu: the smallest
+        // one belongs to the steepest stream
+        int Lc = L;
+        if (MODE >= 2 && b.prune_tau > 0.0) {
+            double acc = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const double rs0 = s.ri[l] * s.gsin[0];
+                acc += (s.ks[l] + s.ka[l]) / sqrt(1.0 - rs0 * rs0) * s.thick[l];
+                if (acc > b.prune_tau) { Lc = l + 1; break; }
+            }
+        }
+        if (Lc < L) {  // reflection of the interface to the first dropped layer, nothing from below
+            if (j < (int)s.nl[Lc - 1]) {
+                const double rs = s.ri[Lc - 1] * s.gsin[j];
+                double R3[3], T3[3];
+                fresnel_RT3(cmk(s.eps_re[Lc - 1], s.eps_im[Lc - 1]), cmk(s.eps_re[Lc], s.eps_im[Lc]), sqrt(1.0 - rs * rs), R3, T3);
+                Rt = R3[pol];
+            }
+        } else
         if (b.sub_kind == SUB_FLAT && j < (int)s.nl[L - 1]) {  // specular reflection of the substrate
             const double rs = s.ri[L - 1] * s.gsin[j];
             double R3[3], T3[3];
             fresnel_RT3(cmk(s.eps_re[L - 1], s.eps_im[L - 1]), cmk(b.sub_p1[gp], b.sub_p2[gp]), sqrt(1.0 - rs * rs), R3, T3);
             Rt = R3[pol];
         }
-        for (int l = L - 1; l >= 0; --l) {
+        for (int l = Lc - 1; l >= 0; --l) {
             const int n = (int)s.nl[l];
             const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
             const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
@@ -200,7 +219,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             s.swphi[k] = end ? 0.0 : base * 2.0 * sin((double)m * ph);
         }
         block_sync();
-        for (int l = L - 1; l >= 0; --l) {
+        int Lk = L;  // layers kept by prune_deep_snowpack for this azimuth mode (s.pa is free in the finish kernels)
+        if (MODE >= 2 && b.prune_tau > 0.0)
+            Lk = pruned_layer_count<NT>(*stg, (p * (long long)(m_max + 1) + m) * b.Lmax, L, s.thick, s.pa, b.prune_tau);
+        for (int l = Lk - 1; l >= 0; --l) {
             const int n = (int)s.nl[l];
             const int N = n * P;
             n3 += (double)N * N * N;
@@ -213,13 +235,16 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (l > 0)
                 for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
             const long long item = (p * (long long)(m_max + 1) + m) * b.Lmax + l;   // staging slot (MODE 1 / 3)
-            if (MODE != 1 && l == L - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
+            if (MODE != 1 && l == Lk - 1) for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
             if (MODE != 1) for (int r = t; r < N; r += NT) { s.svec[r] = 0.0; s.tq[r] = 0.0; }
             block_sync();
-            if (MODE != 1 && l == L - 1 && b.sub_kind == SUB_FLAT) {  // substrate: R_sub (V, H, U) on the diagonal
+            if (MODE != 1 && l == Lk - 1 && (Lk < L || b.sub_kind == SUB_FLAT)) {
+                // substrate: R_sub (V, H, U) on the diagonal; with deeper layers pruned: the interface to the first
+                // dropped layer instead (dort.py:446-452)
+                const cplx ebelow = (Lk < L) ? cmk(s.eps_re[l + 1], s.eps_im[l + 1]) : cmk(b.sub_p1[gp], b.sub_p2[gp]);
                 for (int j = t; j < n; j += NT) {
                     double R3[3], T3[3];
-                    fresnel_RT3(el, cmk(b.sub_p1[gp], b.sub_p2[gp]), s.mu[j], R3, T3);
+                    fresnel_RT3(el, ebelow, s.mu[j], R3, T3);
                     for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
                 }
             }

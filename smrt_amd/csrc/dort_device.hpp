@@ -50,6 +50,7 @@ struct DevBatch {
     const double* sub_T;                  // [S], <= 0: no emission
     const double *atm_down, *atm_up, *atm_trans;  // [F] or null
     double phi;
+    double prune_tau;  // > 0: optical depth beyond which the deeper layers are dropped (dort.py:443-452); pipeline only
     double* out;
     int* status;
     double* layer_out;
@@ -1818,6 +1819,41 @@ SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// DORT option prune_deep_snowpack (smrt/rtsolver/dort.py:443-452): the reference stops assembling its boundary system
+// after the layer in which the running optical depth sum_l min|beta_l| thickness_l passes the threshold and cuts the
+// rows / unknowns of everything below.  Here: the number of layers the bottom-up recursion starts from.  The
+// eigenvalues (singular values) of all the layers of this pair (and azimuth mode) lie in the staging area of the
+// pipeline; tau is an LDS scratch of Lmax doubles.  Workgroup-uniform result.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+SMRT_DEV int pruned_layer_count(const DevStage& stg, long long item0, int L, const double* thick, double* tau,
+                                double limit) {
+    const int t = tid();
+    const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    for (int l = wave; l < L; l += NW) {
+        const long long item = item0 + l;
+        const int N = stg.n[item];
+        double m = 1e300;
+        for (int r = lane; r < N; r += SMRT_LANES) {
+            const double sg = stg.sigma[item * stg.vec_stride + r];
+            m = sg < m ? sg : m;
+        }
+        for (int k = 1; k < SMRT_LANES; k <<= 1) { const double o = shfl_xor(m, k); m = o < m ? o : m; }
+        if (lane == 0) tau[l] = m * thick[l];
+    }
+    block_sync();
+    double acc = 0.0;
+    int keep = L;
+    for (int l = 0; l < L; ++l) {
+        acc += tau[l];
+        if (acc > limit) { keep = l + 1; break; }
+    }
+    block_sync();
+    return keep;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // the per-pair solve (passive mode, azimuth mode 0, 2 polarisations)
 // ------------------------------------------------------------------------------------------------------------
 template <int NT>
@@ -1985,8 +2021,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
 
     double n3 = 0.0;
     int n_sweeps = 0;
+    // layers kept by prune_deep_snowpack (finish kernels: s.pa is free there)
+    int Lk = L;
+    if (MODE >= 2 && b.prune_tau > 0.0) Lk = pruned_layer_count<NT>(*stg, p * (long long)b.Lmax, L, s.thick, s.pa, b.prune_tau);
     // ---- bottom-up over the layers -------------------------------------------------------------------------
-    for (int l = L - 1; l >= 0; --l) {
+    for (int l = Lk - 1; l >= 0; --l) {
         const int n = (int)s.nl[l];
         const int N = n * P;
         n3 += (double)N * N * N;
@@ -2001,15 +2040,21 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
         if (l > 0)
             for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
-        if (MODE != 1 && l == L - 1) {
+        if (MODE != 1 && l == Lk - 1) {
             // what the last layer sees below: nothing (rtsolver_utils.py:548-551,601-603), or a substrate: specular
             // reflection R_sub on the diagonal and its emission (1 - R_sub) B(T_sub) (rtsolver_utils.py:544-547,
-            // 579-584; dort.py:429-441)
+            // 579-584; dort.py:429-441); or, when deeper layers were pruned, the reflection of the interface to the
+            // first dropped layer and nothing coming up through it (dort.py:446-452)
             for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
             block_sync();
             for (int r = t; r < N; r += NT) {
                 double Rs = 0.0, src = 0.0;
-                if (b.sub_kind != SUB_NONE) {
+                if (Lk < L) {
+                    const double rs = s.ri[l] * s.gsin[r >> 1];
+                    double Rv, Rh;
+                    fresnel_RvRh(el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs), &Rv, &Rh);
+                    Rs = (r & 1) ? Rh : Rv;
+                } else if (b.sub_kind != SUB_NONE) {
                     const long long gpi = b.pair_begin + p;
                     const double q1 = b.sub_p1[gpi], q2 = b.sub_p2[gpi];
                     if (b.sub_kind == SUB_FLAT) {

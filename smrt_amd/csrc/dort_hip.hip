@@ -446,6 +446,16 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
             ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 2).total * sizeof(double)
             : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
     }
+    if (b->prune_optical_depth > 0.0) {
+        // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:
+        // only the three-kernel pipelines have them at that point
+        const bool pipeline = ctx->chunk_pairs > 0 && (ctx->gmem_path || !ctx->active || ctx->finish2);
+        if (!pipeline) {
+            ctx->err = "prune_deep_snowpack needs the three-kernel pipeline (streams x polarisations <= 128, pipeline "
+                       "1, or 2 in passive mode)";
+            return -1;
+        }
+    }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
     if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;
@@ -498,6 +508,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     d.atm_down = has_atm ? (const double*)ctx->d_atm.p : nullptr;
     d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
     d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
+    d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
     d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
     ctx->lds_bytes = lds;

@@ -33,9 +33,15 @@ class DORT(object):
                  rayleigh_jeans_approximation=False, devices=None, block_threads=0):
         if stream_mode != "most_refringent":
             raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
-        if phase_symmetrization or process_coherent_layers or prune_deep_snowpack or diagonalization_cache:
-            raise SMRTError("phase_symmetrization, process_coherent_layers, prune_deep_snowpack and "
-                            "diagonalization_cache are outside the scope of smrt_amd's DORT")
+        if phase_symmetrization or process_coherent_layers:
+            raise SMRTError("phase_symmetrization and process_coherent_layers are outside the scope of smrt_amd's DORT")
+        # diagonalization_cache only saves the reference repeated eigen-decompositions of identical layers: accepted,
+        # no effect here.  prune_deep_snowpack: True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
+        if prune_deep_snowpack is True:
+            prune_deep_snowpack = 6
+        if prune_deep_snowpack is not None and prune_deep_snowpack is not False and not float(prune_deep_snowpack) > 0:
+            raise SMRTError("prune_deep_snowpack must be None, True or a positive optical depth")
+        self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         if diagonalization_method not in _DIAG_METHODS:
             raise SMRTError(f"Unknown method '{diagonalization_method}' to diagonalize the matrix")
         if error_handling not in ("exception", "nan"):
@@ -142,7 +148,7 @@ class DORT(object):
                             mode=mode, n_max_stream=self.n_max_stream, m_max=self.m_max,
                             phase_normalization=self.phase_normalization,
                             rayleigh_jeans=self.rayleigh_jeans_approximation, phi=phi, substrate=substrate,
-                            atmosphere=atmosphere)
+                            atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack)
         wanted = np.array([f_index[float(simulations[i][0].frequency)] * S + sp_index[id(simulations[i][1])]
                            for i in idx])
         out = run_on_devices(batch, self.devices, self.block_threads, needed=np.unique(wanted))

@@ -31,7 +31,11 @@ def snowpack_dict(d):
 
 
 def fixture_options(d):
-    return dict(n_max_stream=int(d.get("opt_n_max_stream", 32)), m_max=int(d.get("opt_m_max", 2)))
+    o = dict(n_max_stream=int(d.get("opt_n_max_stream", 32)), m_max=int(d.get("opt_m_max", 2)))
+    if "opt_prune_deep_snowpack" in d:
+        v = np.asarray(d["opt_prune_deep_snowpack"])
+        o["prune_deep_snowpack"] = 6.0 if v.dtype == bool else float(v)  # True means 6 (dort.py:176-177)
+    return o
 
 
 def fixture_substrate(d, i):
@@ -77,7 +81,8 @@ def packed_batch_from_fixture(d, freqs=None):
     return PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2,
                        d["frequency"][sel], np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]),
                        emmodel=str(d["emmodel"]), microstructure=ms, mode="A" if active else "P",
-                       n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere)
+                       n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
+                       prune_deep_snowpack=o.get("prune_deep_snowpack"))
 
 
 SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",
@@ -96,6 +101,10 @@ PASSIVE_FIXTURES = [
 ]
 ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_L4_n32_ku", "dmrt_active_L3_n12",
                    "iba_shs_active_L3_n8", "iba_active_L3_n10_m1_steep", "iba_active_L3_n12_flat_substrate"]
+# DORT option prune_deep_snowpack: cut at layer 5 / 1 / not at all depending on the frequency; with a substrate that
+# disappears from the pruned solves; DMRT; active (a different cut for each azimuth mode and the coherent solve)
+PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12_prune"]
+PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)
 
 

@@ -337,6 +337,36 @@ def main():
         save("nonscattering_L3_n10_substrate", run_new("nonscattering", passive([6.925e9, 36.5e9], [20, 55]), spx,
                                                        rtsolver_options=dict(n_max_stream=10)))
 
+    # DORT option prune_deep_snowpack (dort.py:117-124,176-178,443-452): layers below the optical depth are dropped.
+    # Chosen so that the pack is cut at different layers for different frequencies / azimuth modes, not at all for
+    # the lowest frequency, and -- for the substrate case -- so that the substrate disappears from the pruned solves.
+    def coarse(seed, L, micro, thick, **kw):
+        rng = np.random.default_rng(seed)
+        dens = rng.uniform(200, 420, L)
+        temp = rng.uniform(235, 268, L)
+        th = rng.uniform(0.6 * thick, 1.4 * thick, L)
+        if micro == "exponential":
+            return make_snowpack(th, micro, density=dens, temperature=temp, corr_length=rng.uniform(1.5e-4, 4e-4, L), **kw)
+        return make_snowpack(th, micro, density=dens, temperature=temp, radius=rng.uniform(0.8e-4, 1.8e-4, L),
+                             stickiness=0.2, **kw)
+
+    if wanted("iba_L8_n12_prune"):
+        spx = coarse(81, 8, "exponential", 0.3)
+        save("iba_L8_n12_prune", run_new("iba", passive([10.65e9, 36.5e9, 89e9], [30, 55]), spx,
+                                         rtsolver_options=dict(n_max_stream=12, prune_deep_snowpack=2.5)))
+    if wanted("iba_L6_n16_prune_substrate"):
+        spx = coarse(82, 6, "exponential", 0.3, substrate=Flat(temperature=272.0, permittivity_model=8.0 + 1.0j))
+        save("iba_L6_n16_prune_substrate", run_new("iba", passive([18.7e9, 36.5e9, 89e9], [40, 55]), spx,
+                                                   rtsolver_options=dict(n_max_stream=16, prune_deep_snowpack=1.3)))
+    if wanted("dmrt_L7_n12_prune"):
+        spx = coarse(83, 7, "sticky_hard_spheres", 0.4)
+        save("dmrt_L7_n12_prune", run_new("dmrt_qca_shortrange", passive([36.5e9, 89e9], [55]), spx,
+                                          rtsolver_options=dict(n_max_stream=12, prune_deep_snowpack=3)))
+    if wanted("iba_active_L6_n10_prune"):
+        spx = coarse(84, 6, "exponential", 0.35)
+        save("iba_active_L6_n10_prune", run_new("iba", active(17.2e9, [30, 45]), spx,
+                                                 rtsolver_options=dict(n_max_stream=10, m_max=2, prune_deep_snowpack=0.45)))
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

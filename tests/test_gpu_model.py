@@ -86,6 +86,26 @@ def test_substrate_and_atmosphere_through_the_model():
     np.testing.assert_allclose(np.ravel(res.TbH()), T, atol=1e-3)
 
 
+def test_prune_deep_snowpack_through_the_model():
+    """rtsolver_options=dict(prune_deep_snowpack=...) like in the reference (smrt/rtsolver/dort.py:117-124), against a
+    fixture the reference produced with the option; without it the same pack is up to 48 K away."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.substrate.flat import Flat
+
+    d = load_golden("iba_L6_n16_prune_substrate")
+    sub = Flat(temperature=float(d["substrate_temperature"]), permittivity_model=complex(d["substrate_eps"][0]))
+    sp = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                       corr_length=d["corr_length"], substrate=sub)
+    sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+    opts = dict(n_max_stream=16, prune_deep_snowpack=float(d["opt_prune_deep_snowpack"]))
+    res = make_model("iba", "dort", rtsolver_options=opts).run(sensor, sp)
+    full = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16)).run(sensor, sp)
+    for i, f in enumerate(d["frequency"]):
+        np.testing.assert_allclose(res.TbV(frequency=f), d["result"][i, 0], atol=1e-6)
+        np.testing.assert_allclose(res.TbH(frequency=f), d["result"][i, 1], atol=1e-6)
+    assert np.abs(np.ravel(full.TbV(frequency=36.5e9)) - d["result"][1, 0]).max() > 10.0
+
+
 def test_other_emmodels_through_the_model():
     """dmrt_qcacp_shortrange (the reference's known answer, smrt/test/test_dmrtdort.py:20-37) and nonscattering over a
     Flat substrate through make_model()/Model.run()."""

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options,
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options,
                       load_golden, packed_batch_from_fixture, snowpack_dict)
 
 pytestmark = pytest.mark.gpu
@@ -175,6 +175,95 @@ def test_full_size_batch_properties(ctx):
     cv = c.values.reshape(5, S, 2, 1)
     assert np.array_equal(cv, av[:, perm])
     assert (a.values > 50).all() and (a.values < temp.max()).all()
+
+
+# ---- DORT option prune_deep_snowpack ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", PRUNE_FIXTURES + PRUNE_ACTIVE_FIXTURES)
+@pytest.mark.parametrize("pipeline", [1, 2])
+def test_prune_deep_snowpack_golden(ctx, name, pipeline):
+    """Fixtures generated by the reference with prune_deep_snowpack set (cut at different layers per frequency and
+    azimuth mode, with and without a substrate): both finish-kernel shapes of the pipeline."""
+    d = load_golden(name)
+    active = name in PRUNE_ACTIVE_FIXTURES
+    if active and pipeline == 2:
+        pytest.skip("active mode has the two-slot finish kernel only")
+    ctx.set_pipeline(pipeline)
+    try:
+        out = ctx.run(batch_from_fixture(d))
+    finally:
+        ctx.set_pipeline(1)
+    assert (out.status == 0).all(), out.status
+    if active:
+        assert_backscatter_close(out.values, d["result"])
+    else:
+        assert np.abs(out.values - d["result"]).max() < TB_TOL
+
+
+def test_prune_deep_snowpack_needs_the_pipeline(ctx):
+    """The fused kernel learns a layer's eigenvalues only when the recursion reaches it: the option is refused
+    loudly there instead of being ignored."""
+    from smrt_amd.core.error import SMRTError
+
+    d = load_golden(PRUNE_FIXTURES[0])
+    ctx.set_pipeline(0)
+    try:
+        with pytest.raises(SMRTError, match="prune_deep_snowpack"):
+            ctx.run(batch_from_fixture(d))
+    finally:
+        ctx.set_pipeline(1)
+    out = ctx.run(batch_from_fixture(d))
+    assert (out.status == 0).all() and np.abs(out.values - d["result"]).max() < TB_TOL
+
+
+def test_prune_deep_snowpack_global_workspace_and_batches(ctx):
+    """Pruning on the global-workspace pipeline (40 streams: N = 80) and in a ragged batch where every pair is cut at
+    its own depth, passive and active, against the CPU oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(21)
+    S, L = 3, 7
+    nl = np.array([7, 5, 3], np.int32)
+    thick = rng.uniform(0.2, 0.6, (S, L))
+    dens = rng.uniform(200, 420, (S, L))
+    temp = rng.uniform(235, 268, (S, L))
+    lc = rng.uniform(1.5e-4, 4e-4, (S, L))
+    freqs = np.array([18.7e9, 36.5e9, 89e9])
+    for nstream, prune in ((40, 2.0), (16, True)):
+        b = PackedBatch(nl, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad([40.0, 55.0]), emmodel="iba",
+                        microstructure="exponential", n_max_stream=nstream, prune_deep_snowpack=prune)
+        out = ctx.run(b)
+        assert (out.status == 0).all(), out.status
+        cuts = set()
+        for f in range(len(freqs)):
+            for s_ in range(S):
+                n = nl[s_]
+                sp = dict(thickness=thick[s_, :n], density=dens[s_, :n], temperature=temp[s_, :n],
+                          microstructure="exponential", corr_length=lc[s_, :n])
+                det = {}
+                ref = O.solve(sp, freqs[f], [40.0, 55.0], n_max_stream=nstream, prune_deep_snowpack=prune, details=det)
+                cuts.add(tuple(det["pruned_at"]))
+                assert np.abs(out.values[f * S + s_] - ref).max() < TB_TOL
+        assert len(cuts) >= 3  # uncut pairs and at least two different cuts
+    theta = np.array([30.0, 45.0])
+    fa = np.array([13.4e9, 17.2e9])
+    for nstream in (12, 24):  # N = 36: LDS pipeline; N = 72: global workspace
+        b = PackedBatch(nl, thick, dens / 916.7, temp, lc, None, fa, np.deg2rad(theta), emmodel="iba",
+                        microstructure="exponential", mode="A", n_max_stream=nstream, m_max=2, prune_deep_snowpack=0.4)
+        out = ctx.run(b)
+        assert (out.status == 0).all(), out.status
+        cuts = set()
+        for f in range(len(fa)):
+            for s_ in range(S):
+                n = nl[s_]
+                sp = dict(thickness=thick[s_, :n], density=dens[s_, :n], temperature=temp[s_, :n],
+                          microstructure="exponential", corr_length=lc[s_, :n])
+                det = {}
+                ref = O.solve(sp, fa[f], theta, mode="A", theta_inc_deg=theta, n_max_stream=nstream, m_max=2,
+                              method="schur_forcedtriu", prune_deep_snowpack=0.4, details=det)
+                cuts.add(tuple(det["pruned_at"]))
+                assert_backscatter_close(out.values[f * S + s_], ref)
+        assert len(cuts) >= 2
 
 
 # ---- active mode (backscatter) ---------------------------------------------------------------------------------------

@@ -189,7 +189,17 @@ def test_dort_option_validation():
     from smrt_amd.rtsolver.dort import DORT
 
     DORT(n_max_stream=64, diagonalization_method="half_rank_eig", error_handling="nan")
-    for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=6), dict(diagonalization_method="foo"),
-                dict(error_handling="ignore"), dict(process_coherent_layers=True)):
+    for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=-1), dict(diagonalization_method="foo"),
+                dict(error_handling="ignore"), dict(process_coherent_layers=True), dict(phase_symmetrization=True)):
         with pytest.raises(SMRTError):
             DORT(**bad)
+    # prune_deep_snowpack: True is an optical depth of 6 (smrt/rtsolver/dort.py:176-178); the cache option is a no-op
+    assert DORT(prune_deep_snowpack=True).prune_deep_snowpack == 6.0
+    assert DORT(prune_deep_snowpack=2.5, diagonalization_cache=True).prune_deep_snowpack == 2.5
+    assert DORT(prune_deep_snowpack=False).prune_deep_snowpack is None and DORT().prune_deep_snowpack is None
+    from smrt_amd._native import PackedBatch
+
+    def pb(**kw):
+        return PackedBatch([1], [[1.0]], [[0.3]], [[260.0]], [[1e-4]], None, [37e9], [0.9], **kw).struct.prune_optical_depth
+
+    assert pb() == 0.0 and pb(prune_deep_snowpack=True) == 6.0 and pb(prune_deep_snowpack=1.5) == 1.5

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, packed_batch_from_fixture)
+from conftest import (PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, packed_batch_from_fixture)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
 EMU_DIR = os.path.join(ROOT, "tests", "hostemu")
@@ -58,6 +58,22 @@ def test_emulated_kernel_substrate_atmosphere(emu, name, nt, order):
     out, st, ref = run_fixture(emu, name, nt=nt, order=order)
     assert (st == 0).all()
     assert np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,nt,pipeline", [(PRUNE_FIXTURES[0], 64, 1), (PRUNE_FIXTURES[1], 128, 2),
+                                              (PRUNE_FIXTURES[2], 256, 1), (PRUNE_ACTIVE_FIXTURES[0], 64, 1)])
+def test_emulated_kernel_prune_deep_snowpack(emu, name, nt, pipeline):
+    """DORT option prune_deep_snowpack on the device code (three-kernel pipelines: two-slot and four-slot finish)."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        out, st, ref = run_fixture(emu, name, nt=nt)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    if name in PRUNE_ACTIVE_FIXTURES:
+        assert_backscatter_close(out, ref)
+    else:
+        assert np.abs(out - ref).max() < 1e-6
 
 
 def test_emulated_kernel_is_schedule_independent(emu):

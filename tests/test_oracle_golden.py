@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, SUBSTRATE_FIXTURES, fixture_atmosphere, fixture_options,
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES, fixture_atmosphere, fixture_options,
                       fixture_substrate, load_golden, snowpack_dict)
 from oracle import dort_oracle as O
 
@@ -35,9 +35,10 @@ def test_passive_tb(name, method):
         assert np.abs(tb - d["result"][i]).max() < TB_TOL
 
 
-@pytest.mark.parametrize("name", SUBSTRATE_FIXTURES)
+@pytest.mark.parametrize("name", SUBSTRATE_FIXTURES + PRUNE_FIXTURES)
 def test_passive_tb_substrate_atmosphere(name):
-    """Flat / Reflector substrates (with and without emission) and a SimpleIsotropicAtmosphere."""
+    """Flat / Reflector substrates (with and without emission) and a SimpleIsotropicAtmosphere; the DORT option
+    prune_deep_snowpack (fixtures generated with it by the reference)."""
     d = load_golden(name)
     sp = snowpack_dict(d)
     for i, f in enumerate(d["frequency"]):
@@ -46,7 +47,29 @@ def test_passive_tb_substrate_atmosphere(name):
         assert np.abs(tb - d["result"][i]).max() < TB_TOL
 
 
-@pytest.mark.parametrize("name", ACTIVE_FIXTURES)
+def test_prune_fixtures_do_prune():
+    """The pruning fixtures cut where they were designed to (so that they test something), and the option matters."""
+    expect = {"iba_L8_n12_prune": [[], [5], [1]], "iba_L6_n16_prune_substrate": [[], [3], [1]],
+              "dmrt_L7_n12_prune": [[], [4]], "iba_active_L6_n10_prune": [[4, 4, 5]]}
+    for name, cuts in expect.items():
+        d = load_golden(name)
+        sp = snowpack_dict(d)
+        act = str(d["mode"]) == "A"
+        for i, f in enumerate(d["frequency"]):
+            det = {}
+            kw = dict(mode="A", theta_inc_deg=d["theta_inc_deg"]) if act else {}
+            r = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), substrate=fixture_substrate(d, i),
+                        details=det, **kw, **fixture_options(d))
+            assert det["pruned_at"] == cuts[i]
+            if cuts[i]:
+                o = fixture_options(d)
+                o.pop("prune_deep_snowpack")
+                r0 = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), substrate=fixture_substrate(d, i),
+                             **kw, **o)
+                assert np.abs(r - r0).max() > (1e-3 * np.abs(r0).max() if act else 0.1)
+
+
+@pytest.mark.parametrize("name", ACTIVE_FIXTURES + PRUNE_ACTIVE_FIXTURES)
 @pytest.mark.parametrize("method", ["half_rank_eig", "schur_forcedtriu"])
 def test_active_backscatter(name, method):
     d = load_golden(name)
