@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector == matrix peak (AMD spec sheet); SURVEY.md 8(d)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOPS_PER_N3 = 68.0  # algorithmic flops per layer = 68 N^3 (N = streams x polarisations)
 FREQS = np.array([10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
 N_SNOWPACKS = 1024
@@ -207,6 +208,10 @@ def main():
                 "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per pipeline launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                # the north star also asks for the fraction of the HBM roofline: measured bytes / pipeline time / 8 TB/s
+                "hbm": (None if traffic is None or kernel_ms <= 0 else
+                        {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}),
                 "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish2_kernel (one launch each per "
                           "step; kernel_ms is their summed HIP-event time on the launch stream)",
                 "kernel_ms": kernel_ms,
