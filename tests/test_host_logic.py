@@ -203,3 +203,27 @@ def test_dort_option_validation():
         return PackedBatch([1], [[1.0]], [[0.3]], [[260.0]], [[1e-4]], None, [37e9], [0.9], **kw).struct.prune_optical_depth
 
     assert pb() == 0.0 and pb(prune_deep_snowpack=True) == 6.0 and pb(prune_deep_snowpack=1.5) == 1.5
+
+
+def test_sensor_catalogue_matches_reference():
+    """amsre / amsr2 / cimr / quikscat / ascat / sentinel1 / smos / smap: same frequencies, angles, polarisations,
+    channel maps (names and order), sensor names and error types as the reference's smrt/inputs/sensor_list.py
+    (golden data written by tests/golden/make_sensor_golden.py from the reference)."""
+    import json
+    import os
+    import sys
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        from make_sensor_golden import describe
+    finally:
+        sys.path.remove(here)
+    from smrt_amd.inputs import sensor_list
+
+    with open(os.path.join(here, "sensor_catalogue.json")) as fh:
+        ref = json.load(fh)
+    mine = json.loads(json.dumps(describe(sensor_list), sort_keys=True))
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):
+        assert a == b, (a["call"], a, b)
