@@ -401,8 +401,8 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     size_t lds = (size_t)plan.total * sizeof(double);
     ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds || getenv("SMRT_DORT_FORCE_GLOBAL_WORKSPACE") != nullptr);
     if (ctx->gmem_path) {
-        if (plan.NMAX > 256) {
-            ctx->err = "streams x polarisations above 256 (n_max_stream > 128 passive, > 85 active) is not supported by this build";
+        if (plan.NMAX > 384) {
+            ctx->err = "streams x polarisations above 384 (n_max_stream > 192 passive, > 128 active) is not supported by this build";
             return -1;
         }
         plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 1);   // with an LDS Jacobi matrix
@@ -536,7 +536,8 @@ int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     if (ctx->gmem_path) {
         if (ctx->gmem_split) e = launch_split_gmem(ctx, d);
         else if (ctx->nmax_rows <= 128) e = launch_gmem<256, 2>(ctx, d);
-        else e = launch_gmem<256, 4>(ctx, d);
+        else if (ctx->nmax_rows <= 256) e = launch_gmem<256, 4>(ctx, d);
+        else e = launch_gmem<256, 6>(ctx, d);
         HIPCHK(e);
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         ctx->timing_pending = true;

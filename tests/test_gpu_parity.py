@@ -384,6 +384,40 @@ def test_error_statuses_through_every_path(ctx):
         assert np.isfinite(out.values[1][:2, :2] if mode == "A" else out.values[1]).all()
 
 
+@pytest.mark.parametrize("mode,n", [("P", 100), ("P", 150), ("A", 128)])
+def test_large_stream_counts_against_oracle(ctx, mode, n):
+    """Streams x polarisations beyond the pipelines: N = 200 (four 64-row chunks per lane), N = 300 and N = 384 (six;
+    the 128-stream active shape of BASELINE configs[3]) on the fused global-workspace kernel, against the CPU oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(17)
+    L = 2
+    thick = np.array([[rng.uniform(0.05, 0.3), 20.0]])
+    dens, temp, lc = rng.uniform(150, 450, (1, L)), rng.uniform(230, 270, (1, L)), rng.uniform(5e-5, 3e-4, (1, L))
+    theta = np.array([30.0, 50.0])
+    freq = 13.4e9 if mode == "A" else 36.5e9
+    b = PackedBatch([L], thick, dens / 916.7, temp, lc, None, [freq], np.deg2rad(theta), emmodel="iba",
+                    microstructure="exponential", mode=mode, n_max_stream=n, m_max=2)
+    out = ctx.run(b)
+    assert (out.status == 0).all(), out.status
+    sp = dict(thickness=thick[0], density=dens[0], temperature=temp[0], microstructure="exponential", corr_length=lc[0])
+    ref = O.solve(sp, freq, theta, mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2, method="schur_forcedtriu")
+    if mode == "P":
+        assert np.abs(out.values[0] - ref).max() < TB_TOL
+    else:
+        assert_backscatter_close(out.values[0], ref)
+
+
+def test_stream_count_limit_is_reported(ctx):
+    from smrt_amd._native import PackedBatch
+    from smrt_amd.core.error import SMRTError
+
+    b = PackedBatch([1], [[1.0]], [[0.3]], [[260.0]], [[1e-4]], None, [37e9], [0.9], n_max_stream=200)
+    with pytest.raises(SMRTError, match="384"):
+        ctx.run(b)
+
+
 def test_pipeline_shapes_agree(ctx):
     """Every way the library can run a batch -- three kernels with the two-slot finish (1, default), with the four-slot
     finish (2), one fused kernel (0) -- on the LDS-resident path (N <= 64) and on the global-workspace path
