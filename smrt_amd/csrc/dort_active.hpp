@@ -222,6 +222,17 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         int Lk = L;  // layers kept by prune_deep_snowpack for this azimuth mode (s.pa is free in the finish kernels)
         if (MODE >= 2 && b.prune_tau > 0.0)
             Lk = pruned_layer_count<NT>(*stg, (p * (long long)(m_max + 1) + m) * b.Lmax, L, s.thick, s.pa, b.prune_tau);
+        if (MODE >= 2) {  // failures recorded per layer by the prep / Jacobi kernels: only the kept layers count; the
+                          // mode-0 assembly of a layer also provides the normalisation of its higher modes
+            int bad = first_failed_layer(*stg, (p * (long long)(m_max + 1) + m) * b.Lmax, Lk);
+            if (bad == ST_OK && m > 0) bad = first_failed_layer(*stg, (p * (long long)(m_max + 1)) * b.Lmax, Lk);
+            if (bad != ST_OK) { fail_pair<NT>(b, p, bad, out_stride); return; }
+        }
+        auto layer_failed = [&](int l, int code) {   // prep kernel: record and skip the layer (uniform)
+            block_sync();
+            if (t == 0) { stg->n[(p * (long long)(m_max + 1) + m) * b.Lmax + l] = -code; s.ints[0] = ST_OK; }
+            block_sync();
+        };
         for (int l = Lk - 1; l >= 0; --l) {
             const int n = (int)s.nl[l];
             const int N = n * P;
@@ -367,7 +378,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 s.d[r] = su_of(r, P) * uu / s.wrow[r];
             }
             block_sync();
-            if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+            if (s.ints[0] != ST_OK) {
+                if (MODE == 1) { layer_failed(l, s.ints[0]); continue; }
+                fail_pair<NT>(b, p, s.ints[0], out_stride); return;
+            }
             // -- X+- (lower triangles), symmetric positive definite thanks to the sqrt(2) scaling of U
             for_2d<NT>(N, N, [&](int r, int c) {
                 if (r >= c) {
@@ -380,6 +394,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             block_sync();
             if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, (MODE == 1 && CH == 1) ? stg->Linv + item * 1024 : nullptr)
                           : chol2<NT>(s.M0, s.M1, N, LD))) {
+                if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
                 fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
             }
             if (MODE == 1) {  // B = L+^T L- (columns reversed), L+ and d to the staging area; the Jacobi kernel is next

@@ -1833,24 +1833,38 @@ SMRT_DEV int pruned_layer_count(const DevStage& stg, long long item0, int L, con
     constexpr int NW = NT / SMRT_LANES;
     for (int l = wave; l < L; l += NW) {
         const long long item = item0 + l;
-        const int N = stg.n[item];
+        const int N = stg.n[item];   // < 0: the diagonalisation of this layer failed (see first_failed_layer)
         double m = 1e300;
         for (int r = lane; r < N; r += SMRT_LANES) {
             const double sg = stg.sigma[item * stg.vec_stride + r];
             m = sg < m ? sg : m;
         }
         for (int k = 1; k < SMRT_LANES; k <<= 1) { const double o = shfl_xor(m, k); m = o < m ? o : m; }
-        if (lane == 0) tau[l] = m * thick[l];
+        if (lane == 0) tau[l] = (N > 0) ? m * thick[l] : -1.0;
     }
     block_sync();
     double acc = 0.0;
     int keep = L;
     for (int l = 0; l < L; ++l) {
+        if (tau[l] < 0.0) break;  // a failed layer above the cut: the reference reaches it too (keep everything,
+                                  // the failure is reported by the caller)
         acc += tau[l];
         if (acc > limit) { keep = l + 1; break; }
     }
     block_sync();
     return keep;
+}
+
+// The prep and Jacobi kernels of the pipelines record a failed layer (renormalisation beyond 30 %, albedo >= 1, no
+// convergence) as n[item] = -status instead of failing the pair: the reference diagonalises its layers from the top
+// inside the loop that assembles the boundary system (dort.py:312-336) and never reaches the layers that
+// prune_deep_snowpack cuts away, so only a failure among the kept layers counts -- the first one from the top.
+SMRT_DEV int first_failed_layer(const DevStage& stg, long long item0, int n_kept) {
+    for (int l = 0; l < n_kept; ++l) {
+        const int n = stg.n[item0 + l];
+        if (n < 0) return -n;
+    }
+    return ST_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2024,6 +2038,16 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     // layers kept by prune_deep_snowpack (finish kernels: s.pa is free there)
     int Lk = L;
     if (MODE >= 2 && b.prune_tau > 0.0) Lk = pruned_layer_count<NT>(*stg, p * (long long)b.Lmax, L, s.thick, s.pa, b.prune_tau);
+    if (MODE >= 2) {
+        const int bad = first_failed_layer(*stg, p * (long long)b.Lmax, Lk);
+        if (bad != ST_OK) { fail_pair<NT>(b, p, bad, out_stride); return; }
+    }
+    // prep kernel: a layer that cannot be diagonalised is recorded and skipped (uniform)
+    auto layer_failed = [&](int l, int code) {
+        block_sync();
+        if (t == 0) { stg->n[p * (long long)b.Lmax + l] = -code; s.ints[0] = ST_OK; }
+        block_sync();
+    };
     // ---- bottom-up over the layers -------------------------------------------------------------------------
     for (int l = Lk - 1; l >= 0; --l) {
         const int n = (int)s.nl[l];
@@ -2167,7 +2191,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             s.d[r] = uu / s.wrow[r];
         }
         block_sync();
-        if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
+        if (s.ints[0] != ST_OK) {
+            if (MODE == 1) { layer_failed(l, s.ints[0]); continue; }
+            fail_pair<NT>(b, p, s.ints[0], out_stride); return;
+        }
         // -- X+- = M^-1/2 T (ke I - c N S+- W) T^-1 M^-1/2, symmetric positive definite (lower triangles)
         for_2d<NT>(N, N, [&](int r, int c) {
             if (r >= c) {
@@ -2182,6 +2209,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
                                        (MODE == 1 && CH == 1) ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
                       : chol2<NT>(s.M0, s.M1, N, LD))) {
+            if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
         }
         SMRT_STAGE(SG_BTL);
@@ -2608,6 +2636,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2);
     const int LD = plan.LD, LDJ = plan.LDJ;
     const int N = stg.n[item];
+    if (N <= 0) return;                       // the prep kernel flagged this layer (uniform)
     double* M = lds;
     double* sigma = lds + plan.o_sigma;
     double* nrm = lds + plan.o_rsig;
@@ -2622,7 +2651,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     block_sync();
     const bool ok = (b.mode == 1) ? jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], 1e-30, 1e-22)
                                   : jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0]);
-    if (!ok) { if (t == 0) gmem_max(&b.status[p], ST_EIGEN); return; }
+    if (!ok) { if (t == 0) stg.n[item] = -ST_EIGEN; return; }   // per layer, like the prep kernel's failures
     for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
     for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
 }

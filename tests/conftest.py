@@ -103,7 +103,8 @@ ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_
                    "iba_shs_active_L3_n8", "iba_active_L3_n10_m1_steep", "iba_active_L3_n12_flat_substrate"]
 # DORT option prune_deep_snowpack: cut at layer 5 / 1 / not at all depending on the frequency; with a substrate that
 # disappears from the pruned solves; DMRT; active (a different cut for each azimuth mode and the coherent solve)
-PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12_prune"]
+PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12_prune",
+                  "dmrt_L6_n10_prune_over_bad_layer"]  # the last one: layers that cannot be diagonalised below the cut
 PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)
 

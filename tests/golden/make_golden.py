@@ -362,6 +362,14 @@ def main():
         spx = coarse(83, 7, "sticky_hard_spheres", 0.4)
         save("dmrt_L7_n12_prune", run_new("dmrt_qca_shortrange", passive([36.5e9, 89e9], [55]), spx,
                                           rtsolver_options=dict(n_max_stream=12, prune_deep_snowpack=3)))
+    if wanted("dmrt_L6_n10_prune_over_bad_layer"):
+        # layers 5 and 6 have spheres far too large for DMRT at 89 GHz (albedo >= 1: the diagonalisation fails), but the
+        # pack is cut after layer 4 there, so the reference never diagonalises them and succeeds
+        spx = make_snowpack([0.3, 0.4, 0.35, 0.5, 0.4, 0.6], "sticky_hard_spheres", density=[250, 300, 280, 330, 350, 380],
+                            temperature=[250, 252, 255, 258, 260, 262],
+                            radius=[1.5e-4, 1.7e-4, 1.6e-4, 1.8e-4, 6e-4, 6e-4], stickiness=0.2)
+        save("dmrt_L6_n10_prune_over_bad_layer", run_new("dmrt_qca_shortrange", passive([18.7e9, 89e9], [55]), spx,
+                                                         rtsolver_options=dict(n_max_stream=10, prune_deep_snowpack=3)))
     if wanted("iba_active_L6_n10_prune"):
         spx = coarse(84, 6, "exponential", 0.35)
         save("iba_active_L6_n10_prune", run_new("iba", active(17.2e9, [30, 45]), spx,

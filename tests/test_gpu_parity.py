@@ -215,6 +215,35 @@ def test_prune_deep_snowpack_needs_the_pipeline(ctx):
     assert (out.status == 0).all() and np.abs(out.values - d["result"]).max() < TB_TOL
 
 
+def test_failed_layers_count_only_when_kept(ctx):
+    """A layer that cannot be diagonalised (DMRT spheres far too large: albedo >= 1) fails its pair only if the solve
+    reaches it: the reference diagonalises the layers from the top while it assembles the boundary system and stops at
+    the prune_deep_snowpack cut (dort.py:312-336,443-452).  89 GHz: cut after layer 4 -> fine; 36.5 GHz: no cut ->
+    status 3; without the option both fail; other pairs of the batch are unaffected."""
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden("dmrt_L6_n10_prune_over_bad_layer")
+    sp = snowpack_dict(d)
+    L = len(sp["thickness"])
+    rad = np.stack([sp["radius"], np.minimum(sp["radius"], 1.8e-4)])   # second snowpack: healthy everywhere
+    two = lambda a: np.stack([a, a])  # noqa: E731
+    stick = np.broadcast_to(sp["stickiness"], (2, L))
+    freqs = np.array([18.7e9, 36.5e9, 89e9])
+
+    def run(prune):
+        b = PackedBatch([L, L], two(sp["thickness"]), two(sp["frac_volume"]), two(sp["temperature"]), rad, stick, freqs,
+                        np.deg2rad(d["theta_deg"]), emmodel="dmrt_qca_shortrange", microstructure="sticky_hard_spheres",
+                        n_max_stream=10, prune_deep_snowpack=prune)
+        return ctx.run(b)
+
+    out = run(3.0)
+    assert list(out.status) == [0, 0, 3, 0, 0, 0], out.status        # pair index = frequency * 2 + snowpack
+    assert np.abs(out.values[0] - d["result"][0]).max() < TB_TOL and np.abs(out.values[4] - d["result"][1]).max() < TB_TOL
+    assert np.isnan(out.values[2]).all()
+    out = run(None)
+    assert list(out.status) == [0, 0, 3, 0, 3, 0], out.status
+
+
 def test_prune_deep_snowpack_global_workspace_and_batches(ctx):
     """Pruning on the global-workspace pipeline (40 streams: N = 80) and in a ragged batch where every pair is cut at
     its own depth, passive and active, against the CPU oracle."""

@@ -61,7 +61,8 @@ def test_emulated_kernel_substrate_atmosphere(emu, name, nt, order):
 
 
 @pytest.mark.parametrize("name,nt,pipeline", [(PRUNE_FIXTURES[0], 64, 1), (PRUNE_FIXTURES[1], 128, 2),
-                                              (PRUNE_FIXTURES[2], 256, 1), (PRUNE_ACTIVE_FIXTURES[0], 64, 1)])
+                                              (PRUNE_FIXTURES[2], 256, 1), (PRUNE_FIXTURES[3], 128, 1),
+                                              (PRUNE_ACTIVE_FIXTURES[0], 64, 1)])
 def test_emulated_kernel_prune_deep_snowpack(emu, name, nt, pipeline):
     """DORT option prune_deep_snowpack on the device code (three-kernel pipelines: two-slot and four-slot finish)."""
     C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline

@@ -50,7 +50,8 @@ def test_passive_tb_substrate_atmosphere(name):
 def test_prune_fixtures_do_prune():
     """The pruning fixtures cut where they were designed to (so that they test something), and the option matters."""
     expect = {"iba_L8_n12_prune": [[], [5], [1]], "iba_L6_n16_prune_substrate": [[], [3], [1]],
-              "dmrt_L7_n12_prune": [[], [4]], "iba_active_L6_n10_prune": [[4, 4, 5]]}
+              "dmrt_L7_n12_prune": [[], [4]], "iba_active_L6_n10_prune": [[4, 4, 5]],
+              "dmrt_L6_n10_prune_over_bad_layer": [[], [4]]}
     for name, cuts in expect.items():
         d = load_golden(name)
         sp = snowpack_dict(d)
@@ -64,6 +65,10 @@ def test_prune_fixtures_do_prune():
             if cuts[i]:
                 o = fixture_options(d)
                 o.pop("prune_deep_snowpack")
+                if name == "dmrt_L6_n10_prune_over_bad_layer":  # without the cut the solve reaches the bad layers
+                    with pytest.raises(O.OracleError):
+                        O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), **kw, **o)
+                    continue
                 r0 = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), substrate=fixture_substrate(d, i),
                              **kw, **o)
                 assert np.abs(r - r0).max() > (1e-3 * np.abs(r0).max() if act else 0.1)
