@@ -13,7 +13,8 @@ import numpy as np
 from .core.error import SMRTError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmrt_dort.so")
+# SMRT_DORT_LIB: an alternative build of the same library (profiling / ablation builds made by tools/), never a fallback
+LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
 EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3}
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
