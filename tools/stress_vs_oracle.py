@@ -3,7 +3,7 @@
 emmodels, stream counts that exercise every kernel path (LDS pipeline, global-workspace pipeline, scalar kernel),
 passive / active, with and without substrate and atmosphere, ragged layer counts -- every pair against the CPU oracle.
 
-    python tools/stress_vs_oracle.py [seed]
+    python tools/stress_vs_oracle.py [seed] [prune]      ("prune": also draw a prune_deep_snowpack threshold per case)
 """
 import os, sys, time
 import numpy as np
@@ -13,6 +13,9 @@ from oracle import dort_oracle as O  # checker only
 from smrt_amd._native import DortContext, PackedBatch
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+with_prune = len(sys.argv) > 2 and sys.argv[2] == "prune"
+rng_prune = np.random.default_rng(1000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 1))   # keeps the snowpack stream intact
+n_pruned = 0
 ctx = DortContext(0)
 worst_tb, worst_co, worst_cx, n_checked = 0.0, 0.0, 0.0, 0
 case_co = case_cx = case_ratio = 0.0
@@ -43,8 +46,11 @@ for mode, n, em, ms in cases:
         sub = ("flat", np.full((len(freqs), S), eps.real), np.full((len(freqs), S), eps.imag), Ts)
     if mode == "P" and rng.random() < 0.5:
         atm = (rng.uniform(5, 40, len(freqs)), rng.uniform(2, 15, len(freqs)), rng.uniform(0.8, 1.0, len(freqs)))
+    prune = None
+    if with_prune and n * (3 if mode == "A" else 2) <= 128:   # the option needs a pipeline
+        prune = [0.3, 1.0, 3.0, True][int(rng_prune.integers(0, 4))]
     b = PackedBatch(nl, thick, dens / 916.7, temp, p1, p2, freqs, np.deg2rad(theta), emmodel=em, microstructure=ms, mode=mode,
-                    n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm)
+                    n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm, prune_deep_snowpack=prune)
     out = ctx.run(b)
     case_co = case_cx = 0.0; case_ratio = 1.0
     for f in range(len(freqs)):
@@ -57,8 +63,10 @@ for mode, n, em, ms in cases:
             oatm = None if atm is None else dict(tb_down=atm[0][f], tb_up=atm[1][f], transmittance=atm[2][f])
             p = f * S + s
             try:
+                det = {}
                 ref = O.solve(sp, float(freqs[f]), theta, emmodel=em, mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2,
-                              method="schur_forcedtriu", substrate=osub, atmosphere=oatm)
+                              method="schur_forcedtriu", substrate=osub, atmosphere=oatm, prune_deep_snowpack=prune, details=det)
+                n_pruned += bool(det["pruned_at"]) and min(det["pruned_at"]) < k
             except O.OracleError as e:
                 assert out.status[p] == e.status, (mode, n, em, out.status[p], e.status)
                 continue
@@ -81,5 +89,6 @@ for mode, n, em, ms in cases:
                 if ratio > 1e-3: worst_cx = max(worst_cx, e_cx)
     extra = "" if mode == "P" else "  co %.1e  cross(own) %.1e  min cross/co %.1e" % (case_co, case_cx, case_ratio)
     print("%s n=%-3d %-22s %-20s sub=%d atm=%d  ok  (%.0f s)%s" % (mode, n, em, ms, sub is not None, atm is not None, time.time() - t0, extra), flush=True)
+if with_prune: print("prune_deep_snowpack drawn per case: %d of the checked pairs were cut above their last layer" % n_pruned)
 print("checked %d pairs: max |dTb| = %.2e K, backscatter max rel (co-pol scale) = %.2e, cross-pol own scale (where cross/co > 1e-3) = %.2e" % (n_checked, worst_tb, worst_co, worst_cx))
 assert worst_tb < 1e-6 and worst_co < 1e-8 and worst_cx < 1e-6
