@@ -1563,6 +1563,11 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
             x[r][j] = (row < N && j < nbk) ? v : 0.0;
         }
         used[r] = (row < N) ? (rowblk[rc] >= 0) : true;
+#ifdef SMRT_GJ_DIAG_PIVOT
+        // numerical experiment: pivots only from the 16 rows of the diagonal block -- what a panel
+        // built from a 16 x 16 inverse and MFMA products would do
+        if (row < k0 || row >= k0 + 16) used[r] = true;
+#endif
         mine[r] = false;
     }
     bool ok = true;
@@ -2652,8 +2657,23 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     const bool ok = (b.mode == 1) ? jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], 1e-30, 1e-22)
                                   : jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0]);
     if (!ok) { if (t == 0) stg.n[item] = -ST_EIGEN; return; }   // per layer, like the prep kernel's failures
+#ifdef SMRT_SORT_EIGENPAIRS
+    // eigenpairs in ascending order of the singular value (the order of the streams in the no-scattering limit, where
+    // column c then belongs to row c): rank by counting, the dead norm buffer holds the permutation
+    int* src = (int*)nrm;
+    for (int r = t; r < N; r += NT) {
+        const double sg = sigma[r];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) { const double sj = sigma[j]; rank += (sj < sg || (sj == sg && j < r)) ? 1 : 0; }
+        src[rank] = r;
+    }
+    block_sync();
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[src[c] * LDJ + r]; });
+    for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[src[r]];
+#else
     for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
     for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
+#endif
 }
 
 template <int NT>
