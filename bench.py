@@ -102,7 +102,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    # SMRT_BENCH_DIST=1: take the torch.distributed / RCCL path with a single rank too (tests/test_gpu_bench.py checks
+    # the code the multi-GPU runs execute on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("SMRT_BENCH_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -123,14 +126,14 @@ def main():
 
     out_t = status_t = None
     gathered = [None, None]
-    if world > 1:
+    if use_dist:
         from smrt_amd.runner.distributed import gather_to_root
 
         out_t = torch.empty((n_pairs, 2), dtype=torch.float64, device="cuda")
         status_t = torch.empty((n_pairs,), dtype=torch.int32, device="cuda")
 
     def step():
-        if world > 1:
+        if use_dist:
             ctx.launch(out_t.data_ptr(), status_t.data_ptr())
             ctx.sync()  # the kernel runs on the context's own stream; RCCL runs on torch's
             gathered[0], gathered[1] = gather_to_root(dist, out_t, status_t, dst=0)  # the only collective
@@ -139,7 +142,7 @@ def main():
 
     def fence():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -154,14 +157,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms_total, n_launch = ctx.total_kernel_ms()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     res = ctx.download()
     n_fail = int((res.status != 0).sum())
-    if world > 1:
+    if use_dist:
         res.values = out_t.cpu().numpy().reshape(res.values.shape)  # rank-local rows for the oracle cross-check
         if rank == 0:
             n_fail = int((gathered[1] != 0).sum().item())
@@ -228,7 +231,7 @@ def main():
             line["cpu_baseline"] = cb
             line["config"]["max_abs_dTb_vs_oracle_K"] = err
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

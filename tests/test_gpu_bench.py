@@ -1,0 +1,84 @@
+"""bench.py on the GPU box: the JSON contract of the single-GPU line, and the torch.distributed / RCCL code path of the
+multi-GPU runs (launched exactly like the driver launches it, with one rank, SMRT_BENCH_DIST=1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check_line(line, n_gpus):
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == n_gpus and d["unit"] == "solves/s" and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert d["config"]["failed_solves"] == 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - n_gpus * 5120 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    return d
+
+
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = _check_line(lines[0], 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["config"]["max_abs_dTb_vs_oracle_K"] < 1e-6
+
+
+def test_bench_distributed_path_one_rank():
+    """What `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` executes: RCCL process group,
+    kernels writing into torch device buffers, the gather to rank 0 inside every step, max-over-ranks timing."""
+    env = dict(os.environ, SMRT_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = _check_line(lines[0], 1)
+    assert "cpu_baseline" not in d
+
+
+def test_launch_into_torch_buffers_matches_download():
+    """smrt_dort_launch(out_dev, status_dev) with device pointers owned by torch (the multi-GPU bench does this)."""
+    import torch
+
+    from smrt_amd._native import DortContext, PackedBatch
+
+    rng = np.random.default_rng(5)
+    S, L = 6, 4
+    b = PackedBatch([L] * S, rng.uniform(0.05, 0.3, (S, L)), rng.uniform(0.2, 0.45, (S, L)), rng.uniform(235, 268, (S, L)),
+                    rng.uniform(5e-5, 3e-4, (S, L)), None, [18.7e9, 36.5e9], np.deg2rad([55.0]), n_max_stream=16)
+    ctx = DortContext(0)
+    try:
+        ref = ctx.run(b)
+        out_t = torch.full((b.n_pairs, 2), -1.0, dtype=torch.float64, device="cuda")
+        st_t = torch.full((b.n_pairs,), -1, dtype=torch.int32, device="cuda")
+        ctx.upload(b)
+        ctx.launch(out_t.data_ptr(), st_t.data_ptr())
+        ctx.sync()
+        assert (st_t.cpu().numpy() == 0).all()
+        assert np.array_equal(out_t.cpu().numpy().reshape(ref.values.shape), ref.values)
+    finally:
+        ctx.close()
