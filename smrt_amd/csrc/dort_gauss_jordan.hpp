@@ -1,0 +1,310 @@
+// 16-wide blocked Gauss-Jordan solves of the layer recursion.
+// Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
+#pragma once
+#include "spmd.hpp"
+#include <math.h>
+#include <string.h>
+#include "dort_dense.hpp"
+
+namespace smrt {
+
+// ---- 16-wide blocked Gauss-Jordan (N <= 128): ONE workgroup barrier per 16 columns ---------------------------------
+// Gauss-Jordan with implicit partial pivoting: per block one wavefront factorises the panel (lane = row, arg-max over
+// the rows not used yet by DPP on a 32-bit key; rows are never swapped, the permutation is undone once at the end) and
+// tracks the columns u_j = T[:, p_j] - e_pj of the accumulated row transformation T, so that the whole block update is
+// C <- C + U R_P with the ORIGINAL pivot rows R_P (no inverse to form); the pivot rows come out normalised, so after
+// the last block row perm[k] of B is row k of the solution.  (An earlier version used 4-column blocks with a side
+// buffer for U and a copy of the pivot rows, two barriers per block.)  Design points of this one:
+//   * block width 16 = one MFMA tile column = four chained v_mfma_f64_16x16x4 per tile (the C tile is loaded and
+//     stored once per 16 eliminated columns instead of once per 4);
+//   * the multipliers u_j are written into the panel's own, now dead, columns of A -- no side buffer;
+//   * the pivot rows of the running block are NOT touched by the tile updates (stores to them are masked), so they
+//     can be read in place as the B operand by every wavefront; their own new values R_P + U_P R_P are computed as
+//     one extra "virtual" tile per column tile, kept in registers across the block barrier and stored after it.
+// Every wavefront owns fixed absolute column tiles of [A | B] for the whole solve, so the only cross-wavefront
+// traffic per block is the panel (u columns, permutation, row states), published by the one barrier.  The panel of
+// block k+1 is factorised by the owner of that column tile right after it has updated the tile (look-ahead).
+// RPLN = rows per lane: 1 for N <= 64 (lane = row), 2 for N <= 128 (lane holds rows lane and lane + 64).
+template <bool TR, int RPLN>
+SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+    // x[r][s] holds panel column s of row (lane + 64 r) until the column has been a pivot column, its multiplier u_s
+    // afterwards: both kinds of slot receive the same update x[s] += u_j * x[s][pivot row], so a step treats all
+    // slots but the pivot one alike.  The loop is unrolled by four only, with the slots rotated by four after every
+    // group (the pivot slot index stays a compile-time constant): a fully unrolled panel is ~18 KB of straight-line
+    // code that is executed once per call and does not live in the instruction cache next to the rest of the kernel.
+    const int k0 = 16 * k;
+    const int nbk = (N - k0 < 16) ? N - k0 : 16;
+    double x[RPLN][16];
+    bool used[RPLN], mine[RPLN];
+#pragma unroll
+    for (int r = 0; r < RPLN; ++r) {
+        const int row = lane + 64 * r;
+        const int rc = row < N ? row : N - 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int cc = (k0 + j < N) ? k0 + j : N - 1;
+            const double v = at<TR>(A, rc, cc, LD);
+            x[r][j] = (row < N && j < nbk) ? v : 0.0;
+        }
+        used[r] = (row < N) ? (rowblk[rc] >= 0) : true;
+#ifdef SMRT_GJ_DIAG_PIVOT
+        // numerical experiment: pivots only from the 16 rows of the diagonal block -- what a panel
+        // built from a 16 x 16 inverse and MFMA products would do
+        if (row < k0 || row >= k0 + 16) used[r] = true;
+#endif
+        mine[r] = false;
+    }
+    bool ok = true;
+    int pj_store = 0;
+    int grp = 0;
+    for (; grp * 4 < nbk; ++grp) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = grp * 4 + q;
+            if (j < nbk) {   // uniform
+                // arg-max over the unused rows: float magnitude bits with (255 - row) in the 8 low mantissa bits
+                unsigned key = 0u;
+#pragma unroll
+                for (int r = 0; r < RPLN; ++r) {
+                    if (!used[r]) {
+                        const float xr = (float)fabs(x[r][q]);
+                        unsigned kr;
+                        memcpy(&kr, &xr, 4);
+                        kr = (kr & ~0xFFu) | (unsigned)(255 - (lane + 64 * r));
+                        key = kr > key ? kr : key;
+                    }
+                }
+                key = wave_max_u32(key);
+                if (key < 256u) ok = false;
+                const int p = ok ? 255 - (int)(key & 0xFFu) : 0;
+                if (lane == j) pj_store = p;
+                const int pl = p & 63, ps = p >> 6;   // lane and slot of the pivot row (uniform)
+                double pvq = x[0][q];
+                if (RPLN > 1) pvq = ps ? x[RPLN - 1][q] : x[0][q];
+                const double rpv = fast_rcp(ok ? wave_bcast(pvq, pl) : 1.0);
+                double pr[16];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    if (s2 != q) {
+                        double src = x[0][s2];
+                        if (RPLN > 1) src = ps ? x[RPLN - 1][s2] : x[0][s2];
+                        pr[s2] = wave_bcast(src, pl);
+                    }
+                }
+#if !defined(SMRT_HOST_EMU)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int r = 0; r < RPLN; ++r) {
+                    const bool isp = (lane == pl) && (r == ps);
+                    if (isp) { used[r] = true; mine[r] = true; }
+                    // the pivot row itself is scaled by 1/pivot: a - (1 - 1/pv) a = a / pv, i.e. the same update as
+                    // every other row with the multiplier 1 - 1/pv
+                    const double uj = isp ? rpv - 1.0 : -(x[r][q] * rpv);
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2)
+                        if (s2 != q) x[r][s2] = __builtin_fma(uj, pr[s2], x[r][s2]);
+                    x[r][q] = uj;
+                }
+            }
+        }
+        // rotate the slots left by four: slot s now holds what slot s + 4 held
+#pragma unroll
+        for (int r = 0; r < RPLN; ++r) {
+            const double t0 = x[r][0], t1 = x[r][1], t2 = x[r][2], t3 = x[r][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 12; ++s2) x[r][s2] = x[r][s2 + 4];
+            x[r][12] = t0; x[r][13] = t1; x[r][14] = t2; x[r][15] = t3;
+        }
+    }
+    // after grp rotations slot s holds column (s + 4 grp) mod 16
+#pragma unroll
+    for (int r = 0; r < RPLN; ++r) {
+        const int row = lane + 64 * r;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int j = (s2 + 4 * grp) & 15;
+            if (row < N && j < nbk) at<TR>(A, row, k0 + j, LD) = ok ? x[r][s2] : 0.0;
+        }
+        if (mine[r] && ok) rowblk[row] = k;
+    }
+    if (lane < nbk) perm[k0 + lane] = pj_store;
+    return ok;
+}
+
+// result_in_A: leave the solution in A (one pass and one barrier less than copying it back over Bm), optionally scaled
+// X[k][c] * rs[k] * cs[c] on the way (the t Q t scaling of the recursion).
+template <int NT, bool TR>
+SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
+                           const double* rs = nullptr, const double* cs = nullptr) {
+    const int t = tid();
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int NMX = s.gj_nmax;
+    int* perm = (int*)s.gj;                     // [NMX + 16] pivot row of every column
+    int* rowblk = perm + NMX + 16;              // [NMX] block in which the row was a pivot row, -1 before
+    int* fail = rowblk + NMX;
+    const bool has_v = (v != nullptr);
+    const int RT = (N + 15) >> 4;
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int r = t; r < NMX; r += NT) rowblk[r] = -1;
+    if (t == 0) *fail = 0;
+    block_sync();
+#ifdef SMRT_STAGE_TIMING
+    long long tg0 = cycle_counter();
+#define SMRT_GSUB(k) do { const long long n_ = cycle_counter(); if (t == 0 && s.sub_acc) s.sub_acc[k] += (double)(n_ - tg0); tg0 = n_; } while (0)
+#else
+#define SMRT_GSUB(k) do {} while (0)
+#endif
+    auto panel = [&](int kb) { return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk); };
+    if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
+    SMRT_GSUB(0);
+    block_sync();
+    if (*fail) return false;  // uniform
+
+    for (int k = 0; k < RT; ++k) {
+        const int k0 = 16 * k;
+        const int nbk = (N - k0 < 16) ? N - k0 : 16;
+        // one absolute column tile g of [A | B]: all row tiles (pivot rows masked) + the virtual pivot-row tile -> pvt
+        auto do_tile = [&](int g, double (&pvt)[4]) {
+            double* Mat = (g < RT) ? A : Bm;
+            const int col = ((g < RT) ? g : g - RT) * 16 + lr;
+            const bool cin = col < N;
+            const int colc = cin ? col : 0;
+            double bop[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk;
+                const int pr = (j < nbk) ? perm[k0 + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                bop[kk] = (cin && j < nbk) ? x : 0.0;
+            }
+            for (int ti = 0; ti < RT; ++ti) {
+                double c[4];
+                bool keep[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    const int rowc = row < N ? row : 0;
+                    const double x = at<TR>(Mat, rowc, colc, LD);
+                    keep[reg] = cin && row < N && rowblk[rowc] != k;
+                    c[reg] = keep[reg] ? x : 0.0;
+                }
+                const int arow = ti * 16 + lr;
+                const int arowc = arow < N ? arow : 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int j = 4 * kk + lk;
+                    const int jc = (j < nbk) ? j : 0;
+                    const double x = at<TR>(A, arowc, k0 + jc, LD);
+                    mfma_f64_16x16x4((arow < N && j < nbk) ? x : 0.0, bop[kk], c);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    if (keep[reg]) at<TR>(Mat, row, col, LD) = c[reg];
+                }
+            }
+            // new pivot rows: R_P + U_P R_P with U_P[j][i] = u_i[p_j]
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                const int pr = (j < nbk) ? perm[k0 + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                pvt[reg] = (cin && j < nbk) ? x : 0.0;
+            }
+            const int prl = (lr < nbk) ? perm[k0 + lr] : 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk;
+                const int jc = (j < nbk) ? j : 0;
+                const double x = at<TR>(A, prl, k0 + jc, LD);
+                mfma_f64_16x16x4((lr < nbk && j < nbk) ? x : 0.0, bop[kk], pvt);
+            }
+        };
+        auto store_pivot_rows = [&](int g, const double (&pvt)[4]) {
+            double* Mat = (g < RT) ? A : Bm;
+            const int col = ((g < RT) ? g : g - RT) * 16 + lr;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                if (col < N && j < nbk) at<TR>(Mat, perm[k0 + j], col, LD) = pvt[reg];
+            }
+        };
+
+        // Work distribution of block k: the owner of the next panel (wavefront gnext mod NW) takes only that column
+        // tile and then factorises the panel; the other live column tiles ([A | B] minus the dead A tiles) go round
+        // robin to the remaining wavefronts.  A column tile is read and written by exactly one wavefront per block
+        // (pivot rows included: only the tile's own pivot-row entries serve as its B operand), so the new pivot rows
+        // are stored right away and the block barrier is the only synchronisation.
+        const int gnext = k + 1;
+        const bool has_next = gnext < RT;
+        const int owner = has_next ? (gnext % NW) : -1;
+        if (has_next && wave == owner) {
+            double tmp[4];
+            do_tile(gnext, tmp);
+            wave_sync_lds();
+            store_pivot_rows(gnext, tmp);
+            wave_sync_lds();
+            if (!panel(k + 1) && lane == 0) *fail = 1;
+        }
+        const bool worker = (NW == 1) || !has_next || wave != owner;
+        const int nworkers = (NW == 1 || !has_next) ? NW : NW - 1;
+        const int widx = (NW == 1 || !has_next) ? wave : (wave - owner - 1 + NW) % NW;
+        if (worker) {
+            int idx = 0;
+            for (int g = (has_next ? gnext + 1 : RT); g < 2 * RT; ++g, ++idx) {
+                if (idx % nworkers != widx) continue;
+                double tmp[4];
+                do_tile(g, tmp);
+                wave_sync_lds();
+                store_pivot_rows(g, tmp);
+                wave_sync_lds();
+            }
+            if (has_v && widx == 0) {  // extra right-hand side: same transformation, rows lane and lane + 64
+                double acc[2] = {0.0, 0.0};
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const int row = lane + 64 * r2;
+                    if (row < N) {
+                        acc[r2] = v[row];
+                        for (int j = 0; j < nbk; ++j) acc[r2] += at<TR>(A, row, k0 + j, LD) * v[perm[k0 + j]];
+                    }
+                }
+                wave_sync_lds();
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+                    if (lane + 64 * r2 < N) v[lane + 64 * r2] = acc[r2];
+            }
+        }
+        block_sync();
+        if (*fail) return false;  // uniform
+    }
+    block_sync();
+    SMRT_GSUB(1);
+    // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
+    if (rs) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD) * (rs[k] * cs[c]); });
+    else for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
+    double vk[2] = {0.0, 0.0};   // N <= 128 <= 2 NT
+    if (has_v) {
+        if (t < N) vk[0] = v[perm[t]];
+        if (t + NT < N) vk[1] = v[perm[t + NT]];
+    }
+    block_sync();
+    if (!result_in_A) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
+    if (has_v) {
+        if (t < N) v[t] = vk[0];
+        if (t + NT < N) v[t + NT] = vk[1];
+    }
+    block_sync();
+    SMRT_GSUB(2);
+    return true;
+}
+
+// the Gauss-Jordan entry point of the drivers (solution copied back over Bm)
+template <int NT, bool TR>
+SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
+    return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD);
+}
+
+}  // namespace smrt

@@ -1,0 +1,615 @@
+// The per-pair driver (passive mode) in its fused / prep / finish shapes, with the pieces the active driver shares
+// (pair_setup, pruning, per-layer failure records).
+// Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
+#pragma once
+#include "spmd.hpp"
+#include <math.h>
+#include <string.h>
+#include "dort_gauss_jordan.hpp"
+
+namespace smrt {
+
+// ------------------------------------------------------------------------------------------------------------
+// DORT option prune_deep_snowpack (smrt/rtsolver/dort.py:443-452): the reference stops assembling its boundary system
+// after the layer in which the running optical depth sum_l min|beta_l| thickness_l passes the threshold and cuts the
+// rows / unknowns of everything below.  Here: the number of layers the bottom-up recursion starts from.  The
+// eigenvalues (singular values) of all the layers of this pair (and azimuth mode) lie in the staging area of the
+// pipeline; tau is an LDS scratch of Lmax doubles.  Workgroup-uniform result.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+SMRT_DEV int pruned_layer_count(const DevStage& stg, long long item0, int L, const double* thick, double* tau,
+                                double limit) {
+    const int t = tid();
+    const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    for (int l = wave; l < L; l += NW) {
+        const long long item = item0 + l;
+        const int N = stg.n[item];   // < 0: the diagonalisation of this layer failed (see first_failed_layer)
+        double m = 1e300;
+        for (int r = lane; r < N; r += SMRT_LANES) {
+            const double sg = stg.sigma[item * stg.vec_stride + r];
+            m = sg < m ? sg : m;
+        }
+        for (int k = 1; k < SMRT_LANES; k <<= 1) { const double o = shfl_xor(m, k); m = o < m ? o : m; }
+        if (lane == 0) tau[l] = (N > 0) ? m * thick[l] : -1.0;
+    }
+    block_sync();
+    double acc = 0.0;
+    int keep = L;
+    for (int l = 0; l < L; ++l) {
+        if (tau[l] < 0.0) break;  // a failed layer above the cut: the reference reaches it too (keep everything,
+                                  // the failure is reported by the caller)
+        acc += tau[l];
+        if (acc > limit) { keep = l + 1; break; }
+    }
+    block_sync();
+    return keep;
+}
+
+// The prep and Jacobi kernels of the pipelines record a failed layer (renormalisation beyond 30 %, albedo >= 1, no
+// convergence) as n[item] = -status instead of failing the pair: the reference diagonalises its layers from the top
+// inside the loop that assembles the boundary system (dort.py:312-336) and never reaches the layers that
+// prune_deep_snowpack cuts away, so only a failure among the kept layers counts -- the first one from the top.
+SMRT_DEV int first_failed_layer(const DevStage& stg, long long item0, int n_kept) {
+    for (int l = 0; l < n_kept; ++l) {
+        const int n = stg.n[item0 + l];
+        if (n < 0) return -n;
+    }
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the per-pair solve (passive mode, azimuth mode 0, 2 polarisations)
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride) {
+    const int t = tid();
+    for (int i = t; i < out_stride; i += NT) b.out[p * out_stride + i] = NAN;
+    if (t == 0) b.status[p] = code;
+}
+
+
+// ---- stages 0 and 1 of a pair, shared by the passive and the active drivers ---------------------------------------
+// Layer scalars (one thread per layer), Gauss-Legendre sines, number of streams per layer and the air streams
+// (streams.py:136-223).  s.ints[0..7] must be zero on entry.  Returns the status, uniform over the workgroup; on
+// ST_OK s.ints[4] = most refringent layer, s.ints[5] = n_air.
+template <int NT>
+SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L, const double* thickness,
+                        const double* fracvol, const double* temperature, const double* mp1, const double* mp2) {
+    const int t = tid();
+    const int nmax = b.n_max_stream;
+    for (int l = t; l < L; l += NT) {
+        cplx ee; double ks, ka, pa, pb; int bad = 0;
+        layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
+        s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
+        s.thick[l] = thickness[l];
+        s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
+        if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
+    }
+    for (int j = t; j < nmax; j += NT) {
+        const double m = b.gl_mu[j];
+        s.gmu[j] = m; s.gsin[j] = sqrt(1.0 - m * m);
+    }
+    block_sync();
+    if (s.ints[0] != ST_OK) return s.ints[0];
+    if (t == 0) {
+        int ks_ = 0;
+        for (int l = 1; l < L; ++l)  // np.argmax on complex: lexicographic, first maximum
+            if (s.eps_re[l] > s.eps_re[ks_] || (s.eps_re[l] == s.eps_re[ks_] && s.eps_im[l] > s.eps_im[ks_])) ks_ = l;
+        s.ints[4] = ks_;
+    }
+    block_sync();
+    {
+        const cplx estar = cmk(s.eps_re[s.ints[4]], s.eps_im[s.ints[4]]);
+        for (int l = t; l < L; l += NT) {
+            const double ri = csqrt_(cdiv(estar, cmk(s.eps_re[l], s.eps_im[l]))).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) n += (ri * s.gsin[j] < 1.0) ? 1 : 0;
+            s.ri[l] = ri; s.nl[l] = (double)n;
+            if (n < 2) lds_max(&s.ints[0], ST_INPUT);
+        }
+        if (t == NT - 1) {
+            const double ria = csqrt_(estar).re;
+            int n = 0;
+            for (int j = 0; j < nmax; ++j) {
+                const double rs = ria * s.gsin[j];
+                if (rs < 1.0) { s.outmu[n] = sqrt(1.0 - rs * rs); ++n; }
+            }
+            s.ints[5] = n;
+            if (n < 1) lds_max(&s.ints[0], ST_INPUT);
+        }
+    }
+    block_sync();
+    return s.ints[0];
+}
+
+#ifdef SMRT_EMU_DEBUG
+#include <cstdio>
+#define SMRT_DUMP(tag, M, NN) do { block_sync(); if (t == 0) { char fn[128]; snprintf(fn, 128, "/tmp/dump_l%d_%s.bin", l, tag); FILE* f = fopen(fn, "wb"); for (int c_ = 0; c_ < (NN); ++c_) fwrite((M) + c_ * LD, 8, (NN), f); fclose(f);} block_sync(); } while (0)
+#else
+#define SMRT_DUMP(tag, M, NN) do {} while (0)
+#endif
+// Optional per-stage cycle accounting (profiling builds only): thread 0 accumulates s_memtime deltas.
+#ifdef SMRT_STAGE_TIMING
+#define SMRT_STAGE(k) do { const long long now_ = cycle_counter(); stage_acc[stage_cur] += (double)(now_ - stage_t0); stage_t0 = now_; stage_cur = (k); } while (0)
+#else
+#define SMRT_STAGE(k) do {} while (0)
+#endif
+enum { SG_SETUP = 0, SG_ASSEMBLE, SG_CHOL, SG_BTL, SG_JACOBI, SG_TRI, SG_R1, SG_LU1, SG_R45, SG_LU2, SG_R78, SG_OUT, SG_COUNT };
+
+// MODE 0: the whole solve in one workgroup (fused).  MODE 1 ("prep"): per layer assemble X+-, factorise, form
+// B = L+^T L- and park L+, B, d in the staging area.  MODE 2 ("finish"): pick up L+, B' (rotated by the Jacobi
+// kernel) and the singular values, build the eigenvectors and run the layer recursion.
+// MODE 3 ("finish", two LDS slots): the same recursion with only two N x N matrices in LDS, so that TWO workgroups
+// share a CU (the Gauss-Jordan panels are wavefront-serial: a second resident workgroup fills the idle SIMDs).
+//   slot X: B' -> Ep' -> Wk (matrix of solve 1) -> t Q t -> W (matrix of solve 2) -> K
+//   slot R: R~ (carried between layers) -> right-hand side of solve 1 -> Y (right-hand side of solve 2) -> next R~
+//   global: L+ is used where it lies in the staging area; Em' -> G overwrites the item's B slot, F the item's L
+//   slot (both dead by then); the 16x16 diagonal-block inverses of L+ come from the prep kernel.
+template <int NT, int CH, int MODE = 0>
+SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base, double* gmem_mat = nullptr,
+                                const DevStage* stg = nullptr) {
+    constexpr int P = 2;
+    constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;  // wavefronts rotating columns (one per SIMD)
+    constexpr int GS = 8;                                             // lanes per Jacobi column pair
+    constexpr int RPL = (64 * CH + GS - 1) / GS;                      // rows per lane (N <= 64 CH)
+    const int t = tid();
+    const int lane = t % SMRT_LANES, wave = t / SMRT_LANES;
+    constexpr int NW = NT / SMRT_LANES;
+    const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
+    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
+                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
+                                   (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
+    Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
+    // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
+    // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
+    // (the prep half only needs the 512-double Cholesky scratch, which its slim plan has)
+    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1));
+    double* dense_scratch = (CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
+#ifdef SMRT_STAGE_TIMING
+    double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    s.sub_acc = sub_acc_store;
+#endif
+    const int LD = plan.LD;
+    const int nmax = b.n_max_stream;
+    const int out_stride = P * b.n_theta;
+
+    const long long gp = b.pair_begin + p;
+    const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
+    const double frequency = b.frequency[fi];
+    const int L = b.n_layers[si];
+    const double* thickness = b.thickness + (long long)si * b.Lmax;
+    const double* fracvol = b.frac_volume + (long long)si * b.Lmax;
+    const double* temperature = b.temperature + (long long)si * b.Lmax;
+    const double* mp1 = b.p1 + (long long)si * b.Lmax;
+    const double* mp2 = b.p2 + (long long)si * b.Lmax;
+
+#ifdef SMRT_STAGE_TIMING
+    double stage_acc[SG_COUNT];
+    for (int k = 0; k < SG_COUNT; ++k) stage_acc[k] = 0.0;
+    long long stage_t0 = cycle_counter();
+    int stage_cur = SG_SETUP;
+#endif
+    // ---- stage 0: layer scalars, azimuth table, Gauss-Legendre sines -------------------------------------
+    if (t < 8) s.ints[t] = 0;
+    block_sync();
+    if (MODE >= 2) {  // a failure recorded by the prep or Jacobi kernel
+        const int prev = b.status[p];
+        if (prev != ST_OK) { fail_pair<NT>(b, p, prev, out_stride); return; }
+    }
+    for (int k = t; k < nphi && MODE < 2; k += NT) {  // azimuth table of the phase-matrix assembly
+        const double ph = kPi * (double)k / (double)(nphi - 1);
+        const double c = cos(ph), sn = sin(ph);
+        s.cphi[k] = c; s.s2phi[k] = sn * sn;
+        s.wphi[k] = ((k == 0 || k == nphi - 1) ? 1.0 : 2.0) / (double)(2 * (nphi - 1));
+    }
+    {
+        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2);
+        if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
+    }
+    const int n_air = s.ints[5];
+
+    if (MODE != 1 && b.want_layer_out) {
+        double* lo = b.layer_out + p * (long long)b.Lmax * 5;
+        for (int l = t; l < b.Lmax; l += NT) {
+            const bool in = l < L;
+            lo[l * 5 + 0] = in ? s.eps_re[l] : 0.0; lo[l * 5 + 1] = in ? s.eps_im[l] : 0.0;
+            lo[l * 5 + 2] = in ? s.ks[l] : 0.0; lo[l * 5 + 3] = in ? s.ka[l] : 0.0;
+            lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
+        }
+    }
+    if (MODE != 1 && b.want_stream_out) {
+        double* so = b.stream_out + p * (long long)(1 + nmax);
+        if (t == 0) so[0] = (double)n_air;
+        for (int j = t; j < nmax; j += NT) so[1 + j] = (j < n_air) ? s.outmu[j] : 0.0;
+    }
+
+    double n3 = 0.0;
+    int n_sweeps = 0;
+    // layers kept by prune_deep_snowpack (finish kernels: s.pa is free there)
+    int Lk = L;
+    if (MODE >= 2 && b.prune_tau > 0.0) Lk = pruned_layer_count<NT>(*stg, p * (long long)b.Lmax, L, s.thick, s.pa, b.prune_tau);
+    if (MODE >= 2) {
+        const int bad = first_failed_layer(*stg, p * (long long)b.Lmax, Lk);
+        if (bad != ST_OK) { fail_pair<NT>(b, p, bad, out_stride); return; }
+    }
+    // prep kernel: a layer that cannot be diagonalised is recorded and skipped (uniform)
+    auto layer_failed = [&](int l, int code) {
+        block_sync();
+        if (t == 0) { stg->n[p * (long long)b.Lmax + l] = -code; s.ints[0] = ST_OK; }
+        block_sync();
+    };
+    // ---- bottom-up over the layers -------------------------------------------------------------------------
+    for (int l = Lk - 1; l >= 0; --l) {
+        const int n = (int)s.nl[l];
+        const int N = n * P;
+        n3 += (double)N * N * N;
+        const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
+        const double ks = s.ks[l], ke = s.ks[l] + s.ka[l];
+        const double Bl = s.BT[l];
+        const int nu = (l > 0) ? (int)s.nl[l - 1] : 0;
+        const int Nu = nu * P;
+
+        SMRT_STAGE(SG_SETUP);
+        // -- stream cosines of this layer and of the layer above
+        for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
+        if (l > 0)
+            for (int j = t; j < nu; j += NT) { const double rs = s.ri[l - 1] * s.gsin[j]; s.muu[j] = sqrt(1.0 - rs * rs); }
+        if (MODE != 1 && l == Lk - 1) {
+            // what the last layer sees below: nothing (rtsolver_utils.py:548-551,601-603), or a substrate: specular
+            // reflection R_sub on the diagonal and its emission (1 - R_sub) B(T_sub) (rtsolver_utils.py:544-547,
+            // 579-584; dort.py:429-441); or, when deeper layers were pruned, the reflection of the interface to the
+            // first dropped layer and nothing coming up through it (dort.py:446-452)
+            for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = 0.0; });
+            block_sync();
+            for (int r = t; r < N; r += NT) {
+                double Rs = 0.0, src = 0.0;
+                if (Lk < L) {
+                    const double rs = s.ri[l] * s.gsin[r >> 1];
+                    double Rv, Rh;
+                    fresnel_RvRh(el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs), &Rv, &Rh);
+                    Rs = (r & 1) ? Rh : Rv;
+                } else if (b.sub_kind != SUB_NONE) {
+                    const long long gpi = b.pair_begin + p;
+                    const double q1 = b.sub_p1[gpi], q2 = b.sub_p2[gpi];
+                    if (b.sub_kind == SUB_FLAT) {
+                        const double rs = s.ri[l] * s.gsin[r >> 1];
+                        double Rv, Rh;
+                        fresnel_RvRh(el, cmk(q1, q2), sqrt(1.0 - rs * rs), &Rv, &Rh);
+                        Rs = (r & 1) ? Rh : Rv;
+                    } else Rs = (r & 1) ? q2 : q1;
+                    const double Ts = b.sub_T[si];
+                    if (Ts > 0.0) src = (1.0 - Rs) * (b.rayleigh_jeans ? Ts : planck_radiance(frequency, Ts));
+                }
+                s.M3[r * LD + r] = Rs;
+                s.svec[r] = src;
+            }
+        }
+        block_sync();
+        // -- weights (streams.py:324-330), per-row copies, interface diagonals
+        for (int j = t; j < n; j += NT) {
+            double w;
+            if (j == 0) w = 1.0 - 0.5 * (s.mu[0] + s.mu[1]);
+            else if (j == n - 1) w = fabs(0.5 * (s.mu[n - 2] + s.mu[n - 1]));
+            else w = fabs(0.5 * (s.mu[j - 1] - s.mu[j + 1]));
+            s.w[j] = w;
+            if (MODE < 2) {
+                s.mrow[2 * j] = s.mu[j]; s.mrow[2 * j + 1] = s.mu[j];
+                s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
+            }
+            if (MODE == 1) continue;  // the interfaces belong to the finish kernel
+            double Rv, Rh;
+            const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
+            fresnel_RvRh(el, eup, s.mu[j], &Rv, &Rh);
+            s.Rtop[2 * j] = Rv; s.Rtop[2 * j + 1] = Rh;
+            s.Ttop[2 * j] = 1.0 - Rv; s.Ttop[2 * j + 1] = 1.0 - Rh;
+        }
+        if (MODE != 1 && l > 0)
+            for (int j = t; j < nu; j += NT) {
+                double Rv, Rh;
+                fresnel_RvRh(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], &Rv, &Rh);
+                s.Rbu[2 * j] = Rv; s.Rbu[2 * j + 1] = Rh;
+                s.Tbu[2 * j] = 1.0 - Rv; s.Tbu[2 * j + 1] = 1.0 - Rh;
+            }
+
+        SMRT_STAGE(SG_ASSEMBLE);
+        if (MODE < 2) {
+        // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
+        //    (lower triangle by stream blocks; the matrices are symmetric)
+        {
+            const int T = n * (n + 1) / 2;
+            const double pa = s.pa[l], pb = s.pb[l];
+            const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+            for (int idx = t; idx < T; idx += NT) {
+                int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+                while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                while (i * (i + 1) / 2 > idx) --i;
+                const int j = idx - i * (i + 1) / 2;
+                const double mi = s.mu[i], mj = s.mu[j];
+                double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
+                if (b.emmodel != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
+                    const double a2 = mi * mi, b2 = mj * mj;
+                    pvv_p = pa * (0.5 * a2 * b2 + (1.0 - a2) * (1.0 - b2));
+                    pvh_p = pa * 0.5 * a2; phv_p = pa * 0.5 * b2; phh_p = pa * 0.5;
+                    pvv_m = pvv_p; pvh_m = pvh_p; phv_m = phv_p; phh_m = phh_p;
+                } else {
+                    const double sisj = sqrt(1.0 - mi * mi) * sqrt(1.0 - mj * mj);
+                    const double mm = mi * mj;
+                    const double a2 = mi * mi, b2 = mj * mj;
+                    pvv_p = pvh_p = phv_p = phh_p = pvv_m = pvh_m = phv_m = phh_m = 0.0;
+                    for (int k = 0; k < nphi; ++k) {
+                        const double c = s.cphi[k], s2 = s.s2phi[k], wk = s.wphi[k];
+                        double ct_p = mm + sisj * c;       // cos(scattering angle), mu' = +mu_j
+                        double ct_m = -mm + sisj * c;      // mu' = -mu_j
+                        ct_p = ct_p > 1.0 ? 1.0 : (ct_p < -1.0 ? -1.0 : ct_p);
+                        ct_m = ct_m > 1.0 ? 1.0 : (ct_m < -1.0 ? -1.0 : ct_m);
+                        double Cp, Cm;
+                        if (b.micro == MS_EXP) {
+                            const double dp = 1.0 + pb * (1.0 - ct_p), dm = 1.0 + pb * (1.0 - ct_m);
+                            Cp = pa * fast_rcp(dp * dp); Cm = pa * fast_rcp(dm * dm);   // 1 / (dp dm)^2 without the IEEE division
+                        } else {
+                            Cp = pa * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
+                            Cm = pa * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
+                        }
+                        Cp *= wk; Cm *= wk;
+                        const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
+                        pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;
+                        pvh_p += s2 * a2 * Cp; pvh_m += s2 * a2 * Cm;
+                        phv_p += s2 * b2 * Cp; phv_m += s2 * b2 * Cm;
+                        phh_p += c * c * Cp; phh_m += c * c * Cm;
+                    }
+                }
+                const int r0 = 2 * i, c0 = 2 * j;
+                s.M0[c0 * LD + r0] = pvv_p + pvv_m;             s.M1[c0 * LD + r0] = pvv_p - pvv_m;
+                s.M0[(c0 + 1) * LD + r0] = pvh_p + pvh_m;       s.M1[(c0 + 1) * LD + r0] = pvh_p - pvh_m;
+                s.M0[c0 * LD + r0 + 1] = phv_p + phv_m;         s.M1[c0 * LD + r0 + 1] = phv_p - phv_m;
+                s.M0[(c0 + 1) * LD + r0 + 1] = phh_p + phh_m;   s.M1[(c0 + 1) * LD + r0 + 1] = phh_p - phh_m;
+            }
+        }
+        block_sync();
+        // -- energy-conserving renormalisation (dort.py:782-819): norm_r = ks / (c sum_c S+[r,c] w_c), c = 1/2
+        for (int r = t; r < N; r += NT) {
+            double rs = 0.0;
+            for (int c = 0; c <= r; ++c) rs += s.M0[c * LD + r] * s.wrow[c];
+            for (int c = r + 1; c < N; ++c) rs += s.M0[r * LD + c] * s.wrow[c];
+            double nr = 1.0;
+            if (b.normalization != 0 && ks != 0.0) {
+                nr = ks / (0.5 * rs);
+                if (b.normalization == 1 && !(fabs(nr - 1.0) <= 0.3)) lds_max(&s.ints[0], ST_NORM);
+            }
+            const double uu = sqrt(nr * s.wrow[r] / s.mrow[r]);
+            s.u[r] = uu;
+            s.d[r] = uu / s.wrow[r];
+        }
+        block_sync();
+        if (s.ints[0] != ST_OK) {
+            if (MODE == 1) { layer_failed(l, s.ints[0]); continue; }
+            fail_pair<NT>(b, p, s.ints[0], out_stride); return;
+        }
+        // -- X+- = M^-1/2 T (ke I - c N S+- W) T^-1 M^-1/2, symmetric positive definite (lower triangles)
+        for_2d<NT>(N, N, [&](int r, int c) {
+            if (r >= c) {
+                const double uu = 0.5 * s.u[r] * s.u[c];
+                const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
+                s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
+                s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
+            }
+        });
+        block_sync();
+        SMRT_STAGE(SG_CHOL);
+        if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
+                                       (MODE == 1 && CH == 1) ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
+                      : chol2<NT>(s.M0, s.M1, N, LD))) {
+            if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
+            fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
+        }
+        SMRT_STAGE(SG_BTL);
+        if (MODE == 1) {  // B = L+^T L- straight from the accumulators into the staging area
+            lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD,
+#ifdef SMRT_NO_COLUMN_REVERSAL
+                                false);
+#else
+                                true);
+#endif
+        } else {
+        if (dense_mfma) lt_times_l_mfma<NT>(s.M0, s.M1, s.M2, N, LD);     // B = L+^T L-
+        else lt_times_l<NT>(s.M0, s.M1, s.M2, N, LD);
+        }
+        }  // MODE < 2
+        if (MODE == 1) {  // park L+ and d for the finish kernel (B is already there)
+            const long long item = p * (long long)b.Lmax + l;
+            double* gL = stg->L + item * stg->mat_stride;
+            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; });
+            for (int r = t; r < N; r += NT) stg->d[item * stg->vec_stride + r] = s.d[r];
+            if (t == 0) stg->n[item] = N;
+            block_sync();
+            continue;
+        }
+        SMRT_STAGE(SG_JACOBI);
+        if (MODE == 0) {
+            // global-workspace kernels: the rotations run on an LDS copy of B when one fits next to the vectors
+            double* Jm = (plan.o_jac >= 0) ? lds_base + plan.o_jac : s.M2;
+            if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { Jm[c * LD + r] = s.M2[c * LD + r]; }); block_sync(); }
+            if (!jacobi_onesided<NT, JW, GS, RPL>(Jm, N, LD, s.sigma, s.rsig, &s.ints[1], &n_sweeps, s.sub_acc)) {
+                fail_pair<NT>(b, p, ST_EIGEN, out_stride); return;
+            }
+            if (Jm != s.M2) { for_2d<NT>(N, N, [&](int r, int c) { s.M2[c * LD + r] = Jm[c * LD + r]; }); block_sync(); }
+        } else {  // MODE 2 / 3: pick up L+, B' = B V, d and the singular values
+            const long long item = p * (long long)b.Lmax + l;
+            const double* gL = stg->L + item * stg->mat_stride;
+            const double* gB = stg->B + item * stg->mat_stride;
+            if (MODE == 3) for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gB[c * LD + r]; });   // B' -> slot X
+            else for_2d<NT>(N, N, [&](int r, int c) { s.M0[c * LD + r] = gL[c * LD + r]; s.M2[c * LD + r] = gB[c * LD + r]; });
+            for (int r = t; r < N; r += NT) {
+                s.d[r] = stg->d[item * stg->vec_stride + r];
+                const double sg = stg->sigma[item * stg->vec_stride + r];
+                s.sigma[r] = sg; s.rsig[r] = 1.0 / sg;
+            }
+            block_sync();
+        }
+        SMRT_STAGE(SG_TRI);
+        double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+        double r1a[RowTiles<NT>::RPW][16];   // MODE 3: rows of R~ of this wavefront's row tile (A operands of R1)
+        if (MODE == 3) {
+            const long long item = p * (long long)b.Lmax + l;
+            double* gL = stg->L + item * stg->mat_stride;   // L+, later F
+            double* gB = stg->B + item * stg->mat_stride;   // (B' is in slot X by now) Em', later G
+            // R~ goes into registers now, which frees slot R for L+ during the triangular stage (its transposed walk in
+            // the solve is uncoalesced in global memory) and, after that, for the LDS copy of F
+            r1_load<NT>(s.M3, r1a, s.cvec, s.svec, Bl, N, LD);
+            for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = gL[c * LD + r]; });
+            block_sync();
+            l_times_m_mfma<NT>(s.M3, s.M0, gB, N, LD);                                          // Em' = L+ B'
+            lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * 1024, N, LD, true);                // Ep' = L+^-T B'
+            // F, G to global memory (A operands and elementwise terms of the second GEMM pass) and to slots R, X
+            // (B operands of the first one)
+            for_2d<NT>(N, N, [&](int i, int c) {
+                const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
+                const double hd = 0.5 * s.d[i];
+                const double fv = hd * (ep + em), gv = hd * (ep - em);
+                gL[c * LD + i] = fv; s.M3[c * LD + i] = fv;
+                gB[c * LD + i] = gv; s.M0[c * LD + i] = gv;
+            });
+            F = gL; G = gB;
+        } else {
+        if (dense_mfma) l_times_m_mfma<NT>(s.M0, s.M2, s.M1, N, LD);      // Em' = L+ B'
+        else l_times_m<NT>(s.M0, s.M2, s.M1, N, LD);
+        if (dense_mfma) lt_solve_mfma<NT>(s.M0, s.M2, dense_scratch, N, LD);       // Ep' = L+^-T B'
+        else lt_solve<NT>(s.M0, s.M2, N, LD);
+        // -- F = (Ep - Em)/2 -> M2, G = (Ep + Em)/2 -> M1, with Ep = d Ep', Em = -d Em' / sigma
+        for_2d<NT>(N, N, [&](int i, int c) {
+            const double ep = s.M2[c * LD + i], em = s.M1[c * LD + i] * s.rsig[c];
+            const double hd = 0.5 * s.d[i];
+            s.M2[c * LD + i] = hd * (ep + em);
+            s.M1[c * LD + i] = hd * (ep - em);
+        });
+        }
+        for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
+        block_sync();
+        SMRT_DUMP("F", F, N); SMRT_DUMP("G", G, N); SMRT_DUMP("Rt", Rt, N);
+
+        SMRT_STAGE(SG_R1);
+        if (MODE == 3) {
+            r1_compute<NT>(s.M3, s.M0, r1a, N, LD);   // Wk -> slot X, R~ F - G -> slot R
+        } else if (CH == 1) {
+            r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        } else if (CH == 2 && dense_mfma) {
+            r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        } else {
+            r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        }
+        SMRT_DUMP("M1", Wk, N); SMRT_DUMP("RHS", Rt, N);
+        SMRT_STAGE(SG_LU1);
+        // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
+        if (MODE == 3) {  // the solution t Q t stays in slot X (one pass over the matrix instead of three)
+            if (!gj_solve_b16<NT, false>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        } else
+        if (!(CH <= 2 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        SMRT_STAGE(SG_R45);
+        double* Q = (MODE == 3) ? Wk : Rt;
+        SMRT_DUMP("Q", Q, N);
+        if (MODE != 3) for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
+        for (int r = t; r < N; r += NT) s.tq[r] = s.t[r] * s.cvec[r];
+        block_sync();
+        if (MODE == 3) {
+            r45_mfma2<NT>(F, G, Q, Rt, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot R, W -> slot X (over Q)
+        } else if (CH == 1) {
+            r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
+        } else if (CH == 2 && dense_mfma) {
+            r45_mfma_big<NT, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+        } else {
+            r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+        }
+        SMRT_DUMP("Y", Wk, N); SMRT_DUMP("W", F, N);
+        SMRT_STAGE(SG_LU2);
+        // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
+        if (MODE == 3) {  // A = W (slot X), B = Y (slot R); K is left in slot X
+            if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        } else
+        if (!(CH <= 2 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        SMRT_STAGE(SG_R78);
+        double* K = Wk;
+        SMRT_DUMP("K", K, N);
+        // -- upwelling intensity just below the top interface of layer l: up = F tq + B - K g
+        for (int i = t; i < N; i += NT) {
+            double acc = s.upb[i];
+            for (int k = 0; k < N; ++k) acc -= K[k * LD + i] * s.g[k];
+            s.up[i] = acc;
+        }
+        block_sync();
+        if (l > 0) {
+            // reflection matrix and source seen from the bottom of layer l-1 (streams paired by index)
+            const int nc = (N < Nu) ? N : Nu;
+            for_2d<NT>(Nu, Nu, [&](int i, int j) {
+                double v = (i == j) ? s.Rbu[i] : 0.0;
+                if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
+                s.M3[j * LD + i] = v;
+            });
+            for (int i = t; i < Nu; i += NT) s.svec[i] = (i < nc) ? s.Ttop[i] * s.up[i] : 0.0;
+            block_sync();
+        }
+    }
+
+    if (MODE == 1) {
+        if (t == 0) b.status[p] = ST_OK;
+        return;
+    }
+    SMRT_STAGE(SG_OUT);
+    // ---- emerging brightness temperature at the air streams, then at the sensor angles ---------------------
+    {
+        // atmosphere (rtsolver_utils.py:251-260,302-305): isotropic downwelling radiation I_dn enters through the
+        // surface (dort.py:391-395), is reflected by it (dort.py:484) and by the snowpack (K_0 of the top layer is
+        // still in the work matrix), and the result is tb_up + transmittance * (...)
+        const bool atm = (b.atm_down != nullptr);
+        const double Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
+        const double Iup = atm ? (b.rayleigh_jeans ? b.atm_up[fi] : planck_radiance(frequency, b.atm_up[fi])) : 0.0;
+        const double trans = atm ? b.atm_trans[fi] : 1.0;
+        const double* K0 = s.M0;
+        const cplx e0 = cmk(s.eps_re[0], s.eps_im[0]);
+        for (int i = t; i < n_air * P; i += NT) {
+            double I0 = s.Ttop[i] * s.up[i];  // dort.py:484
+            if (atm && Idn != 0.0) {
+                double acc = 0.0;
+                for (int j = 0; j < n_air; ++j) {
+                    double Rv, Rh;
+                    fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[j], &Rv, &Rh);
+                    acc += K0[(2 * j) * LD + i] * (1.0 - Rv) + K0[(2 * j + 1) * LD + i] * (1.0 - Rh);
+                }
+                double Rv, Rh;
+                fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[i >> 1], &Rv, &Rh);
+                I0 += ((i & 1) ? Rh : Rv) * Idn + s.Ttop[i] * acc * Idn;
+            }
+            if (atm) I0 = Iup + trans * I0;
+            s.tb[i] = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
+        }
+    }
+    block_sync();
+    for (int idx = t; idx < P * b.n_theta; idx += NT) {
+        const int pol = idx / b.n_theta, it = idx % b.n_theta;
+        const double um = cos(b.theta[it]);
+        // outmu is descending; a virtual node mu = 1 holding mean(V,H) of the steepest stream is prepended when the
+        // request is steeper than every stream (rtsolver_utils.py:191-198); linear inter/extrapolation otherwise
+        double x0, x1, y0, y1;
+        const double top = 0.5 * (s.tb[0] + s.tb[1]);
+        if (um > s.outmu[0]) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = s.tb[pol]; }
+        else if (n_air == 1) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = s.tb[pol]; }
+        else {
+            int k = 0;  // segment [outmu[k+1], outmu[k]] containing um, clamped for extrapolation
+            while (k < n_air - 2 && um < s.outmu[k + 1]) ++k;
+            x0 = s.outmu[k]; y0 = s.tb[2 * k + pol]; x1 = s.outmu[k + 1]; y1 = s.tb[2 * (k + 1) + pol];
+        }
+        b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
+    }
+    if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+#ifdef SMRT_STAGE_TIMING
+    SMRT_STAGE(SG_OUT);
+    if (t == 0 && b.stage_out) {
+        for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+        b.stage_out[p * 16 + 12] = (double)n_sweeps;
+        for (int k = 0; k < 3; ++k) b.stage_out[p * 16 + 13 + k] = sub_acc_store[k];
+        b.stage_out[p * 16 + 0] = sub_acc_store[3]; b.stage_out[p * 16 + 1] = sub_acc_store[4]; b.stage_out[p * 16 + 2] = sub_acc_store[5];  // (overrides setup/assemble/cholesky slots in this debug build)
+    }
+#endif
+}
+
+}  // namespace smrt

@@ -1,0 +1,238 @@
+// Complex helpers, layer electromagnetics (ice permittivity, mixing, IBA / DMRT coefficients, microstructure
+// Fourier transforms), Planck functions and Fresnel coefficients.
+// Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
+#pragma once
+#include "spmd.hpp"
+#include <math.h>
+#include <string.h>
+#include "dort_layout.hpp"
+
+namespace smrt {
+
+// ------------------------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------------------------
+struct cplx { double re, im; };
+SMRT_DEV cplx cmk(double a, double b) { cplx z; z.re = a; z.im = b; return z; }
+SMRT_DEV cplx cadd(cplx a, cplx b) { return cmk(a.re + b.re, a.im + b.im); }
+SMRT_DEV cplx csub(cplx a, cplx b) { return cmk(a.re - b.re, a.im - b.im); }
+SMRT_DEV cplx cmul(cplx a, cplx b) { return cmk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+SMRT_DEV cplx cscale(cplx a, double s) { return cmk(a.re * s, a.im * s); }
+SMRT_DEV cplx cconj(cplx a) { return cmk(a.re, -a.im); }
+SMRT_DEV double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
+SMRT_DEV cplx cdiv(cplx a, cplx b) {
+    double d = 1.0 / cabs2(b);
+    return cmk((a.re * b.re + a.im * b.im) * d, (a.im * b.re - a.re * b.im) * d);
+}
+SMRT_DEV cplx csqrt_(cplx z) {  // principal branch
+    if (z.re == 0.0 && z.im == 0.0) return cmk(0.0, 0.0);
+    double m = sqrt(cabs2(z));
+    double tt = sqrt(0.5 * (fabs(z.re) + m));
+    if (z.re >= 0.0) return cmk(tt, z.im / (2.0 * tt));
+    return cmk(fabs(z.im) / (2.0 * tt), z.im >= 0.0 ? tt : -tt);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layer electromagnetics
+// ------------------------------------------------------------------------------------------------------------
+SMRT_DEV cplx ice_permittivity(double frequency, double T) {  // Maetzler 2006, permittivity/ice.py:52-73
+    double fg = frequency * 1e-9;
+    double tc = T - kFreezing;
+    double er = 3.1884 + 9.1e-4 * tc;
+    double th = 300.0 / T - 1.0;
+    double alpha = (0.00504 + 0.0062 * th) * exp(-22.1 * th);
+    double eb = exp(335.0 / T);
+    double betam = (0.0207 / T) * (eb / ((eb - 1.0) * (eb - 1.0))) + 1.16e-11 * fg * fg;
+    double dbeta = exp(-9.963 + 0.0372 * tc);
+    return cmk(er, alpha / fg + (betam + dbeta) * fg);
+}
+
+SMRT_DEV double sinc_(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
+
+// FT of the autocorrelation function at wavenumber k (k2 = k*k)
+SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
+    if (micro == MS_EXP) {  // exponential.py:53-58
+        double x = k2 * p1 * p1;
+        double den = 1.0 + x;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
+    }
+    // sticky hard spheres, sticky_hard_spheres.py:63-130
+    double f = fv, tau = p2, radius = p1;
+    double x = sqrt(k2) * radius;
+    double tt = 0.0;
+    if (isfinite(tau) && f > 0.0) {
+        double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
+                      36 * tau * tau - 12 * f;
+        tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
+    }
+    double vd = 4.0 / 3.0 * kPi * radius * radius * radius;
+    double fr = f / (1.0 - f);
+    double c1 = 1.0 - tt * f + 3.0 * fr;
+    double c2 = 3.0 - tt * (1.0 - f);
+    if (fabs(x) <= 1e-3) {
+        double den = fr * (c1 + c2) + 1.0;
+        return f * vd / (den * den);
+    }
+    double vint = 3.0 * (sinc_(x) - cos(x)) / (x * x);
+    double psi = sinc_(x) / vint;
+    double a = fr * (c1 + c2 * psi) + cos(x) / vint;
+    double b = fr * x + sin(x) / vint;
+    return f * vd / (a * a + b * b);
+}
+
+SMRT_DEV double shs_t(double f, double tau, int* bad) {  // sticky_hard_spheres.py:132-167
+    if (isinf(tau)) return 0.0;
+    double a = f / 12.0, b = -(tau + f / (1.0 - f)), c = (1.0 + 0.5 * f) / ((1.0 - f) * (1.0 - f));
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) { *bad = 1; return 0.0; }
+    double sq = sqrt(disc);
+    double tt = (-b - sq) / (2.0 * a);
+    if (tt * f * (1.0 - f) > 1.0 + 2.0 * f) tt = (-b + sq) / (2.0 * a);
+    if (tt * f * (1.0 - f) > 1.0 + 2.0 * f) *bad = 1;
+    return tt;
+}
+
+SMRT_DEV double planck_radiance(double frequency, double T) {  // core/lib.py:594-607
+    if (!(T > 1e-10)) return 0.0;
+    return (2.0 * kPlanck / (kCSpeed * kCSpeed)) * frequency * frequency * frequency /
+           expm1((kPlanck / kBoltzmann) * frequency / T);
+}
+SMRT_DEV double planck_inverse(double frequency, double radiance) {  // core/lib.py:610-620
+    if (!(radiance > 1e-40)) return 0.0;
+    double x = (2.0 * kPlanck / (kCSpeed * kCSpeed)) * frequency * frequency * frequency / radiance;
+    return (kPlanck / kBoltzmann) * frequency / log1p(x);
+}
+
+// One layer: effective permittivity, ks, ka and the parameters of its phase function.
+// pa/pb/pc: IBA+exponential -> C(cosT) = pa / (1 + pb (1 - cosT))^2 ; IBA+SHS -> pa = iba_coeff, pb = kfac^2/2;
+// DMRT -> pa = 1.5 ks.
+SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
+                       double* ks, double* ka, double* pa, double* pb, int* bad) {
+    cplx es = ice_permittivity(frequency, T);
+    if (T > kFreezing) *bad = 1;
+    double k0 = 2.0 * kPi * frequency / kCSpeed;
+    if (b.emmodel == EM_IBA) {
+        // Polder-van Santen, spheres: 2x^2 + bx - eps e0 = 0 (generic_mixing_formula.py:117-145), e0 = 1
+        cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
+        cplx disc = cadd(cmul(bq, bq), cscale(es, 8.0));
+        cplx ee = cscale(csub(csqrt_(disc), bq), 0.25);
+        if (ee.im < -1e-10) *bad = 1;
+        *eps_eff = ee;
+        // mean squared field ratio with depolarisation factors 1/3 (iba.py:152-162)
+        cplx app = cadd(cscale(ee, 2.0 / 3.0), cmk(1.0 / 3.0, 0.0));
+        cplx den = cadd(app, cscale(csub(es, cmk(1.0, 0.0)), 1.0 / 3.0));
+        double y2 = cabs2(cdiv(app, den));
+        double coeff = (1.0 / (4.0 * kPi)) * cabs2(csub(es, cmk(1.0, 0.0))) * y2 * (k0 * k0) * (k0 * k0);
+        cplx sq = csqrt_(ee);
+        *ka = 2.0 * k0 * sq.im;  // iba.py:265
+        // ks: Romberg on 65 samples of mu = 1 - j/32 (iba.py:176-226; scipy.integrate.romb), |sqrt(eps)| here
+        double nabs2 = sqrt(cabs2(ee));  // |sqrt(eps)|^2 = |eps|
+        double S[7];
+        for (int i = 0; i < 7; ++i) S[i] = 0.0;
+        double yend = 0.0;
+        for (int j = 0; j <= 64; ++j) {
+            double mu = 1.0 - j * 0.03125;
+            double k2 = 4.0 * k0 * k0 * (0.5 * (1.0 - mu)) * nabs2;
+            double y = coeff * ft_corr(b.micro, k2, fv, p1, p2) * (mu * mu + 1.0);
+            if (j == 0 || j == 64) { yend += 0.5 * y; continue; }
+            int tz = 0;
+            while (((j >> tz) & 1) == 0) ++tz;
+            for (int i = 6 - tz; i <= 6; ++i) S[i] += y;
+        }
+        double R[7];
+        for (int i = 0; i < 7; ++i) R[i] = (double)(64 >> i) * 0.03125 * (yend + S[i]);
+        double pw = 1.0;
+        for (int j = 1; j <= 6; ++j) {
+            pw *= 4.0;
+            for (int i = 0; i <= 6 - j; ++i) R[i] = (pw * R[i + 1] - R[i]) / (pw - 1.0);
+        }
+        *ks = 0.25 * R[0];
+        double kfac = 2.0 * k0 * sq.re;  // iba.py:233
+        if (b.micro == MS_EXP) {
+            *pa = coeff * fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1;
+            *pb = 0.5 * kfac * kfac * p1 * p1;
+        } else {
+            *pa = coeff;
+            *pb = 0.5 * kfac * kfac;
+        }
+    } else if (b.emmodel == EM_NONSCAT) {
+        // non-scattering medium (nonscattering.py): Polder-van Santen permittivity, absorption only
+        cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
+        cplx ee = cscale(csub(csqrt_(cadd(cmul(bq, bq), cscale(es, 8.0))), bq), 0.25);
+        *eps_eff = ee;
+        *ka = 2.0 * k0 * csqrt_(ee).im;
+        *ks = 0.0; *pa = 0.0; *pb = 0.0;
+    } else if (b.emmodel == EM_QCACP) {
+        // DMRT QCA-CP short range as in DMRT-ML (dmrt_qcacp_shortrange.py:63-125), dense_snow_correction="auto"
+        double f = fv;
+        cplx e0 = cmk(1.0, 0.0), e1 = es;
+        if (f > 0.5) { f = 1.0 - f; e0 = es; e1 = cmk(1.0, 0.0); }
+        int tb = 0;
+        const double tt = shs_t(f, p2, &tb);
+        if (tb) *bad = 1;
+        const cplx de = csub(e1, e0);
+        const cplx bq = csub(cscale(de, (1.0 - 4.0 * f) / 3.0), e0);
+        const cplx cq = cscale(cmul(e0, de), -(1.0 - f) / 3.0);
+        const cplx disc = csqrt_(csub(cmul(bq, bq), cscale(cq, 4.0)));
+        cplx ee0 = cscale(csub(disc, bq), 0.5);
+        if (ee0.re < 1.0) ee0 = cscale(cadd(disc, bq), -0.5);
+        const double x = k0 * p1;  // 2 pi radius / lambda (vacuum wavelength)
+        const double x3 = x * x * x;
+        const double den = 1.0 + 2.0 * f - tt * f * (1.0 - f);
+        const double omf4 = (1.0 - f) * (1.0 - f) * (1.0 - f) * (1.0 - f);
+        const double shape = omf4 / (den * den);
+        const cplx corr = cdiv(de, cadd(cmk(1.0, 0.0), cscale(cdiv(de, cscale(ee0, 3.0)), 1.0 - f)));
+        const cplx fac = cadd(cmk(1.0, 0.0), cscale(cmul(cmul(cmk(0.0, 2.0 / 9.0 * x3), csqrt_(ee0)), corr), shape));
+        const cplx ee = cadd(e0, cmul(csub(ee0, e0), fac));
+        *eps_eff = ee;
+        const double sqim = csqrt_(ee).im;
+        const double albedo = 2.0 / 9.0 * x3 * f / (2.0 * sqim) * cabs2(corr) * shape;
+        const double beta = 2.0 * k0 * sqim;
+        *ks = albedo * beta;
+        *ka = beta - albedo * beta;
+        *pa = 1.5 * albedo * beta;
+        *pb = 0.0;
+    } else {
+        // DMRT QCA short range (dmrt_qca_shortrange.py:65-112), dense_snow_correction="auto"
+        double f = fv;
+        cplx e0 = cmk(1.0, 0.0), e1 = es;
+        if (f > 0.5) { f = 1.0 - f; e0 = es; e1 = cmk(1.0, 0.0); }
+        int tb = 0;
+        double tt = shs_t(f, p2, &tb);
+        if (tb) *bad = 1;
+        cplx y = cdiv(csub(e1, e0), cadd(e1, cscale(e0, 2.0)));
+        cplx fy = cscale(y, f);
+        double kk = k0 * csqrt_(e0).re;
+        double kr3 = (kk * p1) * (kk * p1) * (kk * p1);
+        double den = 1.0 + 2.0 * f - tt * f * (1.0 - f);
+        double omf4 = (1.0 - f) * (1.0 - f) * (1.0 - f) * (1.0 - f);
+        cplx one_m_fy = csub(cmk(1.0, 0.0), fy);
+        // Eeff = e0 + 3 fy e0/(1-fy) * (1 + 2j/3 kr3 y (1-f)^4 / ((1-fy) den^2))
+        cplx corr = cdiv(cscale(cmul(cmk(0.0, 2.0 / 3.0 * kr3 * omf4 / (den * den)), y), 1.0), one_m_fy);
+        cplx fac = cadd(cmk(1.0, 0.0), corr);
+        cplx ee = cadd(e0, cmul(cdiv(cmul(cscale(fy, 3.0), e0), one_m_fy), fac));
+        *eps_eff = ee;
+        double Ks = 2.0 / (9.0 * f) * kk * kr3 * (cabs2(csub(cdiv(ee, e0), cmk(1.0, 0.0))) * omf4 / (den * den));
+        double beta = 2.0 * kk * csqrt_(ee).im;
+        *ks = Ks;
+        *ka = beta - Ks;
+        *pa = 1.5 * Ks;
+        *pb = 0.0;
+    }
+}
+
+// Flat interface, Maezawa & Miyauchi 2009 "rigorous" Fresnel (core/fresnel.py:99-146): power R for V and H.
+SMRT_DEV void fresnel_RvRh(cplx e1, cplx e2, double mu1, double* Rv, double* Rh) {
+    cplx n1 = csqrt_(e1);
+    double kz2 = n1.re * n1.re * (1.0 - mu1 * mu1);
+    cplx kyi = cscale(csqrt_(cmk(e1.re - kz2, e1.im)), -1.0);
+    cplx kyt = cscale(csqrt_(cmk(e2.re - kz2, e2.im)), -1.0);
+    cplx rh = cdiv(csub(kyi, kyt), cadd(cconj(kyi), kyt));
+    cplx num = cmul(cconj(n1), csub(cmul(e2, kyi), cmul(e1, kyt)));
+    cplx den = cmul(n1, cadd(cmul(e2, cconj(kyi)), cmul(cconj(e1), kyt)));
+    cplx rv = cdiv(num, den);
+    *Rv = cabs2(rv);
+    *Rh = cabs2(rh);
+}
+
+}  // namespace smrt

@@ -1,4 +1,4 @@
-"""The DEVICE code (smrt_amd/csrc/dort_device.hpp) executed on the CPU by the fiber emulator (tests/hostemu):
+"""The DEVICE code (smrt_amd/csrc/dort_*.hpp) executed on the CPU by the fiber emulator (tests/hostemu):
 checks the kernel logic against the reference's golden vectors without a GPU, and that the result does not depend on
 the order in which the emulated threads run between barriers (a missing barrier would)."""
 import ctypes as C
@@ -17,9 +17,9 @@ EMU_LIB = os.path.join(EMU_DIR, "libsmrt_emu.so")
 
 @pytest.fixture(scope="module")
 def emu():
-    srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp"),
-            os.path.join(ROOT, "smrt_amd", "csrc", "dort_device.hpp"), os.path.join(ROOT, "smrt_amd", "csrc", "spmd.hpp"),
-            os.path.join(ROOT, "smrt_amd", "csrc", "dort_active.hpp")]
+    csrc = os.path.join(ROOT, "smrt_amd", "csrc")
+    srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp")] + sorted(
+        os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp"))
     if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR, "-o", EMU_LIB, srcs[0]])
     lib = C.CDLL(EMU_LIB)
