@@ -375,6 +375,22 @@ def main():
         save("iba_active_L6_n10_prune", run_new("iba", active(17.2e9, [30, 45]), spx,
                                                  rtsolver_options=dict(n_max_stream=10, m_max=2, prune_deep_snowpack=0.45)))
 
+    # Conditioning of the backscatter over a reflecting substrate (found by tools/stress_vs_oracle.py, seed 14): sigma0
+    # is what is left (-52 dB) after subtracting a coherent reflection ~1e6 times larger, and the reference's own
+    # diagonalisation methods agree to ~1e-8 only.  Stored: the result of each method.
+    if wanted("iba_shs_active_substrate_conditioning"):
+        spx = make_snowpack([0.2130814222075326, 0.5], "sticky_hard_spheres", density=[346.6822783959207, 197.43486773768632],
+                            temperature=[248.17656234012384, 231.0307860458429],
+                            radius=[5.676126417172697e-05, 8.92312279601347e-05], stickiness=0.2,
+                            substrate=Flat(temperature=264.7614846918132,
+                                           permittivity_model=6.012944835080793 + 0.18867742645808616j))
+        se = active(5.405e9, [7.785449934645355, 35.627555790446976])
+        out = run_new("iba", se, spx, rtsolver_options=dict(n_max_stream=16, m_max=2))
+        for meth in ("eig", "half_rank_eig"):
+            alt = run_new("iba", se, spx, rtsolver_options=dict(n_max_stream=16, m_max=2, diagonalization_method=meth))
+            out["result_" + meth] = alt["result"]
+        save("iba_shs_active_substrate_conditioning", out)
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

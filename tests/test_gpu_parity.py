@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options,
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SIGMA_RTOL, SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options,
                       load_golden, packed_batch_from_fixture, snowpack_dict)
 
 pytestmark = pytest.mark.gpu
@@ -314,6 +314,18 @@ def test_active_golden(ctx, name, threads):
         tag = "f%d_" % i
         np.testing.assert_allclose(out.layers[i, :L, 2], d[tag + "ks"], rtol=1e-11)
         np.testing.assert_allclose(out.layers[i, :L, 3], d[tag + "ka"], rtol=1e-10)
+
+
+def test_active_substrate_dominated_pair(ctx):
+    """The conditioning-limited pair of tests/test_oracle_golden.py::test_active_substrate_dominated_conditioning
+    (sigma0 = -52 dB over a reflecting substrate; the reference's own methods agree to 2e-9 .. 4e-9 there): still within
+    1e-8 of the reference's default method."""
+    d = load_golden("iba_shs_active_substrate_conditioning")
+    out = ctx.run(batch_from_fixture(d))
+    assert (out.status == 0).all()
+    ref = d["result"]
+    scale = np.abs(ref[..., :2, :2, :]).max(axis=(-3, -2), keepdims=True)
+    assert (np.abs(out.values - ref)[..., :2, :2, :] / scale).max() < SIGMA_RTOL   # cross-pol is 1e-6 of co-pol here: noise
 
 
 def test_active_random_batch_against_oracle(ctx):

@@ -113,6 +113,25 @@ def test_active_cross_pol_conditioning():
     assert np.abs(b[0, 1] / a[0, 1] - 1).max() < 1e-6
 
 
+def test_active_substrate_dominated_conditioning():
+    """The hardest pair of a 4400-pair randomised sweep (tools/stress_vs_oracle.py, seed 14): sigma0 = -52 dB is what
+    remains after subtracting a coherent substrate reflection ~1e6 times larger.  The fixture holds the reference's
+    result for each of its diagonalisation methods: they differ by 2e-9 .. 4e-9 among themselves, and this
+    restatement of the same algorithms lands 3e-9 .. 8e-9 from the reference (different rounding, same arithmetic):
+    the answer is defined to a few 1e-9, which is why the 1e-8 bar has little margin on such pairs."""
+    d = load_golden("iba_shs_active_substrate_conditioning")
+    sp = snowpack_dict(d)
+    ref = d["result"][0]
+    scale = np.abs(ref[:2, :2]).max(axis=(0, 1))
+    err = lambda a, b: (np.abs(a - b)[:2, :2] / scale).max()  # noqa: E731
+    spread = max(err(d["result_eig"][0], ref), err(d["result_half_rank_eig"][0], ref))
+    assert 1e-9 < spread < SIGMA_RTOL
+    for method, key in (("schur_forcedtriu", "result"), ("eig", "result_eig"), ("half_rank_eig", "result_half_rank_eig")):
+        r = O.solve(sp, float(d["frequency"][0]), d["theta_deg"], emmodel="iba", mode="A", theta_inc_deg=d["theta_inc_deg"],
+                    method=method, substrate=fixture_substrate(d, 0), **fixture_options(d))
+        assert err(r, d[key][0]) < SIGMA_RTOL
+
+
 @pytest.mark.parametrize("name", ["cfg1_iba_onelayer", "iba_2layer_passive37", "cfg2_iba_L20_n32_sp0",
                                   "iba_L6_n8_angles", "dmrt_L8_n16", "cfg4_iba_active_L5_n16"])
 def test_stages(name):
