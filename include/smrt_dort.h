@@ -124,12 +124,22 @@ int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_
                       double* out, int32_t* status, double* layer_out, double* stream_out);
 
 /*
+ * Sparse selection: only the listed pairs of the flattened S x F list (indices p = f * S + s, any order, repeats
+ * allowed); out / status / layer_out / stream_out have n_pairs rows, row i belongs to pairs[i].  This is what a runner
+ * uses when the simulations it is given are not the full Cartesian product -- a sequence of sensors zipped with a
+ * sequence of snowpacks (smrt/core/model.py:505-515), or a list of (sensor, snowpack) pairs handed over one by one.
+ */
+int32_t smrt_dort_run_pairs(smrt_dort_ctx* ctx, const smrt_batch* batch, const int64_t* pairs, int64_t n_pairs,
+                            double* out, int32_t* status, double* layer_out, double* stream_out);
+
+/*
  * Split form for resident data and timing: upload once, launch many times, download.
  * smrt_dort_launch is asynchronous on the context's stream; smrt_dort_sync waits for it.
  * If out_dev / status_dev are non-NULL they are DEVICE pointers (e.g. torch CUDA tensors used as the send
  * buffers of an RCCL gather) that receive the results instead of the context's own buffers.
  */
 int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count);
+int32_t smrt_dort_upload_pairs(smrt_dort_ctx* ctx, const smrt_batch* batch, const int64_t* pairs, int64_t n_pairs);
 int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev);
 int32_t smrt_dort_sync(smrt_dort_ctx* ctx);
 int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, double* layer_out,
@@ -140,7 +150,7 @@ int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, dou
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
 double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset);
 
-/* Tuning knob: threads per workgroup of the pair kernel (64..1024, multiple of 64). 0 = default. */
+/* Tuning knob: threads per workgroup of the per-pair kernels: 64 (one wavefront) or 256 (default, also 0). */
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 
 /* Pipeline shape.  1 (default) = three kernels -- prep per pair, Jacobi per (pair, layer[, azimuth mode]), finish per
@@ -162,6 +172,12 @@ int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16);
 
 /* Positive Gauss-Legendre nodes of order 2n in descending order (smrt/rtsolver/streams.py:300-313). Host only. */
 int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight);
+
+/* Self-description of the ABI for foreign-function bindings: out[0] = sizeof(smrt_batch), out[1..] = byte offset of
+ * every field of smrt_batch in declaration order.  Returns the number of entries of the full description (fields + 1);
+ * at most `capacity` of them are written (out may be NULL to query the count).  A binding checks its own struct
+ * declaration against this at load time (tests/test_host_logic.py::test_ctypes_struct_matches_the_library). */
+int32_t smrt_dort_abi(int32_t* out, int32_t capacity);
 
 const char* smrt_dort_version(void);
 

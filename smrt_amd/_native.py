@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -171,6 +172,13 @@ def load_library():
     lib.smrt_dort_run.restype = C.c_int32
     lib.smrt_dort_upload.argtypes = [C.c_void_p, P(SmrtBatch), C.c_int64, C.c_int64]
     lib.smrt_dort_upload.restype = C.c_int32
+    lib.smrt_dort_run_pairs.argtypes = [C.c_void_p, P(SmrtBatch), P(C.c_int64), C.c_int64, P(C.c_double), P(C.c_int32),
+                                        P(C.c_double), P(C.c_double)]
+    lib.smrt_dort_run_pairs.restype = C.c_int32
+    lib.smrt_dort_upload_pairs.argtypes = [C.c_void_p, P(SmrtBatch), P(C.c_int64), C.c_int64]
+    lib.smrt_dort_upload_pairs.restype = C.c_int32
+    lib.smrt_dort_abi.argtypes = [P(C.c_int32), C.c_int32]
+    lib.smrt_dort_abi.restype = C.c_int32
     lib.smrt_dort_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.smrt_dort_launch.restype = C.c_int32
     lib.smrt_dort_sync.argtypes = [C.c_void_p]
@@ -193,13 +201,32 @@ def load_library():
     lib.smrt_dort_device_count.restype = C.c_int32
     lib.smrt_gauss_legendre_positive.argtypes = [C.c_int32, P(C.c_double), P(C.c_double)]
     lib.smrt_gauss_legendre_positive.restype = C.c_int32
+    check_struct_layout(lib)
     _lib = lib
     return lib
 
 
+def abi_layout(lib):
+    """[sizeof(smrt_batch), offset of every field in declaration order] as the library was compiled (smrt_dort_abi)."""
+    n = lib.smrt_dort_abi(None, 0)
+    a = (C.c_int32 * n)()
+    lib.smrt_dort_abi(a, n)
+    return list(a)
+
+
+def check_struct_layout(lib):
+    """The ctypes declaration above must be the struct the library was compiled with: a stale binding would hand over
+    a short or shifted struct and the library would read garbage pointers."""
+    mine = [C.sizeof(SmrtBatch)] + [getattr(SmrtBatch, name).offset for name, _ in SmrtBatch._fields_]
+    theirs = abi_layout(lib)
+    if mine != theirs:
+        raise SMRTError(f"smrt_batch layout mismatch between smrt_amd/_native.py {mine} and {LIB_PATH} {theirs}: "
+                        "rebuild the library or update the binding (include/smrt_dort.h)")
+
+
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
-    "smrt_dort_upload", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
+    "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version",
 ]
@@ -226,6 +253,9 @@ class DortContext:
             raise SMRTError(f"smrt_dort_create(device={device}) failed with code {rc}: no usable MI355X GPU. "
                             "smrt_amd has no CPU fallback.")
         self.device = int(device)
+        # a context is one set of device buffers and one stream: its calls are serialised (ctypes releases the GIL,
+        # so two Python threads sharing a cached context would otherwise interleave upload / launch / download)
+        self.lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -250,13 +280,24 @@ class DortContext:
         0: one fused kernel per pair."""
         self._check(self._lib.smrt_dort_set_pipeline(self._h, int(split)), "smrt_dort_set_pipeline")
 
-    def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1) -> BatchOutput:
+    def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1, pairs=None) -> BatchOutput:
+        """One shot (H2D, kernels, D2H) for the pair range, or for the listed pair indices (row i = pairs[i])."""
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int64)
+            o = BatchOutput(batch, len(pairs))
+            with self.lock:
+                self._check(self._lib.smrt_dort_run_pairs(
+                    self._h, C.byref(batch.struct), pairs.ctypes.data_as(C.POINTER(C.c_int64)), len(pairs),
+                    _dptr(o.values), o.status.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(o.layers), _dptr(o.streams)),
+                    "smrt_dort_run_pairs")
+            return o
         if pair_count < 0:
             pair_count = batch.n_pairs - pair_begin
         o = BatchOutput(batch, pair_count)
-        self._check(self._lib.smrt_dort_run(self._h, C.byref(batch.struct), pair_begin, pair_count, _dptr(o.values),
-                                            o.status.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(o.layers),
-                                            _dptr(o.streams)), "smrt_dort_run")
+        with self.lock:
+            self._check(self._lib.smrt_dort_run(self._h, C.byref(batch.struct), pair_begin, pair_count, _dptr(o.values),
+                                                o.status.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(o.layers),
+                                                _dptr(o.streams)), "smrt_dort_run")
         return o
 
     def upload(self, batch: PackedBatch, pair_begin=0, pair_count=-1):

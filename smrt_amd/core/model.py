@@ -1,187 +1,292 @@
-"""make_model / Model with the reference's surface (smrt/core/model.py:120-624): same constructor, `run`,
-`prepare_simulations` (frequency-major flattening), `run_single_simulation`, runner protocol and result nesting.
-The default runner is the batching GPU runner."""
+"""make_model / Model: the entry point of the reference's plugin surface (smrt/core/model.py:120-624) for the DORT path.
+
+Kept from the reference: the signatures and meaning of `make_model`, `make_rtsolver`, `make_emmodel`,
+`make_emmodel_instance`, `Model.run`, `Model.prepare_simulations`, `Model.prepare_emmodels`,
+`Model.run_single_simulation`, the runner protocol `runner(function, argument_list)` and the order in which the
+(sensor configuration, snowpack) pairs are flattened (every sensor axis the rtsolver does not broadcast, slowest first,
+then the snowpacks -- frequency-major).
+
+Own structure (GPU-first): the flattening is not a recursive generator but a `SimulationPlan` -- the list of
+single-configuration sensors, the list of snowpacks and two index vectors built with NumPy.  A batching runner takes
+the plan as a whole (`runner.run_plan`): it packs the distinct snowpacks once, launches once per device and returns the
+stacked result directly; any other runner is fed the reference's `(function, argument_list)` protocol and the per-pair
+results are nested afterwards by `nest_results`."""
 import inspect
-import itertools
 from collections.abc import Mapping, Sequence
+from dataclasses import dataclass, field
 
 import numpy as np
 import pandas as pd
 
-from ..runner.hip_batch_runner import HipBatchRunner
-from ..runner.sequential_runner import SequentialRunner
-from .error import SMRTError
+from .error import SMRTError, smrt_warn
 from .plugin import import_class
 from .result import concat_results
-from .sensor import SensorBase
+from .sensor import SensorBase, SensorList
 
 
 def is_sequence(x):
     return isinstance(x, (Sequence, np.ndarray)) and not isinstance(x, str)
 
 
-def _specialize(scope, cls, **options):
+# ---- class factories ---------------------------------------------------------------------------------------------
+def _with_options(scope, cls, options):
+    """The class `cls` (or the plugin named `cls` in `scope`) with constructor keyword defaults bound."""
     if isinstance(cls, str):
         cls = import_class(scope, cls)
     if not options:
         return cls
-    return type(cls.__name__, (cls,), {"__init__": (lambda self, *a, **kw: cls.__init__(self, *a, **{**options, **kw}))})
+
+    def __init__(self, *args, **kwargs):
+        cls.__init__(self, *args, **{**options, **kwargs})
+
+    return type(cls.__name__, (cls,), {"__init__": __init__, "__module__": cls.__module__})
 
 
 def make_rtsolver(rtsolver_class, **options):
-    """make_model(..., make_rtsolver("dort", n_max_stream=128))  (model.py:180-194)."""
-    return _specialize("rtsolver", rtsolver_class, **options)
+    """`make_model("iba", make_rtsolver("dort", n_max_stream=64))`: an rtsolver class with its options bound."""
+    return _with_options("rtsolver", rtsolver_class, options)
 
 
 def make_emmodel(emmodel_class, **options):
-    return _specialize("emmodel", emmodel_class, **options)
+    """`make_model(make_emmodel("iba", ...), "dort")`: an emmodel class with its options bound."""
+    return _with_options("emmodel", emmodel_class, options)
 
 
 def make_emmodel_instance(emmodel, sensor, layer, **emmodel_options):
-    emmodel = make_emmodel(emmodel)
+    """One emmodel object for one layer seen by one (single-frequency) sensor."""
     if not isinstance(sensor, SensorBase):
         raise SMRTError("the first argument of 'run' must be a sensor")
-    return emmodel(sensor, layer, **emmodel_options)
+    return make_emmodel(emmodel)(sensor, layer, **emmodel_options)
 
 
 def make_model(emmodel=None, rtsolver=None, emmodel_options=None, rtsolver_options=None, emmodel_kwargs=None,
                rtsolver_kwargs=None):
-    """Create a new model with a given EM model and RT solver (model.py:120-177)."""
-    if emmodel_kwargs is not None or rtsolver_kwargs is not None:
-        raise DeprecationWarning("Use emmodel_options / rtsolver_options")
+    """Create a model from an electromagnetic model and a radiative-transfer solver, each given by name (resolved by
+    the plugin loader, smrt_amd.core.plugin) or as a class.  `emmodel` may also be a list (one per layer) or a dict
+    (one per layer medium)."""
+    if emmodel_kwargs is not None:
+        raise DeprecationWarning("Use emmodel_options instead of emmodel_kwargs")
+    if rtsolver_kwargs is not None:
+        raise DeprecationWarning("Use rtsolver_options instead of rtsolver_kwargs")
     return Model(emmodel, rtsolver, emmodel_options=emmodel_options, rtsolver_options=rtsolver_options)
 
 
+# ---- the flattened grid ------------------------------------------------------------------------------------------
+@dataclass
+class SimulationPlan:
+    """sensors[sensor_index[i]] x snowpacks[snowpack_index[i]] for simulation i; `dimensions` = [(name, values), ...]
+    from the outermost to the innermost nesting level (their sizes multiply to the number of simulations)."""
+
+    sensors: list
+    snowpacks: list
+    sensor_index: np.ndarray
+    snowpack_index: np.ndarray
+    dimensions: list = field(default_factory=list)
+    scalar_snowpack: bool = False   # a single snowpack was given: no snowpack dimension in the result
+
+    def __len__(self):
+        return len(self.sensor_index)
+
+    def pairs(self):
+        return [(self.sensors[i], self.snowpacks[j]) for i, j in zip(self.sensor_index, self.snowpack_index)]
+
+    @property
+    def shape(self):
+        return tuple(len(values) for _, values in self.dimensions)
+
+
+def nest_results(results, dimensions):
+    """Fold a flat list of per-simulation results into one result with the given leading dimensions."""
+    results = list(results)
+    for name, values in reversed(dimensions):
+        n = len(values)
+        if n == 0 or len(results) % n:
+            raise SMRTError(f"{len(results)} results cannot be folded along '{name}' of size {n}")
+        results = [concat_results(results[k:k + n], (name, values)) for k in range(0, len(results), n)]
+    if len(results) != 1:
+        raise SMRTError(f"the dimensions {[d[0] for d in dimensions]} do not account for all the results")
+    return results[0]
+
+
+def _snowpack_axis(snowpack, snowpack_dimension, snowpack_column):
+    """(list of snowpacks, (name, labels) or None, mother DataFrame or None) from the forms `run` accepts."""
+    mother = None
+    if isinstance(snowpack, Mapping):
+        return list(snowpack.values()), ("snowpack", list(snowpack.keys())), None
+    if isinstance(snowpack, pd.DataFrame):
+        if snowpack_column not in snowpack.columns:
+            raise SMRTError(f"the snowpack DataFrame has no column named '{snowpack_column}'.")
+        mother = snowpack.drop(columns=snowpack_column)
+        snowpack = snowpack[snowpack_column]
+    if isinstance(snowpack, pd.Series):
+        return snowpack.tolist(), (snowpack.index.name or "snowpack", snowpack.index.tolist()), mother
+    if not is_sequence(snowpack):
+        if snowpack_dimension is not None:
+            raise SMRTError("snowpack_dimension needs a sequence of snowpacks")
+        return [snowpack], None, None
+    packs = list(snowpack)
+    if snowpack_dimension is None:
+        name, labels = "snowpack", None
+    elif isinstance(snowpack_dimension, str):
+        name, labels = snowpack_dimension, None
+    else:
+        name, labels = snowpack_dimension
+        if not isinstance(name, str):
+            raise SMRTError("When the 'snowpack_dimension' argument is a tuple, the first argument must be a string")
+    labels = range(len(packs)) if labels is None else labels
+    if len(labels) != len(packs):
+        raise SMRTError("The list of snowpacks must have the same length as the snowpack_dimension")
+    return packs, (name, labels), None
+
+
 class Model(object):
-    """Drive the whole calculation."""
+    """An electromagnetic model + a radiative-transfer solver, ready to `run`."""
 
     def __init__(self, emmodel, rtsolver, emmodel_options=None, rtsolver_options=None):
         if is_sequence(emmodel):
             self.emmodel = [make_emmodel(em) for em in emmodel]
         elif isinstance(emmodel, Mapping):
-            self.emmodel = {k: make_emmodel(em) for k, em in emmodel.items()}
+            self.emmodel = {medium: make_emmodel(em) for medium, em in emmodel.items()}
         else:
-            self.emmodel = make_emmodel(emmodel)
+            self.emmodel = None if emmodel is None else make_emmodel(emmodel)
         self.rtsolver = import_class("rtsolver", rtsolver) if isinstance(rtsolver, str) else rtsolver
-        self.emmodel_options = emmodel_options if emmodel_options is not None else dict()
-        self.rtsolver_options = rtsolver_options if rtsolver_options is not None else dict()
+        self.emmodel_options = dict(emmodel_options or {})
+        self.rtsolver_options = dict(rtsolver_options or {})
 
     def set_rtsolver_options(self, options=None, **kwargs):
-        if options is not None:
-            self.rtsolver_options = dict(options)
-        self.rtsolver_options.update(kwargs)
+        self.rtsolver_options = self._merged(self.rtsolver_options, options, kwargs)
 
     def set_emmodel_options(self, options=None, **kwargs):
-        if options is not None:
-            self.emmodel_options = dict(options)
-        self.emmodel_options.update(kwargs)
+        self.emmodel_options = self._merged(self.emmodel_options, options, kwargs)
+
+    @staticmethod
+    def _merged(current, options, kwargs):
+        if options is not None and not isinstance(options, Mapping):
+            raise SMRTError("options must be a Mapping (eg. dict)")
+        return {**(current if options is None else options), **kwargs}
+
+    # ---- planning ------------------------------------------------------------------------------------------------
+    def split_axes(self, sensor):
+        """The sensor axes one rtsolver call cannot broadcast, hence flattened by the model: [(axis, values), ...]."""
+        broadcast = getattr(self.rtsolver, "_broadcast_capability", ())
+        return [(axis, values) for axis, values in sensor.configurations() if axis not in broadcast]
+
+    def plan(self, sensor, snowpack, snowpack_dimension=None, snowpack_column="snowpack"):
+        packs, pack_dim, _ = _snowpack_axis(snowpack, snowpack_dimension, snowpack_column)
+        n_packs = len(packs)
+        if is_sequence(sensor):  # zip mode: sensor k looks at snowpack k
+            sensors = list(sensor)
+            if len(sensors) != n_packs or pack_dim is None:
+                raise SMRTError("when sensor is a sequence, the length must be the same as snowpack sequence length")
+            if any(self.split_axes(s) for s in sensors):
+                raise SMRTError("a sequence of sensors is run pairwise with the snowpacks: every sensor must hold a "
+                                "single configuration (one frequency)")
+            idx = np.arange(n_packs)
+            return SimulationPlan(sensors, packs, idx, idx.copy(), [pack_dim])
+        axes = self.split_axes(sensor)
+        if isinstance(sensor, SensorList):
+            sensors = list(sensor.iterate())
+            if any(self.split_axes(s) for s in sensors):
+                raise SMRTError("the members of a SensorList must hold a single configuration each")
+        else:
+            sensors = list(sensor.split([axis for axis, _ in axes]))
+        n_sens = len(sensors)
+        dims = list(axes) + ([pack_dim] if pack_dim is not None else [])
+        return SimulationPlan(sensors, packs, np.repeat(np.arange(n_sens), n_packs), np.tile(np.arange(n_packs), n_sens),
+                              dims, scalar_snowpack=pack_dim is None)
+
+    def prepare_simulations(self, sensor, snowpack, snowpack_dimension, snowpack_column):
+        """(simulations, dimensions) in the reference's form: the flat list of (sensor, snowpack) pairs and the
+        (axis, values) pairs used to nest their results."""
+        plan = self.plan(sensor, snowpack, snowpack_dimension, snowpack_column)
+        return plan.pairs(), plan.dimensions
+
+    # ---- running -------------------------------------------------------------------------------------------------
+    def default_runner(self, parallel_computation, progressbar=False):
+        from ..runner.hip_batch_runner import HipBatchRunner
+        from ..runner.sequential_runner import SequentialRunner
+
+        if parallel_computation in ("outer", "auto", "inner", True):
+            return HipBatchRunner(progressbar=progressbar)
+        if parallel_computation in ("none", None, False):
+            return SequentialRunner(progressbar=progressbar)
+        raise SMRTError(f"parallel_computation={parallel_computation} is not valid. Must be 'outer', 'inner', 'none' "
+                        "or None")
 
     def run(self, sensor, snowpack, atmosphere=None, snowpack_dimension=None, snowpack_column="snowpack",
             progressbar=False, parallel_computation="outer", runner=None):
-        """Run the model for the given sensor configuration(s) and snowpack(s) (model.py:310-413)."""
+        """Run the model for the sensor configuration(s) and the snowpack(s): one snowpack, a sequence, a dict, a
+        pandas Series or a DataFrame holding them in `snowpack_column`.  The result gains one dimension per flattened
+        sensor axis and one for the snowpacks."""
         if atmosphere is not None:
-            raise DeprecationWarning("The atmosphere argument of the run method is depreciated.")
-        if not (isinstance(sensor, SensorBase)
-                or (is_sequence(sensor) and all(isinstance(s, SensorBase) for s in sensor))):
+            raise DeprecationWarning("The atmosphere argument of the run method is depreciated. Use instead the "
+                                     "atmosphere argument of make_snowpack (or `atmosphere + snowpack`).")
+        single = isinstance(sensor, SensorBase)
+        if not single and not (is_sequence(sensor) and all(isinstance(s, SensorBase) for s in sensor)):
             raise SMRTError("the first argument of 'run' must be a sensor or a sequence of sensor")
-        simulations, dimensions = self.prepare_simulations(sensor, snowpack, snowpack_dimension, snowpack_column)
+        plan = self.plan(sensor, snowpack, snowpack_dimension, snowpack_column)
         if runner is None:
-            if parallel_computation in ("outer", "auto", True, "inner"):
-                runner = HipBatchRunner(progressbar=progressbar)
-            elif parallel_computation in ("none", None, False):
-                runner = SequentialRunner(progressbar=progressbar)
-            else:
-                raise SMRTError(f"parallel_computation={parallel_computation} is not valid. "
-                                "Must be 'outer', 'inner', 'none' or None")
-        results = list(runner(self.run_single_simulation,
-                              ((simul, atmosphere, parallel_computation) for simul in simulations)))
-        for dimension in reversed(dimensions):
-            n = len(dimension[1])
-            assert n > 0, f"dimension={dimensions}"
-            results = [concat_results(results[i:i + n], dimension) for i in range(0, len(results), n)]
-        assert len(results) == 1, f"Results size is {len(results)=}"
-        results = results[0]
-        if isinstance(snowpack, pd.DataFrame):
-            results.mother_df = snowpack.drop(snowpack_column, axis=1)
-        return results
-
-    def prepare_simulations(self, sensor, snowpack, snowpack_dimension, snowpack_column):
-        """Flat list of (sensor, snowpack) pairs, frequency-major, plus the (axis, values) list used to nest the
-        results (model.py:415-527)."""
-        if isinstance(snowpack, Mapping):
-            snowpack_dimension = "snowpack", list(snowpack.keys())
-            snowpack = list(snowpack.values())
-        if isinstance(snowpack, pd.DataFrame):
-            try:
-                snowpack = snowpack[snowpack_column]
-            except KeyError:
-                raise SMRTError(f"the snowpack DataFrame has no column named '{snowpack_column}'.")
-        if isinstance(snowpack, pd.Series):
-            name = snowpack.index.name or "snowpack"
-            snowpack_dimension = name, snowpack.index.tolist()
-            snowpack = snowpack.tolist()
-        if is_sequence(snowpack):
-            if snowpack_dimension is None:
-                snowpack_dimension = "snowpack", None
-            if snowpack_dimension[1] is None:
-                snowpack_dimension = snowpack_dimension[0], range(len(snowpack))
-            if len(snowpack) != len(snowpack_dimension[1]):
-                raise SMRTError("The list of snowpacks must have the same length as the snowpack_dimension")
-        if isinstance(snowpack_dimension, tuple) and not isinstance(snowpack_dimension[0], str):
-            raise SMRTError("When the 'snowpack_dimension' argument is a tuple, the first argument must be a string")
-
-        def get_sensor_configurations(sensor):
-            capability = getattr(self.rtsolver, "_broadcast_capability", [])
-            return [(axis, values) for (axis, values) in sensor.configurations() if axis not in capability]
-
-        def prepare_recursive(sensor, sensor_configurations, snowpack):
-            if sensor_configurations:
-                axis, _ = sensor_configurations[0]
-                for sensor_subset in sensor.iterate(axis):
-                    yield from prepare_recursive(sensor_subset, sensor_configurations[1:], snowpack)
-            elif is_sequence(snowpack):
-                for sp in snowpack:
-                    yield (sensor, sp)
-            else:
-                yield (sensor, snowpack)
-
-        if is_sequence(sensor):
-            if len(sensor) != len(snowpack):
-                raise SMRTError("when sensor is a sequence, the length must be the same as snowpack sequence length")
-            sensor_configurations = get_sensor_configurations(next(iter(sensor)))
-            simulations = list(itertools.chain(*(prepare_recursive(se, sensor_configurations, sp)
-                                                 for se, sp in zip(sensor, snowpack))))
+            runner = self.default_runner(parallel_computation, progressbar)
+        if hasattr(runner, "run_plan"):
+            result = runner.run_plan(self, plan)
         else:
-            sensor_configurations = get_sensor_configurations(sensor)
-            simulations = prepare_recursive(sensor, list(sensor_configurations), snowpack)
-        dimensions = sensor_configurations
-        if snowpack_dimension is not None:
-            dimensions.append(snowpack_dimension)
-        return simulations, dimensions
+            results = runner(self.run_single_simulation,
+                             ((pair, atmosphere, parallel_computation) for pair in plan.pairs()))
+            result = nest_results(results, plan.dimensions)
+        if isinstance(snowpack, pd.DataFrame):
+            result.mother_df = snowpack.drop(columns=snowpack_column)
+        return result
+
+    # ---- one simulation (the unit a generic runner maps over) ----------------------------------------------------
+    def emmodel_of_layer(self, index, layer, n_layers):
+        """The emmodel class for one layer: from the per-layer list, the per-medium dict, the layer's own attribute or
+        the model-wide class, in the reference's order of precedence (smrt/core/model.py:529-582)."""
+        if isinstance(self.emmodel, list):
+            if len(self.emmodel) != n_layers:
+                raise SMRTError("the list of emmodels must have the same length as the number of layers")
+            chosen = self.emmodel[index]
+        elif isinstance(self.emmodel, dict):
+            if layer.medium not in self.emmodel:
+                raise SMRTError(f"no emmodel is given for the medium '{layer.medium}'")
+            chosen = self.emmodel[layer.medium]
+        else:
+            own = getattr(layer, "emmodel", None)
+            if own is not None:
+                return make_emmodel(own)
+            chosen = self.emmodel
+        if getattr(layer, "emmodel", None) is not None and not isinstance(self.emmodel, type):
+            smrt_warn("a layer defines its own emmodel but the model was given a list / dict of emmodels: the layer's "
+                      "emmodel is ignored")
+        if chosen is None:
+            raise SMRTError("no emmodel: give one to make_model or to every layer")
+        return chosen
+
+    def emmodel_options_of_layer(self, layer):
+        own = getattr(layer, "emmodel_options", None)
+        return own if own else self.emmodel_options
 
     def prepare_emmodels(self, sensor, snowpack):
-        """One emmodel instance per layer (model.py:529-582)."""
-        if is_sequence(self.emmodel):
-            assert len(self.emmodel) == snowpack.nlayer
-            emmodel_list = self.emmodel
-        elif isinstance(self.emmodel, Mapping):
-            emmodel_list = (self.emmodel[layer.medium] for layer in snowpack.layers)
-        else:
-            emmodel_list = (layer.emmodel or self.emmodel for layer in snowpack.layers)
-        return [make_emmodel_instance(em, sensor, layer, **(layer.emmodel_options or self.emmodel_options))
-                for em, layer in zip(emmodel_list, snowpack.layers)]
+        """One emmodel instance per layer."""
+        n = snowpack.nlayer
+        return [make_emmodel_instance(self.emmodel_of_layer(k, layer, n), sensor, layer,
+                                      **self.emmodel_options_of_layer(layer))
+                for k, layer in enumerate(snowpack.layers)]
 
-    def run_single_simulation(self, simulation, atmosphere, parallel_computation):
-        """One (sensor, snowpack) through a fresh rtsolver instance (model.py:584-619)."""
-        sensor, snowpack = simulation
-        emmodel_instances = self.prepare_emmodels(sensor, snowpack)
+    def make_rtsolver_instance(self):
         if self.rtsolver is None:
             return None
         if inspect.isclass(self.rtsolver):
-            rtsolver = self.rtsolver(**self.rtsolver_options)
-        else:
-            if not getattr(self.rtsolver, "_reentrant", False):
-                raise SMRTError("This solver can not be used with an instance")
-            rtsolver = self.rtsolver
-        return rtsolver.solve(snowpack, emmodel_instances, sensor, snowpack.atmosphere or atmosphere,
+            return self.rtsolver(**self.rtsolver_options)
+        if not getattr(self.rtsolver, "_reentrant", False):
+            raise SMRTError("This solver can not be used with an instance")
+        return self.rtsolver
+
+    def run_single_simulation(self, simulation, atmosphere, parallel_computation):
+        """One (sensor, snowpack) pair through a fresh rtsolver instance."""
+        sensor, snowpack = simulation
+        emmodels = self.prepare_emmodels(sensor, snowpack)
+        rtsolver = self.make_rtsolver_instance()
+        if rtsolver is None:
+            return None
+        return rtsolver.solve(snowpack, emmodels, sensor, snowpack.atmosphere or atmosphere,
                               parallel_computation=parallel_computation)

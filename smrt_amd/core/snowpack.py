@@ -14,6 +14,11 @@ class Snowpack:
             raise SMRTError("smrt_amd implements the SimpleIsotropicAtmosphere (smrt_amd.atmosphere)")
         self.layers = list(layers) if layers is not None else []
         self.interfaces = list(interfaces) if interfaces is not None else [Flat() for _ in self.layers]
+        if len(self.interfaces) != len(self.layers):
+            raise SMRTError("a snowpack needs one interface per layer (the interface lies on top of its layer)")
+        for itf in self.interfaces:
+            self._check_interface(itf)
+        self._packed = None
         self.substrate = substrate
         self.atmosphere = atmosphere
 
@@ -38,8 +43,27 @@ class Snowpack:
     def profile(self, property_name):
         return np.array([getattr(lay, property_name) for lay in self.layers])
 
-    def append(self, layer, interface=None):
+    @staticmethod
+    def _check_interface(interface):
         if interface is not None and not isinstance(interface, Flat):
             raise SMRTError("only Flat interfaces are in the scope of smrt_amd")
+
+    def append(self, layer, interface=None):
+        self._check_interface(interface)
         self.layers.append(layer)
         self.interfaces.append(interface or Flat())
+        self._packed = None
+
+    def packed(self):
+        """The per-layer columns of the device batch for this snowpack -- thickness, ice volume fraction, temperature,
+        the two microstructure parameters -- as one (5, n_layers) array, built once (the batching runner stacks these
+        rows of many snowpacks instead of walking their layer objects again for every run)."""
+        if self._packed is None or self._packed.shape[1] != len(self.layers):
+            cols = [(lay.thickness, lay.frac_volume, lay.temperature) + lay.microstructure.device_params
+                    for lay in self.layers]
+            self._packed = np.array(cols, dtype=np.float64).T.reshape(5, len(self.layers))
+        return self._packed
+
+    @property
+    def microstructure_models(self):
+        return {lay.microstructure_model for lay in self.layers}

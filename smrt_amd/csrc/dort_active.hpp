@@ -76,7 +76,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     double* dsg = s.g;                            // row signs of the down-going eigenvectors (not in the prep kernel)
     auto su_of = [](int r, int P) { return (P == 3 && r % 3 == 2) ? 1.4142135623730951 : 1.0; };  // sqrt(2) on U rows
 
-    const long long gp = b.pair_begin + p;
+    const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
     const double frequency = b.frequency[fi];
     const int L = b.n_layers[si];

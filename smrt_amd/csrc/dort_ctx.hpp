@@ -1,0 +1,79 @@
+// Host-side context of libsmrt_dort.so and the launcher interface between its translation units.
+// The kernels are instantiated in separate .hip files (k_*.hip) so that they compile in parallel; dort_hip.hip holds the
+// C ABI (include/smrt_dort.h), the buffers and the chunk loops and calls the launchers declared here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+#include "dort_layout.hpp"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct smrt_dort_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap;
+    smrt::DevBatch dev{};
+    bool uploaded = false;
+    int out_stride = 0;
+    int nt = 256;
+    size_t lds_bytes = 0;
+    size_t prep_lds_bytes = 0;
+    size_t finish2_lds_bytes = 0;
+    bool finish2 = true;        // two-slot finish kernel (set_pipeline(2) selects the LDS-resident one)
+    float last_ms = 0.f;
+    double total_ms = 0.0;
+    int64_t n_launch = 0;
+    bool timing_pending = false;
+    int max_lds = 0;
+    bool split = true;          // three-kernel pipeline on the LDS path (fused single kernel if false)
+    long long chunk_pairs = 0;  // pairs per pipeline pass (bounds the staging area)
+    size_t jacobi_lds = 0;
+    smrt::DevStage stage{};
+    bool gmem_path = false;
+    bool gmem_split = false;    // 64 < N <= 128 passive: three-kernel pipeline on the global workspace
+    int jac_in_lds = 0;
+    bool active = false;
+    int gmem_grid = 0;
+    long long ws_stride = 0;
+    int nmax_rows = 0;
+};
+
+#ifndef SMRT_JACOBI_NT
+#define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
+#endif
+
+// Kernel launchers, one translation unit each (asynchronous on ctx->stream; the returned error is the launch error).
+// `c` is the DevBatch of one chunk (pair_begin / pair_count / output pointers already offset).
+namespace smrt_launch {
+// k_split_passive.hip: prep and finish kernels of the LDS-resident pipeline (N <= 64), nt = 64 or 256
+hipError_t prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
+hipError_t finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt, bool two_slot);
+void occupancy_report(smrt_dort_ctx* ctx, int nt);
+// k_jacobi.hip: one workgroup per staging item (pair, [azimuth mode,] layer)
+hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
+// k_split_active.hip
+hipError_t active_prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
+hipError_t active_finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
+// k_gmem_split.hip: 64 < N <= 128, work matrices in the per-workgroup global workspace, grid-stride over the pairs
+hipError_t prep_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active);
+hipError_t finish_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active);
+// k_fused.hip / k_gmem_fused.hip: everything of a pair in one workgroup
+hipError_t fused(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int nt, bool active);
+hipError_t fused_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int ch, bool active);
+}  // namespace smrt_launch

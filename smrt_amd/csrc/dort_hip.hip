@@ -1,177 +1,21 @@
 // libsmrt_dort.so -- HIP implementation of include/smrt_dort.h for gfx950 (MI355X).
-// Host code: context, device buffers, packing, launch, HIP-event timing.  Kernels: dort_device.hpp.
+// This file: the C ABI, the context, device buffers, packing, the chunk loops and HIP-event timing.  The kernels are
+// instantiated in k_*.hip (one translation unit per kernel family, compiled in parallel) behind the launchers of
+// dort_ctx.hpp; the device code itself is dort_device.hpp and the headers it lists.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "dort_active.hpp"
+#include "dort_ctx.hpp"
+#include "dort_jacobi_kernel.hpp"   // make_jacobi_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
 
 using namespace smrt;
-
-template <int NT, int CH>
-__global__ __launch_bounds__(NT) void dort_passive_kernel(DevBatch b) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
-}
-
-// ---- split pipeline (N <= 64): prep (per pair) -> Jacobi (per pair x layer, 4 workgroups per CU) -> finish (per pair)
-template <int NT>
-__global__ __launch_bounds__(NT) void dort_prep_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
-}
-template <int NT>
-__global__ __launch_bounds__(NT) void dort_jacobi_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_jacobi_item<NT>(b, st, (long long)blockIdx.x, smrt_lds);
-}
-template <int NT>
-__global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 2>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
-}
-#ifndef SMRT_FINISH_WAVES_BIG
-#define SMRT_FINISH_WAVES_BIG 1   // wavefronts per SIMD the 512-thread variant must leave room for (experiments)
-#endif
-// two LDS slots + F, G in the (dead) staging slots of the item: two workgroups per CU
-// (second launch-bound argument on HIP = wavefronts per SIMD the compiler must leave room for: 2 -> <= 256 VGPRs)
-template <int NT>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : SMRT_FINISH_WAVES_BIG)) void dort_finish2_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
-}
-
-// N > 64 (n_max_stream up to 64 x CH/2): same device functions, work matrices in a per-workgroup global workspace
-// (L2 / Infinity-Cache resident), grid-stride over the pairs so the workspace stays bounded.
-template <int NT, int CH>
-__global__ __launch_bounds__(NT) void dort_passive_kernel_gmem(DevBatch b, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, CH>(b, p, smrt_lds, mat);
-        __syncthreads();
-    }
-}
-
-// ---- three-kernel pipeline for 64 < N <= 128 (passive): prep and the four-matrix finish on the per-workgroup global
-// workspace (grid-stride over the pairs), the shared Jacobi kernel with its 128-column LDS matrix in between
-template <int NT>
-__global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, 2, 1>(b, p, smrt_lds, mat, &st);
-        __syncthreads();
-    }
-}
-template <int NT>
-__global__ __launch_bounds__(NT, 2) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, 2, 2>(b, p, smrt_lds, mat, &st);
-        __syncthreads();
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void dort_active_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, 2, 1>(b, p, smrt_lds, mat, &st);
-        __syncthreads();
-    }
-}
-template <int NT>
-__global__ __launch_bounds__(NT, 2) void dort_active_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, 2, 2>(b, p, smrt_lds, mat, &st);
-        __syncthreads();
-    }
-}
-
-// ---- active mode (backscatter): one fused kernel per pair, azimuth modes 0..m_max inside ---------------------------
-template <int NT, int CH>
-__global__ __launch_bounds__(NT) void dort_active_kernel(DevBatch b) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, CH>(b, (long long)blockIdx.x, smrt_lds);
-}
-template <int NT, int CH>
-__global__ __launch_bounds__(NT) void dort_active_kernel_gmem(DevBatch b, double* workspace, long long ws_stride) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    double* mat = workspace + (long long)blockIdx.x * ws_stride;
-    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, CH>(b, p, smrt_lds, mat);
-        __syncthreads();
-    }
-}
-
-// active mode through the three-kernel pipeline (prep and two-slot finish; the Jacobi kernel is shared)
-template <int NT>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_prep_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
-}
-template <int NT>
-__global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_finish_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
-}
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct smrt_dort_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm;
-    DevBatch dev{};
-    bool uploaded = false;
-    int out_stride = 0;
-    int nt = 512;
-    size_t lds_bytes = 0;
-    size_t prep_lds_bytes = 0;
-    size_t finish2_lds_bytes = 0;
-    bool finish2 = true;        // two-slot finish kernel (set_pipeline(2) selects the LDS-resident one)
-    float last_ms = 0.f;
-    double total_ms = 0.0;
-    int64_t n_launch = 0;
-    bool timing_pending = false;
-    int max_lds = 0;
-    bool split = true;          // three-kernel pipeline on the LDS path (fused single kernel if false)
-    long long chunk_pairs = 0;  // pairs per pipeline pass (bounds the staging area)
-    size_t jacobi_lds = 0;
-    DevStage stage{};
-    bool gmem_path = false;
-    bool gmem_split = false;    // 64 < N <= 128 passive: three-kernel pipeline on the global workspace
-    int jac_in_lds = 0;
-    bool active = false;
-    int gmem_grid = 0;
-    long long ws_stride = 0;
-    int nmax_rows = 0;
-};
 
 #define HIPCHK(call)                                                                              \
     do {                                                                                          \
@@ -188,128 +32,42 @@ static int upload_array(smrt_dort_ctx* ctx, DevBuf& buf, const void* src, size_t
     return 0;
 }
 
-template <int NT, int CH>
-static hipError_t launch_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
-    auto kern = ctx->active ? dort_active_kernel_gmem<NT, CH> : dort_passive_kernel_gmem<NT, CH>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ctx->gmem_grid), dim3(NT), ctx->lds_bytes, ctx->stream, d,
-                       (double*)ctx->d_work.p, ctx->ws_stride);
-    return hipGetLastError();
+
+// One chunk of the batch as its own DevBatch (outputs offset to the chunk's rows)
+static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long c0, long long cn) {
+    DevBatch c = d;
+    c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
+    c.out = d.out + c0 * ctx->out_stride; c.status = d.status + c0;
+    c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
+    c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
+    c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
+    return c;
 }
 
-#ifndef SMRT_PREP_THREADS
-#define SMRT_PREP_THREADS 256  // two 256-thread prep workgroups per CU (77 KB of LDS each) beat one of 512
-#endif
-#ifndef SMRT_FINISH_THREADS
-#define SMRT_FINISH_THREADS 256  // likewise for the two-slot finish kernel (80 KB of LDS each)
-#endif
-template <int NT>
-static hipError_t launch_split(smrt_dort_ctx* ctx, const DevBatch& d) {
-    constexpr int PNT = (NT >= 256) ? SMRT_PREP_THREADS : NT;
-    constexpr int FNT = (NT >= 256) ? SMRT_FINISH_THREADS : NT;
-    auto kp = dort_prep_kernel<PNT>;
-    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
-    auto kf = dort_finish_kernel<NT>;
-    auto kf2 = dort_finish2_kernel<FNT>;
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
-    const int out_stride = ctx->out_stride;
-    if (getenv("SMRT_DORT_DEBUG_OCCUPANCY")) {  // resident workgroups per CU as the runtime sees them
-        int op = 0, oj = 0, of2 = 0, of = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&op, kp, PNT, ctx->prep_lds_bytes);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&oj, kj, SMRT_JACOBI_NT, ctx->jacobi_lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of2, kf2, FNT, ctx->finish2_lds_bytes);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, kf, NT, ctx->lds_bytes);
-        fprintf(stderr, "occupancy (workgroups/CU): prep<%d> lds=%zu -> %d | jacobi<256> lds=%zu -> %d | finish2<%d> lds=%zu -> %d | "
-                        "finish<%d> lds=%zu -> %d\n", PNT, ctx->prep_lds_bytes, op, ctx->jacobi_lds, oj, FNT,
-                ctx->finish2_lds_bytes, of2, NT, ctx->lds_bytes, of);
-    }
-    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
-        DevBatch c = d;
-        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
-        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
-        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
-        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
-        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
-        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
-        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * d.Lmax)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
-        if (ctx->finish2) hipLaunchKernelGGL(kf2, dim3((unsigned)cn), dim3(FNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
-        else hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(NT), ctx->lds_bytes, ctx->stream, c, ctx->stage);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
-static hipError_t launch_split_gmem(smrt_dort_ctx* ctx, const DevBatch& d) {
-    constexpr int NT = 256;
-    auto kp = ctx->active ? dort_active_prep_kernel_gmem<NT> : dort_prep_kernel_gmem<NT>;
-    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
-    auto kf = ctx->active ? dort_active_finish_kernel_gmem<NT> : dort_finish_kernel_gmem<NT>;
+// prep -> Jacobi -> finish, chunk by chunk (the staging area holds one chunk)
+static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
-    const int out_stride = ctx->out_stride;
+    if (getenv("SMRT_DORT_DEBUG_OCCUPANCY") && !ctx->gmem_path && !ctx->active) smrt_launch::occupancy_report(ctx, ctx->nt);
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
-        DevBatch c = d;
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
-        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
-        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
-        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
-        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
-        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
-        const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(NT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        const DevBatch c = chunk_of(ctx, d, c0, cn);
+        hipError_t e;
+        if (ctx->gmem_split) {
+            const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
+            if ((e = smrt_launch::prep_gmem(ctx, c, grid, ctx->active)) != hipSuccess) return e;
+            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
+            if ((e = smrt_launch::finish_gmem(ctx, c, grid, ctx->active)) != hipSuccess) return e;
+        } else if (ctx->active) {
+            if ((e = smrt_launch::active_prep(ctx, c, ctx->nt)) != hipSuccess) return e;
+            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
+            if ((e = smrt_launch::active_finish(ctx, c, ctx->nt)) != hipSuccess) return e;
+        } else {
+            if ((e = smrt_launch::prep(ctx, c, ctx->nt)) != hipSuccess) return e;
+            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
+            if ((e = smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2)) != hipSuccess) return e;
+        }
     }
     return hipSuccess;
-}
-
-template <int NT>
-static hipError_t launch_split_active(smrt_dort_ctx* ctx, const DevBatch& d) {
-    constexpr int PNT = (NT >= 256) ? 256 : NT;
-    auto kp = dort_active_prep_kernel<PNT>;
-    auto kj = dort_jacobi_kernel<SMRT_JACOBI_NT>;
-    auto kf = dort_active_finish_kernel<PNT>;
-    hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->prep_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->finish2_lds_bytes)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)kj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->jacobi_lds)) != hipSuccess) return e;
-    const int out_stride = ctx->out_stride;
-    const long long items_per_pair = (long long)(d.m_max + 1) * d.Lmax;
-    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
-        DevBatch c = d;
-        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
-        c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
-        c.out = d.out + c0 * out_stride; c.status = d.status + c0;
-        c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
-        c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
-        c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
-        hipLaunchKernelGGL(kp, dim3((unsigned)cn), dim3(PNT), ctx->prep_lds_bytes, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kj, dim3((unsigned)(cn * items_per_pair)), dim3(SMRT_JACOBI_NT), ctx->jacobi_lds, ctx->stream, c, ctx->stage);
-        hipLaunchKernelGGL(kf, dim3((unsigned)cn), dim3(PNT), ctx->finish2_lds_bytes, ctx->stream, c, ctx->stage);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
-template <int NT>
-static hipError_t launch_nt(smrt_dort_ctx* ctx, const DevBatch& d) {
-    if (ctx->active && ctx->split && ctx->finish2 && ctx->chunk_pairs > 0) return launch_split_active<NT>(ctx, d);
-    if (!ctx->active && ctx->split && ctx->chunk_pairs > 0) return launch_split<NT>(ctx, d);
-    auto kern = ctx->active ? dort_active_kernel<NT, 1> : dort_passive_kernel<NT, 1>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)d.pair_count), dim3(NT), ctx->lds_bytes, ctx->stream, d);
-    return hipGetLastError();
 }
 
 extern "C" {
@@ -356,7 +114,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm};
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -376,24 +134,39 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
 
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
     if (!ctx) return -1;
-    if (threads == 0) threads = 512;
-    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) {
-        ctx->err = "block threads must be 64, 128, 256, 512 or 1024";
+    if (threads == 0) threads = 256;
+    if (threads != 64 && threads != 256) {   // one wavefront (the serial corner of every stage) or the tuned four
+        ctx->err = "block threads must be 64 or 256";
         return -1;
     }
     ctx->nt = threads;
     return 0;
 }
 
-int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count) {
+}  // extern "C"
+
+// pairs == nullptr: the contiguous range [pair_begin, pair_begin + pair_count) of the flattened list; otherwise the
+// n = pair_count listed pairs (pair_begin ignored)
+static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count,
+                           const int64_t* pairs) {
     if (!ctx) return -1;
     const char* why = smrt_host::validate(b);
     if (why) { ctx->err = why; return -1; }
+    // HIP's current device is per host thread: bind it BEFORE the first allocation below, or a buffer that has to
+    // grow would land on whatever device the calling thread used last
+    HIPCHK(hipSetDevice(ctx->device));
     ctx->active = (b->mode == SMRT_MODE_ACTIVE);
     if (ctx->active && (b->m_max < 0 || b->m_max > 64)) { ctx->err = "m_max must be in 0..64"; return -1; }
     const int64_t npairs = (int64_t)b->n_snowpacks * b->n_frequencies;
-    if (pair_count < 0) pair_count = npairs - pair_begin;
-    if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
+    if (pairs) {
+        pair_begin = 0;
+        if (pair_count <= 0) { ctx->err = "empty pair list"; return -1; }
+        for (int64_t i = 0; i < pair_count; ++i)
+            if (pairs[i] < 0 || pairs[i] >= npairs) { ctx->err = "pair index out of bounds"; return -1; }
+    } else {
+        if (pair_count < 0) pair_count = npairs - pair_begin;
+        if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
+    }
     const int P = ctx->active ? 3 : 2;
     const int nphi = ctx->active ? azimuth_samples(b->m_max) / 2 + 1 : 9;
     const int actd = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta) : 0;
@@ -456,7 +229,6 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
             return -1;
         }
     }
-    HIPCHK(hipSetDevice(ctx->device));
     const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
     if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;
     if (upload_array(ctx, ctx->d_thick, b->thickness, sizeof(double) * SL)) return -1;
@@ -466,6 +238,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     if (upload_array(ctx, ctx->d_p2, b->micro_p2 ? b->micro_p2 : b->micro_p1, sizeof(double) * SL)) return -1;
     if (upload_array(ctx, ctx->d_freq, b->frequency, sizeof(double) * b->n_frequencies)) return -1;
     if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
+    if (pairs && upload_array(ctx, ctx->d_pairmap, pairs, sizeof(int64_t) * pair_count)) return -1;
     const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
         if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;
@@ -497,6 +270,7 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     d.want_layer_out = 1; d.want_stream_out = 1;
     d.jac_in_lds = ctx->gmem_path ? ctx->jac_in_lds : 0;
     d.pair_begin = pair_begin; d.pair_count = pair_count;
+    d.pair_map = pairs ? (const long long*)ctx->d_pairmap.p : nullptr;
     d.n_layers = (const int*)ctx->d_nl.p; d.thickness = (const double*)ctx->d_thick.p;
     d.frac_volume = (const double*)ctx->d_fv.p; d.temperature = (const double*)ctx->d_temp.p;
     d.p1 = (const double*)ctx->d_p1.p; d.p2 = (const double*)ctx->d_p2.p;
@@ -517,6 +291,32 @@ int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_b
     return 0;
 }
 
+extern "C" {
+
+int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count) {
+    return upload_impl(ctx, b, pair_begin, pair_count, nullptr);
+}
+
+int32_t smrt_dort_upload_pairs(smrt_dort_ctx* ctx, const smrt_batch* b, const int64_t* pairs, int64_t n_pairs) {
+    if (ctx && !pairs) { ctx->err = "null pair list"; return -1; }
+    return upload_impl(ctx, b, 0, n_pairs, pairs);
+}
+
+int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
+#define SMRT_OFF(f) (int32_t)offsetof(smrt_batch, f)
+    const int32_t desc[] = {(int32_t)sizeof(smrt_batch),
+        SMRT_OFF(n_snowpacks), SMRT_OFF(n_layers_max), SMRT_OFF(n_frequencies), SMRT_OFF(n_theta), SMRT_OFF(emmodel),
+        SMRT_OFF(microstructure), SMRT_OFF(mode), SMRT_OFF(n_max_stream), SMRT_OFF(m_max), SMRT_OFF(phase_normalization),
+        SMRT_OFF(rayleigh_jeans), SMRT_OFF(substrate_kind), SMRT_OFF(n_layers), SMRT_OFF(thickness), SMRT_OFF(frac_volume),
+        SMRT_OFF(temperature), SMRT_OFF(micro_p1), SMRT_OFF(micro_p2), SMRT_OFF(frequency), SMRT_OFF(theta), SMRT_OFF(phi),
+        SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
+        SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth)};
+#undef SMRT_OFF
+    const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
+    for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];
+    return n;
+}
+
 int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     if (!ctx) return -1;
     if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
@@ -533,23 +333,10 @@ int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e;
-    if (ctx->gmem_path) {
-        if (ctx->gmem_split) e = launch_split_gmem(ctx, d);
-        else if (ctx->nmax_rows <= 128) e = launch_gmem<256, 2>(ctx, d);
-        else if (ctx->nmax_rows <= 256) e = launch_gmem<256, 4>(ctx, d);
-        else e = launch_gmem<256, 6>(ctx, d);
-        HIPCHK(e);
-        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-        ctx->timing_pending = true;
-        return 0;
-    }
-    switch (ctx->nt) {
-        case 64: e = launch_nt<64>(ctx, d); break;
-        case 128: e = launch_nt<128>(ctx, d); break;
-        case 256: e = launch_nt<256>(ctx, d); break;
-        case 1024: e = launch_nt<1024>(ctx, d); break;
-        default: e = launch_nt<512>(ctx, d); break;
-    }
+    const bool lds_pipeline = !ctx->gmem_path && ctx->split && ctx->chunk_pairs > 0 && (!ctx->active || ctx->finish2);
+    if (ctx->gmem_split || lds_pipeline) e = launch_pipeline(ctx, d);
+    else if (ctx->gmem_path) e = smrt_launch::fused_gmem(ctx, d, ctx->nmax_rows <= 128 ? 2 : ctx->nmax_rows <= 256 ? 4 : 6, ctx->active);
+    else e = smrt_launch::fused(ctx, d, ctx->nt, ctx->active);
     HIPCHK(e);
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timing_pending = true;
@@ -616,6 +403,13 @@ int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16) {
 int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count, double* out,
                       int32_t* status, double* layer_out, double* stream_out) {
     if (smrt_dort_upload(ctx, batch, pair_begin, pair_count)) return -1;
+    if (smrt_dort_launch(ctx, nullptr, nullptr)) return -1;
+    return smrt_dort_download(ctx, out, status, layer_out, stream_out);
+}
+
+int32_t smrt_dort_run_pairs(smrt_dort_ctx* ctx, const smrt_batch* batch, const int64_t* pairs, int64_t n_pairs, double* out,
+                            int32_t* status, double* layer_out, double* stream_out) {
+    if (smrt_dort_upload_pairs(ctx, batch, pairs, n_pairs)) return -1;
     if (smrt_dort_launch(ctx, nullptr, nullptr)) return -1;
     return smrt_dort_download(ctx, out, status, layer_out, stream_out);
 }

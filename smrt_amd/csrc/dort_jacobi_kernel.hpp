@@ -216,7 +216,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
     const long long p = item / ((long long)b.Lmax * nmodes);
     const int l = (int)(item % b.Lmax);
-    const long long gp = b.pair_begin + p;
+    const long long gp = global_pair(b, p);
     const int si = (int)(gp % b.S);
     if (l >= b.n_layers[si]) return;          // uniform
     if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
@@ -258,14 +258,25 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 #endif
 }
 
+// Rows per lane follow the item's OWN size N = stg.n[item] (streams x polarisations of that layer: total reflection
+// removes streams, so N varies from layer to layer), not the batch maximum: the padded rows RPL * GS are the first
+// multiple of GS >= N (a few sizes are merged to bound the number of instantiations).  The LDS layout (LDJ) is the
+// one of the batch maximum, so every variant fits.
 template <int NT>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
-    const int NMAX = b.n_max_stream * (b.mode == 1 ? 3 : 2);   // rows per lane = ceil(NMAX / 8): RPL * 8 <= NMAX (< LD)
-    constexpr int G = SMRT_JACOBI_GS;   // rows per lane = padded rows / lanes per column pair
-    if (NMAX > 64) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
-    else if (NMAX > 32) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
-    else if (NMAX > 16) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
-    else if (NMAX > 8) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
+    constexpr int G = SMRT_JACOBI_GS;   // lanes per column pair
+    const int nitem = stg.n[item];      // <= 0: nothing to do (the impl returns at once)
+    const int rpl = (nitem + G - 1) / G;
+    if (rpl > 14) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
+    else if (rpl > 12) dort_jacobi_item_impl<NT, 112 / G>(b, stg, item, lds);
+    else if (rpl > 10) dort_jacobi_item_impl<NT, 96 / G>(b, stg, item, lds);
+    else if (rpl > 8) dort_jacobi_item_impl<NT, 80 / G>(b, stg, item, lds);
+    else if (rpl > 7) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
+    else if (rpl > 6) dort_jacobi_item_impl<NT, 56 / G>(b, stg, item, lds);
+    else if (rpl > 5) dort_jacobi_item_impl<NT, 48 / G>(b, stg, item, lds);
+    else if (rpl > 4) dort_jacobi_item_impl<NT, 40 / G>(b, stg, item, lds);
+    else if (rpl > 2) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
+    else if (rpl > 1) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
     else dort_jacobi_item_impl<NT, 8 / G>(b, stg, item, lds);
 }
 

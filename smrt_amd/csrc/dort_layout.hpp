@@ -16,6 +16,8 @@ struct DevBatch {
     int want_layer_out, want_stream_out;
     int jac_in_lds;  // global-workspace kernels: the Jacobi stage runs on an LDS copy of B (host: it fits)
     long long pair_begin, pair_count;
+    const long long* pair_map;  // null: workgroup p solves pair pair_begin + p of the flattened f * S + s list; else
+                                // pair pair_map[pair_begin + p] (sparse selections, smrt_dort_upload_pairs)
     const int* n_layers;
     const double* thickness;
     const double* frac_volume;
@@ -51,6 +53,11 @@ struct DevStage {
     int vec_stride;        // doubles per vector slot (NMAX)
     double* Linv;          // [item][4][256] inverses of the 16x16 diagonal blocks of L+ (written by the prep kernel)
 };
+
+// index into the flattened (frequency-major) pair list of the batch for the p-th workgroup of a launch
+SMRT_DEV long long global_pair(const DevBatch& b, long long p) {
+    return b.pair_map ? b.pair_map[b.pair_begin + p] : b.pair_begin + p;
+}
 
 constexpr double kCSpeed = 299792458.0;
 constexpr double kPlanck = 6.62607015e-34;

@@ -174,7 +174,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
 
-    const long long gp = b.pair_begin + p;
+    const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
     const double frequency = b.frequency[fi];
     const int L = b.n_layers[si];
@@ -270,7 +270,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                     fresnel_RvRh(el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs), &Rv, &Rh);
                     Rs = (r & 1) ? Rh : Rv;
                 } else if (b.sub_kind != SUB_NONE) {
-                    const long long gpi = b.pair_begin + p;
+                    const long long gpi = gp;
                     const double q1 = b.sub_p1[gpi], q2 = b.sub_p2[gpi];
                     if (b.sub_kind == SUB_FLAT) {
                         const double rs = s.ri[l] * s.gsin[r >> 1];

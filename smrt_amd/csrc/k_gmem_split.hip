@@ -1,0 +1,65 @@
+// Three-kernel pipeline for 64 < N <= 128 (passive and active): prep and the four-matrix finish on the per-workgroup
+// global workspace (L2 / Infinity-Cache resident, grid-stride over the pairs so that it stays bounded); the shared
+// Jacobi kernel with its 128-column LDS matrix runs in between.
+#include "dort_ctx.hpp"
+#include "dort_active.hpp"
+
+using namespace smrt;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT, 2) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void dort_active_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT>
+__global__ __launch_bounds__(NT, 2) void dort_active_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+
+namespace smrt_launch {
+
+template <class K>
+static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, size_t lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
+    return hipGetLastError();
+}
+
+hipError_t prep_gmem(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active) {
+    return active ? go(dort_active_prep_kernel_gmem<256>, ctx, c, grid, ctx->prep_lds_bytes)
+                  : go(dort_prep_kernel_gmem<256>, ctx, c, grid, ctx->prep_lds_bytes);
+}
+hipError_t finish_gmem(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active) {
+    return active ? go(dort_active_finish_kernel_gmem<256>, ctx, c, grid, ctx->finish2_lds_bytes)
+                  : go(dort_finish_kernel_gmem<256>, ctx, c, grid, ctx->finish2_lds_bytes);
+}
+
+}  // namespace smrt_launch

@@ -21,16 +21,15 @@ class _DeviceEMModel:
 
     def _device_properties(self):
         if self._props is None:
-            from .._native import DortContext, PackedBatch
+            from .._native import PackedBatch
+            from ..rtsolver.dort import get_context
 
             p1, p2 = self.layer.microstructure.device_params
             batch = PackedBatch([1], [100.0], [self.layer.frac_volume], [self.layer.temperature], [p1], [p2],
                                 [self.frequency], [0.0], emmodel=self.device_name,
                                 microstructure=self.layer.microstructure_model, n_max_stream=4,
                                 phase_normalization="forced")
-            ctx = DortContext(0)
-            out = ctx.run(batch)
-            ctx.close()
+            out = get_context(0).run(batch)   # the shared, cached context of GPU 0 (serialised by its lock)
             lay = out.layers[0, 0]
             self._props = dict(eps=complex(lay[0], lay[1]), ks=float(lay[2]), ka=float(lay[3]))
         return self._props

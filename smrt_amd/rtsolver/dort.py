@@ -1,20 +1,24 @@
 """DORT radiative-transfer solver, MI355X-native (drop-in for smrt/rtsolver/dort.py:84-261).
 
 Same constructor options and `solve()` protocol as the reference class; the numerical work (layer electromagnetics,
-streams, interfaces, eigen-decomposition, boundary conditions) runs in the HIP kernel through the C ABI.  In addition
-to the reference's one-simulation `solve`, `solve_batch` takes a whole list of (sensor, snowpack) simulations and
-launches them at once -- that is what the batching runner calls.
+streams, interfaces, eigen-decomposition, boundary conditions) runs in the HIP kernels through the C ABI
+(include/smrt_dort.h).  Three entry points, from the reference's to the batched one:
+
+* `solve(snowpack, emmodels, sensor, atmosphere)` -- the rtsolver protocol, one simulation (what
+  `Model.run_single_simulation` calls, smrt/core/model.py:596-617);
+* `solve_batch(simulations, emmodel)` -- a list of (single-frequency sensor, snowpack) pairs in one launch per group,
+  one Result each;
+* `solve_plan(model, plan)` -- a whole `SimulationPlan` (smrt_amd/core/model.py): index vectors instead of pair
+  objects, distinct snowpacks packed once, the stacked Result built from the output array without per-pair objects.
 """
 import threading
 
 import numpy as np
 
-from .._native import STATUS_MESSAGES, DortContext, PackedBatch
-from ..core.error import SMRTError, smrt_warn
+from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
+from ..core.error import SMRTError
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack
-from ..emmodel.dmrt_qca_shortrange import DMRT_QCA_ShortRange
-from ..emmodel.iba import IBA
 
 _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
 
@@ -22,8 +26,10 @@ _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88
 class DORT(object):
     """Discrete-ordinate and eigenvalue solver (Picard et al. 2018), device implementation.
 
-    Args follow smrt/rtsolver/dort.py:148-161.  `diagonalization_method` is accepted for compatibility: the device
-    always uses its own symmetric reduction (all reference methods agree with it to ~1e-11 K)."""
+    Arguments as smrt/rtsolver/dort.py:148-161.  `diagonalization_method` and `diagonalization_cache` are accepted for
+    compatibility: the device always uses its own symmetric reduction (every reference method agrees with it to
+    ~1e-11 K) and has nothing to cache.  `devices` (list of GPU indices, default: all visible ones for large batches)
+    and `block_threads` are smrt_amd's own knobs."""
 
     _broadcast_capability = {"theta_inc", "polarization_inc", "theta", "phi", "polarization"}
 
@@ -33,15 +39,12 @@ class DORT(object):
                  rayleigh_jeans_approximation=False, devices=None, block_threads=0):
         if stream_mode != "most_refringent":
             raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
-        if phase_symmetrization or process_coherent_layers:
-            raise SMRTError("phase_symmetrization and process_coherent_layers are outside the scope of smrt_amd's DORT")
-        # diagonalization_cache only saves the reference repeated eigen-decompositions of identical layers: accepted,
-        # no effect here.  prune_deep_snowpack: True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
-        if prune_deep_snowpack is True:
+        if phase_symmetrization:
+            raise SMRTError("phase_symmetrization is outside the scope of smrt_amd's DORT")
+        if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
             prune_deep_snowpack = 6
-        if prune_deep_snowpack is not None and prune_deep_snowpack is not False and not float(prune_deep_snowpack) > 0:
+        if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
             raise SMRTError("prune_deep_snowpack must be None, True or a positive optical depth")
-        self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         if diagonalization_method not in _DIAG_METHODS:
             raise SMRTError(f"Unknown method '{diagonalization_method}' to diagonalize the matrix")
         if error_handling not in ("exception", "nan"):
@@ -53,49 +56,76 @@ class DORT(object):
         self.stream_mode = stream_mode
         self.phase_normalization = phase_normalization
         self.error_handling = error_handling
+        self.process_coherent_layers = bool(process_coherent_layers)
+        self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         self.diagonalization_method = diagonalization_method
         self.rayleigh_jeans_approximation = bool(rayleigh_jeans_approximation)
         self.devices = devices
         self.block_threads = int(block_threads)
 
-    # ---- the reference's protocol --------------------------------------------------------------------------
+    # ---- the reference's protocol --------------------------------------------------------------------------------
     def solve(self, snowpack, emmodels, sensor, atmosphere=None, parallel_computation=None):
-        """Solve one (snowpack, sensor-configuration); `emmodels` are the per-layer instances made by
-        Model.prepare_emmodels (only their class and layer are used: the device recomputes their numbers)."""
+        """One (snowpack, sensor configuration).  `emmodels`: the per-layer instances made by Model.prepare_emmodels;
+        they must be smrt_amd's device-backed classes, all of one kind (the device recomputes their numbers from the
+        layer properties)."""
         if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
             snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
                                 atmosphere=atmosphere)
-        emmodel_cls = type(emmodels[0]) if emmodels else IBA
-        if any(type(e) is not emmodel_cls for e in emmodels):
+        kinds = {type(e) for e in emmodels}
+        if len(kinds) != 1:
             raise SMRTError("smrt_amd's DORT needs the same emmodel in all the layers")
-        return self.solve_batch([(sensor, snowpack)], emmodel_cls)[0]
+        return self.solve_batch([(sensor, snowpack)], kinds.pop())[0]
 
-    # ---- batched entry point -------------------------------------------------------------------------------
-    def solve_batch(self, simulations, emmodel_cls=IBA):
-        """simulations: sequence of (sensor, snowpack) with single-frequency sensors.  Returns one Result each."""
-        simulations = list(simulations)
-        if not simulations:
+    # ---- batched entry points ------------------------------------------------------------------------------------
+    def solve_batch(self, simulations, emmodel_cls):
+        """simulations: sequence of (single-frequency sensor, snowpack).  One Result per simulation, in order."""
+        sensors, packs, si, pi = [], [], [], []
+        seen_s, seen_p = {}, {}
+        for sensor, sp in simulations:
+            si.append(seen_s.setdefault(id(sensor), len(sensors)))
+            if si[-1] == len(sensors):
+                sensors.append(sensor)
+            pi.append(seen_p.setdefault(id(sp), len(packs)))
+            if pi[-1] == len(packs):
+                packs.append(sp)
+        if not si:
             return []
-        device_name = getattr(emmodel_cls, "device_name", None)
-        if device_name is None:
-            raise SMRTError(f"emmodel {emmodel_cls} has no device implementation in smrt_amd (iba, "
-                            "dmrt_qca_shortrange)")
-        results = [None] * len(simulations)
-        # group by everything that must be uniform inside one device batch
-        groups = {}
-        for i, (sensor, sp) in enumerate(simulations):
-            self._check_sensor(sensor)
-            micro = {lay.microstructure_model for lay in sp.layers}
-            if len(micro) != 1:
-                raise SMRTError("smrt_amd's DORT needs the same microstructure model in all the layers")
-            angles = sensor.theta_inc_deg if sensor.mode == "A" else sensor.theta_deg
-            key = (sensor.mode, micro.pop(), tuple(np.round(angles, 12)), float(np.ravel(sensor.phi)[0]),
-                   getattr(sp.substrate, "device_kind", None), id(sp.atmosphere) if sp.atmosphere is not None else None)
-            groups.setdefault(key, []).append(i)
-        for (mode, micro, _, phi, _sub, _atm), idx in groups.items():
-            self._run_group(simulations, idx, device_name, mode, micro, phi, results)
-        return results
+        sol = self._solve_indexed(sensors, packs, np.asarray(si), np.asarray(pi), emmodel_cls)
+        return [sol.result(i) for i in range(len(si))]
 
+    def solve_plan(self, model, plan):
+        """The whole plan of a Model.run: returns the nested Result directly."""
+        from ..core.model import nest_results
+
+        emmodel_cls = self._uniform_emmodel(model, plan)
+        sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, emmodel_cls)
+        stacked = sol.stacked_result(plan)
+        if stacked is not None:
+            return stacked
+        return nest_results([sol.result(i) for i in range(len(plan))], plan.dimensions)
+
+    @staticmethod
+    def _uniform_emmodel(model, plan):
+        """The one emmodel class of the batch, after the same checks the per-simulation route applies through
+        Model.prepare_emmodels (per-layer overrides and emmodel options are not silently dropped): one instance is
+        made for a layer of the first snowpack, which validates the options against the class."""
+        kinds, options = set(), []
+        for sp in plan.snowpacks:
+            n = sp.nlayer
+            for k, layer in enumerate(sp.layers):
+                kinds.add(model.emmodel_of_layer(k, layer, n))
+                if getattr(layer, "emmodel_options", None):
+                    options.append(layer.emmodel_options)
+        if len({getattr(k, "device_name", id(k)) for k in kinds}) != 1:
+            raise SMRTError("smrt_amd's DORT needs the same emmodel in all the layers of a batch")
+        if any(o != model.emmodel_options for o in options):
+            raise SMRTError("smrt_amd's DORT needs the same emmodel options in all the layers of a batch")
+        cls = kinds.pop()
+        first = plan.snowpacks[0]
+        cls(plan.sensors[0], first.layers[0], **model.emmodel_options_of_layer(first.layers[0]))  # validates the options
+        return cls
+
+    # ---- grouping, packing, launching ----------------------------------------------------------------------------
     def _check_sensor(self, sensor):
         if np.ndim(sensor.frequency) != 0:
             raise SMRTError("DORT does not broadcast the frequency: split the sensor first (Model.run does)")
@@ -104,36 +134,59 @@ class DORT(object):
         if sensor.mode == "A" and not np.array_equal(sensor.theta_deg, sensor.theta_inc_deg):
             raise SMRTError("smrt_amd's DORT computes the backscatter (theta == theta_inc) in active mode")
 
-    def _run_group(self, simulations, idx, device_name, mode, micro, phi, results):
-        # distinct snowpacks / frequencies; the device batch is the Cartesian product S x F
-        sps, sp_index = [], {}
-        freqs, f_index = [], {}
-        for i in idx:
-            sensor, sp = simulations[i]
-            if id(sp) not in sp_index:
-                sp_index[id(sp)] = len(sps)
-                sps.append(sp)
-            f = float(sensor.frequency)
-            if f not in f_index:
-                f_index[f] = len(freqs)
-                freqs.append(f)
-        S, F = len(sps), len(freqs)
-        Lmax = max(sp.nlayer for sp in sps)
-        shape = (S, Lmax)
-        thick, fv, temp = np.ones(shape), np.full(shape, 0.3), np.full(shape, 260.0)
-        p1, p2 = np.full(shape, 1e-4), np.full(shape, 0.2)
-        nl = np.empty(S, np.int32)
-        for s, sp in enumerate(sps):
-            n = sp.nlayer
-            nl[s] = n
-            thick[s, :n] = [lay.thickness for lay in sp.layers]
-            fv[s, :n] = [lay.frac_volume for lay in sp.layers]
-            temp[s, :n] = [lay.temperature for lay in sp.layers]
-            pp = [lay.microstructure.device_params for lay in sp.layers]
-            p1[s, :n] = [a for a, _ in pp]
-            p2[s, :n] = [b for _, b in pp]
-        sensor0 = simulations[idx[0]][0]
-        angles = sensor0.theta_inc if mode == "A" else sensor0.theta
+    def _solve_indexed(self, sensors, packs, sens_idx, pack_idx, emmodel_cls):
+        device_name = getattr(emmodel_cls, "device_name", None)
+        if device_name is None:
+            raise SMRTError(f"emmodel {emmodel_cls} has no device implementation in smrt_amd (iba, dmrt_qca_shortrange, "
+                            "dmrt_qcacp_shortrange, nonscattering)")
+        # everything that must be uniform inside one device batch, as small integer codes per sensor / per snowpack
+        sensor_keys, pack_keys = {}, {}
+        s_code = np.empty(len(sensors), np.int64)
+        for k, sensor in enumerate(sensors):
+            self._check_sensor(sensor)
+            angles = sensor.theta_inc_deg if sensor.mode == "A" else sensor.theta_deg
+            key = (sensor.mode, tuple(np.round(angles, 12)), float(np.ravel(sensor.phi)[0]))
+            s_code[k] = sensor_keys.setdefault(key, len(sensor_keys))
+        p_code = np.empty(len(packs), np.int64)
+        for k, sp in enumerate(packs):
+            micro = sp.microstructure_models
+            if len(micro) != 1:
+                raise SMRTError("smrt_amd's DORT needs the same microstructure model in all the layers")
+            key = (next(iter(micro)), getattr(sp.substrate, "device_kind", None),
+                   id(sp.atmosphere) if sp.atmosphere is not None else None)
+            p_code[k] = pack_keys.setdefault(key, len(pack_keys))
+        freq = np.array([float(s.frequency) for s in sensors])
+        code = s_code[sens_idx] * len(pack_keys) + p_code[pack_idx]
+        sol = _Solution(self, sensors, packs, sens_idx, pack_idx)
+        for g in np.unique(code):
+            sel = np.nonzero(code == g)[0]
+            u_packs, inv_p = np.unique(pack_idx[sel], return_inverse=True)
+            u_freq, inv_f = np.unique(freq[sens_idx[sel]], return_inverse=True)
+            sensor0, sp0 = sensors[sens_idx[sel[0]]], packs[u_packs[0]]
+            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, device_name)
+            pairs = inv_f * len(u_packs) + inv_p
+            full = len(pairs) == batch.n_pairs and np.array_equal(pairs, np.arange(batch.n_pairs))
+            out = run_on_devices(batch, self.devices, self.block_threads, pairs=None if full else pairs)
+            bad = np.nonzero(out.status != 0)[0]
+            if len(bad) and self.error_handling == "exception":
+                st = int(out.status[bad[0]])
+                raise SMRTError(STATUS_MESSAGES.get(st, f"DORT failed with status {st}"))
+            sol.add_group(sel, out, sp0)
+        return sol
+
+    def _pack(self, sensor0, sps, freqs, device_name):
+        """The device batch of one group: S distinct snowpacks x F distinct frequencies."""
+        S = len(sps)
+        nl = np.fromiter((sp.nlayer for sp in sps), np.int32, S)
+        Lmax = int(nl.max())
+        if int(nl.min()) == Lmax:
+            cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
+        else:
+            cols = np.empty((5, S, Lmax))
+            cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
+            for s, sp in enumerate(sps):
+                cols[:, s, :nl[s]] = sp.packed()
+        mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate
         if sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
@@ -144,39 +197,62 @@ class DORT(object):
         if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)
             a = np.array([atm0.device_params(f) for f in freqs])  # (F, 3)
             atmosphere = (a[:, 0], a[:, 1], a[:, 2])
-        batch = PackedBatch(nl, thick, fv, temp, p1, p2, freqs, angles, emmodel=device_name, microstructure=micro,
-                            mode=mode, n_max_stream=self.n_max_stream, m_max=self.m_max,
-                            phase_normalization=self.phase_normalization,
-                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=phi, substrate=substrate,
-                            atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack)
-        wanted = np.array([f_index[float(simulations[i][0].frequency)] * S + sp_index[id(simulations[i][1])]
-                           for i in idx])
-        out = run_on_devices(batch, self.devices, self.block_threads, needed=np.unique(wanted))
-        for i, pidx in zip(idx, wanted):
-            sensor, sp = simulations[i]
-            st = int(out.status[pidx])
-            if st != 0 and self.error_handling == "exception":
-                raise SMRTError(STATUS_MESSAGES.get(st, f"DORT failed with status {st}"))
-            results[i] = self._make_result(sensor, sp, out, pidx)
+        return PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs,
+                           sensor0.theta_inc if mode == "A" else sensor0.theta, emmodel=device_name,
+                           microstructure=sps[0].layers[0].microstructure_model, mode=mode,
+                           n_max_stream=self.n_max_stream, m_max=self.m_max,
+                           phase_normalization=self.phase_normalization,
+                           rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
+                           substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack)
 
-    def _make_result(self, sensor, sp, out, p):
-        """Labels and diagnostics of DiscreteOrdinatesMixin.make_result (rtsolver_utils.py:322-344,373-398)."""
-        L = sp.nlayer
+
+class _Solution:
+    """Outputs of the device batches of one call, addressable per simulation and stackable as one Result."""
+
+    def __init__(self, solver, sensors, packs, sens_idx, pack_idx):
+        self.solver, self.sensors, self.packs = solver, sensors, packs
+        self.sens_idx, self.pack_idx = np.asarray(sens_idx), np.asarray(pack_idx)
+        n = len(self.sens_idx)
+        self.group_of = np.full(n, -1, np.int64)
+        self.row_of = np.zeros(n, np.int64)
+        self.outputs = []
+
+    def add_group(self, sel, out, sp0):
+        self.group_of[sel] = len(self.outputs)
+        self.row_of[sel] = np.arange(len(sel))
+        self.outputs.append(out)
+
+    # -- labels ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _coords(sensor):
         if sensor.mode == "P":
-            coords = [("polarization", ["V", "H"]), ("theta", sensor.theta_deg)]
-        else:
-            pola = ["V", "H", "U"]
-            coords = [("polarization_inc", pola), ("polarization", pola), ("theta_inc", sensor.theta_inc_deg)]
-        n_air = int(out.streams[p, 0])
-        outmu = out.streams[p, 1:1 + n_air]
-        if sensor.mode == "A":  # only the incident streams are reported (rtsolver_utils.py:307-316, dort.py:210-226)
+            return [("polarization", ["V", "H"]), ("theta", sensor.theta_deg)]
+        pola = ["V", "H", "U"]
+        return [("polarization_inc", pola), ("polarization", pola), ("theta_inc", sensor.theta_inc_deg)]
+
+    @staticmethod
+    def _reported_streams(sensor, streams_row):
+        """Cosines of the air streams of Result.other_data['stream_angles']: all of them in passive mode, only the
+        incident ones in active mode (rtsolver_utils.py:307-316, dort.py:210-226)."""
+        n_air = int(streams_row[0])
+        outmu = streams_row[1:1 + n_air]
+        if sensor.mode == "A":
             keep = set()
             for mu_inc in np.cos(np.atleast_1d(sensor.theta_inc)):
                 i0 = int(np.searchsorted(-outmu, -mu_inc))
                 keep.update((0,) if i0 == 0 else ((n_air - 1,) if i0 == n_air else (i0, i0 - 1)))
             outmu = outmu[sorted(keep)]
+        return outmu
+
+    def result(self, i):
+        """The Result of simulation i with the labels and diagnostics of DiscreteOrdinatesMixin.make_result
+        (rtsolver_utils.py:322-344,373-398)."""
+        sensor, sp = self.sensors[self.sens_idx[i]], self.packs[self.pack_idx[i]]
+        out, row = self.outputs[self.group_of[i]], self.row_of[i]
+        L = sp.nlayer
+        outmu = self._reported_streams(sensor, out.streams[row])
         layer_idx = ("layer", np.arange(L))
-        lay = out.layers[p, :L]
+        lay = out.layers[row, :L]
         other = {
             "stream_angles": LabeledArray(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
             "effective_permittivity": LabeledArray(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
@@ -185,14 +261,67 @@ class DORT(object):
             "ka": LabeledArray(lay[:, 3].copy(), [layer_idx], name="ka"),
             "thickness": LabeledArray(sp.layer_thicknesses, [layer_idx], name="thickness"),
         }
-        return make_result(sensor, out.values[p], coords, other_data=other)
+        return make_result(sensor, out.values[row], self._coords(sensor), other_data=other)
+
+    def stacked_result(self, plan):
+        """All simulations as ONE Result whose leading dimensions are the plan's -- built from the output arrays by
+        reshaping (no per-simulation objects).  None when the simulations are not one homogeneous grid (several device
+        groups, different channel maps): the caller then nests per-simulation results."""
+        if len(self.outputs) != 1 or not plan.dimensions:
+            return None
+        sensor0 = self.sensors[0]
+        if any(s.channel_map != sensor0.channel_map or s.mode != sensor0.mode for s in self.sensors[1:]):
+            return None
+        out = self.outputs[0]
+        order = self.row_of                       # simulation i -> row of the group output
+        lead = [(name, np.asarray(list(values))) for name, values in plan.dimensions]
+        shape = tuple(len(v) for _, v in lead)
+        if int(np.prod(shape)) != len(order):
+            return None
+        data = LabeledArray(out.values[order].reshape(shape + out.values.shape[1:]), lead + self._coords(sensor0))
+        nl = np.fromiter((sp.nlayer for sp in self.packs), np.int64, len(self.packs))[self.pack_idx]
+        Lmax = int(nl.max())
+        lay = out.layers[order][:, :Lmax].copy()
+        lay[np.arange(Lmax)[None, :] >= nl[:, None]] = np.nan      # ragged packs: NaN below the last layer
+        layer_dim = [("layer", np.arange(Lmax))]
+
+        def stack(values, name=None):
+            return LabeledArray(values.reshape(shape + (Lmax,)), lead + layer_dim, name=name)
+
+        thick = np.full((len(self.packs), Lmax), np.nan)
+        for k, sp in enumerate(self.packs):
+            thick[k, :sp.nlayer] = sp.packed()[0]
+        streams = [self._reported_streams(self.sensors[s], out.streams[r]) for s, r in zip(self.sens_idx, order)] \
+            if sensor0.mode == "A" else None
+        if streams is None:
+            n_air = out.streams[order, 0].astype(np.int64)
+            width = int(n_air.max())
+            mu = out.streams[order, 1:1 + width].copy()
+            mu[np.arange(width)[None, :] >= n_air[:, None]] = np.nan
+        else:
+            width = max(len(s) for s in streams)
+            mu = np.full((len(order), width), np.nan)
+            for k, s in enumerate(streams):
+                mu[k, :len(s)] = s
+        other = {
+            "stream_angles": LabeledArray(np.rad2deg(np.arccos(mu)).reshape(shape + (width,)),
+                                          lead + [("dim_0", np.arange(width))]),
+            "effective_permittivity": stack(lay[:, :, 0] + 1j * lay[:, :, 1]),
+            "ks": stack(lay[:, :, 2], "ks"),
+            "ke": stack(lay[:, :, 2] + lay[:, :, 3], "ke"),
+            "ka": stack(lay[:, :, 3], "ka"),
+            "thickness": stack(thick[self.pack_idx], "thickness"),
+        }
+        return make_result(sensor0, data, other_data=other)
 
 
+# ---- contexts and the multi-GPU fan-out ----------------------------------------------------------------------------
 _ctx_cache = {}
 _ctx_lock = threading.Lock()
 
 
 def get_context(device):
+    """The cached context of a GPU (created on first use; its calls are serialised by DortContext.lock)."""
     with _ctx_lock:
         if device not in _ctx_cache:
             _ctx_cache[device] = DortContext(device)
@@ -200,33 +329,46 @@ def get_context(device):
 
 
 def visible_devices():
-    from .._native import device_count
-
     return list(range(device_count()))
 
 
-def run_on_devices(batch, devices=None, block_threads=0, needed=None):
-    """Run a packed batch, sharding the flattened pair list over the given GPUs (contiguous slices, one host thread
-    and one context per GPU, no collective: the results land in disjoint rows of the same host arrays)."""
-    from .._native import BatchOutput
+def shard_by_cost(cost, n_shards):
+    """Contiguous slices [b[k], b[k+1]) of a cost vector with (nearly) equal cost each: the boundaries are where the
+    running cost crosses k / n_shards of the total (shard by sum_l N_l^3, not by count)."""
+    cost = np.asarray(cost, dtype=np.float64)
+    running = np.concatenate([[0.0], np.cumsum(cost)])
+    targets = running[-1] * np.arange(1, n_shards) / n_shards
+    inner = np.searchsorted(running, targets, side="left")
+    return np.concatenate([[0], np.clip(inner, 0, len(cost)), [len(cost)]]).astype(np.int64)
 
-    n = batch.n_pairs
+
+def run_on_devices(batch, devices=None, block_threads=0, pairs=None, cost=None):
+    """Run a packed batch -- all of it, or the listed pair indices -- sharded over the given GPUs: contiguous slices of
+    the work list (equal cost when `cost` per work item is given, equal counts otherwise), one host thread and one
+    context per GPU, no collective: every GPU writes disjoint rows of the same host arrays."""
+    n = batch.n_pairs if pairs is None else len(pairs)
     if devices is None:
         devices = visible_devices() if n >= 4096 else [0]
     devices = list(devices) or [0]
+
+    def one(dev, lo, hi):
+        ctx = get_context(dev)
+        with ctx.lock:
+            ctx.set_block_threads(block_threads)
+            if pairs is None:
+                return ctx.run(batch, int(lo), int(hi - lo))
+            return ctx.run(batch, pairs=pairs[lo:hi])
+
     if len(devices) == 1:
-        ctx = get_context(devices[0])
-        ctx.set_block_threads(block_threads)
-        return ctx.run(batch)
+        return one(devices[0], 0, n)
+    bounds = shard_by_cost(cost, len(devices)) if cost is not None else \
+        np.linspace(0, n, len(devices) + 1).astype(np.int64)
     out = BatchOutput(batch, n)
-    bounds = np.linspace(0, n, len(devices) + 1).astype(np.int64)
     errors = []
 
     def work(dev, lo, hi):
         try:
-            ctx = get_context(dev)
-            ctx.set_block_threads(block_threads)
-            part = ctx.run(batch, int(lo), int(hi - lo))
+            part = one(dev, lo, hi)
             out.values[lo:hi], out.status[lo:hi] = part.values, part.status
             out.layers[lo:hi], out.streams[lo:hi] = part.layers, part.streams
         except Exception as e:  # noqa: BLE001

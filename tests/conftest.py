@@ -96,6 +96,7 @@ PASSIVE_FIXTURES = [
     "iba_L3_n16_shallow",
     "dmrt_L8_n16",
     "cfg3_dmrt_L50_n64_sp0",
+    "cfg3_dmrt_L50_n64_amsr2_sp1",   # configs[2] at full size: 50 layers, 64 streams, all seven AMSR2 frequencies
     "dmrtcp_2layer_passive37",
     "dmrtcp_L5_n12",
 ]
@@ -106,19 +107,55 @@ ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_
 PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12_prune",
                   "dmrt_L6_n10_prune_over_bad_layer"]  # the last one: layers that cannot be diagonalised below the cut
 PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
+# configs[3] at full size: IBA, sentinel1(), 30 layers, 128 streams, m_max = 2 (N = 256 / 384 rows per azimuth mode)
+BIG_ACTIVE_FIXTURES = ["cfg4_iba_active_L30_n128_sp0", "cfg4_iba_active_L30_n128_sp1"]
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)
 
 
-def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=1e-6):
-    """r, ref: [..., pol, pol_inc, theta_inc].  All four V,H x V,H intensities to `rtol` relative to the co-pol level
-    at that angle.  The cross-polarised terms sit 30-50 dB below co-pol and come out of a cancellation between the
-    azimuth modes: on their OWN scale the reference's diagonalisation methods already differ among themselves by
-    1e-8 .. 1e-7 (eig / half_rank_eig vs schur_forcedtriu, checked in tests/test_oracle_golden.py), so they are held
-    to `cross_rtol` on their own scale on top of `rtol` on the co-pol scale."""
+def reference_method_spread(d):
+    """Element-wise spread of the reference's own answers over its diagonalisation methods (stored in the active
+    fixtures by tests/golden/add_method_spread.py as result_<method>); zeros when the fixture holds none."""
+    ref = np.asarray(d["result"])
+    spread = np.zeros_like(ref)
+    for k in d:
+        if k.startswith("result_"):
+            spread = np.maximum(spread, np.abs(np.asarray(d[k]) - ref))
+    return spread
+
+
+def oracle_method_spread(sp, frequency, theta_deg, ref, methods=("eig", "half_rank_eig"), **solve_kwargs):
+    """The same spread for comparisons against the CPU oracle: |oracle(method) - ref| over the oracle's other
+    diagonalisation methods (a method that fails on the case -- complex pairs on degenerate Rayleigh modes -- is
+    skipped, like in the reference)."""
+    from oracle import dort_oracle as O
+
+    spread = np.zeros_like(np.asarray(ref))
+    for method in methods:
+        try:
+            alt = O.solve(sp, frequency, theta_deg, method=method, **solve_kwargs)
+        except O.OracleError:
+            continue
+        if np.all(np.isfinite(alt)):
+            spread = np.maximum(spread, np.abs(alt - ref))
+    return spread
+
+
+def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=SIGMA_RTOL, spread=None, spread_factor=3.0):
+    """r, ref: [..., pol, pol_inc, theta_inc].  EVERY V,H x V,H intensity to 1e-8 relative on its own scale -- the
+    north_star's bar -- co- and cross-polarised alike.  `spread` (same shape as ref, from reference_method_spread) widens
+    the tolerance of an element to `spread_factor` times the disagreement among the reference's own eigensolvers where
+    that is larger: the cross-polarised terms sit 30-50 dB below co-pol and come out of a cancellation between the
+    azimuth modes, so the reference's answer is itself only defined to that spread (1e-9 .. 1e-7 on the fixtures)."""
     r, ref = np.asarray(r), np.asarray(ref)
-    scale = np.abs(ref[..., :2, :2, :]).max(axis=(-3, -2), keepdims=True)
-    assert (np.abs(r - ref)[..., :2, :2, :] / scale).max() < rtol
-    np.testing.assert_allclose(r[..., 0, 1, :], ref[..., 0, 1, :], rtol=cross_rtol, atol=0)
-    np.testing.assert_allclose(r[..., 1, 0, :], ref[..., 1, 0, :], rtol=cross_rtol, atol=0)
+    tol = np.empty_like(ref)
+    tol[...] = rtol * np.abs(ref)
+    tol[..., 0, 1, :] = cross_rtol * np.abs(ref[..., 0, 1, :])
+    tol[..., 1, 0, :] = cross_rtol * np.abs(ref[..., 1, 0, :])
+    if spread is not None:
+        tol = np.maximum(tol, spread_factor * np.asarray(spread))
+    err = np.abs(r - ref)
+    bad = err[..., :2, :2, :] > tol[..., :2, :2, :]
+    assert not bad.any(), "backscatter off by up to %.2e relative (allowed %.2e there)" % (
+        (err[..., :2, :2, :] / np.abs(ref[..., :2, :2, :]))[bad].max(), (tol[..., :2, :2, :] / np.abs(ref[..., :2, :2, :]))[bad].max())
     # third Stokes rows/columns are multiplied by sin(m pi) ~ 1e-16 in backscatter: only their level is meaningful
     assert np.abs(r[..., 2, :, :]).max() <= 10 * np.abs(ref[..., 2, :, :]).max() + 1e-30

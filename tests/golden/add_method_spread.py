@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Adds to the ACTIVE-mode fixtures the reference's result for each of its diagonalisation methods.
+RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference); the fixtures stay plain data.
+
+Why: the cross-polarised backscatter (HV, VH) is what is left after the azimuth modes cancel each other, 30-50 dB
+below the co-polarised level.  On its own scale the reference's answer depends on which of its own eigensolvers is used
+(`schur_forcedtriu` = default, `eig`, `half_rank_eig`; smrt/rtsolver/dort.py:821-962) at the 1e-9 .. 1e-7 level, so
+"1e-8 relative to the reference" is only defined up to that spread.  The parity tests hold every backscatter
+coefficient to 1e-8 of the reference default on its own scale, widened element by element to the stored spread where
+the reference's methods themselves disagree by more (tests/conftest.py:assert_backscatter_close).
+
+The snowpack is rebuilt from the arrays stored in the fixture (not from the random generator that made them) and the
+default-method result is re-checked against the stored one before anything is added.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/add_method_spread.py [fixture ...]
+"""
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "_refstubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(HERE))
+
+import numpy as np  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+from smrt import make_model, make_snowpack  # noqa: E402
+from smrt.core.sensor import active  # noqa: E402
+from smrt.substrate.flat import Flat  # noqa: E402
+
+METHODS = ("eig", "half_rank_eig")
+
+
+def rebuild(d):
+    kw = {}
+    if str(d["microstructure"]) == "exponential":
+        kw["corr_length"] = d["corr_length"]
+    else:
+        kw["radius"] = d["radius"]
+        kw["stickiness"] = d["stickiness"]
+    substrate = None
+    if "substrate_kind" in d:
+        assert str(d["substrate_kind"]) == "flat"
+        T = float(d["substrate_temperature"])
+        substrate = Flat(temperature=None if np.isnan(T) else T, permittivity_model=complex(d["substrate_eps"][0]))
+    return make_snowpack(d["thickness"], str(d["microstructure"]), density=d["density"], temperature=d["temperature"],
+                         substrate=substrate, **kw)
+
+
+def run(d, sp, **extra):
+    opts = {k[4:]: d[k].item() for k in d if k.startswith("opt_")}
+    opts.update(extra)
+    m = make_model(str(d["emmodel"]), "dort", rtsolver_options=opts)
+    out = []
+    for f in d["frequency"]:
+        se = active(float(f), d["theta_inc_deg"])
+        sims, _ = m.prepare_simulations(se, sp, None, "snowpack")
+        out.append(np.asarray(m.run_single_simulation(list(sims)[0], None, None).data.values))
+    return np.array(out)
+
+
+def main():
+    from conftest import ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES
+
+    names = sys.argv[1:] or (ACTIVE_FIXTURES + PRUNE_ACTIVE_FIXTURES + BIG_ACTIVE_FIXTURES)
+    for name in names:
+        path = os.path.join(HERE, name + ".npz")
+        d = dict(np.load(path))
+        sp = rebuild(d)
+        # the same method on the same inputs, run again: identical on the co-polarised scale, but NOT bit-identical
+        # (threaded LAPACK; observed 1e-12 co-pol, 4e-9 on the cross-polarised terms' own scale) -- stored as one more
+        # member of the spread
+        again = run(d, sp)
+        assert np.abs(again - d["result"]).max() <= 1e-10 * np.abs(d["result"]).max(), name
+        d["result_rerun"] = again
+        for meth in METHODS:
+            try:
+                r = run(d, sp, diagonalization_method=meth)
+            except Exception as e:  # noqa: BLE001  (half_rank_eig: complex pairs on the Rayleigh modes of DMRT)
+                print("  %s: %s fails in the reference (%s)" % (name, meth, type(e).__name__))
+                continue
+            if not np.all(np.isfinite(r)):
+                print("  %s: %s gives non-finite values in the reference" % (name, meth))
+                continue
+            d["result_" + meth] = r
+            ref = d["result"]
+            own = np.abs(r - ref)[:, :2, :2] / np.abs(ref[:, :2, :2])
+            print("  %s: %s vs default, max relative difference co-pol %.1e cross-pol %.1e"
+                  % (name, meth, max(own[:, 0, 0].max(), own[:, 1, 1].max()), max(own[:, 0, 1].max(), own[:, 1, 0].max())))
+        np.savez_compressed(path, **d)
+        print("updated", os.path.relpath(path))
+
+
+if __name__ == "__main__":
+    main()

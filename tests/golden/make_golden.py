@@ -391,6 +391,21 @@ def main():
             out["result_" + meth] = alt["result"]
         save("iba_shs_active_substrate_conditioning", out)
 
+    # Full-size shapes of BASELINE.json's configs[2] and configs[3] (round 2): a second DMRT snowpack at ALL seven AMSR2
+    # frequencies with 64 streams, and the true active shape -- IBA, sentinel1(), 30 thin layers, 128 streams, m_max 2
+    # (N = 384 for the azimuth modes 1, 2).
+    if wanted("cfg3_dmrt_L50_n64_amsr2_sp1"):
+        rng = np.random.default_rng(33)
+        spx = random_snowpack(rng, 50, "sticky_hard_spheres")
+        save("cfg3_dmrt_L50_n64_amsr2_sp1", run_new("dmrt_qca_shortrange", sensor_list.amsr2(), spx,
+                                                     rtsolver_options=dict(n_max_stream=64)))
+    for i in range(2):
+        name = "cfg4_iba_active_L30_n128_sp%d" % i
+        if wanted(name):
+            rng = np.random.default_rng(40 + i)
+            spx = random_snowpack(rng, 30, "exponential", 0.02, 0.10, 1000.0)
+            save(name, run_new("iba", sensor_list.sentinel1(), spx, rtsolver_options=dict(n_max_stream=128, m_max=2)))
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

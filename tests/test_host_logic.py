@@ -39,6 +39,139 @@ def test_simulation_order_matches_reference():
     assert [str(dm[0]) for dm in dims] == list(d["dims"])
 
 
+def test_simulation_plan_shapes_and_zip_mode():
+    """The flattened grid as index vectors (smrt_amd/core/model.py:SimulationPlan): frequency-major for one sensor x
+    many snowpacks, pairwise for a sequence of sensors, no snowpack dimension for a single snowpack; dict / Series /
+    DataFrame inputs name the snowpack dimension like the reference (model.py:415-470)."""
+    import pandas as pd
+
+    from smrt_amd.core.model import SimulationPlan
+
+    m = make_model("iba", "dort")
+    sps = [two_layer() for _ in range(4)]
+    plan = m.plan(sensor_list.amsre(), sps)
+    assert isinstance(plan, SimulationPlan) and len(plan) == 6 * 4 and plan.shape == (6, 4)
+    assert [d[0] for d in plan.dimensions] == ["frequency", "snowpack"]
+    assert list(plan.sensor_index) == sorted(plan.sensor_index) and list(plan.snowpack_index[:4]) == [0, 1, 2, 3]
+    assert all(np.ndim(s.frequency) == 0 for s in plan.sensors)
+    one = m.plan(sensor_list.amsre("37V"), sps[0])
+    assert len(one) == 1 and one.dimensions == [] and one.scalar_snowpack
+    zipped = m.plan([sensor_list.passive(f, 55) for f in (10e9, 19e9, 37e9, 89e9)], sps)
+    assert len(zipped) == 4 and list(zipped.sensor_index) == list(zipped.snowpack_index) == [0, 1, 2, 3]
+    with pytest.raises(SMRTError):
+        m.plan([sensor_list.passive(37e9, 55)] * 3, sps)        # lengths differ
+    with pytest.raises(SMRTError):
+        m.plan([sensor_list.amsre()] * 4, sps)                  # zip mode needs single-configuration sensors
+    named = m.plan(sensor_list.amsre("37V"), {"a": sps[0], "b": sps[1]})
+    assert named.dimensions[0][0] == "snowpack" and list(named.dimensions[0][1]) == ["a", "b"]
+    ser = pd.Series(sps[:2], index=pd.Index([2020, 2021], name="year"))
+    assert m.plan(sensor_list.amsre("37V"), ser).dimensions[0] == ("year", [2020, 2021])
+    df = pd.DataFrame({"snowpack": sps[:2], "site": ["x", "y"]})
+    assert len(m.plan(sensor_list.amsre("37V"), df)) == 2
+    with pytest.raises(SMRTError):
+        m.plan(sensor_list.amsre("37V"), df, snowpack_column="nope")
+    with pytest.raises(SMRTError):
+        m.plan(sensor_list.amsre("37V"), sps, snowpack_dimension=("depth", [1, 2]))  # wrong number of labels
+
+
+def test_sensor_axes_subset_and_sensorlist():
+    """Sensor as a table of axes: subsets keep the derived quantities consistent; SensorList stacks single-configuration
+    sensors along 'channel' or an attribute (smrt/core/sensor.py:379-420)."""
+    from smrt_amd.core.sensor import Sensor, SensorList
+
+    s = sensor_list.passive([10e9, 37e9], [30, 55])
+    assert [a for a, _ in s.configurations()] == ["frequency", "theta", "polarization"]
+    sub = list(s.iterate("frequency"))
+    assert [float(x.frequency) for x in sub] == [10e9, 37e9]
+    assert np.isclose(sub[1].wavelength, 299792458.0 / 37e9) and np.isclose(sub[1].wavenumber, 2 * np.pi * 37e9 / 299792458.0)
+    t = s.subset("theta", 1)
+    assert list(t.theta_deg) == [55.0] and np.isclose(t.mu_s[0], np.cos(np.deg2rad(55))) and list(s.theta_deg) == [30.0, 55.0]
+    assert len(list(s.split(["frequency", "theta"]))) == 4
+    with pytest.raises(SMRTError):
+        s.axis_values("altitude")
+    with pytest.raises(SMRTError):
+        Sensor(theta_deg=55)                       # neither frequency nor wavelength
+    assert np.isclose(Sensor(wavelength=0.21, theta_deg=40).frequency, 299792458.0 / 0.21)
+    a = sensor_list.active(13e9, [30, 40])
+    assert a.mode == "A" and np.allclose(a.phi, np.pi) and list(a.theta_deg) == list(a.theta_inc_deg)
+    sl = SensorList([sensor_list.amsre("19V"), sensor_list.amsre("37H")])
+    assert sl.channel == ["19V", "37H"] and list(dict(sl.configurations())["channel"]) == ["19V", "37H"]
+    assert len(list(sl.iterate())) == 2 and sl.mode == "P"
+    with pytest.raises(SMRTError):
+        SensorList([sensor_list.amsre("19V"), sensor_list.amsre("19V")])
+    with pytest.raises(SMRTError):
+        list(sl.iterate("frequency"))
+    byname = SensorList([sensor_list.passive(19e9, 55, name="a"), sensor_list.passive(37e9, 55, name="b")], axis="name")
+    assert list(dict(byname.configurations())["name"]) == ["a", "b"]
+    plan = make_model("iba", "dort").plan(sl, [two_layer(), two_layer()])
+    assert plan.shape == (2, 2) and plan.dimensions[0][0] == "channel"
+
+
+def test_emmodel_configuration_is_honoured_on_the_batch_path():
+    """Per-layer emmodels and emmodel options reach the same checks on the batching runner as on the per-simulation
+    route (Model.prepare_emmodels): nothing is silently dropped (hip_batch_runner ignored them)."""
+    from smrt_amd.core.layer import Layer
+    from smrt_amd.core.snowpack import Snowpack
+    from smrt_amd.rtsolver.dort import DORT
+
+    sp = two_layer()
+    m = make_model("iba", "dort", emmodel_options=dict(dense_snow_correction="auto"))
+    plan = m.plan(sensor_list.amsre("37V"), [sp])
+    with pytest.raises(SMRTError, match="dense_snow_correction"):
+        DORT._uniform_emmodel(m, plan)
+    with pytest.raises(SMRTError, match="dense_snow_correction"):
+        m.prepare_emmodels(plan.sensors[0], sp)          # the per-simulation route says the same
+    mixed = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
+                             Layer(10.0, "exponential", 400, 250.0, corr_length=5e-5, emmodel="nonscattering")])
+    m2 = make_model("iba", "dort")
+    with pytest.raises(SMRTError, match="same emmodel"):
+        DORT._uniform_emmodel(m2, m2.plan(sensor_list.amsre("37V"), [mixed]))
+    m3 = make_model(["iba", "iba"], "dort")                   # a per-layer list of one kind is fine
+    assert DORT._uniform_emmodel(m3, m3.plan(sensor_list.amsre("37V"), [sp])).device_name == "iba"
+    with pytest.raises(SMRTError):
+        Snowpack(layers=sp.layers, interfaces=["rough", "rough"])   # interfaces are validated by the constructor too
+
+
+def test_ctypes_struct_matches_the_library():
+    """smrt_dort_abi reports sizeof(smrt_batch) and every field offset as compiled; the ctypes declaration and the
+    stub printed in INTEGRATION.md must agree with it (the documented stub had gone stale)."""
+    from smrt_amd import _native
+
+    lib = _native.load_library()          # load_library itself refuses a mismatching layout
+    theirs = _native.abi_layout(lib)
+    mine = [ctypes.sizeof(_native.SmrtBatch)] + [getattr(_native.SmrtBatch, n).offset for n, _ in _native.SmrtBatch._fields_]
+    assert mine == theirs and len(theirs) == len(_native.SmrtBatch._fields_) + 1
+    # field NAMES and ORDER of the ctypes declaration == the header's struct
+    header = open(os.path.join(ROOT, "include", "smrt_dort.h")).read()
+    body = header[header.index("typedef struct smrt_batch {"):header.index("} smrt_batch;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(\w+)\s*;", body)
+    assert names == [n for n, _ in _native.SmrtBatch._fields_]
+    # the stub a maintainer would copy from INTEGRATION.md is generated from the header: it must be current, and it
+    # must run as printed against the library (its last line is the layout assertion)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_ctypes_stub", os.path.join(ROOT, "tools", "gen_ctypes_stub.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    stub = gen.stub()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index(gen.BEGIN) + len(gen.BEGIN):doc.index(gen.END)]
+    assert block.strip() == ("```python\n" + stub + "\n```").strip(), "run `python tools/gen_ctypes_stub.py --update`"
+    exec(compile(stub.replace('"libsmrt_dort.so"', repr(_native.LIB_PATH)), "<INTEGRATION.md stub>", "exec"), {})
+
+
+def test_shard_by_cost_balances_work():
+    from smrt_amd.rtsolver.dort import shard_by_cost
+
+    cost = np.r_[np.full(100, 8.0), np.full(100, 1.0)]          # first half eight times as expensive
+    b = shard_by_cost(cost, 4)
+    assert b[0] == 0 and b[-1] == 200 and np.all(np.diff(b) > 0)
+    per = [cost[b[k]:b[k + 1]].sum() for k in range(4)]
+    assert max(per) - min(per) <= 2 * 8.0                       # every cut within one item of the ideal one
+    assert list(shard_by_cost(np.ones(10), 1)) == [0, 10]
+
+
 def test_sensor_catalogue():
     s = sensor_list.amsre("37V")
     assert float(np.ravel(s.frequency)[0]) == 36.5e9 and s.mode == "P" and list(s.theta_deg) == [55.0]
@@ -190,7 +323,7 @@ def test_dort_option_validation():
 
     DORT(n_max_stream=64, diagonalization_method="half_rank_eig", error_handling="nan")
     for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=-1), dict(diagonalization_method="foo"),
-                dict(error_handling="ignore"), dict(process_coherent_layers=True), dict(phase_symmetrization=True)):
+                dict(error_handling="ignore"), dict(phase_symmetrization=True)):
         with pytest.raises(SMRTError):
             DORT(**bad)
     # prune_deep_snowpack: True is an optical depth of 6 (smrt/rtsolver/dort.py:176-178); the cache option is a no-op

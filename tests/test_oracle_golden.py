@@ -3,8 +3,9 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES, fixture_atmosphere, fixture_options,
-                      fixture_substrate, load_golden, snowpack_dict)
+from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+                      assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
+                      reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
 
 TB_TOL = 1e-6  # K      (BASELINE.json north_star)
@@ -91,17 +92,13 @@ def test_active_backscatter(name, method):
         r = O.solve(sp, float(f), d["theta_deg"], emmodel=str(d["emmodel"]), mode="A",
                     theta_inc_deg=d["theta_inc_deg"], method=method, substrate=fixture_substrate(d, i),
                     **fixture_options(d))
-        ref = d["result"][i]
-        # co- and cross-polarised intensities (V,H x V,H): relative to the co-pol level
-        scale = np.abs(ref[:2, :2]).max(axis=(0, 1))
-        assert (np.abs(r - ref)[:2, :2] / scale).max() < SIGMA_RTOL
-        # cross-pol on its own scale (40-50 dB below co-pol)
-        assert np.allclose(r[0, 1], ref[0, 1], rtol=1e-6, atol=0)
-        assert np.allclose(r[1, 0], ref[1, 0], rtol=1e-6, atol=0)
+        # every coefficient to 1e-8 on its own scale, widened to the spread of the reference's own methods where
+        # those disagree by more (the cross-polarised terms, 40-50 dB below co-pol)
+        assert_backscatter_close(r, d["result"][i], spread=reference_method_spread(d)[i])
 
 
 def test_active_cross_pol_conditioning():
-    """Why the cross-polarised backscatter is held to 1e-6 on its own scale (conftest.assert_backscatter_close): for
+    """Why conftest.assert_backscatter_close widens 1e-8 to the spread of the reference's methods on cross-pol: for
     a weakly scattering 2-layer pack the reference's own diagonalisation methods agree to 1e-10 on co-pol but only
     to ~1e-7 on cross-pol."""
     sp = dict(thickness=np.array([0.05, 0.08]), density=np.array([250.0, 380.0]), temperature=np.array([255.0, 262.0]),
