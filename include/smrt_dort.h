@@ -165,6 +165,12 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
 double smrt_dort_sum_n3(smrt_dort_ctx* ctx);
 
+/* Work estimate of every pair of the uploaded batch BEFORE solving it: sum over its layers (and azimuth modes) of
+ * N_l^3 from the stream counts alone (a cheap kernel: layer permittivities and Snell's law only).  cost: [pair_count]
+ * host doubles; 0 for a pair with invalid input.  What a caller shards by when it splits a batch over several GPUs
+ * (total reflection removes streams, so the work of a pair varies with its density profile). */
+int32_t smrt_dort_pair_cost(smrt_dort_ctx* ctx, double* cost);
+
 /* Profiling builds only (-DSMRT_STAGE_TIMING): shader cycles of workgroup thread 0 per kernel stage, summed over
  * the pairs of the last launch (setup, assemble, cholesky, L^T L, jacobi, triangular, R1, LU1, R45, LU2, R78, out).
  * A regular build returns zeros. */
@@ -172,6 +178,33 @@ int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16);
 
 /* Positive Gauss-Legendre nodes of order 2n in descending order (smrt/rtsolver/streams.py:300-313). Host only. */
 int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight);
+
+/*
+ * Multi-GPU: the (snowpack x frequency) list is embarrassingly parallel (smrt/core/model.py:395-398 maps one function
+ * over it; smrt/runner/joblib_runner.py:45-72 is the reference's fan-out), so every GPU solves its own slice and the
+ * ONLY communication of the path is the gather of the result rows to one rank -- done here with RCCL over xGMI,
+ * device buffer to device buffer, no PyTorch involved.
+ *
+ * One context = one rank.  Either one process per GPU: rank 0 calls smrt_dort_comm_unique_id, the caller ships the
+ * 128 bytes to the other ranks by any means it has (smrt_amd/runner/distributed.py uses a TCP socket on MASTER_ADDR),
+ * every rank calls smrt_dort_comm_init (collective).  Or one process driving several GPUs: smrt_dort_comm_init_all on
+ * the list of contexts (ncclCommInitAll), then smrt_dort_gather from one host thread per context.
+ *
+ * smrt_dort_gather (collective): the rows of the LAST launch of every rank (its own out / status buffers, i.e.
+ * smrt_dort_launch(ctx, NULL, NULL)) land on `root` in rank order; counts[r] = number of pairs of rank r (the
+ * caller's sharding: counts[own rank] must equal the uploaded pair count).  On the root, out [sum counts][out_stride]
+ * and status [sum counts] are HOST buffers (either may be NULL to leave the rows on the device); ignored elsewhere.
+ * It is enqueued on the context's stream behind the kernels and returns when the root has its rows.
+ * smrt_dort_comm_allreduce_max: element-wise maximum over the ranks of n host doubles, in place (the max-over-ranks
+ * of a timing; with n = 0 it is a barrier).
+ */
+#define SMRT_COMM_ID_BYTES 128
+int32_t smrt_dort_comm_unique_id(char* id);
+int32_t smrt_dort_comm_init(smrt_dort_ctx* ctx, int32_t world, int32_t rank, const char* id);
+int32_t smrt_dort_comm_init_all(smrt_dort_ctx** ctxs, int32_t n);
+int32_t smrt_dort_comm_destroy(smrt_dort_ctx* ctx);
+int32_t smrt_dort_gather(smrt_dort_ctx* ctx, int32_t root, const int64_t* counts, double* out, int32_t* status);
+int32_t smrt_dort_comm_allreduce_max(smrt_dort_ctx* ctx, double* values, int32_t n);
 
 /* Self-description of the ABI for foreign-function bindings: out[0] = sizeof(smrt_batch), out[1..] = byte offset of
  * every field of smrt_batch in declaration order.  Returns the number of entries of the full description (fields + 1);

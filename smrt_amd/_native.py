@@ -177,6 +177,20 @@ def load_library():
     lib.smrt_dort_run_pairs.restype = C.c_int32
     lib.smrt_dort_upload_pairs.argtypes = [C.c_void_p, P(SmrtBatch), P(C.c_int64), C.c_int64]
     lib.smrt_dort_upload_pairs.restype = C.c_int32
+    lib.smrt_dort_pair_cost.argtypes = [C.c_void_p, P(C.c_double)]
+    lib.smrt_dort_pair_cost.restype = C.c_int32
+    lib.smrt_dort_comm_unique_id.argtypes = [C.c_char_p]
+    lib.smrt_dort_comm_unique_id.restype = C.c_int32
+    lib.smrt_dort_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]
+    lib.smrt_dort_comm_init.restype = C.c_int32
+    lib.smrt_dort_comm_init_all.argtypes = [P(C.c_void_p), C.c_int32]
+    lib.smrt_dort_comm_init_all.restype = C.c_int32
+    lib.smrt_dort_comm_destroy.argtypes = [C.c_void_p]
+    lib.smrt_dort_comm_destroy.restype = C.c_int32
+    lib.smrt_dort_gather.argtypes = [C.c_void_p, C.c_int32, P(C.c_int64), P(C.c_double), P(C.c_int32)]
+    lib.smrt_dort_gather.restype = C.c_int32
+    lib.smrt_dort_comm_allreduce_max.argtypes = [C.c_void_p, P(C.c_double), C.c_int32]
+    lib.smrt_dort_comm_allreduce_max.restype = C.c_int32
     lib.smrt_dort_abi.argtypes = [P(C.c_int32), C.c_int32]
     lib.smrt_dort_abi.restype = C.c_int32
     lib.smrt_dort_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -226,7 +240,9 @@ def check_struct_layout(lib):
 
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
-    "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
+    "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost",
+    "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
+    "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version",
 ]
@@ -319,6 +335,58 @@ class DortContext:
         self._check(self._lib.smrt_dort_download(self._h, _dptr(o.values), o.status.ctypes.data_as(C.POINTER(C.c_int32)),
                                                  _dptr(o.layers), _dptr(o.streams)), "smrt_dort_download")
         return o
+
+    def pair_cost(self):
+        """Sum of N_l^3 per pair of the uploaded batch (before solving it): what the work is sharded by."""
+        _, pair_count = self._resident
+        cost = np.empty(pair_count)
+        self._check(self._lib.smrt_dort_pair_cost(self._h, _dptr(cost)), "smrt_dort_pair_cost")
+        return cost
+
+    # ---- multi-GPU: the RCCL gather of the C ABI (smrt_dort_comm_*, smrt_dort_gather) ----------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        if lib.smrt_dort_comm_unique_id(buf) != 0:
+            raise SMRTError("smrt_dort_comm_unique_id failed (is librccl available?)")
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id):
+        self._check(self._lib.smrt_dort_comm_init(self._h, int(world), int(rank), bytes(unique_id)), "smrt_dort_comm_init")
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def comm_init_all(contexts):
+        lib = load_library()
+        arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+        if lib.smrt_dort_comm_init_all(arr, len(contexts)) != 0:
+            raise SMRTError("smrt_dort_comm_init_all failed: " + lib.smrt_dort_last_error(contexts[0]._h).decode())
+        for r, c in enumerate(contexts):
+            c.world, c.rank = len(contexts), r
+
+    def gather(self, counts, root=0, want_host=True):
+        """Collective: rows of the last launch of every rank -> root (rank order).  Returns (values, status) on the
+        root (None, None elsewhere, or when want_host is False: the rows then stay on the root's device)."""
+        batch, _ = self._resident
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        is_root = self.rank == root and want_host
+        total = int(counts.sum())
+        values = np.empty((total,) + batch.out_shape()) if is_root else None
+        status = np.empty(total, np.int32) if is_root else None
+        self._check(self._lib.smrt_dort_gather(self._h, int(root), counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               _dptr(values) if is_root else None,
+                                               status.ctypes.data_as(C.POINTER(C.c_int32)) if is_root else None),
+                    "smrt_dort_gather")
+        return values, status
+
+    def allreduce_max(self, values):
+        a = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self._lib.smrt_dort_comm_allreduce_max(self._h, _dptr(a), len(a)), "smrt_dort_comm_allreduce_max")
+        return a
+
+    def barrier(self):
+        self._check(self._lib.smrt_dort_comm_allreduce_max(self._h, None, 0), "smrt_dort_comm_allreduce_max")
 
     def last_kernel_ms(self):
         return float(self._lib.smrt_dort_last_kernel_ms(self._h))

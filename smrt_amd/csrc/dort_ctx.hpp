@@ -52,6 +52,10 @@ struct smrt_dort_ctx {
     int gmem_grid = 0;
     long long ws_stride = 0;
     int nmax_rows = 0;
+    // multi-GPU (dort_comm.hip): the RCCL communicator this context is a rank of, and the root's gather buffers
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    DevBuf d_gather_out, d_gather_status, d_scalar;
 };
 
 #ifndef SMRT_JACOBI_NT
@@ -76,4 +80,6 @@ hipError_t finish_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned gri
 // k_fused.hip / k_gmem_fused.hip: everything of a pair in one workgroup
 hipError_t fused(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int nt, bool active);
 hipError_t fused_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int ch, bool active);
+// k_cost.hip: sum of N_l^3 per pair from the stream counts alone
+hipError_t pair_cost(smrt_dort_ctx* ctx, const smrt::DevBatch& d, double* cost_dev);
 }  // namespace smrt_launch

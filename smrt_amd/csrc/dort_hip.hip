@@ -110,11 +110,13 @@ int32_t smrt_dort_create(smrt_dort_ctx** out, int32_t device) {
 
 void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     if (!ctx) return;
+    (void)smrt_dort_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap};
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -283,6 +285,13 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
     d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
+    // Jacobi thresholds on the squared cosine between two columns: below skip2 a pair is not rotated, a sweep without
+    // a rotation above exit2 is the last one (dort_jacobi_kernel.hpp).  SMRT_DORT_JACOBI_SKIP2 / _EXIT2 override them
+    // for experiments.
+    d.jacobi_skip2 = ctx->active ? 1e-30 : SMRT_JACOBI_SKIP_COS2;
+    d.jacobi_exit2 = ctx->active ? 1e-22 : SMRT_JACOBI_EXIT_COS2;
+    if (const char* e = getenv("SMRT_DORT_JACOBI_SKIP2")) d.jacobi_skip2 = atof(e);
+    if (const char* e = getenv("SMRT_DORT_JACOBI_EXIT2")) d.jacobi_exit2 = atof(e);
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
     d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
     ctx->lds_bytes = lds;
@@ -387,6 +396,17 @@ double smrt_dort_sum_n3(smrt_dort_ctx* ctx) {
     double s = 0.0;
     for (double v : h) s += v;
     return s;
+}
+
+int32_t smrt_dort_pair_cost(smrt_dort_ctx* ctx, double* cost) {
+    if (!ctx || !cost) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    // the work counter buffer of the solve doubles as the output (a launch overwrites it anyway)
+    HIPCHK(smrt_launch::pair_cost(ctx, ctx->dev, ctx->dev.n3_out));
+    HIPCHK(hipMemcpyAsync(cost, ctx->dev.n3_out, sizeof(double) * (size_t)ctx->dev.pair_count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16) {

@@ -32,6 +32,7 @@ struct DevBatch {
     const double* sub_T;                  // [S], <= 0: no emission
     const double *atm_down, *atm_up, *atm_trans;  // [F] or null
     double phi;
+    double jacobi_skip2, jacobi_exit2;  // squared-cosine thresholds of the Jacobi kernel (host: per mode, env override)
     double prune_tau;  // > 0: optical depth beyond which the deeper layers are dropped (dort.py:443-452); pipeline only
     double* out;
     int* status;

@@ -142,20 +142,28 @@ def oracle_method_spread(sp, frequency, theta_deg, ref, methods=("eig", "half_ra
 
 def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=SIGMA_RTOL, spread=None, spread_factor=3.0):
     """r, ref: [..., pol, pol_inc, theta_inc].  EVERY V,H x V,H intensity to 1e-8 relative on its own scale -- the
-    north_star's bar -- co- and cross-polarised alike.  `spread` (same shape as ref, from reference_method_spread) widens
-    the tolerance of an element to `spread_factor` times the disagreement among the reference's own eigensolvers where
-    that is larger: the cross-polarised terms sit 30-50 dB below co-pol and come out of a cancellation between the
-    azimuth modes, so the reference's answer is itself only defined to that spread (1e-9 .. 1e-7 on the fixtures)."""
+    north_star's bar -- co- and cross-polarised alike.  `spread` (same shape as ref, from reference_method_spread /
+    oracle_method_spread) widens that to `spread_factor` times the disagreement among the reference's own eigensolvers
+    where it is larger.  The disagreement is rounding noise, different at every angle, so it is pooled: the largest
+    relative spread over the angles and over the two elements of a kind (HV | VH, or VV | HH) of one solve is the
+    yardstick for all of them.  Background: the cross-polarised terms sit 30-50 dB below co-pol and come out of a
+    cancellation between the azimuth modes, so the reference's answer is itself only defined to that spread (1e-12 ..
+    1e-7 on the fixtures; measured on the GPU the device's deviation follows it pair by pair,
+    profiles/r2_crosspol_probe.txt)."""
     r, ref = np.asarray(r), np.asarray(ref)
-    tol = np.empty_like(ref)
-    tol[...] = rtol * np.abs(ref)
-    tol[..., 0, 1, :] = cross_rtol * np.abs(ref[..., 0, 1, :])
-    tol[..., 1, 0, :] = cross_rtol * np.abs(ref[..., 1, 0, :])
+    rel = np.abs(r - ref)[..., :2, :2, :] / np.abs(ref[..., :2, :2, :])
+    tol = np.empty_like(rel)
+    tol[...] = rtol
+    tol[..., 0, 1, :] = tol[..., 1, 0, :] = cross_rtol
     if spread is not None:
-        tol = np.maximum(tol, spread_factor * np.asarray(spread))
-    err = np.abs(r - ref)
-    bad = err[..., :2, :2, :] > tol[..., :2, :2, :]
-    assert not bad.any(), "backscatter off by up to %.2e relative (allowed %.2e there)" % (
-        (err[..., :2, :2, :] / np.abs(ref[..., :2, :2, :]))[bad].max(), (tol[..., :2, :2, :] / np.abs(ref[..., :2, :2, :]))[bad].max())
+        srel = np.asarray(spread)[..., :2, :2, :] / np.abs(ref[..., :2, :2, :])
+        co = np.maximum(srel[..., 0, 0, :], srel[..., 1, 1, :]).max(axis=-1, keepdims=True)      # pooled per solve
+        cross = np.maximum(srel[..., 0, 1, :], srel[..., 1, 0, :]).max(axis=-1, keepdims=True)
+        tol[..., 0, 0, :] = np.maximum(tol[..., 0, 0, :], spread_factor * co)
+        tol[..., 1, 1, :] = np.maximum(tol[..., 1, 1, :], spread_factor * co)
+        tol[..., 0, 1, :] = np.maximum(tol[..., 0, 1, :], spread_factor * cross)
+        tol[..., 1, 0, :] = np.maximum(tol[..., 1, 0, :], spread_factor * cross)
+    bad = rel > tol
+    assert not bad.any(), "backscatter off by up to %.2e relative (allowed %.2e there)" % (rel[bad].max(), tol[bad].max())
     # third Stokes rows/columns are multiplied by sin(m pi) ~ 1e-16 in backscatter: only their level is meaningful
     assert np.abs(r[..., 2, :, :]).max() <= 10 * np.abs(ref[..., 2, :, :]).max() + 1e-30

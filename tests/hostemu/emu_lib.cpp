@@ -162,6 +162,8 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
+    d.jacobi_skip2 = active ? 1e-30 : SMRT_JACOBI_SKIP_COS2;
+    d.jacobi_exit2 = active ? 1e-22 : SMRT_JACOBI_EXIT_COS2;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
     if (gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {

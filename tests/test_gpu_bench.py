@@ -1,5 +1,6 @@
-"""bench.py on the GPU box: the JSON contract of the single-GPU line, and the torch.distributed / RCCL code path of the
-multi-GPU runs (launched exactly like the driver launches it, with one rank, SMRT_BENCH_DIST=1)."""
+"""bench.py on the GPU box: the JSON contract of the single-GPU line, and the RCCL code path of the multi-GPU runs
+(launched exactly like the driver launches it -- under torch.distributed.run, which is only the launcher: the ranks
+rendezvous over a socket and gather with smrt_dort_gather -- with one rank, SMRT_BENCH_DIST=1)."""
 import json
 import os
 import socket
@@ -42,12 +43,17 @@ def test_bench_single_gpu_line():
     d = _check_line(lines[0], 1)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["blas_threads_per_worker"] == 1                      # measured inside the workers, not assumed
+    assert 0 < cb["reference_default_method"]["value"] <= cb["value"] * 1.5
     assert d["config"]["max_abs_dTb_vs_oracle_K"] < 1e-6
+    # the secondary rates of the same run: host buffers through smrt_dort_run, and the plugin surface end to end
+    assert 0 < d["pcie_inclusive"]["value"] <= d["value"] * 1.05
+    assert d["model_run"]["bitwise_equal_to_c_abi_run"] and 0 < d["model_run"]["value"] <= d["value"] * 1.05
 
 
 def test_bench_distributed_path_one_rank():
-    """What `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` executes: RCCL process group,
-    kernels writing into torch device buffers, the gather to rank 0 inside every step, max-over-ranks timing."""
+    """What `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` executes: socket rendezvous, RCCL
+    communicator inside the library, the gather to rank 0 inside every step, max-over-ranks timing -- no torch import."""
     env = dict(os.environ, SMRT_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
@@ -80,5 +86,34 @@ def test_launch_into_torch_buffers_matches_download():
         ctx.sync()
         assert (st_t.cpu().numpy() == 0).all()
         assert np.array_equal(out_t.cpu().numpy().reshape(ref.values.shape), ref.values)
+    finally:
+        ctx.close()
+
+
+def test_rccl_gather_single_process_communicator():
+    """smrt_dort_comm_init_all (one process driving its GPUs, ncclCommInitAll) + smrt_dort_gather + allreduce_max on the
+    one GPU of this box: the gathered rows are the downloaded rows, host and device side."""
+    from smrt_amd._native import DortContext, PackedBatch
+
+    rng = np.random.default_rng(6)
+    S, L = 9, 5
+    b = PackedBatch([L] * S, rng.uniform(0.05, 0.3, (S, L)), rng.uniform(0.2, 0.45, (S, L)), rng.uniform(235, 268, (S, L)),
+                    rng.uniform(5e-5, 3e-4, (S, L)), None, [18.7e9, 36.5e9, 89e9], np.deg2rad([40.0, 55.0]), n_max_stream=16)
+    ctx = DortContext(0)
+    try:
+        DortContext.comm_init_all([ctx])
+        ctx.upload(b, 4, 20)
+        cost = ctx.pair_cost()
+        assert cost.shape == (20,) and (cost > 0).all()
+        ctx.launch()
+        v, s = ctx.gather([20], root=0)
+        ref = ctx.download()
+        assert np.array_equal(v, ref.values) and np.array_equal(s, ref.status) and (s == 0).all()
+        # the work counter of the solve equals the estimate made before it (same stream counts)
+        assert np.isclose(ctx.sum_n3(), cost.sum(), rtol=1e-12)
+        assert list(ctx.allreduce_max([1.5, -2.0])) == [1.5, -2.0]
+        ctx.barrier()
+        with pytest.raises(Exception):
+            ctx.gather([19], root=0)      # counts[own rank] must be the uploaded pair count
     finally:
         ctx.close()

@@ -228,3 +228,83 @@ def test_physics_nonscattering_limit_and_kirchhoff():
     res_pl = make_model("iba", "dort").run(sensor_list.passive(10e9, [20, 40, 55]), sp)
     assert np.abs(res_pl.data.values - O.solve(spd, 10e9, [20, 40, 55])).max() < 1e-6
     assert np.abs(res_pl.data.values - res.data.values).max() < 0.5
+
+
+def _random_packs(rng, n, L=5):
+    from smrt_amd import make_snowpack
+
+    return [make_snowpack(np.append(rng.uniform(0.05, 0.3, L - 1), 100.0), "exponential",
+                          density=rng.uniform(150, 450, L), temperature=rng.uniform(230, 270, L),
+                          corr_length=rng.uniform(5e-5, 3e-4, L)) for _ in range(n)]
+
+
+def test_zipped_sensors_run_only_the_listed_pairs():
+    """A sequence of sensors zipped with a sequence of snowpacks (smrt/core/model.py:505-515): N pairs, not the N x N
+    product -- the device gets a pair list (smrt_dort_run_pairs) -- and the same bits as the full-grid run."""
+    from smrt_amd import make_model, sensor_list
+    from smrt_amd._native import load_library
+
+    rng = np.random.default_rng(9)
+    sps = _random_packs(rng, 6)
+    freqs = [10.65e9, 18.7e9, 36.5e9, 89e9, 18.7e9, 10.65e9]
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16))
+    grid = m.run(sensor_list.passive(sorted(set(freqs)), 55), sps)          # 4 frequencies x 6 snowpacks
+    zipped = m.run([sensor_list.passive(f, 55) for f in freqs], sps)
+    assert zipped.data.dims == ("snowpack", "polarization", "theta") and zipped.data.shape == (6, 2, 1)
+    for k, f in enumerate(freqs):
+        assert np.array_equal(zipped.data.values[k], grid.data.sel(frequency=f).values[k])
+    # the generic runner protocol with an arbitrary list of pairs goes the same way
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    pairs = [(sensor_list.passive(freqs[k], 55), sps[k]) for k in (4, 1, 1, 3)]
+    res = HipBatchRunner()(m.run_single_simulation, [(p, None, "outer") for p in pairs])
+    assert [float(r.TbV()) for r in res] == [float(zipped.TbV()[k]) for k in (4, 1, 1, 3)]
+    assert load_library() is not None
+
+
+def test_stacked_result_equals_nested_per_pair_results():
+    """Model.run's fast path builds the (frequency, snowpack, ...) Result by reshaping the device output; the generic
+    path nests one Result per pair with concat_results (smrt/core/result.py:768-817).  Same values, coordinates and
+    diagnostics -- also for ragged layer counts (NaN below the last layer, like xr.concat)."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.core.model import nest_results
+
+    rng = np.random.default_rng(10)
+    sps = _random_packs(rng, 3) + [make_snowpack([0.2, 50.0], "exponential", density=[250, 350], temperature=[255, 262],
+                                                 corr_length=[1e-4, 2e-4])]
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16))
+    fast = m.run(sensor_list.amsre(), sps)
+    plan = m.plan(sensor_list.amsre(), sps)
+    slow = nest_results([m.run_single_simulation(pair, None, "none") for pair in plan.pairs()], plan.dimensions)
+    assert fast.data.dims == slow.data.dims and np.array_equal(fast.data.values, slow.data.values)
+    for k in slow.other_data:
+        a, b = fast.other_data[k], slow.other_data[k]
+        assert a.dims == b.dims, k
+        np.testing.assert_array_equal(a.values, b.values, err_msg=k)
+    assert np.isnan(fast.other_data["ks"].values[0, 3, 2:]).all() and np.isfinite(fast.other_data["ks"].values[0, 3, :2]).all()
+
+
+def test_threaded_multi_device_path_and_growing_batches():
+    """run_on_devices with one host thread per context (devices=[0, 0] exercises the threaded path on a one-GPU box)
+    equals the single-context run bit for bit, with count-based and with cost-based shards, for a pair list too; a
+    second, LARGER batch in the same process regrows every device buffer (the growth must happen on the
+    context's own device)."""
+    from smrt_amd._native import PackedBatch
+    from smrt_amd.rtsolver.dort import run_on_devices
+
+    rng = np.random.default_rng(21)
+    for S in (40, 160):
+        L = 6
+        thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 100.0)], axis=1)
+        b = PackedBatch([L] * S, thick, rng.uniform(150, 450, (S, L)) / 916.7, rng.uniform(230, 270, (S, L)),
+                        rng.uniform(5e-5, 3e-4, (S, L)), None, [18.7e9, 36.5e9, 89e9], np.deg2rad([55.0]), n_max_stream=16)
+        one = run_on_devices(b, devices=[0])
+        two = run_on_devices(b, devices=[0, 0])
+        cost = rng.uniform(1, 9, b.n_pairs)
+        three = run_on_devices(b, devices=[0, 0, 0], cost=cost)
+        for other in (two, three):
+            assert np.array_equal(one.values, other.values) and np.array_equal(one.status, other.status)
+            assert np.array_equal(one.layers, other.layers) and np.array_equal(one.streams, other.streams)
+        pick = rng.permutation(b.n_pairs)[: b.n_pairs // 3]
+        sub = run_on_devices(b, devices=[0, 0], pairs=pick)
+        assert np.array_equal(sub.values, one.values[pick]) and np.array_equal(sub.layers, one.layers[pick])

@@ -519,3 +519,32 @@ def test_pipeline_shapes_agree(ctx):
         sel = (slice(None), slice(0, 2), slice(0, 2)) if c["mode"] == "A" else slice(None)
         for o in outs[1:]:
             np.testing.assert_allclose(o.values[sel], ref[sel], rtol=c["rtol"], atol=0)
+
+
+def test_batches_beyond_one_staging_chunk(ctx):
+    """BASELINE configs[4]'s distinguishing feature: batches much larger than the staging chunk of the pipeline
+    (~7.8 k pairs at 20 layers x 32 streams).  4096 snowpacks x 5 frequencies = 20 480 pairs = three chunks in one
+    smrt_dort_run call: bitwise equal to the same pairs run range by range and as a scattered pair list, and 64 sampled
+    pairs against the CPU oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(5)
+    S, L = 4096, 20
+    thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 100.0)], axis=1)
+    dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
+    freqs = np.array([10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
+    b = PackedBatch([L] * S, thick, dens / O.DENSITY_OF_ICE, temp, lc, None, freqs, np.deg2rad([55.0]))
+    full = ctx.run(b)
+    assert b.n_pairs == 20480 and (full.status == 0).all()
+    bounds = [0, 5000, 9000, 16001, 20480]           # ranges that do not line up with the chunk boundaries
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        part = ctx.run(b, pair_begin=lo, pair_count=hi - lo)
+        assert np.array_equal(part.values, full.values[lo:hi]) and np.array_equal(part.layers, full.layers[lo:hi])
+    pick = rng.permutation(b.n_pairs)[:9000]          # a scattered pair list, itself more than one chunk
+    listed = ctx.run(b, pairs=pick)
+    assert np.array_equal(listed.values, full.values[pick]) and np.array_equal(listed.streams, full.streams[pick])
+    for p in rng.choice(b.n_pairs, 64, replace=False):
+        f, s = divmod(int(p), S)
+        sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
+        assert np.abs(full.values[p] - O.solve(sp, freqs[f], [55.0])).max() < TB_TOL

@@ -80,3 +80,43 @@ def test_two_ranks_gloo_gather(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(tmp_path, "result.txt")).read() == "OK"
+
+
+def _rdzv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank))
+    from smrt_amd.runner.distributed import broadcast_from_root
+
+    payload = bytes(range(128)) if rank == 0 else None
+    q.put((rank, broadcast_from_root(payload, rank, world, timeout=60.0)))
+
+
+def test_socket_rendezvous_hands_the_id_to_every_rank():
+    """The PyTorch-free rendezvous of the multi-GPU path (smrt_amd/runner/distributed.py): rank 0 serves 128 bytes (the
+    RCCL unique id in production) on a port next to MASTER_PORT, three other processes fetch it -- late starters and a
+    stranger on the port range included."""
+    import multiprocessing as mp
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    squatter = socket.socket()          # somebody else already listens on the first candidate port
+    try:
+        squatter.bind(("127.0.0.1", port + 1))
+        squatter.listen(1)
+    except OSError:
+        pass
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 4
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q)) for r in (2, 1, 3)]
+    for p in procs:
+        p.start()
+    root = ctx.Process(target=_rdzv_worker, args=(0, world, port, q))   # the root starts last
+    root.start()
+    got = dict(q.get(timeout=90) for _ in range(world))
+    for p in procs + [root]:
+        p.join(30)
+    squatter.close()
+    assert set(got) == {0, 1, 2, 3} and all(v == bytes(range(128)) for v in got.values())
