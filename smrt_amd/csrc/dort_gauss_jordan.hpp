@@ -132,11 +132,159 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
     return ok;
 }
 
+// ---- the fast panel: pivots from the 16 x 16 DIAGONAL block only ----------------------------------------------------
+// With the eigenpairs of a layer sorted by their singular value (the Jacobi kernel does that on the way out), column c
+// of the matrices of the layer recursion "belongs" to row c -- in the no-scattering limit they are diagonal -- and
+// elimination with pivots restricted to the diagonal block has a growth factor of a few units
+// (tests/studies/nopivot_elimination.py).  Then no search over all the rows and no 16 dependent rank-one updates of a
+// lane-per-row panel are needed: with P = A[blk, blk] the accumulated transformation of the block is
+//     U[rows of blk] = P^-1 - I,      U[other rows] = -A[:, blk] P^-1,
+// i.e. one 16 x 16 inversion (partial pivoting INSIDE the block; the wavefront as a 16 x 4 grid of lanes, four entries
+// of a row per lane, row arg-max by DPP inside the 16-lane rows, pivot row and multiplier column moved by ds_bpermute:
+// tools/micro/inv16_bench.hip, 350-425 cycles per column against 1140 for a column of gj_panel16 in situ) and four
+// chained MFMAs per row tile.  The unknowns of the block stay in its own rows: perm is the identity there.
+// Acceptance test: every entry of U (and of P^-1) must be at most `growth_max` in magnitude; otherwise -- a block that
+// needs a pivot row from outside (clusters of equal eigenvalues, whose eigenvectors are arbitrary rotations) -- nothing
+// has been written, 0 is returned and the caller runs the full-pivot panel instead (from then on for every block of
+// the solve: its pivot rows are no longer aligned with the blocks).
+template <bool TR, int MAXRT>
+SMRT_DEV_NOINLINE int gj_panel16_fast(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk,
+                                       double growth_max) {
+    const int k0 = 16 * k;
+    const int nbk = (N - k0 < 16) ? N - k0 : 16;
+    const int RT = (N + 15) >> 4;
+    const int r = lane & 15, g = lane >> 4;
+    // the rows of the block must still be free
+    if (wave_max_u32((r < nbk && rowblk[k0 + r] >= 0) ? 1u : 0u) != 0u) return 0;
+    // (1) P in the 16 x 4 grid layout, identity-padded for a ragged last block: x[s] = P[r][4 g + s]
+    double x[4], x0[4];
+    const int rc = r < nbk ? r : 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 4 * g + s, cc = c < nbk ? c : 0;
+        const double v = at<TR>(A, k0 + rc, k0 + cc, LD);
+        x[s] = (r < nbk && c < nbk) ? v : ((r == c) ? 1.0 : 0.0);
+        x0[s] = x[s];
+    }
+    // (2) in-place Gauss-Jordan inversion with row pivoting inside the block: row piv[j] of the result is row j of the
+    // inverse of the row-permuted block, P^-1[kk][piv[j]] = Z[piv[kk]][j]
+    bool used = false;
+    int myinv = r;          // the step at which this lane's row was the pivot row
+    int piv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int gj = j >> 2, q = j & 3;
+        unsigned key = 0u;
+        if (!used && g == gj) {
+            const float f = (float)fabs(x[q]);
+            memcpy(&key, &f, 4);
+            key = (key & ~0xFu) | (unsigned)(15 - r) | 0x10u;
+        }
+        key = row16_max_u32(key);
+        const int p = 15 - (int)(wave_bcast_u32(key, 16 * gj) & 0xFu);   // uniform
+        piv[j] = p;
+        const double rpv = fast_rcp(wave_bcast(x[q], 16 * gj + p));
+        const bool isp = (r == p);
+        if (isp) { used = true; myinv = j; }
+        const double f = wave_shfl(x[q], r + 16 * gj);          // multiplier of this lane's row
+        double pr[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pr[s] = wave_shfl(x[s], p + 16 * g) * rpv;   // scaled pivot row, own columns
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool pc = (g == gj) && (s == q);
+            const double prs = pc ? rpv : pr[s];
+            const double base = pc ? 0.0 : x[s];
+            x[s] = isp ? prs : __builtin_fma(-f, prs, base);
+        }
+    }
+    // (3) the true inverse into A[blk, blk] (the block is about to be overwritten by U anyway)
+    double amax = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pcol = (g == 0) ? piv[s] : (g == 1) ? piv[4 + s] : (g == 2) ? piv[8 + s] : piv[12 + s];
+        if (myinv < nbk && pcol < nbk) {
+            at<TR>(A, k0 + myinv, k0 + pcol, LD) = x[s];
+            amax = fabs(x[s]) > amax ? fabs(x[s]) : amax;
+        }
+        if (!(fabs(x[s]) <= 1e300)) amax = 1e301;   // NaN / inf anywhere (a zero pivot): reject
+    }
+    wave_sync_lds();
+    // (4) the multiplier block of every other row tile: -A[:, blk] P^-1, kept in registers until accepted
+    const int lr = lane & 15, lk = lane >> 4;
+    double c[MAXRT][4];
+#pragma unroll
+    for (int ti = 0; ti < MAXRT; ++ti) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c[ti][reg] = 0.0;
+        if (ti < RT && ti != k) {   // uniform
+            const int arow = ti * 16 + lr, arowc = arow < N ? arow : 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk, jc = j < nbk ? j : 0, lrc = lr < nbk ? lr : 0;
+                const double av = at<TR>(A, arowc, k0 + jc, LD), bv = at<TR>(A, k0 + jc, k0 + lrc, LD);
+                mfma_f64_16x16x4((arow < N && j < nbk) ? av : 0.0, (j < nbk && lr < nbk) ? bv : 0.0, c[ti]);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double m = fabs(c[ti][reg]);
+                amax = (m > amax || !(m <= 1e300)) ? (m <= 1e300 ? m : 1e301) : amax;
+            }
+        }
+    }
+    {   // uniform verdict: the largest magnitude over the wavefront (float keys order like the values)
+        const float fm = amax > 3e38 ? 3e38f : (float)amax;
+        unsigned key;
+        memcpy(&key, &fm, 4);
+        key = wave_max_u32(key);
+        float gm;
+        memcpy(&gm, &key, 4);
+        if (!((double)gm <= growth_max)) {   // restore the block and let the caller pivot over all the rows
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cc = 4 * g + s;
+                if (r < nbk && cc < nbk) at<TR>(A, k0 + r, k0 + cc, LD) = x0[s];
+            }
+            wave_sync_lds();
+            return 0;
+        }
+    }
+    // (5) U into the panel columns: -A[:, blk] P^-1 outside the block, P^-1 - I inside
+#pragma unroll
+    for (int ti = 0; ti < MAXRT; ++ti) {
+        if (ti < RT && ti != k) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = ti * 16 + lk + 4 * reg;
+                if (row < N && lr < nbk) at<TR>(A, row, k0 + lr, LD) = -c[ti][reg];
+            }
+        }
+    }
+    wave_sync_lds();
+    if (lane < nbk) {
+        at<TR>(A, k0 + lane, k0 + lane, LD) -= 1.0;
+        perm[k0 + lane] = k0 + lane;
+        rowblk[k0 + lane] = k;
+    }
+    return 1;
+}
+
+#if defined(SMRT_HOST_EMU)
+inline long smrt_emu_panels[2] = {0, 0};   // emulator builds count [0] fast and [1] full-pivot panels (tests)
+#define SMRT_COUNT_PANEL(i) do { if (lane == 0) ++smrt_emu_panels[i]; } while (0)
+#else
+#define SMRT_COUNT_PANEL(i) do {} while (0)
+#endif
+
+#ifndef SMRT_GJ_GROWTH_MAX
+#define SMRT_GJ_GROWTH_MAX 64.0   // acceptance threshold of the fast panel on |U| (growth of block-diagonal pivoting)
+#endif
+
 // result_in_A: leave the solution in A (one pass and one barrier less than copying it back over Bm), optionally scaled
 // X[k][c] * rs[k] * cs[c] on the way (the t Q t scaling of the recursion).
 template <int NT, bool TR>
 SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
-                           const double* rs = nullptr, const double* cs = nullptr) {
+                           const double* rs = nullptr, const double* cs = nullptr, bool allow_fast = false) {
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
@@ -144,11 +292,12 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     int* perm = (int*)s.gj;                     // [NMX + 16] pivot row of every column
     int* rowblk = perm + NMX + 16;              // [NMX] block in which the row was a pivot row, -1 before
     int* fail = rowblk + NMX;
+    int* fast = fail + 1;                       // 1 while the blocks so far took their pivots from the diagonal block
     const bool has_v = (v != nullptr);
     const int RT = (N + 15) >> 4;
     const int lr = lane & 15, lk = lane >> 4;
     for (int r = t; r < NMX; r += NT) rowblk[r] = -1;
-    if (t == 0) *fail = 0;
+    if (t == 0) { *fail = 0; *fast = allow_fast ? 1 : 0; }
     block_sync();
 #ifdef SMRT_STAGE_TIMING
     long long tg0 = cycle_counter();
@@ -156,7 +305,17 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 #else
 #define SMRT_GSUB(k) do {} while (0)
 #endif
-    auto panel = [&](int kb) { return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk); };
+    auto panel = [&](int kb) -> bool {   // one wavefront; the flag was published by the previous block's barrier
+        if (*fast) {
+            const int took = (N > 64) ? gj_panel16_fast<TR, 8>(A, N, LD, kb, lane, perm, rowblk, SMRT_GJ_GROWTH_MAX)
+                                      : gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, SMRT_GJ_GROWTH_MAX);
+            if (took) { SMRT_COUNT_PANEL(0); return true; }
+            if (lane == 0) *fast = 0;
+            wave_sync_lds();
+        }
+        SMRT_COUNT_PANEL(1);
+        return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+    };
     if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
     SMRT_GSUB(0);
     block_sync();
@@ -303,8 +462,8 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 
 // the Gauss-Jordan entry point of the drivers (solution copied back over Bm)
 template <int NT, bool TR>
-SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD) {
-    return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD);
+SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool allow_fast = false) {
+    return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD, false, nullptr, nullptr, allow_fast);
 }
 
 }  // namespace smrt

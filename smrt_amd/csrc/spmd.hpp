@@ -46,6 +46,17 @@ SMRT_DEV unsigned wave_max_u32(unsigned k) {
     return k;
 }
 SMRT_DEV double wave_bcast(double v, int src_lane) { return emu::wave_bcast(v, src_lane); }
+// value of lane src_lane (any lane index, different per lane) of the wavefront
+SMRT_DEV double wave_shfl(double v, int src_lane) { return emu::wave_bcast(v, src_lane); }
+SMRT_DEV unsigned wave_bcast_u32(unsigned v, int src_lane) { return (unsigned)emu::wave_bcast((double)v, src_lane); }
+// max over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row
+SMRT_DEV unsigned row16_max_u32(unsigned k) {
+    for (int m = 8; m >= 1; m >>= 1) {
+        unsigned o = (unsigned)emu::shfl_xor((double)k, m);
+        if (o > k) k = o;
+    }
+    return k;
+}
 SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f64_16x16x4(a, b, c); }
 SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
 SMRT_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
@@ -152,6 +163,18 @@ SMRT_DEV double wave_bcast(double v, int src_lane) {
     r.i[0] = __builtin_amdgcn_readlane(a.i[0], src_lane);
     r.i[1] = __builtin_amdgcn_readlane(a.i[1], src_lane);
     return r.d;
+}
+// value of lane src_lane of the wavefront, src_lane different per lane: ds_bpermute_b32 x 2
+SMRT_DEV double wave_shfl(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+SMRT_DEV unsigned wave_bcast_u32(unsigned v, int src_lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, src_lane); }
+// max over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row: four DPP steps
+SMRT_DEV unsigned row16_max_u32(unsigned k) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [1,0,3,2]
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [2,3,0,1]
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;  // row_half_mirror
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;  // row_mirror
+    return k;
 }
 // D = A(16x4) B(4x16) + C on the matrix core, v_mfma_f64_16x16x4_f64.  Lane layout (pinned on gfx950 by
 // tools/micro/mfma_f64_layout.hip): a = A[i = l&15][k = l>>4], b = B[k = l>>4][j = l&15],

@@ -219,3 +219,9 @@ extern "C" int smrt_emu_gauss_legendre(int n, double* mu, double* w) {
     smrt_host::gauss_legendre_positive(n, mu, w);
     return 0;
 }
+
+// panels of the Gauss-Jordan solves since the last call: [0] pivots from the diagonal block, [1] full-pivot fallback
+extern "C" void smrt_emu_panel_counts(long* out2) {
+    out2[0] = smrt::smrt_emu_panels[0]; out2[1] = smrt::smrt_emu_panels[1];
+    smrt::smrt_emu_panels[0] = smrt::smrt_emu_panels[1] = 0;
+}

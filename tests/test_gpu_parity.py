@@ -399,7 +399,8 @@ def test_active_reference_schur_case_m16(ctx):
                     np.deg2rad(th), emmodel="iba", microstructure="exponential", mode="A", n_max_stream=32, m_max=16)
     out = ctx.run(b)
     assert out.status[0] == 0
-    assert_backscatter_close(out.values[0], ref, spread=oracle_method_spread(sp, 10e9, th, ref, methods=("half_rank_eig",), **kw))
+    # (half_rank_eig finds complex pairs on this case and is skipped, like in the reference; `eig` is the yardstick)
+    assert_backscatter_close(out.values[0], ref, spread=oracle_method_spread(sp, 10e9, th, ref, **kw))
 
 
 def test_active_properties(ctx):

@@ -125,3 +125,23 @@ def test_emulated_active_kernel_high_azimuth_order(emu):
 def test_emulated_kernel_flags_albedo_above_one(emu):
     out, st, _ = run_fixture(emu, "dmrt_2layer_passive37")
     assert st[0] == 3 and np.isnan(out).all()
+
+
+@pytest.mark.parametrize("name,freqs,min_fast", [("cfg2_iba_L20_n32_sp0", [4], 0.9), ("iba_L6_n8_angles", None, 0.9),
+                                                 ("cfg4_iba_active_L5_n16", None, 0.6), ("dmrt_active_L3_n12", None, 0.0)])
+def test_gauss_jordan_takes_its_pivots_from_the_diagonal_blocks(emu, name, freqs, min_fast):
+    """With the eigenpairs sorted by the Jacobi kernel the fast panel of the finish kernels (pivots from the 16 x 16
+    diagonal block, dort_gauss_jordan.hpp:gj_panel16_fast) is the one that runs; where its acceptance test refuses a
+    block -- DMRT in active mode: clusters of equal eigenvalues -- the full-pivot panel takes over and the answer still
+    matches the reference."""
+    counts = (C.c_long * 2)()
+    emu.smrt_emu_panel_counts(counts)             # reset
+    out, st, ref = run_fixture(emu, name, nt=64, freqs=freqs)
+    emu.smrt_emu_panel_counts(counts)
+    fast, slow = counts[0], counts[1]
+    assert (st == 0).all() and fast + slow > 0
+    assert fast / (fast + slow) >= min_fast, (fast, slow)
+    if str(load_golden(name)["mode"]) == "A":
+        assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
+    else:
+        assert np.abs(out - ref).max() < 1e-6
