@@ -477,12 +477,12 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;
             if (MODE == 3) {
-                if (!gj_solve_b16<NT, false>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                if (!gj_solve_b16<NT, false, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
                 // -- Y = F tQt + G -> slot R ; W = (D G - Rtop F) tQt + (D F - Rtop G) -> slot X (over tQt) ; K = Y W^-1
                 r45_mfma2<NT, true>(F, G, Wk, Rt, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-                if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                if (!gj_solve_b16<NT, true, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             } else {
-            if (!(CH <= 2 ? gj_solve<NT, false>(Wk, Rt, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!(CH <= 2 ? gj_solve<NT, false, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             double* Q = Rt;
             for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
             block_sync();
@@ -490,7 +490,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else if (CH == 2 && dense_mfma) r45_mfma_big<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-            if (!(CH <= 2 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!(CH <= 2 ? gj_solve<NT, true, (CH > 1)>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }
             if (l > 0) {
                 const int nc = (N < Nu) ? N : Nu;

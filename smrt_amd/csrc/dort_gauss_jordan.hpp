@@ -147,26 +147,26 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
 // needs a pivot row from outside (clusters of equal eigenvalues, whose eigenvectors are arbitrary rotations) -- nothing
 // has been written, 0 is returned and the caller runs the full-pivot panel instead (from then on for every block of
 // the solve: its pivot rows are no longer aligned with the blocks).
-template <bool TR, int MAXRT>
-SMRT_DEV_NOINLINE int gj_panel16_fast(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk,
-                                       double growth_max) {
+// Part one (a separate function, vector instructions only: the matrix-core part stays in the calling kernel, whose
+// register budget it shares): invert the diagonal block into the LDS scratch `pinv` ([16][16], element (i, j) at
+// pinv[16 j + i]); A is not touched.  Returns the largest magnitude of the inverse (1e301 for NaN / inf / a busy row).
+template <bool TR>
+SMRT_DEV_NOINLINE double gj_inv16_block(const double* A, int N, int LD, int k, int lane, const int* rowblk, double* pinv) {
     const int k0 = 16 * k;
     const int nbk = (N - k0 < 16) ? N - k0 : 16;
-    const int RT = (N + 15) >> 4;
     const int r = lane & 15, g = lane >> 4;
     // the rows of the block must still be free
-    if (wave_max_u32((r < nbk && rowblk[k0 + r] >= 0) ? 1u : 0u) != 0u) return 0;
-    // (1) P in the 16 x 4 grid layout, identity-padded for a ragged last block: x[s] = P[r][4 g + s]
-    double x[4], x0[4];
+    if (wave_max_u32((r < nbk && rowblk[k0 + r] >= 0) ? 1u : 0u) != 0u) return 1e301;
+    // P in the 16 x 4 grid layout, identity-padded for a ragged last block: x[s] = P[r][4 g + s]
+    double x[4];
     const int rc = r < nbk ? r : 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c = 4 * g + s, cc = c < nbk ? c : 0;
-        const double v = at<TR>(A, k0 + rc, k0 + cc, LD);
+        const double v = at<TR>(const_cast<double*>(A), k0 + rc, k0 + cc, LD);
         x[s] = (r < nbk && c < nbk) ? v : ((r == c) ? 1.0 : 0.0);
-        x0[s] = x[s];
     }
-    // (2) in-place Gauss-Jordan inversion with row pivoting inside the block: row piv[j] of the result is row j of the
+    // in-place Gauss-Jordan inversion with row pivoting inside the block: row piv[j] of the result is row j of the
     // inverse of the row-permuted block, P^-1[kk][piv[j]] = Z[piv[kk]][j]
     bool used = false;
     int myinv = r;          // the step at which this lane's row was the pivot row
@@ -198,21 +198,39 @@ SMRT_DEV_NOINLINE int gj_panel16_fast(double* A, int N, int LD, int k, int lane,
             x[s] = isp ? prs : __builtin_fma(-f, prs, base);
         }
     }
-    // (3) the true inverse into A[blk, blk] (the block is about to be overwritten by U anyway)
     double amax = 0.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int pcol = (g == 0) ? piv[s] : (g == 1) ? piv[4 + s] : (g == 2) ? piv[8 + s] : piv[12 + s];
-        if (myinv < nbk && pcol < nbk) {
-            at<TR>(A, k0 + myinv, k0 + pcol, LD) = x[s];
-            amax = fabs(x[s]) > amax ? fabs(x[s]) : amax;
-        }
-        if (!(fabs(x[s]) <= 1e300)) amax = 1e301;   // NaN / inf anywhere (a zero pivot): reject
+        pinv[16 * pcol + myinv] = x[s];
+        const double m = fabs(x[s]);
+        amax = (m <= 1e300) ? (m > amax ? m : amax) : 1e301;
     }
     wave_sync_lds();
-    // (4) the multiplier block of every other row tile: -A[:, blk] P^-1, kept in registers until accepted
+    return amax;
+}
+
+// Part two (inline in the caller): the multiplier block of every other row tile, -A[:, blk] P^-1, by MFMA with the
+// inverse as the B operand; acceptance test; U into the panel columns.  Returns 1 if the block was taken.
+template <bool TR, int MAXRT>
+SMRT_DEV int gj_panel16_fast(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk, double* pinv,
+                             double growth_max) {
+    const int k0 = 16 * k;
+    const int nbk = (N - k0 < 16) ? N - k0 : 16;
+    const int RT = (N + 15) >> 4;
+    double amax = gj_inv16_block<TR>(A, N, LD, k, lane, rowblk, pinv);
     const int lr = lane & 15, lk = lane >> 4;
     double c[MAXRT][4];
+    {   // first vote: a busy row or a singular block needs no multiplier block at all
+        const float fm = amax > 3e38 ? 3e38f : (float)amax;
+        unsigned key;
+        memcpy(&key, &fm, 4);
+        key = wave_max_u32(key);
+        float gm;
+        memcpy(&gm, &key, 4);
+        if (!((double)gm <= growth_max)) return 0;
+        amax = (double)gm;
+    }
 #pragma unroll
     for (int ti = 0; ti < MAXRT; ++ti) {
 #pragma unroll
@@ -221,35 +239,27 @@ SMRT_DEV_NOINLINE int gj_panel16_fast(double* A, int N, int LD, int k, int lane,
             const int arow = ti * 16 + lr, arowc = arow < N ? arow : 0;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int j = 4 * kk + lk, jc = j < nbk ? j : 0, lrc = lr < nbk ? lr : 0;
-                const double av = at<TR>(A, arowc, k0 + jc, LD), bv = at<TR>(A, k0 + jc, k0 + lrc, LD);
+                const int j = 4 * kk + lk, jc = j < nbk ? j : 0;
+                const double av = at<TR>(A, arowc, k0 + jc, LD), bv = pinv[16 * lr + j];
                 mfma_f64_16x16x4((arow < N && j < nbk) ? av : 0.0, (j < nbk && lr < nbk) ? bv : 0.0, c[ti]);
             }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const double m = fabs(c[ti][reg]);
-                amax = (m > amax || !(m <= 1e300)) ? (m <= 1e300 ? m : 1e301) : amax;
+                amax = (m <= 1e300) ? (m > amax ? m : amax) : 1e301;
             }
         }
     }
-    {   // uniform verdict: the largest magnitude over the wavefront (float keys order like the values)
+    {   // second vote: the largest multiplier over the wavefront (float keys order like the values)
         const float fm = amax > 3e38 ? 3e38f : (float)amax;
         unsigned key;
         memcpy(&key, &fm, 4);
         key = wave_max_u32(key);
         float gm;
         memcpy(&gm, &key, 4);
-        if (!((double)gm <= growth_max)) {   // restore the block and let the caller pivot over all the rows
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cc = 4 * g + s;
-                if (r < nbk && cc < nbk) at<TR>(A, k0 + r, k0 + cc, LD) = x0[s];
-            }
-            wave_sync_lds();
-            return 0;
-        }
+        if (!((double)gm <= growth_max)) return 0;   // nothing has been written to A
     }
-    // (5) U into the panel columns: -A[:, blk] P^-1 outside the block, P^-1 - I inside
+    // U into the panel columns: -A[:, blk] P^-1 outside the block, P^-1 - I inside
 #pragma unroll
     for (int ti = 0; ti < MAXRT; ++ti) {
         if (ti < RT && ti != k) {
@@ -260,12 +270,16 @@ SMRT_DEV_NOINLINE int gj_panel16_fast(double* A, int N, int LD, int k, int lane,
             }
         }
     }
-    wave_sync_lds();
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = lk + 4 * reg;   // element (i, lr) of the block
+        if (i < nbk && lr < nbk) at<TR>(A, k0 + i, k0 + lr, LD) = pinv[16 * lr + i] - (i == lr ? 1.0 : 0.0);
+    }
     if (lane < nbk) {
-        at<TR>(A, k0 + lane, k0 + lane, LD) -= 1.0;
         perm[k0 + lane] = k0 + lane;
         rowblk[k0 + lane] = k;
     }
+    wave_sync_lds();
     return 1;
 }
 
@@ -282,7 +296,11 @@ inline long smrt_emu_panels[2] = {0, 0};   // emulator builds count [0] fast and
 
 // result_in_A: leave the solution in A (one pass and one barrier less than copying it back over Bm), optionally scaled
 // X[k][c] * rs[k] * cs[c] on the way (the t Q t scaling of the recursion).
-template <int NT, bool TR>
+// BIG: the instantiation may meet N > 64 (two rows per lane in the full-pivot panel, up to eight row tiles in the fast
+// one).  The LDS-resident kernels (N <= 64) pass false: the panels are separate (noinline) functions whose register
+// footprint counts against the kernel's even when they are never called, and the two-workgroups-per-CU finish kernel
+// has none to spare (<= 256 VGPRs).
+template <int NT, bool TR, bool BIG = true>
 SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
                            const double* rs = nullptr, const double* cs = nullptr, bool allow_fast = false) {
     const int t = tid();
@@ -293,10 +311,18 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     int* rowblk = perm + NMX + 16;              // [NMX] block in which the row was a pivot row, -1 before
     int* fail = rowblk + NMX;
     int* fast = fail + 1;                       // 1 while the blocks so far took their pivots from the diagonal block
+    double* pinv = s.gj + (2 * NMX + 18 + 1) / 2 + 1;   // [256] inverse of the running diagonal block (fast panel)
     const bool has_v = (v != nullptr);
     const int RT = (N + 15) >> 4;
     const int lr = lane & 15, lk = lane >> 4;
     for (int r = t; r < NMX; r += NT) rowblk[r] = -1;
+#ifndef SMRT_GJ_FAST_PANEL
+    // Measured on MI355X (profiles/r2_gj_fast_panel.txt): inside the finish kernel the diagonal-block panel costs as
+    // much as the full-pivot one (its ds_bpermute traffic queues behind the LDS reads of the other wavefronts' tile
+    // updates: ~1300 cycles per column in situ against 350-425 alone), so the default build keeps the full-pivot panel,
+    // whose numerics do not depend on the order of the eigenpairs.  -DSMRT_GJ_FAST_PANEL builds take the fast one.
+    allow_fast = false;
+#endif
     if (t == 0) { *fail = 0; *fast = allow_fast ? 1 : 0; }
     block_sync();
 #ifdef SMRT_STAGE_TIMING
@@ -307,14 +333,17 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 #endif
     auto panel = [&](int kb) -> bool {   // one wavefront; the flag was published by the previous block's barrier
         if (*fast) {
-            const int took = (N > 64) ? gj_panel16_fast<TR, 8>(A, N, LD, kb, lane, perm, rowblk, SMRT_GJ_GROWTH_MAX)
-                                      : gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, SMRT_GJ_GROWTH_MAX);
+            int took;
+            if constexpr (BIG) took = (N > 64) ? gj_panel16_fast<TR, 8>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX)
+                                               : gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX);
+            else took = gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX);
             if (took) { SMRT_COUNT_PANEL(0); return true; }
             if (lane == 0) *fast = 0;
             wave_sync_lds();
         }
         SMRT_COUNT_PANEL(1);
-        return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        if constexpr (BIG) return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        else return gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
     };
     if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
     SMRT_GSUB(0);
@@ -461,9 +490,9 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 }
 
 // the Gauss-Jordan entry point of the drivers (solution copied back over Bm)
-template <int NT, bool TR>
+template <int NT, bool TR, bool BIG = true>
 SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool allow_fast = false) {
-    return gj_solve_b16<NT, TR>(A, Bm, v, s, N, LD, false, nullptr, nullptr, allow_fast);
+    return gj_solve_b16<NT, TR, BIG>(A, Bm, v, s, N, LD, false, nullptr, nullptr, allow_fast);
 }
 
 }  // namespace smrt

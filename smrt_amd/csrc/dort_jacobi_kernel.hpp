@@ -238,6 +238,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     block_sync();
     const bool ok = jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], b.jacobi_skip2, b.jacobi_exit2);
     if (!ok) { if (t == 0) stg.n[item] = -ST_EIGEN; return; }   // per layer, like the prep kernel's failures
+#ifdef SMRT_GJ_FAST_PANEL
     // eigenpairs out in ascending order of the singular value -- the order of the streams in the no-scattering limit,
     // where column c of the recursion matrices then belongs to row c: what lets the Gauss-Jordan solves of the finish
     // kernel take their pivots from the diagonal blocks (gj_panel16_fast).  Rank by counting; the dead norm buffer holds
@@ -252,6 +253,10 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     block_sync();
     for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[src[c] * LDJ + r]; });
     for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[src[r]];
+#else
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
+    for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
+#endif
 }
 
 // Rows per lane follow the item's OWN size N = stg.n[item] (streams x polarisations of that layer: total reflection

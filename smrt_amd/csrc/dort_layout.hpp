@@ -136,7 +136,11 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_phi = o; o += (slim == 2 ? 0 : 5 * nphi);
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
-    p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? 88 : !matrices_in_lds ? 2 * p.NMAX / 2 + p.NMAX / 2 + 32 : ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    // Gauss-Jordan bookkeeping: perm [NMAX + 16] + rowblk [NMAX] + two flags (ints), then the 16 x 16 inverse of the
+    // running diagonal block (fast panel): NMAX + 11 + 256 doubles
+    const int gjd = p.NMAX + 12 + 256;
+    const int full = ((16 * p.NMAX + 8 > 1024 + 8) ? 16 * p.NMAX + 8 : 1024 + 8) + (p.NMAX + 8 + 1) / 2;
+    p.o_gj = o; o += slim == 1 ? 520 : slim == 2 ? gjd : !matrices_in_lds ? gjd + p.NMAX / 2 + 32 : (full > gjd ? full : gjd);
     p.o_act = o; o += act_doubles;
     p.o_jac = -1;
     // 1: a whole matrix (Jacobi stage of the fused kernel); 2: only the 16 NMAX doubles of scratch that the blocked

@@ -502,9 +502,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
         if (MODE == 3) {  // the solution t Q t stays in slot X (one pass over the matrix instead of three)
-            if (!gj_solve_b16<NT, false>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve_b16<NT, false, (CH > 1)>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH <= 2 ? gj_solve<NT, false>(Wk, Rt, s.cvec, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH <= 2 ? gj_solve<NT, false, (CH > 1)>(Wk, Rt, s.cvec, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = (MODE == 3) ? Wk : Rt;
         SMRT_DUMP("Q", Q, N);
@@ -524,9 +524,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
         if (MODE == 3) {  // A = W (slot X), B = Y (slot R); K is left in slot X
-            if (!gj_solve_b16<NT, true>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve_b16<NT, true, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH <= 2 ? gj_solve<NT, true>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!(CH <= 2 ? gj_solve<NT, true, (CH > 1)>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);

@@ -129,11 +129,23 @@ def test_emulated_kernel_flags_albedo_above_one(emu):
 
 @pytest.mark.parametrize("name,freqs,min_fast", [("cfg2_iba_L20_n32_sp0", [4], 0.9), ("iba_L6_n8_angles", None, 0.9),
                                                  ("cfg4_iba_active_L5_n16", None, 0.6), ("dmrt_active_L3_n12", None, 0.0)])
-def test_gauss_jordan_takes_its_pivots_from_the_diagonal_blocks(emu, name, freqs, min_fast):
-    """With the eigenpairs sorted by the Jacobi kernel the fast panel of the finish kernels (pivots from the 16 x 16
-    diagonal block, dort_gauss_jordan.hpp:gj_panel16_fast) is the one that runs; where its acceptance test refuses a
-    block -- DMRT in active mode: clusters of equal eigenvalues -- the full-pivot panel takes over and the answer still
-    matches the reference."""
+def test_gauss_jordan_takes_its_pivots_from_the_diagonal_blocks(name, freqs, min_fast):
+    """The optional fast panel of the Gauss-Jordan solves (-DSMRT_GJ_FAST_PANEL builds; pivots from the 16 x 16 diagonal
+    block, dort_gauss_jordan.hpp:gj_panel16_fast, with the eigenpairs sorted by the Jacobi kernel): it is the one that
+    runs; where its acceptance test refuses a block -- DMRT in active mode: clusters of equal eigenvalues -- the
+    full-pivot panel takes over and the answer still matches the reference.  (The default build keeps the full-pivot
+    panel: the fast one brought no speed-up inside the kernel, profiles/r2_gj_fast_panel.txt.)"""
+    lib_path = os.path.join(EMU_DIR, "libsmrt_emu_fastpanel.so")
+    csrc = os.path.join(ROOT, "smrt_amd", "csrc")
+    srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp")] + sorted(
+        os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp"))
+    if not os.path.exists(lib_path) or any(os.path.getmtime(s) > os.path.getmtime(lib_path) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-DSMRT_GJ_FAST_PANEL", "-I", EMU_DIR, "-o",
+                               lib_path, srcs[0]])
+    emu = C.CDLL(lib_path)
+    P = C.POINTER
+    emu.smrt_emu_run.argtypes = [P(SmrtBatch), C.c_longlong, C.c_longlong, C.c_int, C.c_int, P(C.c_double),
+                                 P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_long)]
     counts = (C.c_long * 2)()
     emu.smrt_emu_panel_counts(counts)             # reset
     out, st, ref = run_fixture(emu, name, nt=64, freqs=freqs)
