@@ -64,8 +64,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
-    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1));
-    double* dense_scratch = (CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
+    // N > 128 (CH > 2): always, with the scratch of the blocked solvers behind the work matrices in the global workspace
+    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1)) || (CH > 2);
+    double* dense_scratch = (CH > 2) ? gmem_mat + plan.mat_doubles
+                                     : ((CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0));
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
     const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
@@ -473,24 +475,24 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
             if (MODE == 3) r1_compute<NT>(s.M3, s.M0, r1a, N, LD);
             else if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
-            else if (CH == 2 && dense_mfma) r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            else if (CH >= 2 && dense_mfma) r1_mfma_big<NT, 16 * CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;
             if (MODE == 3) {
-                if (!gj_solve_b16<NT, false, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                if (!gj_solve_b16<NT, false, CH>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
                 // -- Y = F tQt + G -> slot R ; W = (D G - Rtop F) tQt + (D F - Rtop G) -> slot X (over tQt) ; K = Y W^-1
                 r45_mfma2<NT, true>(F, G, Wk, Rt, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-                if (!gj_solve_b16<NT, true, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                if (!gj_solve_b16<NT, true, CH>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             } else {
-            if (!(CH <= 2 ? gj_solve<NT, false, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve<NT, false, CH>(Wk, Rt, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             double* Q = Rt;
             for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
             block_sync();
             // -- Y = F tQt + G ; W = (D G - Rtop F) tQt + (D F - Rtop G) ; K = Y W^-1
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-            else if (CH == 2 && dense_mfma) r45_mfma_big<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            else if (CH >= 2 && dense_mfma) r45_mfma_big<NT, true, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-            if (!(CH <= 2 ? gj_solve<NT, true, (CH > 1)>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve<NT, true, CH>(F, Wk, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }
             if (l > 0) {
                 const int nc = (N < Nu) ? N : Nu;

@@ -719,22 +719,25 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
 // ---- the two row-block passes for 64 < N <= 128 (global-workspace kernels): same algorithm, 32 k-groups per row,
 // up to eight row tiles, one row tile per wavefront at a time (its A operands in registers), operands from wherever
 // the matrices live (all pointers are generic).
-template <int NT>
+// KG = k-groups of four columns a row block spans = 16 per 64 rows (N <= 4 KG): the A operands of one 16-row tile, KG
+// doubles per lane, are pulled into registers before anything of that tile is written (in-place row updates).
+template <int NT, int KG = 32>
 SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* Wk, double* cvec, const double* svec,
                           double Bl, int N, int LD) {
     constexpr int NW = NT / SMRT_LANES;
-    constexpr int RPW = (NW >= 8) ? 1 : (8 + NW - 1) / NW;
-    constexpr int CS = (NW > 8) ? NW / 8 : 1;
+    constexpr int MAXRT = KG / 4;
+    constexpr int RPW = (NW >= MAXRT) ? 1 : (MAXRT + NW - 1) / NW;
+    constexpr int CS = (NW > MAXRT) ? NW / MAXRT : 1;
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
     for (int o = 0; o < RPW; ++o) {
-        const int ti = (NW >= 8) ? (wave & 7) : (wave + o * NW);
-        const int cs = (NW >= 8) ? (wave >> 3) : 0;
+        const int ti = (NW >= MAXRT) ? (wave % MAXRT) : (wave + o * NW);
+        const int cs = (NW >= MAXRT) ? (wave / MAXRT) : 0;
         const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
-        double a[32];
+        double a[KG];
         double rs = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
+        for (int kk = 0; kk < KG; ++kk) {
             const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
             const double x = Rt[kc * LD + ic];
             a[kk] = (ti < RT && i < N && k < N) ? x : 0.0;
@@ -749,7 +752,7 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
                 double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
                 const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
+                for (int kk = 0; kk < KG; ++kk) {
                     if (4 * kk < N) {
                         const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
                         const bool in = (j < N && k < N);
@@ -768,24 +771,25 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
     block_sync();
 }
 
-template <int NT, bool SIGNED>
+template <int NT, bool SIGNED, int KG = 32>
 SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
                            double* upb, double* gvec, double Bl, int N, int LD, const double* dsg) {
     constexpr int NW = NT / SMRT_LANES;
-    constexpr int RPW = (NW >= 8) ? 1 : (8 + NW - 1) / NW;
-    constexpr int CS = (NW > 8) ? NW / 8 : 1;
+    constexpr int MAXRT = KG / 4;
+    constexpr int RPW = (NW >= MAXRT) ? 1 : (MAXRT + NW - 1) / NW;
+    constexpr int CS = (NW > MAXRT) ? NW / MAXRT : 1;
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
     for (int o = 0; o < RPW; ++o) {
-        const int ti = (NW >= 8) ? (wave & 7) : (wave + o * NW);
-        const int cs = (NW >= 8) ? (wave >> 3) : 0;
+        const int ti = (NW >= MAXRT) ? (wave % MAXRT) : (wave + o * NW);
+        const int cs = (NW >= MAXRT) ? (wave / MAXRT) : 0;
         const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
         const double rt = Rtop[ic];
         const double sg = SIGNED ? dsg[ic] : 1.0;
-        double af[32], aw[32];
+        double af[KG], aw[KG];
         double vy = 0.0, vg = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
+        for (int kk = 0; kk < KG; ++kk) {
             const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
             const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
             const bool in = (ti < RT && i < N && k < N);
@@ -803,7 +807,7 @@ SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* 
                 double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
                 const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
+                for (int kk = 0; kk < KG; ++kk) {
                     if (4 * kk < N) {
                         const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
                         const double qv = Q[jc * LD + kc];

@@ -26,7 +26,7 @@ namespace smrt {
 // block k+1 is factorised by the owner of that column tile right after it has updated the tile (look-ahead).
 // RPLN = rows per lane: 1 for N <= 64 (lane = row), 2 for N <= 128 (lane holds rows lane and lane + 64).
 template <bool TR, int RPLN>
-SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+SMRT_DEV bool gj_panel16_impl(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
     // x[r][s] holds panel column s of row (lane + 64 r) until the column has been a pivot column, its multiplier u_s
     // afterwards: both kinds of slot receive the same update x[s] += u_j * x[s][pivot row], so a step treats all
     // slots but the pivot one alike.  The loop is unrolled by four only, with the slots rotated by four after every
@@ -62,7 +62,7 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
         for (int q = 0; q < 4; ++q) {
             const int j = grp * 4 + q;
             if (j < nbk) {   // uniform
-                // arg-max over the unused rows: float magnitude bits with (255 - row) in the 8 low mantissa bits
+                // arg-max over the unused rows: float magnitude bits with (511 - row) in the 9 low mantissa bits (N <= 384)
                 unsigned key = 0u;
 #pragma unroll
                 for (int r = 0; r < RPLN; ++r) {
@@ -70,24 +70,26 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
                         const float xr = (float)fabs(x[r][q]);
                         unsigned kr;
                         memcpy(&kr, &xr, 4);
-                        kr = (kr & ~0xFFu) | (unsigned)(255 - (lane + 64 * r));
+                        kr = (kr & ~0x1FFu) | (unsigned)(511 - (lane + 64 * r));
                         key = kr > key ? kr : key;
                     }
                 }
                 key = wave_max_u32(key);
-                if (key < 256u) ok = false;
-                const int p = ok ? 255 - (int)(key & 0xFFu) : 0;
+                if (key < 512u) ok = false;
+                const int p = ok ? 511 - (int)(key & 0x1FFu) : 0;
                 if (lane == j) pj_store = p;
                 const int pl = p & 63, ps = p >> 6;   // lane and slot of the pivot row (uniform)
                 double pvq = x[0][q];
-                if (RPLN > 1) pvq = ps ? x[RPLN - 1][q] : x[0][q];
+#pragma unroll
+                for (int r2 = 1; r2 < RPLN; ++r2) pvq = (ps == r2) ? x[r2][q] : pvq;
                 const double rpv = fast_rcp(ok ? wave_bcast(pvq, pl) : 1.0);
                 double pr[16];
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) {
                     if (s2 != q) {
                         double src = x[0][s2];
-                        if (RPLN > 1) src = ps ? x[RPLN - 1][s2] : x[0][s2];
+#pragma unroll
+                        for (int r2 = 1; r2 < RPLN; ++r2) src = (ps == r2) ? x[r2][s2] : src;
                         pr[s2] = wave_bcast(src, pl);
                     }
                 }
@@ -130,6 +132,14 @@ SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int
     }
     if (lane < nbk) perm[k0 + lane] = pj_store;
     return ok;
+}
+// RPLN <= 2 (N <= 128): a separate function, so that its registers do not count twice in kernels that call it from two
+// places and must stay within 256 VGPRs; more rows per lane (N <= 64 RPLN, global-workspace kernels with one wavefront
+// per SIMD and the whole register file to themselves): inlined, a callable function would be compiled for a smaller
+// budget and spill its 32 RPLN row registers.
+template <bool TR, int RPLN>
+SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+    return gj_panel16_impl<TR, RPLN>(A, N, LD, k, lane, perm, rowblk);
 }
 
 // ---- the fast panel: pivots from the 16 x 16 DIAGONAL block only ----------------------------------------------------
@@ -300,7 +310,7 @@ inline long smrt_emu_panels[2] = {0, 0};   // emulator builds count [0] fast and
 // one).  The LDS-resident kernels (N <= 64) pass false: the panels are separate (noinline) functions whose register
 // footprint counts against the kernel's even when they are never called, and the two-workgroups-per-CU finish kernel
 // has none to spare (<= 256 VGPRs).
-template <int NT, bool TR, bool BIG = true>
+template <int NT, bool TR, int CHN = 2>   // CHN = the kernel's CH: N <= 64 CHN
 SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
                            const double* rs = nullptr, const double* cs = nullptr, bool allow_fast = false) {
     const int t = tid();
@@ -332,18 +342,26 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 #define SMRT_GSUB(k) do {} while (0)
 #endif
     auto panel = [&](int kb) -> bool {   // one wavefront; the flag was published by the previous block's barrier
+#ifdef SMRT_GJ_FAST_PANEL
         if (*fast) {
             int took;
-            if constexpr (BIG) took = (N > 64) ? gj_panel16_fast<TR, 8>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX)
-                                               : gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX);
+            if constexpr (CHN >= 2) took = (N > 64) ? gj_panel16_fast<TR, 4 * CHN>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX)
+                                                    : gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX);
             else took = gj_panel16_fast<TR, 4>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX);
             if (took) { SMRT_COUNT_PANEL(0); return true; }
             if (lane == 0) *fast = 0;
             wave_sync_lds();
         }
+#endif
         SMRT_COUNT_PANEL(1);
-        if constexpr (BIG) return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
-        else return gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        if constexpr (CHN > 2) {          // rows lane + 64 r, r < CHN, of the panel in registers (inlined, see gj_panel16)
+            if (N > 128) return gj_panel16_impl<TR, CHN>(A, N, LD, kb, lane, perm, rowblk);
+            return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        } else if constexpr (CHN == 2) {
+            return (N > 64) ? gj_panel16<TR, 2>(A, N, LD, kb, lane, perm, rowblk) : gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        } else {
+            return gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
+        }
     };
     if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
     SMRT_GSUB(0);
@@ -449,10 +467,13 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
                 store_pivot_rows(g, tmp);
                 wave_sync_lds();
             }
-            if (has_v && widx == 0) {  // extra right-hand side: same transformation, rows lane and lane + 64
-                double acc[2] = {0.0, 0.0};
+            if (has_v && widx == 0) {  // extra right-hand side: same transformation, rows lane + 64 r2
+                constexpr int VR = CHN < 2 ? 2 : CHN;
+                double acc[VR];
 #pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2) {
+                for (int r2 = 0; r2 < VR; ++r2) acc[r2] = 0.0;
+#pragma unroll
+                for (int r2 = 0; r2 < VR; ++r2) {
                     const int row = lane + 64 * r2;
                     if (row < N) {
                         acc[r2] = v[row];
@@ -461,7 +482,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
                 }
                 wave_sync_lds();
 #pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2)
+                for (int r2 = 0; r2 < VR; ++r2)
                     if (lane + 64 * r2 < N) v[lane + 64 * r2] = acc[r2];
             }
         }
@@ -473,16 +494,21 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     // ---- undo the implicit row permutation: row perm[k] of B is row k of the solution (A is free scratch now)
     if (rs) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD) * (rs[k] * cs[c]); });
     else for_2d<NT>(N, N, [&](int k, int c) { at<TR>(A, k, c, LD) = at<TR>(Bm, perm[k], c, LD); });
-    double vk[2] = {0.0, 0.0};   // N <= 128 <= 2 NT
+    constexpr int VK = (64 * (CHN < 1 ? 1 : CHN) + NT - 1) / NT < 2 ? 2 : (64 * CHN + NT - 1) / NT;   // N <= 64 CHN <= VK NT
+    double vk[VK];
+#pragma unroll
+    for (int q = 0; q < VK; ++q) vk[q] = 0.0;
     if (has_v) {
-        if (t < N) vk[0] = v[perm[t]];
-        if (t + NT < N) vk[1] = v[perm[t + NT]];
+#pragma unroll
+        for (int q = 0; q < VK; ++q)
+            if (t + q * NT < N) vk[q] = v[perm[t + q * NT]];
     }
     block_sync();
     if (!result_in_A) for_2d<NT>(N, N, [&](int k, int c) { at<TR>(Bm, k, c, LD) = at<TR>(A, k, c, LD); });
     if (has_v) {
-        if (t < N) v[t] = vk[0];
-        if (t + NT < N) v[t + NT] = vk[1];
+#pragma unroll
+        for (int q = 0; q < VK; ++q)
+            if (t + q * NT < N) v[t + q * NT] = vk[q];
     }
     block_sync();
     SMRT_GSUB(2);
@@ -490,9 +516,9 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 }
 
 // the Gauss-Jordan entry point of the drivers (solution copied back over Bm)
-template <int NT, bool TR, bool BIG = true>
+template <int NT, bool TR, int CHN = 2>
 SMRT_DEV bool gj_solve(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool allow_fast = false) {
-    return gj_solve_b16<NT, TR, BIG>(A, Bm, v, s, N, LD, false, nullptr, nullptr, allow_fast);
+    return gj_solve_b16<NT, TR, CHN>(A, Bm, v, s, N, LD, false, nullptr, nullptr, allow_fast);
 }
 
 }  // namespace smrt

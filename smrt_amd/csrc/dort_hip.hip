@@ -189,8 +189,8 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         lds = (size_t)plan.total * sizeof(double);
         if (lds > (size_t)ctx->max_lds) { ctx->err = "too many layers for the LDS-resident per-layer tables"; return -1; }
         ctx->gmem_grid = (int)std::min<int64_t>(pair_count, 1024);
-        ctx->ws_stride = plan.mat_doubles;
-        HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * plan.mat_doubles));
+        ctx->ws_stride = (long long)plan.mat_doubles + plan.scratch_doubles;
+        HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * (size_t)ctx->ws_stride));
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;

@@ -79,6 +79,7 @@ struct LdsPlan {
     int slim;             // 0: full layout, 1: prep kernel, 2: two-slot finish kernel (see make_plan)
     int matrices_in_lds;  // 1: the four N x N work matrices are LDS-resident; 0: they live in a global workspace
     int mat_doubles;      // doubles of matrix workspace per workgroup (4 * NMAX * LD)
+    int scratch_doubles;  // global-workspace kernels with N > 128: scratch of the blocked solvers behind the matrices
     int o_M[4];
     int o_rowvec;   // 17 vectors of NMAX
     int o_strvec;   // 6 vectors of nmax
@@ -125,6 +126,7 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.matrices_in_lds = matrices_in_lds;
     const int nmat = slim ? 2 : 4;
     p.mat_doubles = nmat * p.NMAX * p.LD;
+    p.scratch_doubles = (!matrices_in_lds && p.NMAX > 128) ? 16 * p.NMAX : 0;
     int o = 0;
     for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * p.NMAX * p.LD; }
     if (slim == 2) p.o_M[3] = p.NMAX * p.LD;  // the two-slot finish kernel: M0 = X, M3 = R (M1, M2 live in global memory)

@@ -164,8 +164,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
     // (the prep half only needs the 512-double Cholesky scratch, which its slim plan has)
-    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1));
-    double* dense_scratch = (CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0);
+    // N > 128 (CH > 2): always, with the scratch of the blocked solvers behind the work matrices in the global workspace
+    const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1)) || (CH > 2);
+    double* dense_scratch = (CH > 2) ? gmem_mat + plan.mat_doubles
+                                     : ((CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0));
 #ifdef SMRT_STAGE_TIMING
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     s.sub_acc = sub_acc_store;
@@ -493,8 +495,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             r1_compute<NT>(s.M3, s.M0, r1a, N, LD);   // Wk -> slot X, R~ F - G -> slot R
         } else if (CH == 1) {
             r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
-        } else if (CH == 2 && dense_mfma) {
-            r1_mfma_big<NT>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
+        } else if (CH >= 2 && dense_mfma) {
+            r1_mfma_big<NT, 16 * CH>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         } else {
             r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, Bl, N, LD);
         }
@@ -502,9 +504,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_LU1);
         // -- x+ = Q t x- + q : solve (F - Rt G) [Q | q] = [Rt F - G | c]
         if (MODE == 3) {  // the solution t Q t stays in slot X (one pass over the matrix instead of three)
-            if (!gj_solve_b16<NT, false, (CH > 1)>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve_b16<NT, false, CH>(Wk, Rt, s.cvec, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH <= 2 ? gj_solve<NT, false, (CH > 1)>(Wk, Rt, s.cvec, s, N, LD, MODE == 2) : lu_solve<NT, false>(Wk, Rt, s.cvec, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!gj_solve<NT, false, CH>(Wk, Rt, s.cvec, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R45);
         double* Q = (MODE == 3) ? Wk : Rt;
         SMRT_DUMP("Q", Q, N);
@@ -515,8 +517,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             r45_mfma2<NT>(F, G, Q, Rt, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);   // Y -> slot R, W -> slot X (over Q)
         } else if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
-        } else if (CH == 2 && dense_mfma) {
-            r45_mfma_big<NT, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+        } else if (CH >= 2 && dense_mfma) {
+            r45_mfma_big<NT, false, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         } else {
             r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         }
@@ -524,9 +526,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         SMRT_STAGE(SG_LU2);
         // -- K = Y W^-1  (solve W^T K^T = Y^T on the transposed view; K lands in Wk in normal storage)
         if (MODE == 3) {  // A = W (slot X), B = Y (slot R); K is left in slot X
-            if (!gj_solve_b16<NT, true, (CH > 1)>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            if (!gj_solve_b16<NT, true, CH>(Wk, Rt, nullptr, s, N, LD, true, nullptr, nullptr, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         } else
-        if (!(CH <= 2 ? gj_solve<NT, true, (CH > 1)>(F, Wk, nullptr, s, N, LD, MODE == 2) : lu_solve<NT, true>(F, Wk, nullptr, s.sigma, N, LD))) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+        if (!gj_solve<NT, true, CH>(F, Wk, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
         SMRT_STAGE(SG_R78);
         double* K = Wk;
         SMRT_DUMP("K", K, N);

@@ -140,11 +140,16 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     const bool active = (b->mode == SMRT_MODE_ACTIVE);
     const int P = active ? 3 : 2;
     const bool gmem = b->n_max_stream * P > 64;
-    const LdsPlan plan = active ? make_plan(b->n_max_stream, 3, b->n_layers_max, b->n_theta, azimuth_samples(b->m_max) / 2 + 1,
-                                            gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta), 0, gmem ? 1 : 0)
-                                : make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1, 0, 0, gmem ? 1 : 0);
-    if (plan.NMAX > 128) return -2;
-    const size_t matd = gmem ? (size_t)plan.mat_doubles : 0;
+    auto plan_with = [&](int jac) {
+        return active ? make_plan(b->n_max_stream, 3, b->n_layers_max, b->n_theta, azimuth_samples(b->m_max) / 2 + 1,
+                                  gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta), 0, jac)
+                      : make_plan(b->n_max_stream, 2, b->n_layers_max, b->n_theta, 9, gmem ? 0 : 1, 0, 0, jac);
+    };
+    LdsPlan plan = plan_with(gmem ? 1 : 0);
+    int jac_in_lds = gmem ? 1 : 0;
+    if (gmem && (size_t)plan.total * sizeof(double) > 160 * 1024) { plan = plan_with(0); jac_in_lds = 0; }   // like smrt_dort_upload
+    if (plan.NMAX > 384) return -2;
+    const size_t matd = gmem ? (size_t)plan.mat_doubles + plan.scratch_doubles : 0;
     std::vector<double> gl(b->n_max_stream);
     smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
     DevBatch d{};
@@ -152,7 +157,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
     d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
     d.want_layer_out = layer_out ? 1 : 0; d.want_stream_out = stream_out ? 1 : 0;
-    d.jac_in_lds = gmem ? 1 : 0;
+    d.jac_in_lds = jac_in_lds;
     d.pair_begin = pair_begin; d.pair_count = pair_count;
     d.n_layers = b->n_layers; d.thickness = b->thickness; d.frac_volume = b->frac_volume;
     d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
@@ -166,7 +171,12 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.jacobi_exit2 = active ? 1e-22 : SMRT_JACOBI_EXIT_COS2;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    if (gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
+    if (gmem && plan.NMAX > 128) {   // fused global-workspace kernels, four / six 64-row chunks
+        if (nt != 256) return -3;
+        const int ch = plan.NMAX <= 256 ? 4 : 6;
+        if (active) nb = ch == 4 ? run_active<256, 4>(d, order, plan.total, matd) : run_active<256, 6>(d, order, plan.total, matd);
+        else nb = ch == 4 ? run_pairs<256, 4>(d, order, plan.total, matd) : run_pairs<256, 6>(d, order, plan.total, matd);
+    } else if (gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
         nb = active ? run_split_gmem<256, true>(d, order, plan) : run_split_gmem<256, false>(d, order, plan);
     } else if (active) {
         if (gmem) {
