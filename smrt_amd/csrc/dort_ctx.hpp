@@ -46,7 +46,8 @@ struct smrt_dort_ctx {
     size_t jacobi_lds = 0;
     smrt::DevStage stage{};
     bool gmem_path = false;
-    bool gmem_split = false;    // 64 < N <= 128 passive: three-kernel pipeline on the global workspace
+    bool gmem_split = false;    // 64 < N: three-kernel pipeline on the global workspace
+    bool big = false;           // ... with the kernels for N > 128 (matrix larger than LDS in the Jacobi kernel)
     int jac_in_lds = 0;
     bool active = false;
     int gmem_grid = 0;
@@ -77,6 +78,10 @@ hipError_t active_finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
 // k_gmem_split.hip: 64 < N <= 128, work matrices in the per-workgroup global workspace, grid-stride over the pairs
 hipError_t prep_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active);
 hipError_t finish_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active);
+// k_gmem_split_big.hip: the same for 128 < N <= 384 (ch = 4 or 6 row chunks of 64), k_jacobi_big.hip: its Jacobi kernel
+hipError_t prep_gmem_big(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active, int ch);
+hipError_t finish_gmem_big(smrt_dort_ctx* ctx, const smrt::DevBatch& c, unsigned grid, bool active, int ch);
+hipError_t jacobi_big(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_fused.hip / k_gmem_fused.hip: everything of a pair in one workgroup
 hipError_t fused(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int nt, bool active);
 hipError_t fused_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int ch, bool active);

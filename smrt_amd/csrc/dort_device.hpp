@@ -32,3 +32,4 @@
 #include "dort_gauss_jordan.hpp"   // blocked Gauss-Jordan
 #include "dort_passive.hpp"        // per-pair driver, passive mode (dort_active.hpp: active mode)
 #include "dort_jacobi_kernel.hpp"  // Jacobi kernel of the pipelines
+#include "dort_jacobi_big.hpp"     // ... for matrices larger than LDS (N > 128)

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "dort_ctx.hpp"
-#include "dort_jacobi_kernel.hpp"   // make_jacobi_plan (templates only: nothing is instantiated here)
+#include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
 
 using namespace smrt;
@@ -52,7 +52,13 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
         const DevBatch c = chunk_of(ctx, d, c0, cn);
         hipError_t e;
-        if (ctx->gmem_split) {
+        if (ctx->big) {
+            const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
+            const int ch = ctx->nmax_rows <= 256 ? 4 : 6;
+            if ((e = smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ch)) != hipSuccess) return e;
+            if ((e = smrt_launch::jacobi_big(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
+            if ((e = smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ch)) != hipSuccess) return e;
+        } else if (ctx->gmem_split) {
             const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
             if ((e = smrt_launch::prep_gmem(ctx, c, grid, ctx->active)) != hipSuccess) return e;
             if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
@@ -194,13 +200,24 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
-    ctx->gmem_split = ctx->gmem_path && ctx->split && plan.NMAX <= 128 && ctx->jac_in_lds &&
-                      (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
+    // N > 128: the pipeline with the blocked Jacobi kernel (matrix in the staging area, column blocks through LDS)
+    ctx->big = ctx->gmem_path && ctx->split && plan.NMAX > 128 && getenv("SMRT_DORT_NO_BIG_PIPELINE") == nullptr &&
+               (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
+    ctx->gmem_split = ctx->big || (ctx->gmem_path && ctx->split && plan.NMAX <= 128 && ctx->jac_in_lds &&
+                      (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds);
+    if (ctx->big) ctx->jac_in_lds = 0;   // prep / finish of the big pipeline keep no Jacobi buffer in LDS
     if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
         const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer
         const size_t mat = (size_t)plan.NMAX * plan.LD;
         const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
-        long long chunk = (long long)(12.0e9 / (double)per_pair);
+        // staging budget: 12 GB, or -- for the large matrices of the big pipeline, where 12 GB hold too few pairs to fill
+        // the chip -- up to 60 % of the free device memory
+        double budget = 12.0e9;
+        if (ctx->big) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, 0.6 * (double)(free_b + ctx->d_stL.cap + ctx->d_stB.cap));
+        }
+        long long chunk = (long long)(budget / (double)per_pair);
         if (chunk < 1) chunk = 1;
         if (chunk > pair_count) chunk = pair_count;
         ctx->chunk_pairs = chunk;
@@ -215,10 +232,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
         ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
-        ctx->jacobi_lds = (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
+        ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
+                                   : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd, 1).total * sizeof(double);
         ctx->finish2_lds_bytes = ctx->gmem_split
-            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 2).total * sizeof(double)
+            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, ctx->big ? 0 : 2).total * sizeof(double)
             : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
     }
     if (b->prune_optical_depth > 0.0) {

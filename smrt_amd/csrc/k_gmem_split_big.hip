@@ -1,0 +1,51 @@
+// Prep and finish kernels of the three-kernel pipeline for 128 < N <= 384 (BASELINE configs[3]: 128 streams, N = 256 /
+// 384): CH = 4 or 6 row chunks of 64, work matrices and solver scratch in the per-workgroup global workspace, every
+// dense step on the matrix core; the Jacobi kernel in between is dort_jacobi_big_kernel.
+#include "dort_ctx.hpp"
+#include "dort_active.hpp"
+
+using namespace smrt;
+
+template <int NT, int CH, int MODE>
+__global__ __launch_bounds__(NT) void dort_passive_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_passive<NT, CH, MODE>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+template <int NT, int CH, int MODE>
+__global__ __launch_bounds__(NT) void dort_active_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    double* mat = workspace + (long long)blockIdx.x * ws_stride;
+    for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
+        dort_pair_active<NT, CH, MODE>(b, p, smrt_lds, mat, &st);
+        __syncthreads();
+    }
+}
+
+namespace smrt_launch {
+
+template <class K>
+static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, size_t lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
+    return hipGetLastError();
+}
+
+hipError_t prep_gmem_big(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active, int ch) {
+    if (active) return ch <= 4 ? go(dort_active_big_kernel<256, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes)
+                               : go(dort_active_big_kernel<256, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes);
+    return ch <= 4 ? go(dort_passive_big_kernel<256, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes)
+                   : go(dort_passive_big_kernel<256, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes);
+}
+hipError_t finish_gmem_big(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active, int ch) {
+    if (active) return ch <= 4 ? go(dort_active_big_kernel<256, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes)
+                               : go(dort_active_big_kernel<256, 6, 2>, ctx, c, grid, ctx->finish2_lds_bytes);
+    return ch <= 4 ? go(dort_passive_big_kernel<256, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes)
+                   : go(dort_passive_big_kernel<256, 6, 2>, ctx, c, grid, ctx->finish2_lds_bytes);
+}
+
+}  // namespace smrt_launch

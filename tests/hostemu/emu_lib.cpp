@@ -73,6 +73,39 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     return nb;
 }
 
+// 128 < N <= 384: prep / finish with CH row chunks on the global workspace, the blocked Jacobi kernel in between
+template <int CH, bool ACTIVE>
+static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
+    long nb = 0;
+    const size_t items = (size_t)d.pair_count * d.Lmax * (ACTIVE ? d.m_max + 1 : 1);
+    const size_t mat = (size_t)plan.NMAX * plan.LD;
+    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
+    std::vector<int> stn(items, -1);
+    std::vector<double> stinv(items * 1024, NAN);
+    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    std::vector<double> lds(2 * plan.total), ws((size_t)plan.mat_doubles + plan.scratch_doubles);
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        for (auto& x : ws) x = NAN;
+        if (ACTIVE) nb += emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 1>(d, p, lds.data(), ws.data(), &st); });
+        else nb += emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 1>(d, p, lds.data(), ws.data(), &st); });
+    }
+    const JacobiBigPlan jp = make_jacobi_big_plan(d.n_max_stream, ACTIVE ? 3 : 2);
+    std::vector<double> jl(jp.total);
+    for (long long it = 0; it < (long long)items; ++it) {
+        if (stn[it] < 0) continue;
+        for (auto& x : jl) x = NAN;
+        nb += emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, st, it, jl.data()); });
+    }
+    for (long long p = 0; p < d.pair_count; ++p) {
+        for (auto& x : lds) x = NAN;
+        for (auto& x : ws) x = NAN;
+        if (ACTIVE) nb += emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 2>(d, p, lds.data(), ws.data(), &st); });
+        else nb += emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 2>(d, p, lds.data(), ws.data(), &st); });
+    }
+    return nb;
+}
+
 // active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
 template <int NT>
 static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
@@ -171,7 +204,13 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.jacobi_exit2 = active ? 1e-22 : SMRT_JACOBI_EXIT_COS2;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
-    if (gmem && plan.NMAX > 128) {   // fused global-workspace kernels, four / six 64-row chunks
+    if (gmem && plan.NMAX > 128 && smrt_emu_pipeline) {   // the big pipeline (blocked Jacobi kernel)
+        if (nt != 256) return -3;
+        d.jac_in_lds = 0;
+        const LdsPlan bp = plan_with(0);
+        if (active) nb = plan.NMAX <= 256 ? run_split_big<4, true>(d, order, bp) : run_split_big<6, true>(d, order, bp);
+        else nb = plan.NMAX <= 256 ? run_split_big<4, false>(d, order, bp) : run_split_big<6, false>(d, order, bp);
+    } else if (gmem && plan.NMAX > 128) {   // fused global-workspace kernels, four / six 64-row chunks
         if (nt != 256) return -3;
         const int ch = plan.NMAX <= 256 ? 4 : 6;
         if (active) nb = ch == 4 ? run_active<256, 4>(d, order, plan.total, matd) : run_active<256, 6>(d, order, plan.total, matd);
@@ -234,4 +273,20 @@ extern "C" int smrt_emu_gauss_legendre(int n, double* mu, double* w) {
 extern "C" void smrt_emu_panel_counts(long* out2) {
     out2[0] = smrt::smrt_emu_panels[0]; out2[1] = smrt::smrt_emu_panels[1];
     smrt::smrt_emu_panels[0] = smrt::smrt_emu_panels[1] = 0;
+}
+
+// The blocked Jacobi kernel (N > 128) on one matrix: Bm is [N][LD] column-major with LD = (n_max_stream * P + 1) | 1,
+// rotated in place; sigma [N] out.  Returns the status the kernel left in the staging slot (N = ok, -1 = no convergence).
+extern "C" int smrt_emu_jacobi_big(int n_max_stream, int P, int N, double* Bm, double* sigma, int order, double skip2, double exit2) {
+    DevBatch d{};
+    d.S = 1; d.Lmax = 1; d.F = 1; d.mode = (P == 3) ? 1 : 0; d.m_max = 0; d.n_max_stream = n_max_stream;
+    int nl = 1, status = 0;
+    d.n_layers = &nl; d.status = &status; d.pair_begin = 0; d.pair_count = 1;
+    d.jacobi_skip2 = skip2; d.jacobi_exit2 = exit2;
+    const JacobiBigPlan jp = make_jacobi_big_plan(n_max_stream, P);
+    int n = N;
+    DevStage st{nullptr, Bm, nullptr, sigma, &n, (long long)jp.NMAX * jp.LD, jp.NMAX, nullptr};
+    std::vector<double> jl(jp.total, NAN);
+    emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, st, 0, jl.data()); });
+    return n;
 }

@@ -157,3 +157,30 @@ def test_gauss_jordan_takes_its_pivots_from_the_diagonal_blocks(name, freqs, min
         assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
     else:
         assert np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("n_max_stream,N,order", [(70, 140, 0), (70, 97, 1), (100, 170, 2), (70, 24, 1)])
+def test_blocked_jacobi_kernel_gives_the_singular_values(emu, n_max_stream, N, order):
+    """The Jacobi kernel of the N > 128 pipeline (dort_jacobi_big.hpp: matrix in global memory, two column blocks at a
+    time in LDS) on a random matrix: B' = B V has orthogonal columns, V is orthogonal, the column norms are the singular
+    values -- whatever the order in which the emulated threads run between barriers."""
+    emu.smrt_emu_jacobi_big.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                        C.c_double, C.c_double]
+    NMAX = 2 * n_max_stream
+    LD = (NMAX + 1) | 1
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((N, N)) @ np.diag(np.linspace(1, 30, N))
+    buf = np.full((NMAX, LD), np.nan)
+    buf[:N, :N] = A.T                       # column c of the matrix at buf[c, :N]
+    sig = np.zeros(NMAX)
+    rc = emu.smrt_emu_jacobi_big(n_max_stream, 2, N, buf.ctypes.data_as(C.POINTER(C.c_double)),
+                                 sig.ctypes.data_as(C.POINTER(C.c_double)), order, 1e-26, 1e-15)
+    assert rc == N
+    Bp = buf[:N, :N].T
+    V = np.linalg.solve(A, Bp)
+    assert np.abs(V.T @ V - np.eye(N)).max() < 1e-11
+    G = Bp.T @ Bp
+    d = np.sqrt(np.diag(G))
+    assert np.abs(G / np.outer(d, d) - np.eye(N)).max() < 1e-12
+    sv = np.linalg.svd(A, compute_uv=False)
+    np.testing.assert_allclose(np.sort(sig[:N])[::-1], sv, rtol=1e-12)
