@@ -59,7 +59,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int nphi = nsamp / 2 + 1;
     const int nmax = b.n_max_stream;
     const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
-                                   active_doubles(nmax, b.Lmax, b.n_theta), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
+                                   active_doubles(nmax, b.Lmax, b.n_theta, MODE < 2), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
                                    (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
@@ -71,10 +71,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
     const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
-    double* norm0 = s.act;                        // [Lmax][2 nmax]
-    double* total = norm0 + 2 * nmax * b.Lmax;    // [9][NI]
+    double* total = s.act;                        // [9][NI]
     double* coh = total + 9 * NI;                 // [2][NI]
     int* inc = (int*)(coh + 2 * NI);              // [NI], then the count
+    double* norm0 = coh + 2 * NI + (NI + 2) / 2 + 1;   // [Lmax][2 nmax]; absent in the finish kernels (MODE >= 2)
     double* dsg = s.g;                            // row signs of the down-going eigenvectors (not in the prep kernel)
     auto su_of = [](int r, int P) { return (P == 3 && r % 3 == 2) ? 1.4142135623730951 : 1.0; };  // sqrt(2) on U rows
 
@@ -490,7 +490,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             block_sync();
             // -- Y = F tQt + G ; W = (D G - Rtop F) tQt + (D F - Rtop G) ; K = Y W^-1
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-            else if (CH >= 2 && dense_mfma) r45_mfma_big<NT, true, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            else if (CH > 2) {   // two passes with one operand array each (register budget, see r45_mfma_big)
+                r45_mfma_big<NT, true, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+                r45_mfma_big<NT, true, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            } else if (CH == 2 && dense_mfma) r45_mfma_big<NT, true, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             if (!gj_solve<NT, true, CH>(F, Wk, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }

@@ -771,13 +771,17 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
     block_sync();
 }
 
-template <int NT, bool SIGNED, int KG = 32>
+// PASS 0: Y and W together (two A-operand arrays per lane); PASS 1: Y = F tQt + G -> Wk and upb only; PASS 2:
+// W -> over F and gvec only.  For N > 128 the caller runs PASS 1 then PASS 2: one array of KG doubles per lane instead
+// of two keeps the kernel within 256 VGPRs, i.e. two workgroups per CU.
+template <int NT, bool SIGNED, int KG = 32, int PASS = 0>
 SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
                            double* upb, double* gvec, double Bl, int N, int LD, const double* dsg) {
     constexpr int NW = NT / SMRT_LANES;
     constexpr int MAXRT = KG / 4;
     constexpr int RPW = (NW >= MAXRT) ? 1 : (MAXRT + NW - 1) / NW;
     constexpr int CS = (NW > MAXRT) ? NW / MAXRT : 1;
+    constexpr bool DO_Y = (PASS != 2), DO_W = (PASS != 1);
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
     for (int o = 0; o < RPW; ++o) {
@@ -786,21 +790,26 @@ SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* 
         const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
         const double rt = Rtop[ic];
         const double sg = SIGNED ? dsg[ic] : 1.0;
-        double af[KG], aw[KG];
+        double af[DO_Y ? KG : 1], aw[DO_W ? KG : 1];
         double vy = 0.0, vg = 0.0;
 #pragma unroll
         for (int kk = 0; kk < KG; ++kk) {
             const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
-            const double fv = F[kc * LD + ic], gv = G[kc * LD + ic], tk = tq[kc];
+            const double fv = F[kc * LD + ic], tk = tq[kc];
             const bool in = (ti < RT && i < N && k < N);
-            af[kk] = in ? fv : 0.0;
-            aw[kk] = in ? (SIGNED ? sg * gv : gv) - rt * fv : 0.0;
-            vy += af[kk] * tk;
-            vg += aw[kk] * tk;
+            if (DO_Y) { af[kk] = in ? fv : 0.0; vy += af[kk] * tk; }
+            if (DO_W) {
+                const double gv = G[kc * LD + ic];
+                aw[kk] = in ? (SIGNED ? sg * gv : gv) - rt * fv : 0.0;
+                vg += aw[kk] * tk;
+            }
         }
-        vy += shfl_xor(vy, 16); vy += shfl_xor(vy, 32);
-        vg += shfl_xor(vg, 16); vg += shfl_xor(vg, 32);
-        if (cs == 0 && ti < RT && lk == 0 && i < N) { upb[i] = vy + Bl; gvec[i] = vg + (1.0 - rt) * Bl; }
+        if (DO_Y) { vy += shfl_xor(vy, 16); vy += shfl_xor(vy, 32); }
+        if (DO_W) { vg += shfl_xor(vg, 16); vg += shfl_xor(vg, 32); }
+        if (cs == 0 && ti < RT && lk == 0 && i < N) {
+            if (DO_Y) upb[i] = vy + Bl;
+            if (DO_W) gvec[i] = vg + (1.0 - rt) * Bl;
+        }
         block_sync();
         if (ti < RT) {
             for (int tj = cs; tj < RT; tj += CS) {
@@ -812,14 +821,17 @@ SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* 
                         const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
                         const double qv = Q[jc * LD + kc];
                         const double bop = (j < N && k < N) ? qv : 0.0;
-                        mfma_f64_16x16x4(af[kk], bop, cy);
-                        mfma_f64_16x16x4(aw[kk], bop, cw);
+                        if (DO_Y) mfma_f64_16x16x4(af[kk], bop, cy);
+                        if (DO_W) mfma_f64_16x16x4(aw[kk], bop, cw);
                     }
                 }
                 tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
-                    const double fic = F[col * LD + row], gic = G[col * LD + row];
-                    Wk[col * LD + row] = cy[reg] + gic;
-                    F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
+                    const double gic = G[col * LD + row];
+                    if (DO_Y) Wk[col * LD + row] = cy[reg] + gic;
+                    if (DO_W) {
+                        const double fic = F[col * LD + row];
+                        F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
+                    }
                 });
             }
         }

@@ -178,6 +178,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     const int P = ctx->active ? 3 : 2;
     const int nphi = ctx->active ? azimuth_samples(b->m_max) / 2 + 1 : 9;
     const int actd = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta) : 0;
+    const int actd_fin = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta, false) : 0;   // finish kernels
     LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd);
     size_t lds = (size_t)plan.total * sizeof(double);
     ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds || getenv("SMRT_DORT_FORCE_GLOBAL_WORKSPACE") != nullptr);
@@ -236,8 +237,8 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
                                    : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd, 1).total * sizeof(double);
         ctx->finish2_lds_bytes = ctx->gmem_split
-            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, ctx->big ? 0 : 2).total * sizeof(double)
-            : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd, 2).total * sizeof(double);
+            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 0 : 2).total * sizeof(double)
+            : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd_fin, 2).total * sizeof(double);
     }
     if (b->prune_optical_depth > 0.0) {
         // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:

@@ -99,9 +99,10 @@ struct LdsPlan {
 #define SMRT_HD __host__ __device__ inline
 #endif
 
-// doubles of the active-mode region: norm0[Lmax][2 nmax], total[9][2 ntheta], coherent[2][2 ntheta], incident list
-SMRT_HD int active_doubles(int n_max_stream, int Lmax, int ntheta) {
-    return 2 * n_max_stream * Lmax + 9 * 2 * ntheta + 2 * 2 * ntheta + (2 * ntheta + 2) / 2 + 1;
+// doubles of the active-mode region: total[9][2 ntheta], coherent[2][2 ntheta], incident list, then -- only in the
+// kernels that assemble the phase matrices (fused, prep) -- the mode-0 normalisation norm0[Lmax][2 nmax]
+SMRT_HD int active_doubles(int n_max_stream, int Lmax, int ntheta, bool with_norm0 = true) {
+    return 9 * 2 * ntheta + 2 * 2 * ntheta + (2 * ntheta + 2) / 2 + 1 + (with_norm0 ? 2 * n_max_stream * Lmax : 0);
 }
 // azimuth samples of the discrete Fourier decomposition of the phase function (emmodel/common.py:401-414)
 SMRT_HD int azimuth_samples(int m_max) {

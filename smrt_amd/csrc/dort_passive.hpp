@@ -518,7 +518,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         } else if (CH == 1) {
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
         } else if (CH >= 2 && dense_mfma) {
-            r45_mfma_big<NT, false, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+            if (CH > 2) {   // two passes with one operand array each (register budget, see r45_mfma_big)
+                r45_mfma_big<NT, false, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+                r45_mfma_big<NT, false, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+            } else r45_mfma_big<NT, false, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         } else {
             r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         }

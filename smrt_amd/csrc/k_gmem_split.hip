@@ -6,6 +6,10 @@
 
 using namespace smrt;
 
+#ifndef SMRT_GMEM_FINISH_WAVES
+#define SMRT_GMEM_FINISH_WAVES 2   // wavefronts per SIMD the finish kernels leave room for
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
@@ -16,7 +20,7 @@ __global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage
     }
 }
 template <int NT>
-__global__ __launch_bounds__(NT, 2) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, SMRT_GMEM_FINISH_WAVES) void dort_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(NT) void dort_active_prep_kernel_gmem(DevBatch b, D
     }
 }
 template <int NT>
-__global__ __launch_bounds__(NT, 2) void dort_active_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, SMRT_GMEM_FINISH_WAVES) void dort_active_finish_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {

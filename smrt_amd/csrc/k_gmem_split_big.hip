@@ -6,8 +6,14 @@
 
 using namespace smrt;
 
+#ifndef SMRT_BIG_FINISH_WAVES
+#define SMRT_BIG_FINISH_WAVES 2   // wavefronts per SIMD the finish kernels leave room for (2: <= 256 VGPRs, two workgroups per CU)
+#endif
+
+// (finish kernels, MODE 2: <= 256 VGPRs so that two workgroups share a CU -- their LDS is small; the operands of their
+// matrix-core passes come from L2, whose latency a second workgroup hides)
 template <int NT, int CH, int MODE>
-__global__ __launch_bounds__(NT) void dort_passive_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, (MODE == 2 ? SMRT_BIG_FINISH_WAVES : 1)) void dort_passive_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
@@ -16,7 +22,7 @@ __global__ __launch_bounds__(NT) void dort_passive_big_kernel(DevBatch b, DevSta
     }
 }
 template <int NT, int CH, int MODE>
-__global__ __launch_bounds__(NT) void dort_active_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, (MODE == 2 ? SMRT_BIG_FINISH_WAVES : 1)) void dort_active_big_kernel(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
