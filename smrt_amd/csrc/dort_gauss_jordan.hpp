@@ -133,12 +133,13 @@ SMRT_DEV bool gj_panel16_impl(double* A, int N, int LD, int k, int lane, int* pe
     if (lane < nbk) perm[k0 + lane] = pj_store;
     return ok;
 }
-// RPLN <= 2 (N <= 128): a separate function, so that its registers do not count twice in kernels that call it from two
-// places and must stay within 256 VGPRs; more rows per lane (N <= 64 RPLN, global-workspace kernels with one wavefront
-// per SIMD and the whole register file to themselves): inlined, a callable function would be compiled for a smaller
-// budget and spill its 32 RPLN row registers.
+// Inlined into the kernels (it used to be a separate function to save code size): a callable function is compiled
+// without the kernel's register cap, and the compiler then parks values in accumulation registers -- 32 AGPRs in the
+// panel were enough to push the two-slot finish kernel from 256 to 288 registers, i.e. from two workgroups per CU to
+// one (50 ms instead of 29 ms per step, profiles/r2_gj_fast_panel.txt).  The build records the compiler's resource
+// remarks per kernel and tests/test_host_logic.py::test_kernel_occupancy_as_designed checks them.
 template <bool TR, int RPLN>
-SMRT_DEV_NOINLINE bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
+SMRT_DEV bool gj_panel16(double* A, int N, int LD, int k, int lane, int* perm, int* rowblk) {
     return gj_panel16_impl<TR, RPLN>(A, N, LD, k, lane, perm, rowblk);
 }
 

@@ -202,7 +202,9 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
     // N > 128: the pipeline with the blocked Jacobi kernel (matrix in the staging area, column blocks through LDS)
-    ctx->big = ctx->gmem_path && ctx->split && plan.NMAX > 128 && getenv("SMRT_DORT_NO_BIG_PIPELINE") == nullptr &&
+    int big_min = 128;   // SMRT_DORT_BIG_MIN_N: experiments with the big pipeline on smaller matrices
+    if (const char* e = getenv("SMRT_DORT_BIG_MIN_N")) big_min = std::max(64, atoi(e));
+    ctx->big = ctx->gmem_path && ctx->split && plan.NMAX > big_min && getenv("SMRT_DORT_NO_BIG_PIPELINE") == nullptr &&
                (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
     ctx->gmem_split = ctx->big || (ctx->gmem_path && ctx->split && plan.NMAX <= 128 && ctx->jac_in_lds &&
                       (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds);

@@ -127,7 +127,7 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.matrices_in_lds = matrices_in_lds;
     const int nmat = slim ? 2 : 4;
     p.mat_doubles = nmat * p.NMAX * p.LD;
-    p.scratch_doubles = (!matrices_in_lds && p.NMAX > 128) ? 16 * p.NMAX : 0;
+    p.scratch_doubles = !matrices_in_lds ? 16 * p.NMAX : 0;
     int o = 0;
     for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * p.NMAX * p.LD; }
     if (slim == 2) p.o_M[3] = p.NMAX * p.LD;  // the two-slot finish kernel: M0 = X, M3 = R (M1, M2 live in global memory)
