@@ -223,6 +223,10 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         long long chunk = (long long)(budget / (double)per_pair);
         if (chunk < 1) chunk = 1;
         if (chunk > pair_count) chunk = pair_count;
+        {   // equal chunks: a short last chunk would leave most of the chip idle for a whole pipeline pass
+            const long long nchunks = (pair_count + chunk - 1) / chunk;
+            chunk = (pair_count + nchunks - 1) / nchunks;
+        }
         ctx->chunk_pairs = chunk;
         const size_t items = (size_t)chunk * b->n_layers_max * nmodes;
         HIPCHK(ctx->d_stL.reserve(items * mat * sizeof(double)));
