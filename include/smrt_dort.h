@@ -100,6 +100,10 @@ typedef struct smrt_batch {
      * Needs the three-kernel pipeline (the eigenvalues of all the layers are known before the boundary recursion
      * starts): smrt_dort_upload fails for streams x polarisations > 128 or after smrt_dort_set_pipeline(ctx, 0). */
     double prune_optical_depth;
+    /* Heterogeneous snowpacks (a list / dict of emmodels in make_model, per-layer microstructure models in make_snowpack;
+     * smrt/core/model.py:529-582): [S][Lmax] emmodel + 16 * microstructure of every layer (SMRT_EM_* + 16 * SMRT_MS_*).
+     * NULL: every layer uses `emmodel` / `microstructure` above. */
+    const int32_t* layer_kind;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

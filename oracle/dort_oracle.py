@@ -359,15 +359,18 @@ def rayleigh_ft_even_phase(ks, mu_s, mu_i, m_max, npol):
 def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
-    cls = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
-           "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer}[emmodel]
+    classes = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
+               "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer}
     L = len(sp["thickness"])
     fv = sp["frac_volume"] if "frac_volume" in sp else np.asarray(sp["density"]) / DENSITY_OF_ICE
-    micro = str(sp["microstructure"])
-    names = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness")}[micro]
+    # heterogeneous snowpacks (model.py:529-582: a list of emmodels, one per layer; per-layer microstructure models in
+    # make_snowpack): `emmodel` and sp["microstructure"] may be sequences of L names
+    ems = [str(e) for e in np.broadcast_to(np.atleast_1d(emmodel), (L,))]
+    micros = [str(m) for m in np.broadcast_to(np.atleast_1d(sp["microstructure"]), (L,))]
+    args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness")}
     return [
-        cls(frequency, float(fv[l]), float(sp["temperature"][l]), micro,
-            **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in names})
+        classes[ems[l]](frequency, float(fv[l]), float(sp["temperature"][l]), micros[l],
+                        **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in args[micros[l]]})
         for l in range(L)
     ]
 

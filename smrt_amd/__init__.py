@@ -9,7 +9,7 @@
 from .core.error import SMRTError, SMRTWarning  # noqa: F401
 from .core.model import make_emmodel, make_model, make_rtsolver  # noqa: F401
 from .core.plugin import register_package  # noqa: F401
-from .core.result import concat_results  # noqa: F401
+from .core.result import concat_results, open_result  # noqa: F401
 from .core.sensor import Sensor  # noqa: F401
 from .inputs import sensor_list  # noqa: F401
 from .atmosphere.simple_isotropic_atmosphere import make_atmosphere  # noqa: F401

@@ -64,6 +64,7 @@ class SmrtBatch(C.Structure):
         ("atm_tb_up", C.POINTER(C.c_double)),
         ("atm_transmittance", C.POINTER(C.c_double)),
         ("prune_optical_depth", C.c_double),
+        ("layer_kind", C.POINTER(C.c_int32)),
     ]
 
 
@@ -78,11 +79,13 @@ class PackedBatch:
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
-                 prune_deep_snowpack=None):
+                 prune_deep_snowpack=None, layer_kind=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
-        prune_deep_snowpack: None / False, True (= 6, smrt/rtsolver/dort.py:176-177) or the optical depth itself."""
+        prune_deep_snowpack: None / False, True (= 6, smrt/rtsolver/dort.py:176-177) or the optical depth itself.
+        layer_kind: None, or [S][Lmax] integer codes EM_CODES[emmodel] + 16 * MS_CODES[microstructure] for snowpacks
+        that mix emmodels / microstructure models (smrt/core/model.py:529-582)."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
         S = len(self.n_layers)
         two_d = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(S, -1))  # noqa: E731
@@ -130,6 +133,9 @@ class PackedBatch:
             F = len(self.frequency)
             self.atm = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (F,))) for a in atmosphere]
             s.atm_tb_down, s.atm_tb_up, s.atm_transmittance = (_dptr(a) for a in self.atm)
+        if layer_kind is not None:
+            self.layer_kind = np.ascontiguousarray(np.asarray(layer_kind, dtype=np.int32).reshape(S, Lmax))
+            s.layer_kind = self.layer_kind.ctypes.data_as(C.POINTER(C.c_int32))
         self.struct = s
 
     @property
@@ -316,7 +322,14 @@ class DortContext:
                                                 _dptr(o.streams)), "smrt_dort_run")
         return o
 
-    def upload(self, batch: PackedBatch, pair_begin=0, pair_count=-1):
+    def upload(self, batch: PackedBatch, pair_begin=0, pair_count=-1, pairs=None):
+        if pairs is not None:
+            pairs = np.ascontiguousarray(pairs, dtype=np.int64)
+            self._check(self._lib.smrt_dort_upload_pairs(self._h, C.byref(batch.struct),
+                                                         pairs.ctypes.data_as(C.POINTER(C.c_int64)), len(pairs)),
+                        "smrt_dort_upload_pairs")
+            self._resident = (batch, len(pairs))
+            return
         if pair_count < 0:
             pair_count = batch.n_pairs - pair_begin
         self._check(self._lib.smrt_dort_upload(self._h, C.byref(batch.struct), pair_begin, pair_count), "smrt_dort_upload")

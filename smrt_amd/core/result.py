@@ -145,6 +145,63 @@ class LabeledArray:
         return f"LabeledArray(name={self.name!r}, dims={self.dims}, values=\n{self.values})"
 
 
+NETCDF_VARIABLE = "__xarray_dataarray_variable__"   # the name xarray gives an unnamed DataArray in DataArray.to_netcdf
+
+
+def save_labeled_array(arr, filename):
+    """Write a LabeledArray as a netCDF-3 file laid out like xarray's DataArray.to_netcdf (one data variable, one
+    coordinate variable per dimension, strings as character arrays, attributes on the data variable), so that the
+    reference's `open_result` / `xr.open_dataarray` read it.  scipy.io.netcdf_file is the only dependency."""
+    from scipy.io import netcdf_file
+
+    with netcdf_file(filename, "w", version=2) as nc:
+        for dim, values in arr.coords.items():
+            values = np.asarray(values)
+            nc.createDimension(dim, len(values))
+            if values.dtype.kind in "US":
+                width = max(1, max(len(str(v)) for v in values))
+                sdim = "string%d" % width
+                if sdim not in nc.dimensions:
+                    nc.createDimension(sdim, width)
+                var = nc.createVariable(dim, "c", (dim, sdim))
+                var[:] = np.array([list(str(v).ljust(width, "\0")) for v in values], dtype="S1")
+            else:
+                var = nc.createVariable(dim, "d" if values.dtype.kind == "f" else "i", (dim,))
+                var[:] = values
+        data = nc.createVariable(NETCDF_VARIABLE, "d", tuple(arr.coords.keys()))
+        data[:] = np.asarray(arr.values, dtype=np.float64)
+        for k, v in arr.attrs.items():
+            setattr(data, k, v)
+
+
+def load_labeled_array(filename):
+    from scipy.io import netcdf_file
+
+    with netcdf_file(filename, "r", mmap=False) as nc:
+        names = [n for n in nc.variables if n not in nc.dimensions]
+        if len(names) != 1:
+            raise SMRTError(f"'{filename}' does not hold exactly one data variable")
+        var = nc.variables[names[0]]
+        coords = []
+        for dim in var.dimensions:
+            c = nc.variables[dim]
+            v = c[:].copy()
+            if v.dtype.kind == "S" and v.ndim == 2:
+                v = np.array([b"".join(row).rstrip(b"\0").decode() for row in v])
+            coords.append((dim, v))
+        attrs = {k: (v.decode() if isinstance(v, bytes) else v) for k, v in var._attributes.items()}
+        return LabeledArray(var[:].copy(), coords, attrs=attrs)
+
+
+def open_result(filename):
+    """Read a result written by `Result.save` (or by the reference's, when it was written in a netCDF-3 format)."""
+    data = load_labeled_array(filename)
+    mode = data.attrs.get("mode")
+    if mode not in ("A", "P"):
+        mode = "A" if "theta_inc" in data.coords else "P"
+    return (ActiveResult if mode == "A" else PassiveResult)(data)
+
+
 def _strongsqueeze(x):
     x = x.squeeze()
     return float(x) if x.size == 1 else x
@@ -185,6 +242,11 @@ class Result(object):
         if attr != "data" and data is not None and attr in data.coords:
             return data.coords[attr]
         raise AttributeError(f"'{type(self)}' object has no attribute '{attr}'")
+
+    def save(self, filename, netcdf_engine=None):
+        """Save the result to disk as a netCDF file (the data array with its coordinates, like the reference's
+        Result.save, smrt/core/result.py:138-147); read it back with `open_result`."""
+        save_labeled_array(self.data, filename)
 
     def sel_data(self, channel=None, **kwargs):
         raise NotImplementedError

@@ -99,7 +99,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         s.cphi[k] = cos(ph); s.sphi[k] = sin(ph);
     }
     {
-        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2);
+        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
+                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
     const int n_air = s.ints[5];
@@ -293,6 +294,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 const int T = n * (n + 1) / 2;
                 const double pa = s.pa[l], pb = s.pb[l];
                 const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+                const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
                 for (int idx = t; idx < T; idx += NT) {
                     int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
                     while ((i + 1) * (i + 2) / 2 <= idx) ++i;
@@ -302,7 +304,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double sis = sqrt(1.0 - mi * mi), sjs = sqrt(1.0 - mj * mj);
                     double pp[3][3], pm[3][3];
                     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pp[a][c] = 0.0; pm[a][c] = 0.0; }
-                    if (b.emmodel != EM_IBA) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
+                    if (em_l != EM_IBA) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
                         for (int sgn = 0; sgn < 2; ++sgn) {
                             const double x = sgn ? -mj : mj;
                             double (&q)[3][3] = sgn ? pm : pp;
@@ -333,7 +335,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                                 double ct = (sgn ? -mm : mm) + sisj * c;  // cosine of the scattering angle
                                 ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
                                 double C;
-                                if (b.micro == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
+                                if (ms_l == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
                                 else C = pa * ft_corr(MS_SHS, pb * (1.0 - ct), fv, q1, q2);
                                 const double fvv = c * mi * x + sisj, fvh = sn * mi, fhv = -sn * x, fhh = c;
                                 const double Cc = C * cw, Cs = C * sw;

@@ -121,7 +121,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -266,6 +266,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if (upload_array(ctx, ctx->d_freq, b->frequency, sizeof(double) * b->n_frequencies)) return -1;
     if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
     if (pairs && upload_array(ctx, ctx->d_pairmap, pairs, sizeof(int64_t) * pair_count)) return -1;
+    if (b->layer_kind && upload_array(ctx, ctx->d_kind, b->layer_kind, sizeof(int32_t) * SL)) return -1;
     const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
         if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;
@@ -303,6 +304,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.p1 = (const double*)ctx->d_p1.p; d.p2 = (const double*)ctx->d_p2.p;
     d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
     d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
+    d.layer_kind = b->layer_kind ? (const int*)ctx->d_kind.p : nullptr;
     d.sub_kind = b->substrate_kind;
     d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
     const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
@@ -344,7 +346,7 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(rayleigh_jeans), SMRT_OFF(substrate_kind), SMRT_OFF(n_layers), SMRT_OFF(thickness), SMRT_OFF(frac_volume),
         SMRT_OFF(temperature), SMRT_OFF(micro_p1), SMRT_OFF(micro_p2), SMRT_OFF(frequency), SMRT_OFF(theta), SMRT_OFF(phi),
         SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
-        SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth)};
+        SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

@@ -51,14 +51,23 @@ inline const char* validate(const smrt_batch* b) {
     if (b->emmodel < SMRT_EM_IBA || b->emmodel > SMRT_EM_NONSCATTERING) return "unknown emmodel";
     if (b->microstructure != SMRT_MS_EXPONENTIAL && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
         return "unknown microstructure";
-    if ((b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE || b->emmodel == SMRT_EM_DMRT_QCACP_SHORTRANGE) &&
+    if (!b->layer_kind && (b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE || b->emmodel == SMRT_EM_DMRT_QCACP_SHORTRANGE) &&
         b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
         return "the dmrt short-range emmodels are only compatible with sticky_hard_spheres";
+    if (b->layer_kind && b->n_layers)
+        for (int s = 0; s < b->n_snowpacks; ++s)
+            for (int l = 0; l < b->n_layers[s]; ++l) {
+                const int k = b->layer_kind[(long long)s * b->n_layers_max + l], em = k & 15, ms = k >> 4;
+                if (em < SMRT_EM_IBA || em > SMRT_EM_NONSCATTERING || (ms != SMRT_MS_EXPONENTIAL && ms != SMRT_MS_STICKY_HARD_SPHERES))
+                    return "invalid layer_kind entry";
+                if ((em == SMRT_EM_DMRT_QCA_SHORTRANGE || em == SMRT_EM_DMRT_QCACP_SHORTRANGE) && ms != SMRT_MS_STICKY_HARD_SPHERES)
+                    return "the dmrt short-range emmodels are only compatible with sticky_hard_spheres";
+            }
     if (b->mode != SMRT_MODE_PASSIVE && b->mode != SMRT_MODE_ACTIVE) return "unknown mode";
     if (!b->n_layers || !b->thickness || !b->frac_volume || !b->temperature || !b->micro_p1 || !b->frequency ||
         !b->theta)
         return "null input array";
-    if (b->microstructure == SMRT_MS_STICKY_HARD_SPHERES && !b->micro_p2) return "stickiness array missing";
+    if ((b->microstructure == SMRT_MS_STICKY_HARD_SPHERES || b->layer_kind) && !b->micro_p2) return "stickiness array missing";
     if (b->substrate_kind < SMRT_SUBSTRATE_NONE || b->substrate_kind > SMRT_SUBSTRATE_REFLECTOR) return "unknown substrate kind";
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE && (!b->substrate_p1 || !b->substrate_p2 || !b->substrate_temperature))
         return "substrate arrays missing";

@@ -26,6 +26,7 @@ struct DevBatch {
     const double* p2;
     const double* frequency;
     const double* theta;
+    const int* layer_kind;  // [S][Lmax] emmodel + 16 * microstructure of every layer, or null: b.emmodel / b.micro everywhere
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]

@@ -75,13 +75,16 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 // ST_OK s.ints[4] = most refringent layer, s.ints[5] = n_air.
 template <int NT>
 SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L, const double* thickness,
-                        const double* fracvol, const double* temperature, const double* mp1, const double* mp2) {
+                        const double* fracvol, const double* temperature, const double* mp1, const double* mp2,
+                        const int* kinds = nullptr /* this snowpack's row of b.layer_kind, or null */) {
     const int t = tid();
     const int nmax = b.n_max_stream;
     for (int l = t; l < L; l += NT) {
         cplx ee; double ks, ka, pa, pb; int bad = 0;
-        layer_em(b, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
+        const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
+        layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
+        s.pc[l] = (double)kind;
         s.thick[l] = thickness[l];
         s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
         if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
@@ -206,7 +209,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         s.wphi[k] = ((k == 0 || k == nphi - 1) ? 1.0 : 2.0) / (double)(2 * (nphi - 1));
     }
     {
-        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2);
+        const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
+                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
     const int n_air = s.ints[5];
@@ -322,6 +326,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             const int T = n * (n + 1) / 2;
             const double pa = s.pa[l], pb = s.pb[l];
             const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+            const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
             for (int idx = t; idx < T; idx += NT) {
                 int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
                 while ((i + 1) * (i + 2) / 2 <= idx) ++i;
@@ -329,7 +334,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 const int j = idx - i * (i + 1) / 2;
                 const double mi = s.mu[i], mj = s.mu[j];
                 double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
-                if (b.emmodel != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
+                if (em_l != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
                     const double a2 = mi * mi, b2 = mj * mj;
                     pvv_p = pa * (0.5 * a2 * b2 + (1.0 - a2) * (1.0 - b2));
                     pvh_p = pa * 0.5 * a2; phv_p = pa * 0.5 * b2; phh_p = pa * 0.5;
@@ -346,7 +351,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                         ct_p = ct_p > 1.0 ? 1.0 : (ct_p < -1.0 ? -1.0 : ct_p);
                         ct_m = ct_m > 1.0 ? 1.0 : (ct_m < -1.0 ? -1.0 : ct_m);
                         double Cp, Cm;
-                        if (b.micro == MS_EXP) {
+                        if (ms_l == MS_EXP) {
                             const double dp = 1.0 + pb * (1.0 - ct_p), dm = 1.0 + pb * (1.0 - ct_m);
                             Cp = pa * fast_rcp(dp * dp); Cm = pa * fast_rcp(dm * dm);   // 1 / (dp dm)^2 without the IEEE division
                         } else {

@@ -106,12 +106,13 @@ SMRT_DEV double planck_inverse(double frequency, double radiance) {  // core/lib
 // One layer: effective permittivity, ks, ka and the parameters of its phase function.
 // pa/pb/pc: IBA+exponential -> C(cosT) = pa / (1 + pb (1 - cosT))^2 ; IBA+SHS -> pa = iba_coeff, pb = kfac^2/2;
 // DMRT -> pa = 1.5 ks.
-SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
+// em / ms: the emmodel and the microstructure model of THIS layer (a snowpack may mix them, smrt/core/model.py:529-582).
+SMRT_DEV void layer_em(int em, int ms, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
                        double* ks, double* ka, double* pa, double* pb, int* bad) {
     cplx es = ice_permittivity(frequency, T);
     if (T > kFreezing) *bad = 1;
     double k0 = 2.0 * kPi * frequency / kCSpeed;
-    if (b.emmodel == EM_IBA) {
+    if (em == EM_IBA) {
         // Polder-van Santen, spheres: 2x^2 + bx - eps e0 = 0 (generic_mixing_formula.py:117-145), e0 = 1
         cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
         cplx disc = cadd(cmul(bq, bq), cscale(es, 8.0));
@@ -133,7 +134,7 @@ SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T,
         for (int j = 0; j <= 64; ++j) {
             double mu = 1.0 - j * 0.03125;
             double k2 = 4.0 * k0 * k0 * (0.5 * (1.0 - mu)) * nabs2;
-            double y = coeff * ft_corr(b.micro, k2, fv, p1, p2) * (mu * mu + 1.0);
+            double y = coeff * ft_corr(ms, k2, fv, p1, p2) * (mu * mu + 1.0);
             if (j == 0 || j == 64) { yend += 0.5 * y; continue; }
             int tz = 0;
             while (((j >> tz) & 1) == 0) ++tz;
@@ -148,21 +149,21 @@ SMRT_DEV void layer_em(const DevBatch& b, double frequency, double fv, double T,
         }
         *ks = 0.25 * R[0];
         double kfac = 2.0 * k0 * sq.re;  // iba.py:233
-        if (b.micro == MS_EXP) {
+        if (ms == MS_EXP) {
             *pa = coeff * fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1;
             *pb = 0.5 * kfac * kfac * p1 * p1;
         } else {
             *pa = coeff;
             *pb = 0.5 * kfac * kfac;
         }
-    } else if (b.emmodel == EM_NONSCAT) {
+    } else if (em == EM_NONSCAT) {
         // non-scattering medium (nonscattering.py): Polder-van Santen permittivity, absorption only
         cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
         cplx ee = cscale(csub(csqrt_(cadd(cmul(bq, bq), cscale(es, 8.0))), bq), 0.25);
         *eps_eff = ee;
         *ka = 2.0 * k0 * csqrt_(ee).im;
         *ks = 0.0; *pa = 0.0; *pb = 0.0;
-    } else if (b.emmodel == EM_QCACP) {
+    } else if (em == EM_QCACP) {
         // DMRT QCA-CP short range as in DMRT-ML (dmrt_qcacp_shortrange.py:63-125), dense_snow_correction="auto"
         double f = fv;
         cplx e0 = cmk(1.0, 0.0), e1 = es;

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(NT) void dort_cost_kernel(DevBatch b, double* cost)
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
     const int L = b.n_layers[si];
     const long long o = (long long)si * b.Lmax;
-    const int st = pair_setup<NT>(b, s, b.frequency[fi], L, b.thickness + o, b.frac_volume + o, b.temperature + o, b.p1 + o, b.p2 + o);
+    const int st = pair_setup<NT>(b, s, b.frequency[fi], L, b.thickness + o, b.frac_volume + o, b.temperature + o, b.p1 + o, b.p2 + o,
+                                  b.layer_kind ? b.layer_kind + o : nullptr);
     if (t == 0) {
         double c = 0.0;
         if (st == ST_OK)

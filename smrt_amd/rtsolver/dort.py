@@ -71,14 +71,21 @@ class DORT(object):
         if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
             snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
                                 atmosphere=atmosphere)
-        kinds = {type(e) for e in emmodels}
-        if len(kinds) != 1:
-            raise SMRTError("smrt_amd's DORT needs the same emmodel in all the layers")
-        return self.solve_batch([(sensor, snowpack)], kinds.pop())[0]
+        return self.solve_batch([(sensor, snowpack)], [[self._device_name(type(e)) for e in emmodels]])[0]
 
     # ---- batched entry points ------------------------------------------------------------------------------------
-    def solve_batch(self, simulations, emmodel_cls):
-        """simulations: sequence of (single-frequency sensor, snowpack).  One Result per simulation, in order."""
+    @staticmethod
+    def _device_name(emmodel_cls):
+        name = getattr(emmodel_cls, "device_name", None)
+        if name is None:
+            raise SMRTError(f"emmodel {emmodel_cls} has no device implementation in smrt_amd (iba, dmrt_qca_shortrange, "
+                            "dmrt_qcacp_shortrange, nonscattering)")
+        return name
+
+    def solve_batch(self, simulations, emmodel):
+        """simulations: sequence of (single-frequency sensor, snowpack).  One Result per simulation, in order.
+        emmodel: one emmodel class for every layer, or -- aligned with the distinct snowpacks in order of first
+        appearance -- a list of per-layer lists of device names for snowpacks that mix emmodels."""
         sensors, packs, si, pi = [], [], [], []
         seen_s, seen_p = {}, {}
         for sensor, sp in simulations:
@@ -90,40 +97,49 @@ class DORT(object):
                 packs.append(sp)
         if not si:
             return []
-        sol = self._solve_indexed(sensors, packs, np.asarray(si), np.asarray(pi), emmodel_cls)
+        names = emmodel if isinstance(emmodel, list) else self._device_name(emmodel)
+        sol = self._solve_indexed(sensors, packs, np.asarray(si), np.asarray(pi), names)
         return [sol.result(i) for i in range(len(si))]
 
     def solve_plan(self, model, plan):
         """The whole plan of a Model.run: returns the nested Result directly."""
         from ..core.model import nest_results
 
-        emmodel_cls = self._uniform_emmodel(model, plan)
-        sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, emmodel_cls)
+        names = self.emmodel_names(model, plan)
+        sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, names)
         stacked = sol.stacked_result(plan)
         if stacked is not None:
             return stacked
         return nest_results([sol.result(i) for i in range(len(plan))], plan.dimensions)
 
-    @staticmethod
-    def _uniform_emmodel(model, plan):
-        """The one emmodel class of the batch, after the same checks the per-simulation route applies through
-        Model.prepare_emmodels (per-layer overrides and emmodel options are not silently dropped): one instance is
-        made for a layer of the first snowpack, which validates the options against the class."""
-        kinds, options = set(), []
+    @classmethod
+    def emmodel_names(cls, model, plan):
+        """The emmodel of every layer as the device knows it, after the same checks the per-simulation route applies
+        through Model.prepare_emmodels (per-layer overrides, lists / dicts of emmodels and emmodel options are honoured
+        or refused, never dropped): one device name when all the layers of all the snowpacks share it, otherwise a list
+        (per snowpack) of lists (per layer).  One instance is made per distinct (class, options) pair, which validates
+        the options against the class."""
+        simple = isinstance(model.emmodel, type)
+        checked = set()
+        per_pack, distinct = [], set()
         for sp in plan.snowpacks:
             n = sp.nlayer
-            for k, layer in enumerate(sp.layers):
-                kinds.add(model.emmodel_of_layer(k, layer, n))
-                if getattr(layer, "emmodel_options", None):
-                    options.append(layer.emmodel_options)
-        if len({getattr(k, "device_name", id(k)) for k in kinds}) != 1:
-            raise SMRTError("smrt_amd's DORT needs the same emmodel in all the layers of a batch")
-        if any(o != model.emmodel_options for o in options):
-            raise SMRTError("smrt_amd's DORT needs the same emmodel options in all the layers of a batch")
-        cls = kinds.pop()
-        first = plan.snowpacks[0]
-        cls(plan.sensors[0], first.layers[0], **model.emmodel_options_of_layer(first.layers[0]))  # validates the options
-        return cls
+            if simple and not any(getattr(l, "emmodel", None) or getattr(l, "emmodel_options", None) for l in sp.layers):
+                kinds = [model.emmodel] * n                      # the common case, no per-layer look-ups
+                todo = [(model.emmodel, sp.layers[0])]
+            else:
+                kinds = [model.emmodel_of_layer(k, layer, n) for k, layer in enumerate(sp.layers)]
+                todo = list(zip(kinds, sp.layers))
+            for kind, layer in todo:
+                options = model.emmodel_options_of_layer(layer)
+                key = (kind, tuple(sorted(options.items())))
+                if key not in checked:
+                    checked.add(key)
+                    kind(plan.sensors[0], layer, **options)     # validates the options against the class
+            names = [cls._device_name(k) for k in kinds]
+            distinct.update(names)
+            per_pack.append(names)
+        return distinct.pop() if len(distinct) == 1 else per_pack
 
     # ---- grouping, packing, launching ----------------------------------------------------------------------------
     def _check_sensor(self, sensor):
@@ -134,11 +150,7 @@ class DORT(object):
         if sensor.mode == "A" and not np.array_equal(sensor.theta_deg, sensor.theta_inc_deg):
             raise SMRTError("smrt_amd's DORT computes the backscatter (theta == theta_inc) in active mode")
 
-    def _solve_indexed(self, sensors, packs, sens_idx, pack_idx, emmodel_cls):
-        device_name = getattr(emmodel_cls, "device_name", None)
-        if device_name is None:
-            raise SMRTError(f"emmodel {emmodel_cls} has no device implementation in smrt_amd (iba, dmrt_qca_shortrange, "
-                            "dmrt_qcacp_shortrange, nonscattering)")
+    def _solve_indexed(self, sensors, packs, sens_idx, pack_idx, emmodel_names):
         # everything that must be uniform inside one device batch, as small integer codes per sensor / per snowpack
         sensor_keys, pack_keys = {}, {}
         s_code = np.empty(len(sensors), np.int64)
@@ -149,11 +161,7 @@ class DORT(object):
             s_code[k] = sensor_keys.setdefault(key, len(sensor_keys))
         p_code = np.empty(len(packs), np.int64)
         for k, sp in enumerate(packs):
-            micro = sp.microstructure_models
-            if len(micro) != 1:
-                raise SMRTError("smrt_amd's DORT needs the same microstructure model in all the layers")
-            key = (next(iter(micro)), getattr(sp.substrate, "device_kind", None),
-                   id(sp.atmosphere) if sp.atmosphere is not None else None)
+            key = (getattr(sp.substrate, "device_kind", None), id(sp.atmosphere) if sp.atmosphere is not None else None)
             p_code[k] = pack_keys.setdefault(key, len(pack_keys))
         freq = np.array([float(s.frequency) for s in sensors])
         code = s_code[sens_idx] * len(pack_keys) + p_code[pack_idx]
@@ -163,7 +171,8 @@ class DORT(object):
             u_packs, inv_p = np.unique(pack_idx[sel], return_inverse=True)
             u_freq, inv_f = np.unique(freq[sens_idx[sel]], return_inverse=True)
             sensor0, sp0 = sensors[sens_idx[sel[0]]], packs[u_packs[0]]
-            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, device_name)
+            names = emmodel_names if isinstance(emmodel_names, str) else [emmodel_names[k] for k in u_packs]
+            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, names)
             pairs = inv_f * len(u_packs) + inv_p
             full = len(pairs) == batch.n_pairs and np.array_equal(pairs, np.arange(batch.n_pairs))
             out = run_on_devices(batch, self.devices, self.block_threads, pairs=None if full else pairs)
@@ -174,11 +183,26 @@ class DORT(object):
             sol.add_group(sel, out, sp0)
         return sol
 
-    def _pack(self, sensor0, sps, freqs, device_name):
+    def _pack(self, sensor0, sps, freqs, emmodel_names):
         """The device batch of one group: S distinct snowpacks x F distinct frequencies."""
+        from .._native import EM_CODES, MS_CODES
+
         S = len(sps)
         nl = np.fromiter((sp.nlayer for sp in sps), np.int32, S)
         Lmax = int(nl.max())
+        # emmodel + 16 * microstructure per layer; handed to the device only when the batch really mixes them
+        micro = [sp.microstructure_models for sp in sps]
+        uniform_micro = len(set().union(*micro)) == 1
+        layer_kind = None
+        if not (isinstance(emmodel_names, str) and uniform_micro):
+            layer_kind = np.zeros((S, Lmax), np.int32)
+            for s, sp in enumerate(sps):
+                em = [emmodel_names] * nl[s] if isinstance(emmodel_names, str) else emmodel_names[s]
+                if len(em) != nl[s]:
+                    raise SMRTError("one emmodel per layer is needed")
+                layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * MS_CODES[lay.microstructure_model]
+                                         for e, lay in zip(em, sp.layers)]
+        device_name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
         if int(nl.min()) == Lmax:
             cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
         else:
@@ -203,7 +227,8 @@ class DORT(object):
                            n_max_stream=self.n_max_stream, m_max=self.m_max,
                            phase_normalization=self.phase_normalization,
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
-                           substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack)
+                           substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
+                           layer_kind=layer_kind)
 
 
 class _Solution:
@@ -361,8 +386,15 @@ def run_on_devices(batch, devices=None, block_threads=0, pairs=None, cost=None):
 
     if len(devices) == 1:
         return one(devices[0], 0, n)
-    bounds = shard_by_cost(cost, len(devices)) if cost is not None else \
-        np.linspace(0, n, len(devices) + 1).astype(np.int64)
+    if cost is None:   # the work of a pair varies with its stream counts: estimate it on the first device (cheap kernel)
+        ctx = get_context(devices[0])
+        with ctx.lock:
+            if pairs is None:
+                ctx.upload(batch)
+            else:
+                ctx.upload(batch, pairs=pairs)
+            cost = ctx.pair_cost()
+    bounds = shard_by_cost(cost, len(devices))
     out = BatchOutput(batch, n)
     errors = []
 

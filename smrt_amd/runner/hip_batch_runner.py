@@ -67,5 +67,7 @@ class HipBatchRunner(object):
         sensors = list({id(s): s for s, _ in simulations}.values())
         packs = list({id(p): p for _, p in simulations}.values())
         probe = SimulationPlan(sensors, packs, np.zeros(0, int), np.zeros(0, int))
-        emmodel_cls = rtsolver._uniform_emmodel(model, probe) if hasattr(rtsolver, "_uniform_emmodel") else model.emmodel
-        return rtsolver.solve_batch(simulations, emmodel_cls)
+        emmodel = rtsolver.emmodel_names(model, probe) if hasattr(rtsolver, "emmodel_names") else model.emmodel
+        if isinstance(emmodel, str):   # uniform: solve_batch takes the class (any layer's will do)
+            emmodel = model.emmodel_of_layer(0, packs[0].layers[0], packs[0].nlayer)
+        return rtsolver.solve_batch(simulations, emmodel)

@@ -23,7 +23,7 @@ def load_golden(name):
 def snowpack_dict(d):
     """The plain-array snowpack description stored in a fixture."""
     sp = {k: d[k] for k in ("thickness", "density", "temperature", "frac_volume")}
-    sp["microstructure"] = str(d["microstructure"])
+    sp["microstructure"] = str(d["microstructure"]) if np.ndim(d["microstructure"]) == 0 else [str(m) for m in d["microstructure"]]
     for k in ("corr_length", "radius", "stickiness"):
         if k in d:
             sp[k] = d[k]
@@ -62,10 +62,24 @@ def packed_batch_from_fixture(d, freqs=None):
     """The one-snowpack PackedBatch (C-ABI input) of a fixture: all its frequencies, or the listed ones."""
     from smrt_amd._native import PackedBatch
 
+    from smrt_amd._native import EM_CODES, MS_CODES
+
     sp = snowpack_dict(d)
     ms = sp["microstructure"]
-    p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
-    p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
+    layer_kind = None
+    emmodel = str(d["emmodel"]) if np.ndim(d["emmodel"]) == 0 else [str(e) for e in d["emmodel"]]
+    if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
+        L = len(sp["thickness"])
+        msl = ms if isinstance(ms, list) else [ms] * L
+        eml = emmodel if isinstance(emmodel, list) else [emmodel] * L
+        layer_kind = [EM_CODES[e] + 16 * MS_CODES[m] for e, m in zip(eml, msl)]
+        expo = np.array([m == "exponential" for m in msl])
+        p1 = np.where(expo, np.nan_to_num(sp.get("corr_length", np.zeros(L))), np.nan_to_num(sp.get("radius", np.zeros(L))))
+        p2 = np.nan_to_num(np.broadcast_to(sp.get("stickiness", np.zeros(L)), (L,)), nan=0.0)
+        ms, emmodel = msl[0], eml[0]
+    else:
+        p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
+        p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
     sel = slice(None) if freqs is None else freqs
     o = fixture_options(d)
     active = str(d["mode"]) == "A"
@@ -80,9 +94,9 @@ def packed_batch_from_fixture(d, freqs=None):
         atmosphere = (d["atm_tb_down"][sel], d["atm_tb_up"][sel], d["atm_trans"][sel])
     return PackedBatch([len(sp["thickness"])], sp["thickness"], sp["frac_volume"], sp["temperature"], p1, p2,
                        d["frequency"][sel], np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]),
-                       emmodel=str(d["emmodel"]), microstructure=ms, mode="A" if active else "P",
+                       emmodel=emmodel, microstructure=ms, mode="A" if active else "P",
                        n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
-                       prune_deep_snowpack=o.get("prune_deep_snowpack"))
+                       prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind)
 
 
 SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",
@@ -107,6 +121,13 @@ ACTIVE_FIXTURES = ["iba_2layer_active19", "cfg4_iba_active_L5_n16", "iba_active_
 PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12_prune",
                   "dmrt_L6_n10_prune_over_bad_layer"]  # the last one: layers that cannot be diagonalised below the cut
 PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
+# heterogeneous snowpacks: a list of emmodels (one per layer) over layers mixing the two microstructure models
+MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
+
+
+def fixture_emmodel(d):
+    """The emmodel of a fixture in the oracle's form: a name, or a list of names (one per layer)."""
+    return str(d["emmodel"]) if np.ndim(d["emmodel"]) == 0 else [str(e) for e in d["emmodel"]]
 # configs[3] at full size: IBA, sentinel1(), 30 layers, 128 streams, m_max = 2 (N = 256 / 384 rows per azimuth mode)
 BIG_ACTIVE_FIXTURES = ["cfg4_iba_active_L30_n128_sp0", "cfg4_iba_active_L30_n128_sp1"]
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)

@@ -37,6 +37,11 @@ METHODS = ("eig", "half_rank_eig")
 
 def rebuild(d):
     kw = {}
+    if np.ndim(d["microstructure"]) > 0:   # heterogeneous snowpack: per-layer names, None where a parameter is unused
+        none = lambda a: [None if np.isnan(x) else float(x) for x in a]  # noqa: E731
+        return make_snowpack(d["thickness"], [str(m) for m in d["microstructure"]], density=d["density"],
+                             temperature=d["temperature"], corr_length=none(d["corr_length"]), radius=none(d["radius"]),
+                             stickiness=none(d["stickiness"]))
     if str(d["microstructure"]) == "exponential":
         kw["corr_length"] = d["corr_length"]
     else:
@@ -54,7 +59,8 @@ def rebuild(d):
 def run(d, sp, **extra):
     opts = {k[4:]: d[k].item() for k in d if k.startswith("opt_")}
     opts.update(extra)
-    m = make_model(str(d["emmodel"]), "dort", rtsolver_options=opts)
+    em = str(d["emmodel"]) if np.ndim(d["emmodel"]) == 0 else [str(e) for e in d["emmodel"]]
+    m = make_model(em, "dort", rtsolver_options=opts)
     out = []
     for f in d["frequency"]:
         se = active(float(f), d["theta_inc_deg"])

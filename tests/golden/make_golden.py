@@ -38,6 +38,14 @@ def snowpack_arrays(sp):
         temperature=np.array([lay.temperature for lay in sp.layers], float),
         frac_volume=np.array([lay.frac_volume for lay in sp.layers], float),
     )
+    kinds = {type(lay.microstructure).__name__ for lay in sp.layers}
+    if len(kinds) > 1:   # mixed microstructure models: one name per layer, NaN for the parameters a layer does not have
+        get = lambda lay, a: float(getattr(lay.microstructure, a, np.nan))  # noqa: E731
+        out["microstructure"] = np.array(["exponential" if hasattr(lay.microstructure, "corr_length") else
+                                          "sticky_hard_spheres" for lay in sp.layers])
+        for a in ("corr_length", "radius", "stickiness"):
+            out[a] = np.array([get(lay, a) for lay in sp.layers])
+        return out
     ms = sp.layers[0].microstructure
     if hasattr(ms, "corr_length"):
         out["microstructure"] = "exponential"
@@ -57,11 +65,11 @@ def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_lay
     if ONLY and SKIP_OLD[0]:
         return {}
     rtsolver_options = dict(rtsolver_options or {})
-    m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options)
+    m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options)   # emmodel: a name, or a list (one per layer)
     sims, dims = m.prepare_simulations(sensor, sp, None, "snowpack")
     sims = list(sims)
     out = dict(snowpack_arrays(sp))
-    out["emmodel"] = emmodel
+    out["emmodel"] = np.array(emmodel) if isinstance(emmodel, (list, tuple)) else emmodel
     out["mode"] = sensor.mode
     freqs, datas = [], []
     for isim, sim in enumerate(sims):
@@ -390,6 +398,21 @@ def main():
             alt = run_new("iba", se, spx, rtsolver_options=dict(n_max_stream=16, m_max=2, diagonalization_method=meth))
             out["result_" + meth] = alt["result"]
         save("iba_shs_active_substrate_conditioning", out)
+
+    # Heterogeneous snowpacks (smrt/core/model.py:529-582): a list of emmodels, one per layer, over layers that mix the
+    # exponential and the sticky-hard-spheres microstructure models -- passive and active
+    def mixed_pack(**kw):
+        return make_snowpack([0.2, 0.3, 0.25, 10.0], ["exponential", "sticky_hard_spheres", "exponential", "sticky_hard_spheres"],
+                             density=[250, 300, 350, 400], temperature=[255, 258, 261, 264],
+                             corr_length=[1e-4, None, 2e-4, None], radius=[None, 1.2e-4, None, 1.0e-4],
+                             stickiness=[None, 0.2, None, 0.3], **kw)
+
+    if wanted("mixed_L4_n16_passive"):
+        save("mixed_L4_n16_passive", run_new(["iba", "dmrt_qca_shortrange", "iba", "iba"], passive([18.7e9, 36.5e9], [40, 55]),
+                                              mixed_pack(), rtsolver_options=dict(n_max_stream=16)))
+    if wanted("mixed_L4_n12_active"):
+        save("mixed_L4_n12_active", run_new(["iba", "dmrt_qca_shortrange", "nonscattering", "iba"], active(13.4e9, [30, 45]),
+                                             mixed_pack(), rtsolver_options=dict(n_max_stream=12, m_max=2)))
 
     # Full-size shapes of BASELINE.json's configs[2] and configs[3] (round 2): a second DMRT snowpack at ALL seven AMSR2
     # frequencies with 64 streams, and the true active shape -- IBA, sentinel1(), 30 thin layers, 128 streams, m_max 2

@@ -195,6 +195,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.n_layers = b->n_layers; d.thickness = b->thickness; d.frac_volume = b->frac_volume;
     d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
+    d.layer_kind = b->layer_kind;
     d.sub_kind = b->substrate_kind; d.sub_p1 = b->substrate_p1; d.sub_p2 = b->substrate_p2; d.sub_T = b->substrate_temperature;
     const bool has_atm = b->atm_tb_down != nullptr && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;

@@ -308,3 +308,31 @@ def test_threaded_multi_device_path_and_growing_batches():
         pick = rng.permutation(b.n_pairs)[: b.n_pairs // 3]
         sub = run_on_devices(b, devices=[0, 0], pairs=pick)
         assert np.array_equal(sub.values, one.values[pick]) and np.array_equal(sub.layers, one.layers[pick])
+
+
+def test_heterogeneous_snowpacks_through_the_model():
+    """make_model([...one emmodel per layer...]) / a dict per medium / a layer's own emmodel, over a snowpack whose
+    layers mix microstructure models (smrt/core/model.py:529-582), next to homogeneous snowpacks in the same run:
+    the reference fixture, and batch == sequential."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.runner.sequential_runner import SequentialRunner
+
+    d = load_golden("mixed_L4_n16_passive")
+    none = lambda a: [None if np.isnan(x) else float(x) for x in a]  # noqa: E731
+    sp = make_snowpack(d["thickness"], [str(m) for m in d["microstructure"]], density=d["density"],
+                       temperature=d["temperature"], corr_length=none(d["corr_length"]), radius=none(d["radius"]),
+                       stickiness=none(d["stickiness"]))
+    m = make_model([str(e) for e in d["emmodel"]], "dort", rtsolver_options=dict(n_max_stream=16))
+    sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+    res = m.run(sensor, [sp, sp])
+    assert res.data.dims == ("frequency", "snowpack", "polarization", "theta")
+    assert np.abs(res.data.values[:, 0] - d["result"]).max() < 1e-6 and np.array_equal(res.data.values[:, 0], res.data.values[:, 1])
+    seq = m.run(sensor, [sp, sp], runner=SequentialRunner())
+    assert np.array_equal(seq.data.values, res.data.values)
+    # a layer's own emmodel: the same physics said differently
+    sp2 = make_snowpack(d["thickness"], [str(mm) for mm in d["microstructure"]], density=d["density"],
+                        temperature=d["temperature"], corr_length=none(d["corr_length"]), radius=none(d["radius"]),
+                        stickiness=none(d["stickiness"]))
+    sp2.layers[1].emmodel = "dmrt_qca_shortrange"
+    res2 = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16)).run(sensor, sp2)
+    assert np.array_equal(res2.data.values, res.data.values[:, 0])

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -549,3 +549,21 @@ def test_batches_beyond_one_staging_chunk(ctx):
         f, s = divmod(int(p), S)
         sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
         assert np.abs(full.values[p] - O.solve(sp, freqs[f], [55.0])).max() < TB_TOL
+
+
+@pytest.mark.parametrize("name", MIXED_FIXTURES)
+@pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
+def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
+    """smrt_batch.layer_kind: one emmodel per layer (IBA / DMRT QCA short range / non-scattering) over layers mixing the
+    exponential and sticky-hard-spheres microstructure models, passive and active, against the reference."""
+    d = load_golden(name)
+    out = run_variant(ctx, batch_from_fixture(d), threads, pipeline)
+    assert (out.status == 0).all(), out.status
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
+    else:
+        assert np.abs(out.values - d["result"]).max() < TB_TOL
+    L = len(d["thickness"])
+    for i in range(len(d["frequency"])):
+        np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-11)
+        np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-10, atol=1e-300)

@@ -118,16 +118,25 @@ def test_emmodel_configuration_is_honoured_on_the_batch_path():
     m = make_model("iba", "dort", emmodel_options=dict(dense_snow_correction="auto"))
     plan = m.plan(sensor_list.amsre("37V"), [sp])
     with pytest.raises(SMRTError, match="dense_snow_correction"):
-        DORT._uniform_emmodel(m, plan)
+        DORT.emmodel_names(m, plan)
     with pytest.raises(SMRTError, match="dense_snow_correction"):
         m.prepare_emmodels(plan.sensors[0], sp)          # the per-simulation route says the same
     mixed = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
                              Layer(10.0, "exponential", 400, 250.0, corr_length=5e-5, emmodel="nonscattering")])
-    m2 = make_model("iba", "dort")
-    with pytest.raises(SMRTError, match="same emmodel"):
-        DORT._uniform_emmodel(m2, m2.plan(sensor_list.amsre("37V"), [mixed]))
-    m3 = make_model(["iba", "iba"], "dort")                   # a per-layer list of one kind is fine
-    assert DORT._uniform_emmodel(m3, m3.plan(sensor_list.amsre("37V"), [sp])).device_name == "iba"
+    m2 = make_model("iba", "dort")                            # a layer with its own emmodel: a heterogeneous snowpack
+    assert DORT.emmodel_names(m2, m2.plan(sensor_list.amsre("37V"), [mixed, sp])) == [["iba", "nonscattering"], ["iba", "iba"]]
+    m3 = make_model(["iba", "iba"], "dort")                   # a per-layer list of one kind is the uniform case
+    assert DORT.emmodel_names(m3, m3.plan(sensor_list.amsre("37V"), [sp])) == "iba"
+    m4 = make_model({"snow": "iba", "ice": "nonscattering"}, "dort")   # per medium
+    icy = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
+                           Layer(10.0, "exponential", 900, 250.0, corr_length=5e-5, medium="ice")])
+    assert DORT.emmodel_names(m4, m4.plan(sensor_list.amsre("37V"), [icy])) == [["iba", "nonscattering"]]
+    with pytest.raises(SMRTError, match="no device implementation"):
+        class Foreign:
+            def __init__(self, sensor, layer):
+                pass
+        mf = make_model(Foreign, "dort")
+        DORT.emmodel_names(mf, mf.plan(sensor_list.amsre("37V"), [sp]))
     with pytest.raises(SMRTError):
         Snowpack(layers=sp.layers, interfaces=["rough", "rough"])   # interfaces are validated by the constructor too
 
@@ -258,6 +267,31 @@ def test_result_accessors_active_and_concat():
     both = concat_results([r, ActiveResult(2 * I, coords)], ("snowpack", [0, 1]))
     assert both.data.dims == ("snowpack", "polarization_inc", "polarization", "theta_inc")
     assert np.isclose(both.sigmaVV(snowpack=1, theta=40), 2 * r.sigmaVV(theta=40))
+
+
+def test_result_save_and_open(tmp_path):
+    """Result.save / open_result (smrt/core/result.py:52-76,138-147): a netCDF file laid out like xarray's
+    DataArray.to_netcdf -- one data variable, coordinate variables, character arrays for the polarisations."""
+    from scipy.io import netcdf_file
+
+    from smrt_amd import open_result
+
+    vals = np.arange(2 * 3 * 2 * 2, dtype=float).reshape(2, 3, 2, 2) + 200.25
+    res = PassiveResult(vals, [("frequency", [19e9, 37e9]), ("snowpack", [0, 1, 2]), ("polarization", ["V", "H"]),
+                               ("theta", [40.0, 55.0])])
+    path = str(tmp_path / "res.nc")
+    res.save(path)
+    back = open_result(path)
+    assert isinstance(back, PassiveResult) and back.data.dims == res.data.dims
+    assert np.array_equal(back.data.values, vals) and list(back.data.coords["polarization"]) == ["V", "H"]
+    assert float(back.TbV(frequency=37e9, snowpack=2, theta=55)) == vals[1, 2, 0, 1]
+    with netcdf_file(path, "r", mmap=False) as nc:
+        assert "__xarray_dataarray_variable__" in nc.variables and nc.variables["polarization"][:].dtype.kind == "S"
+    act = ActiveResult(np.ones((3, 3, 2)), [("polarization_inc", ["V", "H", "U"]), ("polarization", ["V", "H", "U"]),
+                                            ("theta_inc", [30.0, 40.0])])
+    act.save(str(tmp_path / "act.nc"))
+    back = open_result(str(tmp_path / "act.nc"))
+    assert isinstance(back, ActiveResult) and np.isclose(back.sigmaVV(theta_inc=40.0), 4 * np.pi * np.cos(np.deg2rad(40.0)))
 
 
 def test_labeled_array_sel_errors():

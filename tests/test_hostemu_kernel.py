@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (MIXED_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -184,3 +184,14 @@ def test_blocked_jacobi_kernel_gives_the_singular_values(emu, n_max_stream, N, o
     assert np.abs(G / np.outer(d, d) - np.eye(N)).max() < 1e-12
     sv = np.linalg.svd(A, compute_uv=False)
     np.testing.assert_allclose(np.sort(sig[:N])[::-1], sv, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name,nt", [(MIXED_FIXTURES[0], 64), (MIXED_FIXTURES[1], 256)])
+def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
+    """Per-layer emmodel and microstructure codes (smrt_batch.layer_kind) through the device code."""
+    out, st, ref = run_fixture(emu, name, nt=nt)
+    assert (st == 0).all()
+    if name.endswith("active"):
+        assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
+    else:
+        assert np.abs(out - ref).max() < 1e-6

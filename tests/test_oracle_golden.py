@@ -3,9 +3,9 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
                       assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
-                      reference_method_spread, snowpack_dict)
+                      fixture_emmodel, reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
 
 TB_TOL = 1e-6  # K      (BASELINE.json north_star)
@@ -201,3 +201,19 @@ def test_albedo_above_one_is_flagged():
     with pytest.raises(O.OracleError) as ei:
         O.solve(snowpack_dict(d), float(d["frequency"][0]), d["theta_deg"], emmodel="dmrt_qca_shortrange")
     assert ei.value.status == 3
+
+
+@pytest.mark.parametrize("name", MIXED_FIXTURES)
+def test_heterogeneous_snowpacks(name):
+    """A list of emmodels -- one per layer -- over layers that mix the exponential and the sticky-hard-spheres
+    microstructure models (smrt/core/model.py:529-582), passive and active, against the reference."""
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    act = str(d["mode"]) == "A"
+    kw = dict(mode="A", theta_inc_deg=d["theta_inc_deg"], method="schur_forcedtriu") if act else {}   # the reference default
+    for i, f in enumerate(d["frequency"]):
+        r = O.solve(sp, float(f), d["theta_deg"], emmodel=fixture_emmodel(d), **kw, **fixture_options(d))
+        if act:
+            assert_backscatter_close(r, d["result"][i], spread=reference_method_spread(d)[i])
+        else:
+            assert np.abs(r - d["result"][i]).max() < TB_TOL
