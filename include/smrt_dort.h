@@ -169,6 +169,19 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
 double smrt_dort_sum_n3(smrt_dort_ctx* ctx);
 
+/*
+ * The emmodel protocol's ft_even_phase for ONE layer (smrt/emmodel/common.py:349-399, rayleigh.py:52-127; consumed by
+ * the reference's rtsolvers at smrt/rtsolver/dort.py:231-247): azimuthal modes 0..m_max of the phase matrix on the grid
+ * mu_s (scattered cosines) x mu_i (incident cosines), any signs.  out: [npol][npol][m_max + 1][n_s][n_i], npol = 2 or 3
+ * (V, H[, U]).  The layer is described like a row of smrt_batch: emmodel / microstructure codes, frequency (Hz), ice
+ * volume fraction, temperature (K), micro_p1 / micro_p2 (corr_length | radius, stickiness).  What lets smrt_amd's
+ * emmodel classes serve an rtsolver other than smrt_amd's own DORT (which assembles these modes inside its kernels).
+ */
+int32_t smrt_dort_ft_even_phase(smrt_dort_ctx* ctx, int32_t emmodel, int32_t microstructure, double frequency,
+                                double frac_volume, double temperature, double micro_p1, double micro_p2,
+                                const double* mu_s, int32_t n_s, const double* mu_i, int32_t n_i, int32_t m_max,
+                                int32_t npol, double* out);
+
 /* Work estimate of every pair of the uploaded batch BEFORE solving it: sum over its layers (and azimuth modes) of
  * N_l^3 from the stream counts alone (a cheap kernel: layer permittivities and Snell's law only).  cost: [pair_count]
  * host doubles; 0 for a pair with invalid input.  What a caller shards by when it splits a batch over several GPUs

@@ -183,6 +183,10 @@ def load_library():
     lib.smrt_dort_run_pairs.restype = C.c_int32
     lib.smrt_dort_upload_pairs.argtypes = [C.c_void_p, P(SmrtBatch), P(C.c_int64), C.c_int64]
     lib.smrt_dort_upload_pairs.restype = C.c_int32
+    lib.smrt_dort_ft_even_phase.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                            C.c_double, P(C.c_double), C.c_int32, P(C.c_double), C.c_int32, C.c_int32, C.c_int32,
+                                            P(C.c_double)]
+    lib.smrt_dort_ft_even_phase.restype = C.c_int32
     lib.smrt_dort_pair_cost.argtypes = [C.c_void_p, P(C.c_double)]
     lib.smrt_dort_pair_cost.restype = C.c_int32
     lib.smrt_dort_comm_unique_id.argtypes = [C.c_char_p]
@@ -246,7 +250,7 @@ def check_struct_layout(lib):
 
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
-    "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost",
+    "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost", "smrt_dort_ft_even_phase",
     "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
@@ -348,6 +352,18 @@ class DortContext:
         self._check(self._lib.smrt_dort_download(self._h, _dptr(o.values), o.status.ctypes.data_as(C.POINTER(C.c_int32)),
                                                  _dptr(o.layers), _dptr(o.streams)), "smrt_dort_download")
         return o
+
+    def ft_even_phase(self, emmodel, microstructure, frequency, frac_volume, temperature, p1, p2, mu_s, mu_i, m_max, npol):
+        """Azimuthal modes of the phase matrix of one layer: array [npol, npol, m_max + 1, len(mu_s), len(mu_i)]."""
+        mu_s = np.ascontiguousarray(np.atleast_1d(mu_s), dtype=np.float64)
+        mu_i = np.ascontiguousarray(np.atleast_1d(mu_i), dtype=np.float64)
+        out = np.empty((npol, npol, m_max + 1, len(mu_s), len(mu_i)))
+        with self.lock:
+            self._check(self._lib.smrt_dort_ft_even_phase(
+                self._h, EM_CODES[emmodel], MS_CODES[microstructure], float(frequency), float(frac_volume), float(temperature),
+                float(p1), float(p2), _dptr(mu_s), len(mu_s), _dptr(mu_i), len(mu_i), int(m_max), int(npol), _dptr(out)),
+                "smrt_dort_ft_even_phase")
+        return out
 
     def pair_cost(self):
         """Sum of N_l^3 per pair of the uploaded batch (before solving it): what the work is sharded by."""

@@ -14,6 +14,7 @@
 #include "dort_ctx.hpp"
 #include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
+#include "dort_phase_kernel.hpp"
 
 using namespace smrt;
 
@@ -121,7 +122,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_phase, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -423,6 +424,43 @@ double smrt_dort_sum_n3(smrt_dort_ctx* ctx) {
     double s = 0.0;
     for (double v : h) s += v;
     return s;
+}
+
+int32_t smrt_dort_ft_even_phase(smrt_dort_ctx* ctx, int32_t emmodel, int32_t microstructure, double frequency, double frac_volume,
+                                double temperature, double micro_p1, double micro_p2, const double* mu_s, int32_t n_s,
+                                const double* mu_i, int32_t n_i, int32_t m_max, int32_t npol, double* out) {
+    if (!ctx) return -1;
+    if (!mu_s || !mu_i || !out || n_s < 1 || n_i < 1 || m_max < 0 || m_max > 64 || (npol != 2 && npol != 3)) {
+        ctx->err = "invalid ft_even_phase request";
+        return -1;
+    }
+    if (emmodel < SMRT_EM_IBA || emmodel > SMRT_EM_NONSCATTERING ||
+        (microstructure != SMRT_MS_EXPONENTIAL && microstructure != SMRT_MS_STICKY_HARD_SPHERES)) {
+        ctx->err = "unknown emmodel / microstructure";
+        return -1;
+    }
+    for (int i = 0; i < n_s; ++i) if (!(fabs(mu_s[i]) <= 1.0)) { ctx->err = "cosines must lie in [-1, 1]"; return -1; }
+    for (int i = 0; i < n_i; ++i) if (!(fabs(mu_i[i]) <= 1.0)) { ctx->err = "cosines must lie in [-1, 1]"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n_out = (size_t)npol * npol * (m_max + 1) * n_s * n_i;
+    const size_t bytes = sizeof(double) * (n_out + n_s + n_i) + 16;
+    HIPCHK(ctx->d_phase.reserve(bytes));
+    double* d_out = (double*)ctx->d_phase.p;
+    double* d_mus = d_out + n_out;
+    double* d_mui = d_mus + n_s;
+    int* d_status = (int*)(d_mui + n_i);
+    HIPCHK(hipMemcpyAsync(d_mus, mu_s, sizeof(double) * n_s, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_mui, mu_i, sizeof(double) * n_i, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
+    PhaseRequest q{emmodel, microstructure, frequency, frac_volume, temperature, micro_p1, micro_p2, d_mus, n_s, d_mui, n_i,
+                   m_max, npol, azimuth_samples(m_max), d_out, d_status};
+    HIPCHK(smrt_launch::ft_even_phase(ctx, q));
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&st, d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (st != 0) { ctx->err = "invalid layer properties (temperature above the freezing point?)"; return -1; }
+    return 0;
 }
 
 int32_t smrt_dort_pair_cost(smrt_dort_ctx* ctx, double* cost) {

@@ -52,9 +52,20 @@ class _DeviceEMModel:
     def ke(self, mu, npol=2):
         return np.full((npol, np.size(mu)), self._ks + self.ka)
 
-    def ft_even_phase(self, *args, **kwargs):
-        raise NotImplementedError("the azimuthal modes of the phase matrix are assembled inside the HIP kernel "
-                                  "(smrt_amd/csrc/dort_device.hpp) and are not materialised on the host")
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):
+        """Azimuthal modes 0..m_max of the phase matrix on mu_s x mu_i: array [npol, npol, m_max + 1, len(mu_s),
+        len(mu_i)] with the reference's conventions (smrt/emmodel/common.py:349-399, rayleigh.py:52-127), evaluated on
+        the device (smrt_dort_ft_even_phase).  smrt_amd's own DORT never asks for it (its kernels assemble the modes in
+        place); it is what a foreign rtsolver consumes (smrt/rtsolver/dort.py:231-247)."""
+        from ..rtsolver.dort import get_context
+
+        npol = self.npol if npol is None else npol
+        if np.any(np.asarray(mu_i) == 1) and npol > 2:
+            raise SMRTError("Phase matrix signs for sine elements of mode m = 2 incorrect")
+        p1, p2 = self.layer.microstructure.device_params
+        return get_context(0).ft_even_phase(self.device_name, self.layer.microstructure_model, self.frequency,
+                                            self.layer.frac_volume, self.layer.temperature, p1,
+                                            p2, mu_s, mu_i, m_max, npol)
 
 
 class IBA(_DeviceEMModel):

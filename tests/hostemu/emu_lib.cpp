@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../smrt_amd/csrc/dort_active.hpp"
 #include "../../smrt_amd/csrc/dort_host_common.hpp"
+#include "../../smrt_amd/csrc/dort_phase_kernel.hpp"
 
 using namespace smrt;
 
@@ -290,4 +291,14 @@ extern "C" int smrt_emu_jacobi_big(int n_max_stream, int P, int N, double* Bm, d
     std::vector<double> jl(jp.total, NAN);
     emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, st, 0, jl.data()); });
     return n;
+}
+
+// ft_even_phase of one layer through the device function (one emulated thread per (scattered, incident) pair)
+extern "C" int smrt_emu_ft_even_phase(int em, int ms, double frequency, double fv, double T, double p1, double p2,
+                                      const double* mu_s, int n_s, const double* mu_i, int n_i, int m_max, int npol, double* out) {
+    int status = 0;
+    PhaseRequest q{em, ms, frequency, fv, T, p1, p2, mu_s, n_s, mu_i, n_i, m_max, npol, azimuth_samples(m_max), out, &status};
+    for (int is = 0; is < n_s; ++is)
+        for (int ii = 0; ii < n_i; ++ii) ft_even_phase_entry(q, is, ii);
+    return status;
 }

@@ -336,3 +336,39 @@ def test_heterogeneous_snowpacks_through_the_model():
     sp2.layers[1].emmodel = "dmrt_qca_shortrange"
     res2 = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16)).run(sensor, sp2)
     assert np.array_equal(res2.data.values, res.data.values[:, 0])
+
+
+def test_emmodel_ft_even_phase_on_the_device():
+    """The last piece of the emmodel protocol (smrt/rtsolver/dort.py:231-247 consumes it): ft_even_phase(mu_s, mu_i,
+    m_max, npol) of smrt_amd's emmodel classes, evaluated by the device, against the oracle -- IBA on both
+    microstructure models and a Rayleigh emmodel, both hemispheres, active and passive shapes."""
+    from oracle import dort_oracle as O
+    from smrt_amd import make_snowpack, sensor_list
+    from smrt_amd.core.error import SMRTError
+    from smrt_amd.emmodel.dmrt_qca_shortrange import DMRT_QCA_ShortRange
+    from smrt_amd.emmodel.iba import IBA
+
+    mu = np.array([0.97, 0.7, 0.35, 0.1])
+    mu_full = np.concatenate([mu, -mu])
+    cases = [(IBA, "iba", make_snowpack([1.0], "exponential", density=[300], temperature=[262], corr_length=[2e-4]),
+              dict(microstructure="exponential", corr_length=[2e-4])),
+             (IBA, "iba", make_snowpack([1.0], "sticky_hard_spheres", density=[300], temperature=[262], radius=[1.5e-4], stickiness=[0.25]),
+              dict(microstructure="sticky_hard_spheres", radius=[1.5e-4], stickiness=[0.25])),
+             (DMRT_QCA_ShortRange, "dmrt_qca_shortrange",
+              make_snowpack([1.0], "sticky_hard_spheres", density=[300], temperature=[262], radius=[1.5e-4], stickiness=[0.25]),
+              dict(microstructure="sticky_hard_spheres", radius=[1.5e-4], stickiness=[0.25]))]
+    for cls, name, sp, osp in cases:
+        layer = O.make_layers(name, 36.5e9, dict(thickness=[1.0], density=[300.0], temperature=[262.0], **osp))[0]
+        em_a = cls(sensor_list.active(36.5e9, 40), sp.layers[0])
+        got = em_a.ft_even_phase(mu_full, mu_full, 2)
+        assert got.shape == (3, 3, 3, 8, 8)
+        ref = np.asarray(layer.ft_even_phase(mu_full, mu_full, 2, 3))
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-14 * np.abs(ref).max())
+        em_p = cls(sensor_list.passive(36.5e9, 55), sp.layers[0])
+        got = em_p.ft_even_phase(mu, mu_full, 0)
+        assert got.shape == (2, 2, 1, 4, 8)
+        np.testing.assert_allclose(got, np.asarray(layer.ft_even_phase(mu, mu_full, 0, 2)), rtol=1e-11)
+        # energy conservation of mode 0 (what the reference's test_iba.py checks): the (V, H) column sums integrate to ks
+        assert np.isclose(em_p.ks(mu)[0, 0], layer.ks, rtol=1e-11)
+    with pytest.raises(SMRTError):
+        em_a.ft_even_phase(mu, np.array([1.0, 0.5]), 2)     # mu_i = 1 with three polarisations (common.py:389-390)

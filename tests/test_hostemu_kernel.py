@@ -195,3 +195,32 @@ def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
         assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
     else:
         assert np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("emmodel,micro,npol,m_max", [("iba", "exponential", 3, 2), ("iba", "sticky_hard_spheres", 3, 3),
+                                                      ("iba", "exponential", 2, 0), ("dmrt_qca_shortrange", "sticky_hard_spheres", 3, 3),
+                                                      ("nonscattering", "exponential", 2, 1)])
+def test_device_ft_even_phase_against_the_oracle(emu, emmodel, micro, npol, m_max):
+    """The emmodel protocol's ft_even_phase evaluated by the device function (dort_phase_kernel.hpp) on arbitrary
+    cosine grids -- both hemispheres -- against the oracle's restatement of smrt/emmodel/common.py:56-131,349-399 and
+    rayleigh.py:52-127 (itself pinned by the A-matrix stage fixtures of the reference)."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import EM_CODES, MS_CODES
+
+    emu.smrt_emu_ft_even_phase.argtypes = [C.c_int, C.c_int] + [C.c_double] * 5 + [C.POINTER(C.c_double), C.c_int,
+                                           C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    mu_s = np.array([0.95, 0.6, 0.2, -0.3, -0.85])
+    mu_i = np.array([0.9, 0.45, -0.1, -0.7])
+    f, fv, T = 36.5e9, 0.3, 262.0
+    mp = dict(corr_length=1.8e-4) if micro == "exponential" else dict(radius=1.4e-4, stickiness=0.2)
+    layer = O.make_layers(emmodel, f, dict(thickness=[1.0], frac_volume=[fv], temperature=[T], microstructure=micro,
+                                          **{k: [v] for k, v in mp.items()}))[0]
+    ref = layer.ft_even_phase(mu_s, mu_i, m_max, npol)
+    out = np.empty((npol, npol, m_max + 1, len(mu_s), len(mu_i)))
+    p1, p2 = (mp["corr_length"], 0.0) if micro == "exponential" else (mp["radius"], mp["stickiness"])
+    rc = emu.smrt_emu_ft_even_phase(EM_CODES[emmodel], MS_CODES[micro], f, fv, T, p1, p2,
+                                    mu_s.ctypes.data_as(C.POINTER(C.c_double)), len(mu_s),
+                                    mu_i.ctypes.data_as(C.POINTER(C.c_double)), len(mu_i), m_max, npol,
+                                    out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    np.testing.assert_allclose(out, np.asarray(ref), rtol=1e-11, atol=1e-14 * max(np.abs(ref).max(), 1e-300))
