@@ -363,11 +363,11 @@ def test_emmodel_ft_even_phase_on_the_device():
         got = em_a.ft_even_phase(mu_full, mu_full, 2)
         assert got.shape == (3, 3, 3, 8, 8)
         ref = np.asarray(layer.ft_even_phase(mu_full, mu_full, 2, 3))
-        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-14 * np.abs(ref).max())
+        np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13 * np.abs(ref).max())   # sums that cancel: absolute floor
         em_p = cls(sensor_list.passive(36.5e9, 55), sp.layers[0])
         got = em_p.ft_even_phase(mu, mu_full, 0)
         assert got.shape == (2, 2, 1, 4, 8)
-        np.testing.assert_allclose(got, np.asarray(layer.ft_even_phase(mu, mu_full, 0, 2)), rtol=1e-11)
+        np.testing.assert_allclose(got, np.asarray(layer.ft_even_phase(mu, mu_full, 0, 2)), rtol=1e-10)
         # energy conservation of mode 0 (what the reference's test_iba.py checks): the (V, H) column sums integrate to ks
         assert np.isclose(em_p.ks(mu)[0, 0], layer.ks, rtol=1e-11)
     with pytest.raises(SMRTError):
