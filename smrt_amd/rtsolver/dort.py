@@ -41,6 +41,9 @@ class DORT(object):
             raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
         if phase_symmetrization:
             raise SMRTError("phase_symmetrization is outside the scope of smrt_amd's DORT")
+        if process_coherent_layers:
+            raise SMRTError("process_coherent_layers is not implemented by smrt_amd's DORT (DESIGN.md 7.3: the removed "
+                            "layers become frequency-dependent Fabry-Perot interfaces)")
         if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
             prune_deep_snowpack = 6
         if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
@@ -56,7 +59,7 @@ class DORT(object):
         self.stream_mode = stream_mode
         self.phase_normalization = phase_normalization
         self.error_handling = error_handling
-        self.process_coherent_layers = bool(process_coherent_layers)
+        self.process_coherent_layers = False
         self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         self.diagonalization_method = diagonalization_method
         self.rayleigh_jeans_approximation = bool(rayleigh_jeans_approximation)

@@ -357,7 +357,7 @@ def test_dort_option_validation():
 
     DORT(n_max_stream=64, diagonalization_method="half_rank_eig", error_handling="nan")
     for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=-1), dict(diagonalization_method="foo"),
-                dict(error_handling="ignore"), dict(phase_symmetrization=True)):
+                dict(error_handling="ignore"), dict(phase_symmetrization=True), dict(process_coherent_layers=True)):
         with pytest.raises(SMRTError):
             DORT(**bad)
     # prune_deep_snowpack: True is an optical depth of 6 (smrt/rtsolver/dort.py:176-178); the cache option is a no-op
