@@ -210,6 +210,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
 
     double n3 = 0.0;
     int n_sweeps = 0;
+    if (MODE == 1 && b.pair_done && b.pair_done[p]) return;   // every azimuth mode of this pair is cut above this round's layers
     for (int m = 0; m <= m_max; ++m) {
         const int P = (m == 0) ? 2 : 3;
         const double cc = (m == 0) ? 0.5 : 0.25;  // dort.py:716-721
@@ -237,6 +238,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             block_sync();
         };
         for (int l = Lk - 1; l >= 0; --l) {
+            if (MODE == 1 && (l < b.layer_lo || l >= b.layer_hi)) continue;   // not in this round of the prep kernel
             const int n = (int)s.nl[l];
             const int N = n * P;
             n3 += (double)N * N * N;

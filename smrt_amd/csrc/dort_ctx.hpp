@@ -29,7 +29,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase, d_done;
     smrt::DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -89,6 +89,8 @@ hipError_t fused(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int nt, bool activ
 hipError_t fused_gmem(smrt_dort_ctx* ctx, const smrt::DevBatch& d, int ch, bool active);
 // k_phase.hip: ft_even_phase of one layer (emmodel protocol)
 hipError_t ft_even_phase(smrt_dort_ctx* ctx, const smrt::PhaseRequest& q);
+// k_cost.hip: which pairs have reached their prune_deep_snowpack cut within the layers processed so far
+hipError_t prune_mark(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int* done_dev);
 // k_cost.hip: sum of N_l^3 per pair from the stream counts alone
 hipError_t pair_cost(smrt_dort_ctx* ctx, const smrt::DevBatch& d, double* cost_dev);
 }  // namespace smrt_launch

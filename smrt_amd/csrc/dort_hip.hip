@@ -45,34 +45,45 @@ static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long 
     return c;
 }
 
-// prep -> Jacobi -> finish, chunk by chunk (the staging area holds one chunk)
+// prep -> Jacobi -> finish, chunk by chunk (the staging area holds one chunk).  Under prune_deep_snowpack the prep and
+// Jacobi kernels run in up to four ROUNDS over successive layer ranges, top-down, with a small kernel in between that
+// marks the pairs whose cut has been reached: the layers below a cut are never diagonalised (like in the reference),
+// exactly -- the decision uses the same singular values as the finish kernel.
 static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
+    const long long modes = ctx->active ? d.m_max + 1 : 1;
     if (getenv("SMRT_DORT_DEBUG_OCCUPANCY") && !ctx->gmem_path && !ctx->active) smrt_launch::occupancy_report(ctx, ctx->nt);
+    const int rounds = (d.prune_tau > 0.0 && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
+    auto prep = [&](const DevBatch& c, unsigned grid) {
+        if (ctx->big) return smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->gmem_split) return smrt_launch::prep_gmem(ctx, c, grid, ctx->active);
+        return ctx->active ? smrt_launch::active_prep(ctx, c, ctx->nt) : smrt_launch::prep(ctx, c, ctx->nt);
+    };
+    auto finish = [&](const DevBatch& c, unsigned grid) {
+        if (ctx->big) return smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->gmem_split) return smrt_launch::finish_gmem(ctx, c, grid, ctx->active);
+        return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
+    };
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
-        const DevBatch c = chunk_of(ctx, d, c0, cn);
+        DevBatch c = chunk_of(ctx, d, c0, cn);
+        const unsigned grid = (unsigned)(ctx->gmem_path ? std::min<long long>(cn, ctx->gmem_grid) : cn);
         hipError_t e;
-        if (ctx->big) {
-            const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
-            const int ch = ctx->nmax_rows <= 256 ? 4 : 6;
-            if ((e = smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ch)) != hipSuccess) return e;
-            if ((e = smrt_launch::jacobi_big(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
-            if ((e = smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ch)) != hipSuccess) return e;
-        } else if (ctx->gmem_split) {
-            const unsigned grid = (unsigned)std::min<long long>(cn, ctx->gmem_grid);
-            if ((e = smrt_launch::prep_gmem(ctx, c, grid, ctx->active)) != hipSuccess) return e;
-            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
-            if ((e = smrt_launch::finish_gmem(ctx, c, grid, ctx->active)) != hipSuccess) return e;
-        } else if (ctx->active) {
-            if ((e = smrt_launch::active_prep(ctx, c, ctx->nt)) != hipSuccess) return e;
-            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
-            if ((e = smrt_launch::active_finish(ctx, c, ctx->nt)) != hipSuccess) return e;
-        } else {
-            if ((e = smrt_launch::prep(ctx, c, ctx->nt)) != hipSuccess) return e;
-            if ((e = smrt_launch::jacobi(ctx, c, cn * items_per_pair)) != hipSuccess) return e;
-            if ((e = smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2)) != hipSuccess) return e;
+        if (rounds > 1) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
+            if ((e = hipMemsetAsync(ctx->stage.n, 0, sizeof(int) * (size_t)(cn * items_per_pair), ctx->stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(ctx->d_done.p, 0, sizeof(int) * (size_t)cn, ctx->stream)) != hipSuccess) return e;
+            c.pair_done = (const int*)ctx->d_done.p;
         }
+        for (int r = 0; r < rounds; ++r) {
+            c.layer_lo = (int)((long long)d.Lmax * r / rounds);
+            c.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
+            if ((e = prep(c, grid)) != hipSuccess) return e;
+            const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
+            if ((e = ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems)) != hipSuccess) return e;
+            if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, (int*)ctx->d_done.p)) != hipSuccess) return e;
+        }
+        c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
+        if ((e = finish(c, grid)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -122,7 +133,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_phase, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_phase, &ctx->d_done, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -313,6 +324,8 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
     d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
+    d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
+    if (d.prune_tau > 0.0) HIPCHK(ctx->d_done.reserve(sizeof(int) * (size_t)std::max<long long>(ctx->chunk_pairs, 1)));
     // Jacobi thresholds on the squared cosine between two columns: below skip2 a pair is not rotated, a sweep without
     // a rotation above exit2 is the last one (dort_jacobi_kernel.hpp).  SMRT_DORT_JACOBI_SKIP2 / _EXIT2 override them
     // for experiments.

@@ -35,6 +35,12 @@ struct DevBatch {
     double phi;
     double jacobi_skip2, jacobi_exit2;  // squared-cosine thresholds of the Jacobi kernel (host: per mode, env override)
     double prune_tau;  // > 0: optical depth beyond which the deeper layers are dropped (dort.py:443-452); pipeline only
+    // Rounds of the pipelines under prune_deep_snowpack: the prep and Jacobi kernels of one round cover the layers
+    // [layer_lo, layer_hi) of the pairs whose cut has not been reached yet (pair_done[p] == 0; null: every pair), so the
+    // layers below a cut are never diagonalised -- like in the reference, which stops assembling there.  Otherwise
+    // layer_lo = 0 and layer_hi = Lmax.
+    int layer_lo, layer_hi;
+    const int* pair_done;
     double* out;
     int* status;
     double* layer_out;
@@ -59,6 +65,13 @@ struct DevStage {
 // index into the flattened (frequency-major) pair list of the batch for the p-th workgroup of a launch
 SMRT_DEV long long global_pair(const DevBatch& b, long long p) {
     return b.pair_map ? b.pair_map[b.pair_begin + p] : b.pair_begin + p;
+}
+
+// staging item of the blk-th workgroup of a Jacobi launch that covers the layers [layer_lo, layer_hi) of every
+// (pair, azimuth mode): item = (pair * modes + mode) * Lmax + layer
+SMRT_DEV long long jacobi_item_of_block(const DevBatch& b, long long blk) {
+    const int span = b.layer_hi - b.layer_lo;
+    return (blk / span) * b.Lmax + b.layer_lo + (blk % span);
 }
 
 constexpr double kCSpeed = 299792458.0;

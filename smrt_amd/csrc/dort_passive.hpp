@@ -46,6 +46,39 @@ SMRT_DEV int pruned_layer_count(const DevStage& stg, long long item0, int L, con
     return keep;
 }
 
+// After a round of prep + Jacobi over the layers [0, layer_hi) under prune_deep_snowpack (one wavefront per pair):
+// done[p] = 1 when the running optical depth sum_l min|beta_l| thickness_l of EVERY azimuth mode of pair p has passed the
+// threshold within the layers processed so far (or a layer above failed: the finish kernel reports that, the layers
+// below do not matter), so that the next rounds leave the pair alone (dort.py:443-452: the reference stops assembling
+// at the cut).  The decision uses the very singular values the finish kernel's pruned_layer_count will use.
+SMRT_DEV void prune_mark_pair(const DevBatch& b, const DevStage& stg, long long p, int* done) {
+    const int lane = tid() % SMRT_LANES;
+    const long long gp = global_pair(b, p);
+    const int si = (int)(gp % b.S);
+    const int L = b.n_layers[si];
+    const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;
+    const double* thick = b.thickness + (long long)si * b.Lmax;
+    const int upto = b.layer_hi < L ? b.layer_hi : L;
+    bool all_cut = true;
+    for (int m = 0; m < nmodes; ++m) {
+        double acc = 0.0;
+        bool cut = false;
+        for (int l = 0; l < upto && !cut; ++l) {   // uniform over the wavefront
+            const long long item = (p * nmodes + m) * b.Lmax + l;
+            const int N = stg.n[item];
+            if (N < 0) { cut = true; break; }   // failed layer: nothing below it is needed
+            if (N == 0) break;                  // not processed (cannot happen above the running round)
+            double mn = 1e300;
+            for (int r = lane; r < N; r += SMRT_LANES) { const double sg = stg.sigma[item * stg.vec_stride + r]; mn = sg < mn ? sg : mn; }
+            for (int k = 1; k < SMRT_LANES; k <<= 1) { const double o = shfl_xor(mn, k); mn = o < mn ? o : mn; }
+            acc += mn * thick[l];
+            if (acc > b.prune_tau) cut = true;
+        }
+        all_cut = all_cut && cut;
+    }
+    if (lane == 0) done[p] = all_cut ? 1 : 0;
+}
+
 // The prep and Jacobi kernels of the pipelines record a failed layer (renormalisation beyond 30 %, albedo >= 1, no
 // convergence) as n[item] = -status instead of failing the pair: the reference diagonalises its layers from the top
 // inside the loop that assembles the boundary system (dort.py:312-336) and never reaches the layers that
@@ -246,7 +279,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         block_sync();
     };
     // ---- bottom-up over the layers -------------------------------------------------------------------------
+    if (MODE == 1 && b.pair_done && b.pair_done[p]) return;   // the cut of this pair lies above this round's layers (uniform)
     for (int l = Lk - 1; l >= 0; --l) {
+        if (MODE == 1 && (l < b.layer_lo || l >= b.layer_hi)) continue;   // not in this round of the prep kernel
         const int n = (int)s.nl[l];
         const int N = n * P;
         n3 += (double)N * N * N;

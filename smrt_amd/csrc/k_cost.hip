@@ -32,7 +32,16 @@ __global__ __launch_bounds__(NT) void dort_cost_kernel(DevBatch b, double* cost)
     }
 }
 
+// see prune_mark_pair (dort_passive.hpp): one wavefront per pair
+__global__ __launch_bounds__(64) void dort_prune_mark_kernel(DevBatch b, DevStage stg, int* done) {
+    prune_mark_pair(b, stg, (long long)blockIdx.x, done);
+}
+
 namespace smrt_launch {
+hipError_t prune_mark(smrt_dort_ctx* ctx, const DevBatch& c, int* done_dev) {
+    hipLaunchKernelGGL(dort_prune_mark_kernel, dim3((unsigned)c.pair_count), dim3(64), 0, ctx->stream, c, ctx->stage, done_dev);
+    return hipGetLastError();
+}
 hipError_t pair_cost(smrt_dort_ctx* ctx, const DevBatch& d, double* cost_dev) {
     const int P = d.mode == 1 ? 3 : 2;
     const size_t lds = (size_t)make_plan(d.n_max_stream, P, d.Lmax, d.n_theta, 1, 0, 0, 1).total * sizeof(double);

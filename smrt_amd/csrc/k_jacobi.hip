@@ -8,7 +8,7 @@ using namespace smrt;
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_jacobi_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_jacobi_item<NT>(b, st, (long long)blockIdx.x, smrt_lds);
+    dort_jacobi_item<NT>(b, st, jacobi_item_of_block(b, (long long)blockIdx.x), smrt_lds);
 }
 
 namespace smrt_launch {

@@ -7,7 +7,7 @@ using namespace smrt;
 
 __global__ __launch_bounds__(SMRT_JACOBI_BIG_NT) void dort_jacobi_big_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(b, st, (long long)blockIdx.x, smrt_lds);
+    dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(b, st, jacobi_item_of_block(b, (long long)blockIdx.x), smrt_lds);
 }
 
 namespace smrt_launch {

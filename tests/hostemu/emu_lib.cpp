@@ -41,128 +41,106 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
     return nb;
 }
 
-// 64 < N <= 128, passive: three-kernel pipeline with prep / finish on a global workspace
+// The three-kernel pipelines under emulation, like launch_pipeline of the library: prep for every pair, Jacobi for every
+// staged item, finish for every pair -- in up to four rounds over successive layer ranges with the pruning marks in
+// between when prune_deep_snowpack is set (the layers below a cut are never staged).
+struct Staging {
+    std::vector<double> L, B, d, sigma, inv;
+    std::vector<int> n;
+    DevStage st;
+    Staging(size_t items, const LdsPlan& plan) : L(items * (size_t)plan.NMAX * plan.LD, NAN), B(L.size(), NAN), d(items * plan.NMAX, NAN),
+                                                 sigma(items * plan.NMAX, NAN), inv(items * 1024, NAN), n(items, -1) {
+        st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, inv.data()};
+    }
+};
+
+template <class Prep, class Jac, class Fin>
+static long run_rounds(DevBatch& d, int order, int nmodes, Staging& sg, Prep prep, Jac jac, Fin fin) {
+    long nb = 0;
+    const int rounds = d.prune_tau > 0.0 ? (d.Lmax < 4 ? d.Lmax : 4) : 1;
+    std::vector<int> done((size_t)d.pair_count, 0);
+    if (rounds > 1) { for (auto& x : sg.n) x = 0; d.pair_done = done.data(); }
+    for (int r = 0; r < rounds; ++r) {
+        d.layer_lo = (int)((long long)d.Lmax * r / rounds);
+        d.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
+        for (long long p = 0; p < d.pair_count; ++p) nb += prep(p);
+        const long long blocks = d.pair_count * nmodes * (d.layer_hi - d.layer_lo);
+        for (long long blk = 0; blk < blocks; ++blk) {
+            const long long item = jacobi_item_of_block(d, blk);
+            if (sg.n[item] <= 0) continue;   // nothing staged (beyond the snowpack, rejected by prep, or below a cut)
+            nb += jac(item);
+        }
+        if (r + 1 < rounds)
+            for (long long p = 0; p < d.pair_count; ++p)
+                nb += emu::run_block(64, order, [&]() { prune_mark_pair(d, sg.st, p, done.data()); });
+    }
+    d.layer_lo = 0; d.layer_hi = d.Lmax; d.pair_done = nullptr;
+    for (long long p = 0; p < d.pair_count; ++p) nb += fin(p);
+    return nb;
+}
+
+// 64 < N <= 128: prep / finish on a global workspace
 template <int NT, bool ACTIVE>
 static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
-    long nb = 0;
-    const size_t items = (size_t)d.pair_count * d.Lmax * (ACTIVE ? d.m_max + 1 : 1);
-    const size_t mat = (size_t)plan.NMAX * plan.LD;
-    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
-    std::vector<int> stn(items, -1);
-    std::vector<double> stinv(items * 1024, NAN);
-    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
-    std::vector<double> lds(2 * plan.total), ws(plan.mat_doubles);   // generous: the three kernels lay out LDS differently
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        for (auto& x : ws) x = NAN;
-        if (ACTIVE) nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
-        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &st); });
-    }
+    const int nmodes = ACTIVE ? d.m_max + 1 : 1;
+    Staging sg((size_t)d.pair_count * d.Lmax * nmodes, plan);
+    std::vector<double> lds(2 * plan.total), ws((size_t)plan.mat_doubles + plan.scratch_doubles);   // generous: the kernels lay out LDS differently
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, ACTIVE ? 3 : 2);
     std::vector<double> jl(jp.total);
-    for (long long it = 0; it < (long long)items; ++it) {
-        if (stn[it] < 0) continue;
-        for (auto& x : jl) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, st, it, jl.data()); });
-    }
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        for (auto& x : ws) x = NAN;
-        if (ACTIVE) nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
-        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &st); });
-    }
-    return nb;
+    auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };
+    return run_rounds(d, order, nmodes, sg,
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
+        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
 // 128 < N <= 384: prep / finish with CH row chunks on the global workspace, the blocked Jacobi kernel in between
 template <int CH, bool ACTIVE>
 static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
-    long nb = 0;
-    const size_t items = (size_t)d.pair_count * d.Lmax * (ACTIVE ? d.m_max + 1 : 1);
-    const size_t mat = (size_t)plan.NMAX * plan.LD;
-    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
-    std::vector<int> stn(items, -1);
-    std::vector<double> stinv(items * 1024, NAN);
-    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    const int nmodes = ACTIVE ? d.m_max + 1 : 1;
+    Staging sg((size_t)d.pair_count * d.Lmax * nmodes, plan);
     std::vector<double> lds(2 * plan.total), ws((size_t)plan.mat_doubles + plan.scratch_doubles);
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        for (auto& x : ws) x = NAN;
-        if (ACTIVE) nb += emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 1>(d, p, lds.data(), ws.data(), &st); });
-        else nb += emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 1>(d, p, lds.data(), ws.data(), &st); });
-    }
     const JacobiBigPlan jp = make_jacobi_big_plan(d.n_max_stream, ACTIVE ? 3 : 2);
     std::vector<double> jl(jp.total);
-    for (long long it = 0; it < (long long)items; ++it) {
-        if (stn[it] < 0) continue;
-        for (auto& x : jl) x = NAN;
-        nb += emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, st, it, jl.data()); });
-    }
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        for (auto& x : ws) x = NAN;
-        if (ACTIVE) nb += emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 2>(d, p, lds.data(), ws.data(), &st); });
-        else nb += emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 2>(d, p, lds.data(), ws.data(), &st); });
-    }
-    return nb;
+    auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };
+    return run_rounds(d, order, nmodes, sg,
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
+        [&](long long it) { for (auto& x : jl) x = NAN;
+                            return emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
 // active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
 template <int NT>
 static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
-    long nb = 0;
-    const size_t items = (size_t)d.pair_count * (d.m_max + 1) * d.Lmax;
-    const size_t mat = (size_t)plan.NMAX * plan.LD;
-    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
-    std::vector<int> stn(items, -1);
-    std::vector<double> stinv(items * 1024, NAN);
-    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    const int nmodes = d.m_max + 1;
+    Staging sg((size_t)d.pair_count * d.Lmax * nmodes, plan);
     std::vector<double> lds(lds_doubles);
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 1>(d, p, lds.data(), nullptr, &st); });
-    }
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 3);
     std::vector<double> jl(jp.total);
-    for (long long it = 0; it < (long long)items; ++it) {
-        if (stn[it] < 0) continue;   // unused slot (layer beyond the snowpack, or a pair the prep kernel rejected)
-        for (auto& x : jl) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, st, it, jl.data()); });
-    }
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 3>(d, p, lds.data(), nullptr, &st); });
-    }
-    return nb;
+    return run_rounds(d, order, nmodes, sg,
+        [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
+        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 3>(d, p, lds.data(), nullptr, &sg.st); }); });
 }
 
-// three-kernel pipeline under emulation: prep for every pair, Jacobi for every (pair, layer), finish for every pair
+// passive, N <= 64: the LDS-resident pipeline (two-slot or four-slot finish)
 template <int NT>
 static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
-    long nb = 0;
-    const size_t items = (size_t)d.pair_count * d.Lmax;
-    const size_t mat = (size_t)plan.NMAX * plan.LD;
-    std::vector<double> stL(items * mat, NAN), stB(items * mat, NAN), std_(items * plan.NMAX, NAN), sts(items * plan.NMAX, NAN);
-    std::vector<int> stn(items, -1);
-    std::vector<double> stinv(items * 1024, NAN);
-    DevStage st{stL.data(), stB.data(), std_.data(), sts.data(), stn.data(), (long long)mat, plan.NMAX, stinv.data()};
+    Staging sg((size_t)d.pair_count * d.Lmax, plan);
     std::vector<double> lds(lds_doubles);
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &st); });
-    }
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
-    for (long long it = 0; it < (long long)items; ++it) {
-        for (auto& x : jl) x = NAN;
-        nb += emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, st, it, jl.data()); });
-    }
-    for (long long p = 0; p < d.pair_count; ++p) {
-        for (auto& x : lds) x = NAN;
-        if (smrt_emu_pipeline == 2) nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &st); });
-        else nb += emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 3>(d, p, lds.data(), nullptr, &st); });
-    }
-    return nb;
+    return run_rounds(d, order, 1, sg,
+        [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
+        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long p) { for (auto& x : lds) x = NAN;
+                           return smrt_emu_pipeline == 2 ? emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &sg.st); })
+                                                         : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 3>(d, p, lds.data(), nullptr, &sg.st); }); });
 }
 
 
@@ -202,6 +180,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
+    d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
     d.jacobi_skip2 = active ? 1e-30 : SMRT_JACOBI_SKIP_COS2;
     d.jacobi_exit2 = active ? 1e-22 : SMRT_JACOBI_EXIT_COS2;
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;

@@ -567,3 +567,35 @@ def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
     for i in range(len(d["frequency"])):
         np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-11)
         np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-10, atol=1e-300)
+
+
+def test_prune_rounds_skip_the_layers_below_the_cut(ctx):
+    """Under prune_deep_snowpack the prep and Jacobi kernels run in rounds over successive layer ranges and leave alone
+    the pairs whose cut has been reached: same bits as processing every layer (SMRT_DORT_NO_PRUNE_ROUNDS=1), in a
+    fraction of the time when the cut is shallow (20 one-metre layers at 89 GHz: cut inside the first round)."""
+    import os
+
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(8)
+    S, L = 512, 20
+    thick = rng.uniform(0.8, 1.2, (S, L))
+    b = PackedBatch([L] * S, thick, rng.uniform(250, 400, (S, L)) / 916.7, rng.uniform(240, 265, (S, L)),
+                    rng.uniform(1.5e-4, 3e-4, (S, L)), None, [36.5e9, 89e9], np.deg2rad([55.0]), n_max_stream=32,
+                    prune_deep_snowpack=6.0)
+
+    def timed():
+        ctx.upload(b)
+        ctx.launch(); ctx.sync()
+        ctx.launch(); ctx.sync()
+        return ctx.download(), ctx.last_kernel_ms()
+
+    with_rounds, t_rounds = timed()
+    os.environ["SMRT_DORT_NO_PRUNE_ROUNDS"] = "1"
+    try:
+        all_layers, t_all = timed()
+    finally:
+        del os.environ["SMRT_DORT_NO_PRUNE_ROUNDS"]
+    assert (with_rounds.status == 0).all()
+    assert np.array_equal(with_rounds.values, all_layers.values)
+    assert t_rounds < 0.7 * t_all, (t_rounds, t_all)
