@@ -34,6 +34,7 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_EM_DMRT_QCA_SHORTRANGE 1
 #define SMRT_EM_DMRT_QCACP_SHORTRANGE 2
 #define SMRT_EM_NONSCATTERING 3
+#define SMRT_EM_HOST 4   /* any other emmodel, evaluated by the caller: see smrt_batch.host_layer / host_phase */
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1
@@ -104,6 +105,24 @@ typedef struct smrt_batch {
      * smrt/core/model.py:529-582): [S][Lmax] emmodel + 16 * microstructure of every layer (SMRT_EM_* + 16 * SMRT_MS_*).
      * NULL: every layer uses `emmodel` / `microstructure` above. */
     const int32_t* layer_kind;
+    /* Electromagnetic models evaluated by the caller -- any object with the reference's emmodel protocol
+     * (effective_permittivity, ks, ka, ft_even_phase; smrt/rtsolver/dort.py:189,231-247,714-762).  Layers whose kind is
+     * SMRT_EM_HOST take their scalars and the azimuth modes of their phase matrix from these arrays instead of
+     * evaluating an emmodel on the device; everything else (streams, interfaces, diagonalisation, boundary system) is
+     * the same device path.  Indexed by the pair p = f * S + s.  All NULL when no layer is of that kind.
+     *   host_layer   [F * S][Lmax][4]: ks, ka (1/m, isotropic), Re and Im of the effective permittivity
+     *   host_streams [F * S][Lmax]: number of streams of the layer as the caller computed it (streams.py:136-223);
+     *                the device checks it against its own count (SMRT_ERR_INPUT on a mismatch)
+     *   host_phase   [F * S][Lmax][modes][2][NE * NE], modes = 1 (passive) or m_max + 1 (active), NE = n_max_stream *
+     *                polarisations (2 passive, 3 active): ft_even_phase(mu, +mu') and ft_even_phase(mu, -mu') of
+     *                mode m on the layer's own stream cosines, compressed like smrt/core/lib.py:336-347 (row =
+     *                stream_s * polarisations + pol_s, column = stream_i * polarisations + pol_i), row-major with
+     *                leading dimension NE; only the rows / columns below n_l * polarisations are read.  The matrix
+     *                must obey reciprocity (symmetric P(mu,+mu'), P(mu,-mu') up to the sign / factor 2 conventions
+     *                of the U polarisation, emmodel/common.py:40-50): the device reads its lower triangle. */
+    const double* host_layer;
+    const int32_t* host_streams;
+    const double* host_phase;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

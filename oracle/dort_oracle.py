@@ -253,6 +253,36 @@ class NonScatteringLayer(LayerEM):
         return np.zeros((npol, npol, m_max + 1, len(mu_s), len(mu_i)))
 
 
+class RayleighLayer(LayerEM):
+    """smrt/emmodel/rayleigh.py:22-51: sparse medium of small independent spheres (background permittivity as the
+    effective one), Rayleigh phase matrix."""
+
+    kind = "rayleigh"
+
+    def __init__(self, frequency, frac_volume, temperature, microstructure, radius, **mp):
+        e0, eps = 1.0, ice_permittivity_maetzler06(frequency, temperature)
+        k0 = 2.0 * np.pi * frequency / C_SPEED
+        self.eps_eff = complex(e0)
+        self.ks = float(frac_volume * 2 * abs((eps - e0) / (eps + 2 * e0)) ** 2 * radius**3 * abs(e0) ** 2 * k0**4)
+        self.ka = float(frac_volume * k0 * eps.imag * abs(3 * e0 / (eps + 2 * e0)) ** 2
+                        + (1 - frac_volume) * 2 * k0 * np.sqrt(complex(e0)).imag)
+
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol):
+        return rayleigh_ft_even_phase(self.ks, mu_s, mu_i, m_max, npol)
+
+
+class PrescribedLayer(LayerEM):
+    """smrt/emmodel/prescribed_kskaeps.py: ks, ka and the effective permittivity are layer attributes."""
+
+    kind = "prescribed_kskaeps"
+
+    def __init__(self, frequency, frac_volume, temperature, microstructure, ks, ka, eps_re, eps_im, **mp):
+        self.ks, self.ka, self.eps_eff = float(ks), float(ka), complex(eps_re, eps_im)
+
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol):
+        return rayleigh_ft_even_phase(self.ks, mu_s, mu_i, m_max, npol)
+
+
 def romberg65(y, dx):
     """Romberg extrapolation of the trapezoid rule on 2**6+1 equally spaced samples (scipy.integrate.romb, called at
     smrt/emmodel/iba.py:179)."""
@@ -360,17 +390,20 @@ def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
     classes = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
-               "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer}
+               "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer,
+               "rayleigh": RayleighLayer, "prescribed_kskaeps": PrescribedLayer}
     L = len(sp["thickness"])
     fv = sp["frac_volume"] if "frac_volume" in sp else np.asarray(sp["density"]) / DENSITY_OF_ICE
     # heterogeneous snowpacks (model.py:529-582: a list of emmodels, one per layer; per-layer microstructure models in
     # make_snowpack): `emmodel` and sp["microstructure"] may be sequences of L names
     ems = [str(e) for e in np.broadcast_to(np.atleast_1d(emmodel), (L,))]
     micros = [str(m) for m in np.broadcast_to(np.atleast_1d(sp["microstructure"]), (L,))]
-    args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness")}
+    args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
+            "independent_sphere": ("radius",), "homogeneous": ()}
+    extra = {"prescribed_kskaeps": ("ks", "ka", "eps_re", "eps_im")}   # layer attributes that emmodel reads
     return [
         classes[ems[l]](frequency, float(fv[l]), float(sp["temperature"][l]), micros[l],
-                        **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in args[micros[l]]})
+                        **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in args[micros[l]] + extra.get(ems[l], ())})
         for l in range(L)
     ]
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMRT_DORT_LIB: an alternative build of the same library (profiling / ablation builds made by tools/), never a fallback
 LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
-EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3}
+EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4}
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
 SUBSTRATE_CODES = {"flat": 1, "reflector": 2}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}
@@ -65,6 +65,9 @@ class SmrtBatch(C.Structure):
         ("atm_transmittance", C.POINTER(C.c_double)),
         ("prune_optical_depth", C.c_double),
         ("layer_kind", C.POINTER(C.c_int32)),
+        ("host_layer", C.POINTER(C.c_double)),
+        ("host_streams", C.POINTER(C.c_int32)),
+        ("host_phase", C.POINTER(C.c_double)),
     ]
 
 
@@ -79,13 +82,15 @@ class PackedBatch:
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
-                 prune_deep_snowpack=None, layer_kind=None):
+                 prune_deep_snowpack=None, layer_kind=None, host_emmodel=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
         prune_deep_snowpack: None / False, True (= 6, smrt/rtsolver/dort.py:176-177) or the optical depth itself.
         layer_kind: None, or [S][Lmax] integer codes EM_CODES[emmodel] + 16 * MS_CODES[microstructure] for snowpacks
-        that mix emmodels / microstructure models (smrt/core/model.py:529-582)."""
+        that mix emmodels / microstructure models (smrt/core/model.py:529-582).
+        host_emmodel: None, or (host_layer[F*S][Lmax][4], host_streams[F*S][Lmax], host_phase[F*S][Lmax][modes][2][NE][NE])
+        for the layers of kind "host" (emmodels evaluated by the caller, include/smrt_dort.h)."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
         S = len(self.n_layers)
         two_d = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(S, -1))  # noqa: E731
@@ -136,6 +141,16 @@ class PackedBatch:
         if layer_kind is not None:
             self.layer_kind = np.ascontiguousarray(np.asarray(layer_kind, dtype=np.int32).reshape(S, Lmax))
             s.layer_kind = self.layer_kind.ctypes.data_as(C.POINTER(C.c_int32))
+        if host_emmodel is not None:
+            hl, hs, hp = host_emmodel
+            FS = S * len(self.frequency)
+            modes = 1 if mode == "P" else int(m_max) + 1
+            ne = int(n_max_stream) * (2 if mode == "P" else 3)
+            self.host_layer = np.ascontiguousarray(np.asarray(hl, np.float64).reshape(FS, Lmax, 4))
+            self.host_streams = np.ascontiguousarray(np.asarray(hs, np.int32).reshape(FS, Lmax))
+            self.host_phase = np.ascontiguousarray(np.asarray(hp, np.float64).reshape(FS, Lmax, modes, 2, ne, ne))
+            s.host_layer, s.host_phase = _dptr(self.host_layer), _dptr(self.host_phase)
+            s.host_streams = self.host_streams.ctypes.data_as(C.POINTER(C.c_int32))
         self.struct = s
 
     @property

@@ -20,10 +20,15 @@ class Microstructure:
     def device_params(self):
         if self.name == "exponential":
             return float(self.corr_length), 0.0
+        if self.name == "homogeneous":
+            return 0.0, 0.0
         return float(self.radius), float(getattr(self, "stickiness", np.inf))
 
 
-MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness")}
+MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
+                       # these two have no device emmodel: they serve the emmodels evaluated on the host
+                       "independent_sphere": ("radius",), "homogeneous": ()}
+DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres")
 
 
 class Layer:
@@ -60,7 +65,21 @@ class Layer:
         self.microstructure = Microstructure(name, frac_volume, **mparams)
         for k, v in mparams.items():
             setattr(self, k, v)
+        for k, v in params.items():   # anything else rides along as a layer attribute (e.g. ks / ka / effective_permittivity
+            if k not in mparams:      # for the prescribed_kskaeps emmodel)
+                setattr(self, k, v)
 
     @property
     def frac_volume(self):
         return self.microstructure.frac_volume
+
+    def permittivity(self, i, frequency):
+        """Permittivity of the background (i = 0: air) or of the scatterers (i = 1: pure ice), smrt/core/layer.py:120-156
+        for dry snow.  The device emmodels compute the same on the GPU; this is for emmodels evaluated on the host."""
+        if i == 0:
+            return 1.0
+        if i == 1:
+            from ..permittivity.ice import ice_permittivity_maetzler06
+
+            return ice_permittivity_maetzler06(frequency, self.temperature)
+        raise SMRTError("a snow layer has two constituents (0: air, 1: ice)")

@@ -100,7 +100,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     }
     {
         const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
-                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr);
+                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr, gp);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
     const int n_air = s.ints[5];
@@ -306,7 +306,16 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double sis = sqrt(1.0 - mi * mi), sjs = sqrt(1.0 - mj * mj);
                     double pp[3][3], pm[3][3];
                     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pp[a][c] = 0.0; pm[a][c] = 0.0; }
-                    if (em_l != EM_IBA) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
+                    if (em_l == EM_HOST) {  // mode m of the caller's ft_even_phase(mu, +-mu'), compressed (smrt_dort.h)
+                        const int NE = b.host_ne;
+                        const double* hp = b.host_phase + ((gp * b.Lmax + l) * (long long)b.host_modes + m) * 2 * NE * NE;
+                        const double* hm = hp + (long long)NE * NE;
+                        for (int a = 0; a < P; ++a)
+                            for (int c = 0; c < P; ++c) {
+                                pp[a][c] = hp[(3 * i + a) * NE + 3 * j + c];   // the caller compresses every mode
+                                pm[a][c] = hm[(3 * i + a) * NE + 3 * j + c];   // with three polarisations
+                            }
+                    } else if (em_l != EM_IBA) {  // rayleigh.py:70-127 (with the sign convention of :121-124)
                         for (int sgn = 0; sgn < 2; ++sgn) {
                             const double x = sgn ? -mj : mj;
                             double (&q)[3][3] = sgn ? pm : pp;

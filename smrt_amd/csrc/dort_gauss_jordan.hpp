@@ -177,6 +177,14 @@ SMRT_DEV_NOINLINE double gj_inv16_block(const double* A, int N, int LD, int k, i
         const double v = at<TR>(const_cast<double*>(A), k0 + rc, k0 + cc, LD);
         x[s] = (r < nbk && c < nbk) ? v : ((r == c) ? 1.0 : 0.0);
     }
+#ifdef SMRT_ABLATE_INV16
+    {   // timing experiment only: "inverse" = reciprocal diagonal
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pinv[16 * (4 * g + s) + r] = (r == 4 * g + s) ? 1.0 / x[s] : 0.0;
+        wave_sync_lds();
+        return 1.0;
+    }
+#endif
     // in-place Gauss-Jordan inversion with row pivoting inside the block: row piv[j] of the result is row j of the
     // inverse of the row-permuted block, P^-1[kk][piv[j]] = Z[piv[kk]][j]
     bool used = false;
@@ -343,6 +351,14 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
 #define SMRT_GSUB(k) do {} while (0)
 #endif
     auto panel = [&](int kb) -> bool {   // one wavefront; the flag was published by the previous block's barrier
+#ifdef SMRT_ABLATE_PANEL
+        {   // timing experiment only: identity pivots, no arithmetic
+            const int k0 = 16 * kb;
+            if (lane < 16 && k0 + lane < N) { perm[k0 + lane] = k0 + lane; rowblk[k0 + lane] = kb; }
+            wave_sync_lds();
+            return true;
+        }
+#endif
 #ifdef SMRT_GJ_FAST_PANEL
         if (*fast) {
             int took;
@@ -462,6 +478,9 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             int idx = 0;
             for (int g = (has_next ? gnext + 1 : RT); g < 2 * RT; ++g, ++idx) {
                 if (idx % nworkers != widx) continue;
+#ifdef SMRT_ABLATE_GJ_WORKERS
+                continue;   // timing experiment only: wrong results
+#endif
                 double tmp[4];
                 do_tile(g, tmp);
                 wave_sync_lds();

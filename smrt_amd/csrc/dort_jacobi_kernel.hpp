@@ -266,18 +266,17 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 template <int NT>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     constexpr int G = SMRT_JACOBI_GS;   // lanes per column pair
-    const int nitem = stg.n[item];      // <= 0: nothing to do (the impl returns at once)
-    const int rpl = (nitem + G - 1) / G;
-    if (rpl > 14) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
-    else if (rpl > 12) dort_jacobi_item_impl<NT, 112 / G>(b, stg, item, lds);
-    else if (rpl > 10) dort_jacobi_item_impl<NT, 96 / G>(b, stg, item, lds);
-    else if (rpl > 8) dort_jacobi_item_impl<NT, 80 / G>(b, stg, item, lds);
-    else if (rpl > 7) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
-    else if (rpl > 6) dort_jacobi_item_impl<NT, 56 / G>(b, stg, item, lds);
-    else if (rpl > 5) dort_jacobi_item_impl<NT, 48 / G>(b, stg, item, lds);
-    else if (rpl > 4) dort_jacobi_item_impl<NT, 40 / G>(b, stg, item, lds);
-    else if (rpl > 2) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
-    else if (rpl > 1) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
+    const int rows = stg.n[item];       // <= 0: nothing to do (the impl returns at once)
+    if (rows > 112) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
+    else if (rows > 96) dort_jacobi_item_impl<NT, 112 / G>(b, stg, item, lds);
+    else if (rows > 80) dort_jacobi_item_impl<NT, 96 / G>(b, stg, item, lds);
+    else if (rows > 64) dort_jacobi_item_impl<NT, 80 / G>(b, stg, item, lds);
+    else if (rows > 56) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
+    else if (rows > 48) dort_jacobi_item_impl<NT, 56 / G>(b, stg, item, lds);
+    else if (rows > 40) dort_jacobi_item_impl<NT, 48 / G>(b, stg, item, lds);
+    else if (rows > 32) dort_jacobi_item_impl<NT, 40 / G>(b, stg, item, lds);
+    else if (rows > 16) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
+    else if (rows > 8) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
     else dort_jacobi_item_impl<NT, 8 / G>(b, stg, item, lds);
 }
 

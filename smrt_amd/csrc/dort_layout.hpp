@@ -27,6 +27,11 @@ struct DevBatch {
     const double* frequency;
     const double* theta;
     const int* layer_kind;  // [S][Lmax] emmodel + 16 * microstructure of every layer, or null: b.emmodel / b.micro everywhere
+    // emmodels evaluated by the caller (layers of kind EM_HOST), indexed by the global pair f * S + s (smrt_dort.h)
+    const double* host_layer;    // [F * S][Lmax][4] ks, ka, Re eps, Im eps
+    const int* host_streams;     // [F * S][Lmax]
+    const double* host_phase;    // [F * S][Lmax][host_modes][2][host_ne * host_ne]
+    int host_modes, host_ne;
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]
@@ -80,7 +85,7 @@ constexpr double kBoltzmann = 1.380649e-23;
 constexpr double kFreezing = 273.15;
 constexpr double kPi = 3.14159265358979323846;
 
-enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3 };  // every emmodel but IBA has a Rayleigh phase matrix
+enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3, EM_HOST = 4 };  // 1-3 have a Rayleigh phase matrix; 4: host arrays
 enum { MS_EXP = 0, MS_SHS = 1 };
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5 };
 enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2 };

@@ -109,12 +109,21 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 template <int NT>
 SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L, const double* thickness,
                         const double* fracvol, const double* temperature, const double* mp1, const double* mp2,
-                        const int* kinds = nullptr /* this snowpack's row of b.layer_kind, or null */) {
+                        const int* kinds = nullptr /* this snowpack's row of b.layer_kind, or null */,
+                        long long gp = 0 /* global pair f * S + s: row of the host-evaluated emmodel arrays */) {
     const int t = tid();
     const int nmax = b.n_max_stream;
     for (int l = t; l < L; l += NT) {
         cplx ee; double ks, ka, pa, pb; int bad = 0;
         const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
+        if ((kind & 15) == EM_HOST) {   // evaluated by the caller (smrt_batch.host_layer)
+            if (b.host_layer) {
+                const double* h = b.host_layer + (gp * b.Lmax + l) * 4;
+                ks = h[0]; ka = h[1]; ee = cmk(h[2], h[3]);
+                if (!(ka >= 0.0) || !(ee.re > 0.0)) bad = 1;
+            } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
+            pa = pb = 0.0;
+        } else
         layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)kind;
@@ -143,6 +152,9 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
             for (int j = 0; j < nmax; ++j) n += (ri * s.gsin[j] < 1.0) ? 1 : 0;
             s.ri[l] = ri; s.nl[l] = (double)n;
             if (n < 2) lds_max(&s.ints[0], ST_INPUT);
+            // the phase matrix of a host-evaluated layer was sampled on the caller's streams: same count or nothing
+            if (((int)s.pc[l] & 15) == EM_HOST && !(b.host_streams && b.host_phase && b.host_streams[gp * b.Lmax + l] == n))
+                lds_max(&s.ints[0], ST_INPUT);
         }
         if (t == NT - 1) {
             const double ria = csqrt_(estar).re;
@@ -243,7 +255,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     }
     {
         const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
-                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr);
+                                      b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr, gp);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
     }
     const int n_air = s.ints[5];
@@ -369,7 +381,16 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 const int j = idx - i * (i + 1) / 2;
                 const double mi = s.mu[i], mj = s.mu[j];
                 double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
-                if (em_l != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
+                if (em_l == EM_HOST) {  // mode 0 of the caller's ft_even_phase(mu, +-mu'), compressed (smrt_dort.h)
+                    const int NE = b.host_ne;
+                    const double* hp = b.host_phase + ((gp * b.Lmax + l) * (long long)b.host_modes) * 2 * NE * NE;
+                    const double* hm = hp + (long long)NE * NE;
+                    const int r0 = 2 * i, c0 = 2 * j;
+                    pvv_p = hp[r0 * NE + c0]; pvh_p = hp[r0 * NE + c0 + 1];
+                    phv_p = hp[(r0 + 1) * NE + c0]; phh_p = hp[(r0 + 1) * NE + c0 + 1];
+                    pvv_m = hm[r0 * NE + c0]; pvh_m = hm[r0 * NE + c0 + 1];
+                    phv_m = hm[(r0 + 1) * NE + c0]; phh_m = hm[(r0 + 1) * NE + c0 + 1];
+                } else if (em_l != EM_IBA) {  // closed form, rayleigh.py:70-76; even in mu'
                     const double a2 = mi * mi, b2 = mj * mj;
                     pvv_p = pa * (0.5 * a2 * b2 + (1.0 - a2) * (1.0 - b2));
                     pvh_p = pa * 0.5 * a2; phv_p = pa * 0.5 * b2; phh_p = pa * 0.5;

@@ -74,7 +74,8 @@ class DORT(object):
         if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
             snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
                                 atmosphere=atmosphere)
-        return self.solve_batch([(sensor, snowpack)], [[self._device_name(type(e)) for e in emmodels]])[0]
+        entries = [getattr(type(e), "device_name", None) or e for e in emmodels]   # instances: evaluated on the host
+        return self.solve_batch([(sensor, snowpack)], [entries])[0]
 
     # ---- batched entry points ------------------------------------------------------------------------------------
     @staticmethod
@@ -139,10 +140,12 @@ class DORT(object):
                 if key not in checked:
                     checked.add(key)
                     kind(plan.sensors[0], layer, **options)     # validates the options against the class
-            names = [cls._device_name(k) for k in kinds]
-            distinct.update(names)
+            # a class without a device implementation is evaluated on the host, layer by layer (_evaluate_on_host)
+            names = [getattr(k, "device_name", None) or (k, model.emmodel_options_of_layer(layer))
+                     for k, layer in zip(kinds, sp.layers)]
+            distinct.update(n if isinstance(n, str) else "host" for n in names)
             per_pack.append(names)
-        return distinct.pop() if len(distinct) == 1 else per_pack
+        return distinct.pop() if len(distinct) == 1 and "host" not in distinct else per_pack
 
     # ---- grouping, packing, launching ----------------------------------------------------------------------------
     def _check_sensor(self, sensor):
@@ -175,7 +178,8 @@ class DORT(object):
             u_freq, inv_f = np.unique(freq[sens_idx[sel]], return_inverse=True)
             sensor0, sp0 = sensors[sens_idx[sel[0]]], packs[u_packs[0]]
             names = emmodel_names if isinstance(emmodel_names, str) else [emmodel_names[k] for k in u_packs]
-            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, names)
+            sensor_of = {float(sensors[k].frequency): sensors[k] for k in sens_idx[sel]}
+            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, names, sensor_of)
             pairs = inv_f * len(u_packs) + inv_p
             full = len(pairs) == batch.n_pairs and np.array_equal(pairs, np.arange(batch.n_pairs))
             out = run_on_devices(batch, self.devices, self.block_threads, pairs=None if full else pairs)
@@ -186,7 +190,7 @@ class DORT(object):
             sol.add_group(sel, out, sp0)
         return sol
 
-    def _pack(self, sensor0, sps, freqs, emmodel_names):
+    def _pack(self, sensor0, sps, freqs, emmodel_names, sensor_of=None):
         """The device batch of one group: S distinct snowpacks x F distinct frequencies."""
         from .._native import EM_CODES, MS_CODES
 
@@ -196,16 +200,26 @@ class DORT(object):
         # emmodel + 16 * microstructure per layer; handed to the device only when the batch really mixes them
         micro = [sp.microstructure_models for sp in sps]
         uniform_micro = len(set().union(*micro)) == 1
-        layer_kind = None
-        if not (isinstance(emmodel_names, str) and uniform_micro):
+        layer_kind = host = None
+        if not isinstance(emmodel_names, str):
+            for s, sp in enumerate(sps):
+                if len(emmodel_names[s]) != nl[s]:
+                    raise SMRTError("one emmodel per layer is needed")
+        if not isinstance(emmodel_names, str) and any(not isinstance(e, str) for row in emmodel_names for e in row):
+            # at least one emmodel without a device implementation: the whole group is evaluated through the emmodel
+            # protocol on the host (the device classes speak it too) and handed to the device as numbers
+            host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
+            layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
+        elif not (isinstance(emmodel_names, str) and uniform_micro):
             layer_kind = np.zeros((S, Lmax), np.int32)
             for s, sp in enumerate(sps):
                 em = [emmodel_names] * nl[s] if isinstance(emmodel_names, str) else emmodel_names[s]
-                if len(em) != nl[s]:
-                    raise SMRTError("one emmodel per layer is needed")
-                layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * MS_CODES[lay.microstructure_model]
-                                         for e, lay in zip(em, sp.layers)]
-        device_name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
+                layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * self._ms_code(lay) for e, lay in zip(em, sp.layers)]
+        if host is None:
+            for sp in sps:
+                for lay in sp.layers:
+                    self._ms_code(lay)
+        device_name = "host" if host is not None else (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
             cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
         else:
@@ -226,12 +240,102 @@ class DORT(object):
             atmosphere = (a[:, 0], a[:, 1], a[:, 2])
         return PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs,
                            sensor0.theta_inc if mode == "A" else sensor0.theta, emmodel=device_name,
-                           microstructure=sps[0].layers[0].microstructure_model, mode=mode,
+                           microstructure=sps[0].layers[0].microstructure_model if host is None else "exponential",
+                           mode=mode,
                            n_max_stream=self.n_max_stream, m_max=self.m_max,
                            phase_normalization=self.phase_normalization,
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
-                           layer_kind=layer_kind)
+                           layer_kind=layer_kind, host_emmodel=host)
+
+    @staticmethod
+    def _ms_code(layer):
+        from .._native import MS_CODES
+
+        code = MS_CODES.get(layer.microstructure_model)
+        if code is None:
+            raise SMRTError(f"the microstructure model '{layer.microstructure_model}' has no device implementation: it "
+                            "can only be used with an emmodel evaluated on the host (e.g. rayleigh, prescribed_kskaeps)")
+        return code
+
+    # ---- emmodels evaluated on the host (include/smrt_dort.h: SMRT_EM_HOST) ----------------------------------------
+    HOST_PHASE_BYTES_MAX = 8e9
+
+    def _evaluate_on_host(self, sensor0, sps, freqs, entries, nl, Lmax, sensor_of):
+        """What smrt/rtsolver/dort.py:189,231-247,714-762 asks of the emmodels -- effective permittivity, ks, ka and the
+        azimuth modes of the phase matrix on the layer's own streams -- for every (frequency, snowpack, layer) of the
+        group, as the three arrays of PackedBatch(host_emmodel=...).  An entry is a device emmodel name, an (emmodel
+        class, options) pair or a ready instance (rtsolver protocol).  The streams are the ones the device will find
+        (Gauss-Legendre nodes in the most refringent layer + Snell, streams.py:136-223); it checks the counts."""
+        import copy
+
+        from .._native import gauss_legendre_positive
+        from ..core.plugin import import_class
+
+        mode = sensor0.mode
+        P = 2 if mode == "P" else 3
+        modes = 1 if mode == "P" else self.m_max + 1
+        m_arg = modes - 1
+        F, S, NE = len(freqs), len(sps), self.n_max_stream * P
+        nbytes = 8.0 * F * S * Lmax * modes * 2 * NE * NE
+        if nbytes > self.HOST_PHASE_BYTES_MAX:
+            raise SMRTError(f"the phase matrices of this batch would take {nbytes / 1e9:.1f} GB on the host: run emmodels "
+                            "without a device implementation in smaller groups of snowpacks")
+        hl = np.zeros((F, S, Lmax, 4))
+        hl[..., 2] = 1.0
+        hs = np.zeros((F, S, Lmax), np.int32)
+        hp = np.zeros((F, S, Lmax, modes, 2, NE, NE))
+        gmu, _ = gauss_legendre_positive(self.n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+
+        def instance(entry, sensor, layer):
+            if isinstance(entry, str):
+                return import_class("emmodel", entry)(sensor, layer)
+            if isinstance(entry, tuple):
+                return entry[0](sensor, layer, **entry[1])
+            return entry
+
+        def scalar(value, what):
+            a = np.asarray(value, float).ravel()
+            if a.size == 0 or not np.allclose(a, a[0], rtol=1e-12, atol=0.0):
+                raise SMRTError(f"smrt_amd's DORT needs an isotropic {what} (one number per layer)")
+            return float(a[0])
+
+        for fi, f in enumerate(freqs):
+            sensor = sensor_of.get(float(f))
+            if sensor is None:
+                sensor = copy.copy(sensor0)
+                sensor.frequency = float(f)
+            for s, sp in enumerate(sps):
+                ems = [instance(entries[s][l], sensor, layer) for l, layer in enumerate(sp.layers)]
+                eps = np.array([complex(em.effective_permittivity()) for em in ems])
+                star = max(range(len(eps)), key=lambda l: (eps[l].real, eps[l].imag, -l))   # np.argmax on complex
+                for l, em in enumerate(ems):
+                    rs = np.sqrt(eps[star] / eps[l]).real * gsin
+                    mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+                    n = len(mu)
+                    ks = em.ks(mu, P) if callable(getattr(em, "ks", None)) else em.ks
+                    ka = em.ka(mu, P) if callable(getattr(em, "ka", None)) else em.ka
+                    hl[fi, s, l] = scalar(ks, "ks"), scalar(ka, "ka"), eps[l].real, eps[l].imag
+                    hs[fi, s, l] = n
+                    if hl[fi, s, l, 0] == 0.0 or n == 0:
+                        continue
+                    full = np.concatenate((mu, -mu))
+                    ft = np.asarray(em.ft_even_phase(full, full, m_arg, npol=P), float)
+                    if ft.shape != (P, P, modes, 2 * n, 2 * n):
+                        raise SMRTError(f"ft_even_phase returned the shape {ft.shape}, expected {(P, P, modes, 2 * n, 2 * n)}")
+                    # (ps, pi, m, mu_s, mu_i) -> m, (mu_s, ps), (mu_i, pi): the compressed order of core/lib.py:336-347
+                    C = np.transpose(ft, (2, 3, 0, 4, 1)).reshape(modes, 2 * n * P, 2 * n * P)
+                    nP = n * P
+                    vh = np.arange(nP)[np.arange(nP) % P < 2]
+                    for blk in (C[0][:nP, :nP], C[0][:nP, nP:]):   # the device reads the lower triangles only
+                        sub = blk[np.ix_(vh, vh)]
+                        if not np.allclose(sub, sub.T, rtol=1e-9, atol=1e-12 * np.abs(sub).max()):
+                            raise SMRTError("the phase matrix of this emmodel does not obey reciprocity: smrt_amd's DORT "
+                                            "(symmetric eigenproblem) cannot solve it")
+                    hp[fi, s, l, :, 0, :nP, :nP] = C[:, :nP, :nP]
+                    hp[fi, s, l, :, 1, :nP, :nP] = C[:, :nP, nP:]
+        return hl, hs, hp
 
 
 class _Solution:

@@ -24,7 +24,7 @@ def snowpack_dict(d):
     """The plain-array snowpack description stored in a fixture."""
     sp = {k: d[k] for k in ("thickness", "density", "temperature", "frac_volume")}
     sp["microstructure"] = str(d["microstructure"]) if np.ndim(d["microstructure"]) == 0 else [str(m) for m in d["microstructure"]]
-    for k in ("corr_length", "radius", "stickiness"):
+    for k in ("corr_length", "radius", "stickiness", "ks", "ka", "eps_re", "eps_im"):
         if k in d:
             sp[k] = d[k]
     return sp
@@ -123,6 +123,41 @@ PRUNE_FIXTURES = ["iba_L8_n12_prune", "iba_L6_n16_prune_substrate", "dmrt_L7_n12
 PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
 # heterogeneous snowpacks: a list of emmodels (one per layer) over layers mixing the two microstructure models
 MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
+# emmodels without a device implementation (evaluated on the host, SMRT_EM_HOST): the reference's rayleigh on
+# independent spheres, passive and active, and prescribed_kskaeps on a homogeneous microstructure
+HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
+
+
+def model_snowpack_from_fixture(d):
+    """smrt_amd's own Snowpack object for a (uniform-microstructure) fixture, with the layer attributes the
+    prescribed_kskaeps emmodel reads when the fixture holds them."""
+    from smrt_amd import make_snowpack
+
+    ms = str(d["microstructure"])
+    kw = {k: d[k] for k in ("corr_length", "radius", "stickiness") if k in d}
+    sp = make_snowpack(d["thickness"], ms, density=d["density"], temperature=d["temperature"], **kw)
+    if "ks" in d:
+        for l, lay in enumerate(sp.layers):
+            lay.ks, lay.ka = float(d["ks"][l]), float(d["ka"][l])
+            lay.effective_permittivity = complex(d["eps_re"][l], d["eps_im"][l])
+    return sp
+
+
+def host_batch_from_fixture(d):
+    """The PackedBatch of a fixture whose emmodel has no device implementation: the product's own host evaluation
+    (smrt_amd.rtsolver.dort.DORT._evaluate_on_host via _pack) -- runs without a GPU, only the launch needs one."""
+    from smrt_amd.core.plugin import import_class
+    from smrt_amd.core.sensor import active, passive
+    from smrt_amd.rtsolver.dort import DORT
+
+    o = fixture_options(d)
+    solver = DORT(n_max_stream=o["n_max_stream"], m_max=o["m_max"])
+    sp = model_snowpack_from_fixture(d)
+    act = str(d["mode"]) == "A"
+    f0 = float(d["frequency"][0])
+    sensor0 = active(f0, d["theta_inc_deg"]) if act else passive(f0, d["theta_deg"])
+    cls = import_class("emmodel", str(d["emmodel"]))
+    return solver._pack(sensor0, [sp], np.asarray(d["frequency"], float), [[(cls, {})] * sp.nlayer])
 
 
 def fixture_emmodel(d):

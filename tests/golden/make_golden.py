@@ -47,7 +47,17 @@ def snowpack_arrays(sp):
             out[a] = np.array([get(lay, a) for lay in sp.layers])
         return out
     ms = sp.layers[0].microstructure
-    if hasattr(ms, "corr_length"):
+    if getattr(sp.layers[0], "ks", None) is not None:   # prescribed_kskaeps reads these layer attributes
+        out["ks"] = np.array([lay.ks for lay in sp.layers], float)
+        out["ka"] = np.array([lay.ka for lay in sp.layers], float)
+        out["eps_re"] = np.array([complex(lay.effective_permittivity).real for lay in sp.layers])
+        out["eps_im"] = np.array([complex(lay.effective_permittivity).imag for lay in sp.layers])
+    if type(ms).__name__ == "IndependentSphere":
+        out["microstructure"] = "independent_sphere"
+        out["radius"] = np.array([lay.microstructure.radius for lay in sp.layers], float)
+    elif type(ms).__name__ == "Homogeneous":
+        out["microstructure"] = "homogeneous"
+    elif hasattr(ms, "corr_length"):
         out["microstructure"] = "exponential"
         out["corr_length"] = np.array([lay.microstructure.corr_length for lay in sp.layers], float)
     elif hasattr(ms, "stickiness"):
@@ -428,6 +438,24 @@ def main():
             rng = np.random.default_rng(40 + i)
             spx = random_snowpack(rng, 30, "exponential", 0.02, 0.10, 1000.0)
             save(name, run_new("iba", sensor_list.sentinel1(), spx, rtsolver_options=dict(n_max_stream=128, m_max=2)))
+
+    # (iv-c) emmodels WITHOUT a device implementation (evaluated on the host and handed over as numbers): the
+    # reference's rayleigh (independent spheres) and prescribed_kskaeps
+    if wanted("rayleigh_L3_n16_passive") or wanted("rayleigh_L3_n12_active"):
+        spr = make_snowpack([0.2, 0.3, 100.0], "independent_sphere", density=[120.0, 180.0, 250.0],
+                            temperature=[255.0, 260.0, 266.0], radius=[2.0e-4, 3.0e-4, 2.5e-4])
+        if wanted("rayleigh_L3_n16_passive"):
+            save("rayleigh_L3_n16_passive", run_new("rayleigh", sensor_list.passive([18.7e9, 36.5e9], [40.0, 55.0]), spr,
+                                                    rtsolver_options=dict(n_max_stream=16)))
+        if wanted("rayleigh_L3_n12_active"):
+            save("rayleigh_L3_n12_active", run_new("rayleigh", sensor_list.active(13.4e9, [30.0, 45.0]), spr,
+                                                   rtsolver_options=dict(n_max_stream=12, m_max=2)))
+    if wanted("prescribed_L3_n16_passive"):
+        spp = make_snowpack([0.15, 0.4, 50.0], "homogeneous", density=[200.0, 300.0, 350.0], temperature=[250.0, 258.0, 265.0])
+        for lay, ks, ka, eps in zip(spp.layers, (0.4, 1.1, 0.7), (0.05, 0.12, 0.2), (1.35 + 2e-4j, 1.6 + 5e-4j, 1.75 + 8e-4j)):
+            lay.ks, lay.ka, lay.effective_permittivity = ks, ka, eps
+        save("prescribed_L3_n16_passive", run_new("prescribed_kskaeps", sensor_list.passive(36.5e9, [30.0, 55.0]), spp,
+                                                  rtsolver_options=dict(n_max_stream=16)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -372,3 +372,62 @@ def test_emmodel_ft_even_phase_on_the_device():
         assert np.isclose(em_p.ks(mu)[0, 0], layer.ks, rtol=1e-11)
     with pytest.raises(SMRTError):
         em_a.ft_even_phase(mu, np.array([1.0, 0.5]), 2)     # mu_i = 1 with three polarisations (common.py:389-390)
+
+
+def test_emmodels_without_a_device_implementation_through_the_model():
+    """make_model("rayleigh" | "prescribed_kskaeps", "dort").run(...): emmodels evaluated on the host (smrt_amd's
+    rtsolver asks them for effective_permittivity / ks / ka / ft_even_phase like smrt/rtsolver/dort.py does) feeding the
+    device solver, against the reference; then the same route with a user-defined emmodel class wrapped around IBA,
+    which must agree with the device's own IBA."""
+    from conftest import HOST_EMMODEL_FIXTURES, model_snowpack_from_fixture
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.emmodel.iba import IBA
+
+    for name in HOST_EMMODEL_FIXTURES:
+        d = load_golden(name)
+        sp = model_snowpack_from_fixture(d)
+        act = str(d["mode"]) == "A"
+        opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+        if act:
+            opts["m_max"] = int(d["opt_m_max"])
+            sensor = sensor_list.active(list(d["frequency"]), list(d["theta_inc_deg"]))
+        else:
+            sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+        res = make_model(str(d["emmodel"]), "dort", rtsolver_options=opts).run(sensor, sp)
+        for i, f in enumerate(d["frequency"]):
+            sel = dict(frequency=f) if len(d["frequency"]) > 1 else {}   # a single frequency is not a dimension
+            if act:
+                got = np.array([res.sigmaVV(**sel), res.sigmaHH(**sel)])
+                ref = 4 * np.pi * np.cos(np.deg2rad(d["theta_inc_deg"])) * np.array([d["result"][i, 0, 0], d["result"][i, 1, 1]])
+                np.testing.assert_allclose(np.squeeze(got), ref, rtol=1e-8)
+            else:
+                np.testing.assert_allclose(np.ravel(res.TbV(**sel)), d["result"][i, 0], atol=1e-6)
+                np.testing.assert_allclose(np.ravel(res.TbH(**sel)), d["result"][i, 1], atol=1e-6)
+        L = len(d["thickness"])
+        np.testing.assert_allclose(np.ravel(res.other_data["ks"].values)[-L:], d["f%d_ks" % (len(d["frequency"]) - 1)], rtol=1e-12)
+
+    class WrappedIBA:   # no device_name: goes through the host route
+        def __init__(self, sensor, layer):
+            self.inner = IBA(sensor, layer)
+            self.ka = self.inner.ka
+
+        def effective_permittivity(self):
+            return self.inner.effective_permittivity()
+
+        def ks(self, mu, npol=2):
+            return self.inner.ks(mu, npol)
+
+        def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):
+            return self.inner.ft_even_phase(mu_s, mu_i, m_max, npol=npol)
+
+    sp = make_snowpack([0.2, 0.5, 100], "exponential", density=[220, 300, 380], temperature=[255, 260, 268],
+                       corr_length=[8e-5, 2e-4, 1.5e-4])
+    sensor = sensor_list.passive([18.7e9, 36.5e9], 55)
+    opts = dict(n_max_stream=16)
+    native = make_model("iba", "dort", rtsolver_options=opts).run(sensor, sp)
+    wrapped = make_model(WrappedIBA, "dort", rtsolver_options=opts).run(sensor, sp)
+    np.testing.assert_allclose(wrapped.TbV(), native.TbV(), atol=1e-7)
+    np.testing.assert_allclose(wrapped.TbH(), native.TbH(), atol=1e-7)
+    # a layer list that mixes a device emmodel with a host one takes the host route as a whole
+    mixed = make_model([WrappedIBA, "iba", WrappedIBA], "dort", rtsolver_options=opts).run(sensor, sp)
+    np.testing.assert_allclose(mixed.TbV(), native.TbV(), atol=1e-7)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -567,6 +567,26 @@ def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
     for i in range(len(d["frequency"])):
         np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-11)
         np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", HOST_EMMODEL_FIXTURES)
+@pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
+def test_host_evaluated_emmodels_golden(ctx, name, threads, pipeline):
+    """SMRT_EM_HOST: emmodels without a device implementation (the reference's rayleigh on independent spheres,
+    prescribed_kskaeps on a homogeneous medium).  The emmodel protocol is evaluated on the host by the product
+    (DORT._evaluate_on_host); ks, ka, the permittivity and the azimuth modes of the phase matrix reach the kernels as
+    numbers.  Against the reference itself, every kernel shape, passive and active."""
+    d = load_golden(name)
+    out = run_variant(ctx, host_batch_from_fixture(d), threads, pipeline)
+    assert (out.status == 0).all(), out.status
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
+    else:
+        assert np.abs(out.values - d["result"]).max() < TB_TOL
+    L = len(d["thickness"])
+    for i in range(len(d["frequency"])):
+        np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-12)
+        np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-12)
 
 
 def test_prune_rounds_skip_the_layers_below_the_cut(ctx):

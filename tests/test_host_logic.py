@@ -131,12 +131,11 @@ def test_emmodel_configuration_is_honoured_on_the_batch_path():
     icy = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
                            Layer(10.0, "exponential", 900, 250.0, corr_length=5e-5, medium="ice")])
     assert DORT.emmodel_names(m4, m4.plan(sensor_list.amsre("37V"), [icy])) == [["iba", "nonscattering"]]
-    with pytest.raises(SMRTError, match="no device implementation"):
-        class Foreign:
-            def __init__(self, sensor, layer):
-                pass
-        mf = make_model(Foreign, "dort")
-        DORT.emmodel_names(mf, mf.plan(sensor_list.amsre("37V"), [sp]))
+    class Foreign:   # a class without a device implementation is evaluated on the host: (class, options) per layer
+        def __init__(self, sensor, layer):
+            pass
+    mf = make_model(Foreign, "dort")
+    assert DORT.emmodel_names(mf, mf.plan(sensor_list.amsre("37V"), [sp])) == [[(Foreign, {}), (Foreign, {})]]
     with pytest.raises(SMRTError):
         Snowpack(layers=sp.layers, interfaces=["rough", "rough"])   # interfaces are validated by the constructor too
 
@@ -420,3 +419,56 @@ def test_kernel_occupancy_as_designed():
         hits = [v for k, v in waves.items() if key in k]
         assert hits, key
         assert min(hits) >= minimum, (key, hits)
+
+
+def test_host_evaluated_emmodels_are_packed_for_the_device():
+    """DORT._evaluate_on_host (no GPU needed): shapes and contents of the SMRT_EM_HOST arrays, the compressed ordering of
+    the phase-matrix modes, and the refusals (anisotropic ks, a phase matrix without reciprocity)."""
+    from conftest import host_batch_from_fixture, load_golden
+    from oracle import dort_oracle as O
+    from smrt_amd import make_snowpack
+    from smrt_amd.core.error import SMRTError
+    from smrt_amd.core.sensor import passive
+    from smrt_amd.emmodel.rayleigh import Rayleigh
+    from smrt_amd.rtsolver.dort import DORT
+
+    d = load_golden("rayleigh_L3_n12_active")
+    b = host_batch_from_fixture(d)
+    L, n, m_max = 3, 12, 2
+    assert b.host_layer.shape == (1, L, 4) and b.host_streams.shape == (1, L) and b.host_phase.shape == (1, L, m_max + 1, 2, 3 * n, 3 * n)
+    assert int(b.struct.emmodel) == 4 and (b.layer_kind == 4).all()
+    np.testing.assert_allclose(b.host_layer[0, :, 0], d["f0_ks"], rtol=1e-12)
+    np.testing.assert_allclose(b.host_layer[0, :, 1], d["f0_ka"], rtol=1e-12)
+    # against the oracle's statement of the reference's table (rayleigh.py:52-127), layer 1, every mode
+    sp = dict(thickness=d["thickness"], density=d["density"], temperature=d["temperature"], frac_volume=d["frac_volume"],
+              microstructure="independent_sphere", radius=d["radius"])
+    ems = O.make_layers("rayleigh", float(d["frequency"][0]), sp)
+    st = O.compute_streams(n, np.array([e.eps_eff for e in ems]))
+    nl = int(b.host_streams[0, 1])
+    assert nl == st.n[1]
+    full = np.concatenate((st.mu[1], -st.mu[1]))
+    ft = ems[1].ft_even_phase(full, full, m_max, 3)
+    for m in range(m_max + 1):
+        Cm = O.compress(ft[:, :, m])
+        np.testing.assert_allclose(b.host_phase[0, 1, m, 0, :3 * nl, :3 * nl], Cm[:3 * nl, :3 * nl], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(b.host_phase[0, 1, m, 1, :3 * nl, :3 * nl], Cm[:3 * nl, 3 * nl:], rtol=1e-12, atol=1e-18)
+
+    sp2 = make_snowpack([0.3, 10], "independent_sphere", density=[150, 200], temperature=[260, 265], radius=[2e-4, 3e-4])
+    solver = DORT(n_max_stream=8)
+
+    class Anisotropic(Rayleigh):
+        def ks(self, mu, npol=2):
+            return np.outer(np.ones(npol), 1.0 + np.asarray(mu))
+
+    class NotReciprocal(Rayleigh):
+        def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):
+            P = super().ft_even_phase(mu_s, mu_i, m_max, npol)
+            P[0, 0, 0] *= 1.0 + np.asarray(mu_i)[None, :]
+            return P
+
+    for cls, msg in ((Anisotropic, "isotropic"), (NotReciprocal, "reciprocity")):
+        with pytest.raises(SMRTError, match=msg):
+            solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(cls, {})] * 2])
+    # a device emmodel on a microstructure it does not know is refused before anything is launched
+    with pytest.raises(SMRTError, match="no device implementation"):
+        solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), "iba")

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (MIXED_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -195,6 +195,33 @@ def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
         assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
     else:
         assert np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,nt,order", [(HOST_EMMODEL_FIXTURES[0], 64, 0), (HOST_EMMODEL_FIXTURES[1], 256, 1),
+                                           (HOST_EMMODEL_FIXTURES[2], 128, 2)])
+def test_emulated_kernel_with_host_evaluated_emmodels(emu, name, nt, order):
+    """Emmodels without a device implementation (the reference's rayleigh and prescribed_kskaeps): the product
+    evaluates the emmodel protocol on the host (DORT._evaluate_on_host), the device code takes ks / ka / permittivity /
+    phase-matrix modes as numbers (SMRT_EM_HOST) and must reproduce the reference."""
+    d = load_golden(name)
+    b = host_batch_from_fixture(d)
+    n = b.n_pairs
+    out = np.empty((n,) + b.out_shape())
+    st = np.empty(n, np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    nb = C.c_long()
+    rc = emu.smrt_emu_run(C.byref(b.struct), 0, n, nt, order, dp(out), st.ctypes.data_as(C.POINTER(C.c_int32)), None,
+                          None, None, C.byref(nb))
+    assert rc == 0 and (st == 0).all()
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out, d["result"], spread=reference_method_spread(d))
+    else:
+        assert np.abs(out - d["result"]).max() < 1e-6
+    # a stream count that differs from the device's own is refused, not silently used
+    b.host_streams[0, 0] += 1
+    rc = emu.smrt_emu_run(C.byref(b.struct), 0, 1, nt, order, dp(out), st.ctypes.data_as(C.POINTER(C.c_int32)), None,
+                          None, None, C.byref(nb))
+    assert rc == 0 and st[0] == 5
 
 
 @pytest.mark.parametrize("emmodel,micro,npol,m_max", [("iba", "exponential", 3, 2), ("iba", "sticky_hard_spheres", 3, 3),
