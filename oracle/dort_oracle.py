@@ -477,6 +477,61 @@ def flat_transmission(eps1, eps2, mu1, npol):
     return np.array(out)
 
 
+def coherent_slab(frequency, eps1, eps2, mu1, slab_eps, slab_thickness):
+    """A thin layer and its two flat interfaces collapsed into one (smrt/interface/coherent_flat.py:163-186):
+    field reflection / transmission coefficients of the slab seen from medium 1, and the cosine in medium 2."""
+    r01v, r01h, mu_1 = fresnel_rigorous(eps1, slab_eps, mu1)  # (core/fresnel.py:342: the rigorous field coefficients)
+    r1tv, r1th, mu_t = fresnel_rigorous(slab_eps, eps2, np.maximum(mu_1, 1e-4))
+    k1 = 2 * np.pi / C_SPEED * frequency * np.sqrt(complex(slab_eps))
+    phase = k1 * mu_1 * slab_thickness  # (coherent_flat.py:179-181: the "incoherent" reset has no effect)
+    e1, e2 = np.exp(1j * phase), np.exp(2j * phase)
+    Rv = (r01v + r1tv * e2) / (1 + r01v * r1tv * e2)
+    Rh = (r01h + r1th * e2) / (1 + r01h * r1th * e2)
+    Tv = (1 + r01v) * (1 + r1tv) * e1 / (1 + r01v * r1tv * e2)
+    Th = (1 + r01h) * (1 + r1th) * e1 / (1 + r01h * r1th * e2)
+    return Rv, Rh, Tv, Th, mu_t
+
+
+def coherent_reflection(frequency, eps1, eps2, mu1, npol, slab):
+    """coherent_flat.py:76-105."""
+    Rv, Rh, _, _, _ = coherent_slab(frequency, eps1, eps2, mu1, *slab)
+    out = [abs(Rv) ** 2, abs(Rh) ** 2]
+    if npol >= 3:
+        out.append((Rv * np.conj(Rh)).real)
+    return np.array(out)
+
+
+def coherent_transmission(frequency, eps1, eps2, mu1, npol, slab):
+    """coherent_flat.py:110-147."""
+    Rv, Rh, Tv, Th, mu_t = coherent_slab(frequency, eps1, eps2, mu1, *slab)
+    nt = np.sqrt(complex(eps2) / complex(eps1)).real
+    out = [abs(Tv) ** 2 * mu_t / mu1 / nt, abs(Th) ** 2 * mu_t / mu1 * nt]
+    if npol >= 3:
+        out.append(mu_t / mu1 * ((1 + Rv) * np.conj(1 + Rh)).real)
+    return np.array(out)
+
+
+def process_coherent_layers(frequency, eps, thickness):
+    """smrt/interface/coherent_flat.py:16-57: the layers thinner than 3/8 of a wavelength (k Re(n) d < 3 pi / 4) are
+    removed; each becomes the slab of the interface ON TOP of the layer that followed it.  Returns the indices of the
+    kept layers and, per kept layer, None or (slab permittivity, slab thickness)."""
+    k0 = 2 * np.pi * frequency / C_SPEED
+    coherent = np.array([k0 * np.sqrt(complex(e)).real * d < 3 * np.pi / 4 for e, d in zip(eps, thickness)])
+    if coherent[-1]:
+        raise OracleError("The last layer is coherent, this is not supported", status=6)
+    keep, slabs, pending = [], [], None
+    for l in range(len(eps)):
+        if coherent[l]:
+            if coherent[l - 1]:  # (index -1 = the last layer: never coherent here)
+                raise OracleError("Two successive layers are coherent, this is not yet supported", status=6)
+            pending = (complex(eps[l]), float(thickness[l]))
+        else:
+            keep.append(l)
+            slabs.append(pending)
+            pending = None
+    return keep, slabs
+
+
 def _flatten_pol(d, mode):
     """(npol, n) -> stream-major, polarisation-fastest vector; mode 0 keeps V,H only (core/lib.py:355-363)."""
     if mode == 0:
@@ -484,20 +539,28 @@ def _flatten_pol(d, mode):
     return d.T.reshape(-1)
 
 
-def interface_diagonals(eps, st, npol, substrate=None):
+def interface_diagonals(eps, st, npol, substrate=None, slabs=None, frequency=None):
     """Flat interfaces: smrt/rtsolver/rtsolver_utils.py:473-644 (coherent terms only).  substrate: None, or a dict
     {"kind": "flat", "eps": complex} (smrt/substrate/flat.py via core/interface.py:169-240: Fresnel reflection /
     transmission against the substrate permittivity) or {"kind": "reflector", "R": (R_V, R_H)}
     (smrt/substrate/reflector.py: prescribed specular reflection, emissivity 1 - R; two polarisations only)."""
     L = len(eps)
     itf = dict(Rtop=[], Ttop=[], Rbot=[], Tbot=[])
+    slabs = slabs or [None] * L  # slabs[l]: the coherent layer collapsed into the interface on top of layer l
+
+    def refl(e1, e2, mu, slab):
+        return flat_reflection(e1, e2, mu, npol) if slab is None else coherent_reflection(frequency, e1, e2, mu, npol, slab)
+
+    def trans(e1, e2, mu, slab):
+        return flat_transmission(e1, e2, mu, npol) if slab is None else coherent_transmission(frequency, e1, e2, mu, npol, slab)
+
     for l in range(L):
         e_up = eps[l - 1] if l > 0 else 1.0
-        itf["Rtop"].append(flat_reflection(eps[l], e_up, st.mu[l], npol))
-        itf["Ttop"].append(flat_transmission(eps[l], e_up, st.mu[l], npol))
+        itf["Rtop"].append(refl(eps[l], e_up, st.mu[l], slabs[l]))
+        itf["Ttop"].append(trans(eps[l], e_up, st.mu[l], slabs[l]))
         if l < L - 1:
-            itf["Rbot"].append(flat_reflection(eps[l], eps[l + 1], st.mu[l], npol))
-            itf["Tbot"].append(flat_transmission(eps[l], eps[l + 1], st.mu[l], npol))
+            itf["Rbot"].append(refl(eps[l], eps[l + 1], st.mu[l], slabs[l + 1]))
+            itf["Tbot"].append(trans(eps[l], eps[l + 1], st.mu[l], slabs[l + 1]))
         elif substrate is not None and substrate["kind"] == "flat":  # rtsolver_utils.py:544-547,579-584
             itf["Rbot"].append(flat_reflection(eps[l], substrate["eps"], st.mu[l], npol))
             itf["Tbot"].append(flat_transmission(eps[l], substrate["eps"], st.mu[l], npol))
@@ -510,8 +573,8 @@ def interface_diagonals(eps, st, npol, substrate=None):
         else:  # nothing below (rtsolver_utils.py:548-551,601-603)
             itf["Rbot"].append(np.zeros((npol, st.n[l])))
             itf["Tbot"].append(np.zeros((npol, st.n[l])))
-    itf["Rbot_air"] = flat_reflection(1.0, eps[0], st.outmu, npol)
-    itf["Tbot_air"] = flat_transmission(1.0, eps[0], st.outmu, npol)
+    itf["Rbot_air"] = refl(1.0, eps[0], st.outmu, slabs[0])
+    itf["Tbot_air"] = trans(1.0, eps[0], st.outmu, slabs[0])
     return itf
 
 
@@ -733,8 +796,10 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
 # ----------------------------------------------------------------------------------------------------------------
 def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None, phi=np.pi, n_max_stream=32,
           m_max=2, method="half_rank_eig", phase_normalization=True, rayleigh_jeans=False, details=None,
-          substrate=None, atmosphere=None, prune_deep_snowpack=None):
+          substrate=None, atmosphere=None, prune_deep_snowpack=None, process_coherent_layers_=False):
     """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces.
+
+    process_coherent_layers_: DORT option process_coherent_layers (dort.py:110,156,203; rtsolver_utils.py:349-365).
 
     substrate: None or a dict, see interface_diagonals, plus "temperature" (None: no emission).
     atmosphere: None or a dict {"tb_down", "tb_up", "transmittance"} (K, K, -) of a SimpleIsotropicAtmosphere at this
@@ -755,12 +820,19 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
         details["pruned_at"] = prune["pruned_at"] = []
     ems = make_layers(emmodel, frequency, sp)
     eps = np.array([e.eps_eff for e in ems])
-    st = compute_streams(n_max_stream, eps)
     thickness = np.asarray(sp["thickness"], float)
+    slabs = None
+    if process_coherent_layers_:
+        keep, slabs = process_coherent_layers(frequency, eps, thickness)
+        ems, eps, thickness = [ems[l] for l in keep], eps[keep], thickness[keep]
+        sp = dict(sp, temperature=np.asarray(sp["temperature"], float)[keep])
+        if details is not None:
+            details["kept_layers"] = keep
+    st = compute_streams(n_max_stream, eps)
     active = mode == "A"
     npol = 3 if active else 2
     mm = m_max if active else 0
-    itf = interface_diagonals(eps, st, npol, substrate)
+    itf = interface_diagonals(eps, st, npol, substrate, slabs, frequency)
     leig = [LayerEigen(ems[l], st.mu[l], st.weight[l], mm, npol, method, phase_normalization)
             for l in range(len(ems))]
     if details is not None:

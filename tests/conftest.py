@@ -38,6 +38,10 @@ def fixture_options(d):
     return o
 
 
+def fixture_coherent(d):
+    return bool(d["opt_process_coherent_layers"]) if "opt_process_coherent_layers" in d else False
+
+
 def fixture_substrate(d, i):
     """Substrate description of frequency index i of a fixture, in the oracle's form (None if there is none)."""
     if "substrate_kind" not in d:
@@ -126,6 +130,10 @@ MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
 # emmodels without a device implementation (evaluated on the host, SMRT_EM_HOST): the reference's rayleigh on
 # independent spheres, passive and active, and prescribed_kskaeps on a homogeneous microstructure
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
+
+
+# DORT option process_coherent_layers: a 2 mm crust and a 3 mm ice lens become coherent interfaces, frequency by frequency
+COHERENT_FIXTURES = ["coherent_L5_n16_passive", "coherent_L5_n12_active"]
 
 
 def model_snowpack_from_fixture(d):

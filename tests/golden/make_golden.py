@@ -457,6 +457,31 @@ def main():
         save("prescribed_L3_n16_passive", run_new("prescribed_kskaeps", sensor_list.passive(36.5e9, [30.0, 55.0]), spp,
                                                   rtsolver_options=dict(n_max_stream=16)))
 
+    # (iv-d) DORT option process_coherent_layers: thin ice lenses / crusts become coherent (Fabry-Perot) interfaces.
+    # One frequency per run (the reference's test `if coherent_layers[-1]` breaks on the frequency arrays of a
+    # multi-frequency Model.run; single-frequency sensors are what works).  Which layers are coherent depends on the
+    # frequency: at 10.65 GHz both the 2 mm crust on top and the 3 mm lens, at 36.5 GHz only ... none of the 3 mm one.
+    for name, sens, opts in (
+        ("coherent_L5_n16_passive", [sensor_list.passive(f, [40.0, 55.0]) for f in (10.65e9, 18.7e9, 36.5e9)],
+         dict(n_max_stream=16)),
+        ("coherent_L5_n12_active", [sensor_list.active(f, [30.0, 45.0]) for f in (5.4e9, 13.4e9)],
+         dict(n_max_stream=12, m_max=2)),
+    ):
+        if wanted(name):
+            spc = make_snowpack([0.002, 0.25, 0.003, 0.4, 100.0], "exponential", density=[600.0, 250.0, 900.0, 330.0, 400.0],
+                                temperature=[262.0, 260.0, 261.0, 264.0, 268.0],
+                                corr_length=[2e-5, 1.2e-4, 1e-5, 2.0e-4, 2.5e-4])
+            parts = [run_new("iba", se, spc, rtsolver_options=dict(opts, process_coherent_layers=True)) for se in sens]
+            out = dict(parts[0])
+            out["frequency"] = np.concatenate([p_["frequency"] for p_ in parts])
+            out["result"] = np.concatenate([p_["result"] for p_ in parts])
+            for i, p_ in enumerate(parts):      # per-frequency diagnostics: the kept layers differ
+                for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+                    out["f%d_%s" % (i, k)] = p_["f0_" + k]
+            # and without the option, to show the fixtures are sensitive to it
+            out["result_incoherent"] = np.concatenate([run_new("iba", se, spc, rtsolver_options=opts)["result"] for se in sens])
+            save(name, out)
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA
