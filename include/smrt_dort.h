@@ -58,6 +58,7 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_ERR_ALBEDO 3          /* single scattering albedo >= 1: no real eigenvalues (dort.py:941)    */
 #define SMRT_ERR_SINGULAR 4        /* singular boundary-condition system                                  */
 #define SMRT_ERR_INPUT 5           /* invalid layer input (e.g. T > 273.15 K, ice.py:56-57; < 2 streams)   */
+#define SMRT_ERR_COHERENT 6        /* process_coherent_layers: the last layer, or two layers in a row, are coherent (coherent_flat.py:26,34) */
 
 /*
  * A batch = S snowpacks x F frequencies, flattened frequency-major exactly like Model.prepare_simulations
@@ -123,6 +124,13 @@ typedef struct smrt_batch {
     const double* host_layer;
     const int32_t* host_streams;
     const double* host_phase;
+    /* DORT option process_coherent_layers (dort.py:110,156,203; rtsolver_utils.py:349-365; interface/coherent_flat.py):
+     * non-zero = per pair, every layer with k0 Re(sqrt(eps_eff)) thickness < 3 pi / 4 at the pair's frequency is taken
+     * out of the snowpack and becomes a coherent (Fabry-Perot) interface on top of the layer below it; layer_out then
+     * holds the remaining layers, top first, and zeros after them, with 1024 x (index of the layer in the input) added to
+     * the stream count of column 4 so that the caller can tell which layers were kept.  Not combined with SMRT_EM_HOST
+     * layers. */
+    int32_t process_coherent_layers;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

@@ -29,6 +29,7 @@ STATUS_MESSAGES = {
        "emmodel?).",
     4: "The boundary-condition system is singular.",
     5: "Invalid layer properties (temperature above the freezing point, or fewer than two streams in a layer).",
+    6: "process_coherent_layers: the last layer is coherent, or two successive layers are coherent; this is not supported.",
 }
 
 
@@ -68,6 +69,7 @@ class SmrtBatch(C.Structure):
         ("host_layer", C.POINTER(C.c_double)),
         ("host_streams", C.POINTER(C.c_int32)),
         ("host_phase", C.POINTER(C.c_double)),
+        ("process_coherent_layers", C.c_int32),
     ]
 
 
@@ -82,7 +84,7 @@ class PackedBatch:
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
-                 prune_deep_snowpack=None, layer_kind=None, host_emmodel=None):
+                 prune_deep_snowpack=None, layer_kind=None, host_emmodel=None, process_coherent_layers=False):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
@@ -151,6 +153,7 @@ class PackedBatch:
             self.host_phase = np.ascontiguousarray(np.asarray(hp, np.float64).reshape(FS, Lmax, modes, 2, ne, ne))
             s.host_layer, s.host_phase = _dptr(self.host_layer), _dptr(self.host_phase)
             s.host_streams = self.host_streams.ctypes.data_as(C.POINTER(C.c_int32))
+        s.process_coherent_layers = 1 if process_coherent_layers else 0
         self.struct = s
 
     @property

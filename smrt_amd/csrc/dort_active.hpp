@@ -26,7 +26,19 @@ namespace smrt {
 
 // Flat interface, Maezawa & Miyauchi 2009 Fresnel (core/fresnel.py:99-146): power R and T for V, H and the
 // coherency term U (fresnel.py:417-474).
-SMRT_DEV void fresnel_RT3(cplx e1, cplx e2, double mu1, double* R3, double* T3) {
+// With slab_thickness > 0: the coherent interface of process_coherent_layers (coherent_flat.py:76-147, see coherent_slab).
+SMRT_DEV void fresnel_RT3(cplx e1, cplx e2, double mu1, double* R3, double* T3, double frequency = 0.0,
+                          cplx es = cplx{0.0, 0.0}, double slab_thickness = 0.0) {
+    if (slab_thickness > 0.0) {
+        const SlabRT q = coherent_slab(frequency, e1, e2, mu1, es, slab_thickness);
+        const double nt = csqrt_(cdiv(e2, e1)).re;
+        R3[0] = cabs2(q.Rv); R3[1] = cabs2(q.Rh);
+        R3[2] = q.Rv.re * q.Rh.re + q.Rv.im * q.Rh.im;
+        T3[0] = cabs2(q.Tv) * q.mu_t / mu1 / nt;
+        T3[1] = cabs2(q.Th) * q.mu_t / mu1 * nt;
+        T3[2] = q.mu_t / mu1 * ((1.0 + q.Rv.re) * (1.0 + q.Rh.re) + q.Rv.im * q.Rh.im);
+        return;
+    }
     cplx n1 = csqrt_(e1);
     double kz2 = n1.re * n1.re * (1.0 - mu1 * mu1);
     cplx kyi = cscale(csqrt_(cmk(e1.re - kz2, e1.im)), -1.0);
@@ -81,7 +93,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
     const double frequency = b.frequency[fi];
-    const int L = b.n_layers[si];
+    int L = b.n_layers[si];
     const double* thickness = b.thickness + (long long)si * b.Lmax;
     const double* fracvol = b.frac_volume + (long long)si * b.Lmax;
     const double* temperature = b.temperature + (long long)si * b.Lmax;
@@ -102,6 +114,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
                                       b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr, gp);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
+        L = s.ints[6];   // fewer than the snowpack's under process_coherent_layers
     }
     const int n_air = s.ints[5];
     if (MODE != 1 && b.want_layer_out) {
@@ -110,7 +123,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             const bool in = l < L;
             lo[l * 5 + 0] = in ? s.eps_re[l] : 0.0; lo[l * 5 + 1] = in ? s.eps_im[l] : 0.0;
             lo[l * 5 + 2] = in ? s.ks[l] : 0.0; lo[l * 5 + 3] = in ? s.ka[l] : 0.0;
-            lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
+            lo[l * 5 + 4] = in ? s.nl[l] + (b.coherent ? 1024.0 * s.lo[l] : 0.0) : 0.0;   // + 1024 x index in the input (smrt_dort.h)
         }
     }
     if (MODE != 1 && b.want_stream_out) {
@@ -165,7 +178,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (j < (int)s.nl[Lc - 1]) {
                 const double rs = s.ri[Lc - 1] * s.gsin[j];
                 double R3[3], T3[3];
-                fresnel_RT3(cmk(s.eps_re[Lc - 1], s.eps_im[Lc - 1]), cmk(s.eps_re[Lc], s.eps_im[Lc]), sqrt(1.0 - rs * rs), R3, T3);
+                fresnel_RT3(cmk(s.eps_re[Lc - 1], s.eps_im[Lc - 1]), cmk(s.eps_re[Lc], s.eps_im[Lc]), sqrt(1.0 - rs * rs), R3, T3,
+                            frequency, cmk(s.slab_re[Lc], s.slab_im[Lc]), s.slab_th[Lc]);
                 Rt = R3[pol];
             }
         } else
@@ -185,7 +199,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 const double rs = s.ri[l] * s.gsin[j];
                 const double mu = sqrt(1.0 - rs * rs);
                 double R3[3], T3[3];
-                fresnel_RT3(el, eup, mu, R3, T3);
+                fresnel_RT3(el, eup, mu, R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
                 const double tt = exp(-(s.ks[l] + s.ka[l]) * s.thick[l] / mu);
                 const double y = tt * tt * Rt;
                 K = y / (1.0 - R3[pol] * y);
@@ -197,13 +211,13 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double rs = s.ri[l - 1] * s.gsin[j];
                     const double muu = sqrt(1.0 - rs * rs);
                     double R3[3], T3[3];
-                    fresnel_RT3(eup, el, muu, R3, T3);
+                    fresnel_RT3(eup, el, muu, R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
                     Rt = R3[pol] + Tt * K * T3[pol];
                 } else Rt = 0.0;
             } else Ttop0 = Tt;
         }
         double Ra[3], Ta[3];
-        fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta);
+        fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta, frequency, cmk(s.slab_re[0], s.slab_im[0]), s.slab_th[0]);
         coh[pol * NI + jn] = Ra[pol] + Ttop0 * K * Ta[pol];
     }
     block_sync();
@@ -260,7 +274,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 const cplx ebelow = (Lk < L) ? cmk(s.eps_re[l + 1], s.eps_im[l + 1]) : cmk(b.sub_p1[gp], b.sub_p2[gp]);
                 for (int j = t; j < n; j += NT) {
                     double R3[3], T3[3];
-                    fresnel_RT3(el, ebelow, s.mu[j], R3, T3);
+                    if (Lk < L) fresnel_RT3(el, ebelow, s.mu[j], R3, T3, frequency, cmk(s.slab_re[l + 1], s.slab_im[l + 1]), s.slab_th[l + 1]);
+                    else fresnel_RT3(el, ebelow, s.mu[j], R3, T3);
                     for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
                 }
             }
@@ -272,7 +287,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 s.w[j] = w;
                 double R3[3], T3[3];
                 const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
-                fresnel_RT3(el, eup, s.mu[j], R3, T3);
+                fresnel_RT3(el, eup, s.mu[j], R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
                 for (int q = 0; q < P; ++q) {
                     const int r = P * j + q;
                     if (MODE < 2) { s.mrow[r] = s.mu[j]; s.wrow[r] = w; }
@@ -285,7 +300,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             if (MODE != 1 && l > 0)
                 for (int j = t; j < nu; j += NT) {
                     double R3[3], T3[3];
-                    fresnel_RT3(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], R3, T3);
+                    fresnel_RT3(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
                     for (int q = 0; q < P; ++q) { s.Rbu[P * j + q] = R3[q]; s.Tbu[P * j + q] = T3[q]; }
                 }
 
@@ -295,7 +310,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             {
                 const int T = n * (n + 1) / 2;
                 const double pa = s.pa[l], pb = s.pb[l];
-                const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+                const int lo = (int)s.lo[l];   // the layer's index in the input arrays
+                const double fv = fracvol[lo], q1 = mp1[lo], q2 = mp2[lo];
                 const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
                 for (int idx = t; idx < T; idx += NT) {
                     int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
@@ -526,7 +542,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const int jn = idx / (P * P), rem = idx - jn * P * P, po = rem / P, pi = rem - po * P;
                     const int j = inc[jn];
                     double Ra[3], Ta[3];
-                    fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta);
+                    fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta, frequency, cmk(s.slab_re[0], s.slab_im[0]), s.slab_th[0]);
                     double w;  // outweight (streams.py:324-330 on outmu)
                     if (n_air == 1) w = 1.0;
                     else if (j == 0) w = 1.0 - 0.5 * (s.outmu[0] + s.outmu[1]);

@@ -53,7 +53,9 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
     const long long modes = ctx->active ? d.m_max + 1 : 1;
     if (getenv("SMRT_DORT_DEBUG_OCCUPANCY") && !ctx->gmem_path && !ctx->active) smrt_launch::occupancy_report(ctx, ctx->nt);
-    const int rounds = (d.prune_tau > 0.0 && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
+    // (under process_coherent_layers the layer indices of a pair are its own: one round, and the staging counts of the
+    // removed layers must read "nothing staged")
+    const int rounds = (d.prune_tau > 0.0 && !d.coherent && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
     auto prep = [&](const DevBatch& c, unsigned grid) {
         if (ctx->big) return smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
         if (ctx->gmem_split) return smrt_launch::prep_gmem(ctx, c, grid, ctx->active);
@@ -69,8 +71,10 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         DevBatch c = chunk_of(ctx, d, c0, cn);
         const unsigned grid = (unsigned)(ctx->gmem_path ? std::min<long long>(cn, ctx->gmem_grid) : cn);
         hipError_t e;
-        if (rounds > 1) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
+        if (rounds > 1 || d.coherent) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
             if ((e = hipMemsetAsync(ctx->stage.n, 0, sizeof(int) * (size_t)(cn * items_per_pair), ctx->stream)) != hipSuccess) return e;
+        }
+        if (rounds > 1) {
             if ((e = hipMemsetAsync(ctx->d_done.p, 0, sizeof(int) * (size_t)cn, ctx->stream)) != hipSuccess) return e;
             c.pair_done = (const int*)ctx->d_done.p;
         }
@@ -329,6 +333,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.host_streams = has_host ? (const int*)ctx->d_hoststreams.p : nullptr;
     d.host_phase = has_host ? (const double*)ctx->d_hostphase.p : nullptr;
     d.host_modes = (int)host_modes; d.host_ne = (int)host_ne;
+    d.coherent = b->process_coherent_layers ? 1 : 0;
     d.sub_kind = b->substrate_kind;
     d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
     const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
@@ -373,7 +378,7 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(temperature), SMRT_OFF(micro_p1), SMRT_OFF(micro_p2), SMRT_OFF(frequency), SMRT_OFF(theta), SMRT_OFF(phi),
         SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
         SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
-        SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase)};
+        SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

@@ -32,6 +32,7 @@ struct DevBatch {
     const int* host_streams;     // [F * S][Lmax]
     const double* host_phase;    // [F * S][Lmax][host_modes][2][host_ne * host_ne]
     int host_modes, host_ne;
+    int coherent;  // DORT option process_coherent_layers
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]
@@ -87,7 +88,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3, EM_HOST = 4 };  // 1-3 have a Rayleigh phase matrix; 4: host arrays
 enum { MS_EXP = 0, MS_SHS = 1 };
-enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5 };
+enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5, ST_COHERENT = 6 };
 enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -102,7 +103,7 @@ struct LdsPlan {
     int o_M[4];
     int o_rowvec;   // 17 vectors of NMAX
     int o_strvec;   // 6 vectors of nmax
-    int o_layvec;   // 11 vectors of Lmax
+    int o_layvec;   // 15 vectors of Lmax
     int o_phi;      // 5 vectors of nphi
     int o_tb;       // NMAX
     int o_int;      // 16 ints (8 doubles)
@@ -154,7 +155,7 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.slim = slim;
     p.o_rowvec = o; o += (slim == 1 ? 4 : slim == 2 ? 14 : 17) * p.NMAX;  // slim 2: no mrow / wrow / u
     p.o_strvec = o; o += 6 * p.nmax;
-    p.o_layvec = o; o += 11 * Lmax;
+    p.o_layvec = o; o += 15 * Lmax;
     p.o_phi = o; o += (slim == 2 ? 0 : 5 * nphi);
     p.o_tb = o; o += p.NMAX;
     p.o_int = o; o += 8;
@@ -177,10 +178,11 @@ struct Lds {
     double *mrow, *wrow, *u, *d, *sigma, *rsig, *t, *Rtop, *Ttop, *Rbu, *Tbu, *cvec, *tq, *svec, *g, *upb, *up;
     double *gmu, *gsin, *outmu, *mu, *w, *muu;
     double *eps_re, *eps_im, *ks, *ka, *pa, *pb, *pc, *BT, *thick, *ri, *nl;
+    double *slab_re, *slab_im, *slab_th, *lo;  // coherent slab on top of the layer (thickness 0: none); index of the layer in the input
     double *cphi, *s2phi, *wphi, *sphi, *swphi;
     double* tb;
     double* act;  // active-mode region (see active_doubles)
-    int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air
+    int* ints;  // [0] status  [1] jacobi flag  [2] pivot  [3] pivot fail  [4] kstar  [5] n_air  [6] layers after process_coherent_layers
     double* gj;  // blocked Gauss-Jordan scratch
     int gj_nmax;
     double* sub_acc;  // profiling builds: [0] GJ panel cycles, [1] GJ update cycles, [2] GJ permutation cycles
@@ -202,6 +204,7 @@ SMRT_DEV Lds carve(double* base, double* mat_base, const LdsPlan& p) {
     const int L = p.Lmax;
     s.eps_re = v; s.eps_im = v + L; s.ks = v + 2 * L; s.ka = v + 3 * L; s.pa = v + 4 * L; s.pb = v + 5 * L;
     s.pc = v + 6 * L; s.BT = v + 7 * L; s.thick = v + 8 * L; s.ri = v + 9 * L; s.nl = v + 10 * L;
+    s.slab_re = v + 11 * L; s.slab_im = v + 12 * L; s.slab_th = v + 13 * L; s.lo = v + 14 * L;
     v = base + p.o_phi;
     s.cphi = v; s.s2phi = v + p.nphi; s.wphi = v + 2 * p.nphi; s.sphi = v + 3 * p.nphi; s.swphi = v + 4 * p.nphi;
     s.act = base + p.o_act;

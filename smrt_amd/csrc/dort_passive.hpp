@@ -107,7 +107,7 @@ SMRT_DEV void fail_pair(const DevBatch& b, long long p, int code, int out_stride
 // (streams.py:136-223).  s.ints[0..7] must be zero on entry.  Returns the status, uniform over the workgroup; on
 // ST_OK s.ints[4] = most refringent layer, s.ints[5] = n_air.
 template <int NT>
-SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L, const double* thickness,
+SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L /* layers of the snowpack; s.ints[6] on return */, const double* thickness,
                         const double* fracvol, const double* temperature, const double* mp1, const double* mp2,
                         const int* kinds = nullptr /* this snowpack's row of b.layer_kind, or null */,
                         long long gp = 0 /* global pair f * S + s: row of the host-evaluated emmodel arrays */) {
@@ -118,7 +118,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
         if ((kind & 15) == EM_HOST) {   // evaluated by the caller (smrt_batch.host_layer)
             if (b.host_layer) {
-                const double* h = b.host_layer + (gp * b.Lmax + l) * 4;
+                const double* h = b.host_layer + (gp * b.Lmax + l) * 4;   // (not combined with process_coherent_layers)
                 ks = h[0]; ka = h[1]; ee = cmk(h[2], h[3]);
                 if (!(ka >= 0.0) || !(ee.re > 0.0)) bad = 1;
             } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
@@ -127,6 +127,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)kind;
+        s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;
         s.thick[l] = thickness[l];
         s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
         if (bad || !(ks >= 0.0)) lds_max(&s.ints[0], ST_INPUT);
@@ -135,8 +136,42 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         const double m = b.gl_mu[j];
         s.gmu[j] = m; s.gsin[j] = sqrt(1.0 - m * m);
     }
+    if (t == 0) s.ints[6] = L;
     block_sync();
     if (s.ints[0] != ST_OK) return s.ints[0];
+    if (b.coherent) {
+        // DORT option process_coherent_layers (smrt/interface/coherent_flat.py:16-57): a layer with k Re(n) d < 3 pi / 4
+        // at this frequency is taken out and becomes the slab of the interface on top of the layer that follows it;
+        // the per-layer tables are compacted in place (lo[] keeps the index in the input arrays), everything after
+        // this point -- streams, staging items, the layer loops of the three kernels -- sees the shorter snowpack
+        if (t == 0) {
+            const double k0 = 2.0 * kPi * frequency / kCSpeed;
+            int j = 0, bad = 0;
+            bool pending = false, prev = false;
+            double pr = 0.0, pi = 0.0, pth = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const cplx e = cmk(s.eps_re[l], s.eps_im[l]);
+                const bool coh = k0 * csqrt_(e).re * s.thick[l] < 0.75 * kPi;
+                if (coh) {
+                    if (l == L - 1 || prev) { bad = 1; break; }   // the last layer / two in a row: not supported (:26,:34)
+                    pr = e.re; pi = e.im; pth = s.thick[l]; pending = true;
+                } else {
+                    s.eps_re[j] = s.eps_re[l]; s.eps_im[j] = s.eps_im[l]; s.ks[j] = s.ks[l]; s.ka[j] = s.ka[l];
+                    s.pa[j] = s.pa[l]; s.pb[j] = s.pb[l]; s.pc[j] = s.pc[l]; s.BT[j] = s.BT[l]; s.thick[j] = s.thick[l];
+                    s.slab_re[j] = pending ? pr : 0.0; s.slab_im[j] = pending ? pi : 0.0; s.slab_th[j] = pending ? pth : 0.0;
+                    s.lo[j] = (double)l;
+                    pending = false;
+                    ++j;
+                }
+                prev = coh;
+            }
+            s.ints[6] = j;
+            if (bad) s.ints[0] = ST_COHERENT;
+        }
+        block_sync();
+        if (s.ints[0] != ST_OK) return s.ints[0];
+        L = s.ints[6];
+    }
     if (t == 0) {
         int ks_ = 0;
         for (int l = 1; l < L; ++l)  // np.argmax on complex: lexicographic, first maximum
@@ -227,7 +262,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
     const double frequency = b.frequency[fi];
-    const int L = b.n_layers[si];
+    int L = b.n_layers[si];
     const double* thickness = b.thickness + (long long)si * b.Lmax;
     const double* fracvol = b.frac_volume + (long long)si * b.Lmax;
     const double* temperature = b.temperature + (long long)si * b.Lmax;
@@ -257,6 +292,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         const int st = pair_setup<NT>(b, s, frequency, L, thickness, fracvol, temperature, mp1, mp2,
                                       b.layer_kind ? b.layer_kind + (long long)si * b.Lmax : nullptr, gp);
         if (st != ST_OK) { fail_pair<NT>(b, p, st, out_stride); return; }
+        L = s.ints[6];   // fewer than the snowpack's under process_coherent_layers
     }
     const int n_air = s.ints[5];
 
@@ -266,7 +302,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             const bool in = l < L;
             lo[l * 5 + 0] = in ? s.eps_re[l] : 0.0; lo[l * 5 + 1] = in ? s.eps_im[l] : 0.0;
             lo[l * 5 + 2] = in ? s.ks[l] : 0.0; lo[l * 5 + 3] = in ? s.ka[l] : 0.0;
-            lo[l * 5 + 4] = in ? s.nl[l] : 0.0;
+            lo[l * 5 + 4] = in ? s.nl[l] + (b.coherent ? 1024.0 * s.lo[l] : 0.0) : 0.0;   // + 1024 x index in the input (smrt_dort.h)
         }
     }
     if (MODE != 1 && b.want_stream_out) {
@@ -319,8 +355,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 double Rs = 0.0, src = 0.0;
                 if (Lk < L) {
                     const double rs = s.ri[l] * s.gsin[r >> 1];
-                    double Rv, Rh;
-                    fresnel_RvRh(el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs), &Rv, &Rh);
+                    double Rv, Rh, Tv, Th;
+                    interface_RT(frequency, el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs),
+                                 cmk(s.slab_re[l + 1], s.slab_im[l + 1]), s.slab_th[l + 1], &Rv, &Rh, &Tv, &Th);
                     Rs = (r & 1) ? Rh : Rv;
                 } else if (b.sub_kind != SUB_NONE) {
                     const long long gpi = gp;
@@ -351,18 +388,20 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 s.wrow[2 * j] = w; s.wrow[2 * j + 1] = w;
             }
             if (MODE == 1) continue;  // the interfaces belong to the finish kernel
-            double Rv, Rh;
+            double Rv, Rh, Tv, Th;
             const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
-            fresnel_RvRh(el, eup, s.mu[j], &Rv, &Rh);
+            const cplx slab = cmk(s.slab_re[l], s.slab_im[l]);   // a coherent layer collapsed into this interface, if any
+            interface_RT(frequency, el, eup, s.mu[j], slab, s.slab_th[l], &Rv, &Rh, &Tv, &Th);
             s.Rtop[2 * j] = Rv; s.Rtop[2 * j + 1] = Rh;
-            s.Ttop[2 * j] = 1.0 - Rv; s.Ttop[2 * j + 1] = 1.0 - Rh;
+            s.Ttop[2 * j] = Tv; s.Ttop[2 * j + 1] = Th;
         }
         if (MODE != 1 && l > 0)
             for (int j = t; j < nu; j += NT) {
-                double Rv, Rh;
-                fresnel_RvRh(cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], &Rv, &Rh);
+                double Rv, Rh, Tv, Th;
+                interface_RT(frequency, cmk(s.eps_re[l - 1], s.eps_im[l - 1]), el, s.muu[j], cmk(s.slab_re[l], s.slab_im[l]),
+                             s.slab_th[l], &Rv, &Rh, &Tv, &Th);
                 s.Rbu[2 * j] = Rv; s.Rbu[2 * j + 1] = Rh;
-                s.Tbu[2 * j] = 1.0 - Rv; s.Tbu[2 * j + 1] = 1.0 - Rh;
+                s.Tbu[2 * j] = Tv; s.Tbu[2 * j + 1] = Th;
             }
 
         SMRT_STAGE(SG_ASSEMBLE);
@@ -372,7 +411,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         {
             const int T = n * (n + 1) / 2;
             const double pa = s.pa[l], pb = s.pb[l];
-            const double fv = fracvol[l], q1 = mp1[l], q2 = mp2[l];
+            const int lo = (int)s.lo[l];   // the layer's index in the input arrays
+            const double fv = fracvol[lo], q1 = mp1[lo], q2 = mp2[lo];
             const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
             for (int idx = t; idx < T; idx += NT) {
                 int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
@@ -636,13 +676,13 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             double I0 = s.Ttop[i] * s.up[i];  // dort.py:484
             if (atm && Idn != 0.0) {
                 double acc = 0.0;
+                const cplx slab0 = cmk(s.slab_re[0], s.slab_im[0]);
+                double Rv, Rh, Tv, Th;
                 for (int j = 0; j < n_air; ++j) {
-                    double Rv, Rh;
-                    fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[j], &Rv, &Rh);
-                    acc += K0[(2 * j) * LD + i] * (1.0 - Rv) + K0[(2 * j + 1) * LD + i] * (1.0 - Rh);
+                    interface_RT(frequency, cmk(1.0, 0.0), e0, s.outmu[j], slab0, s.slab_th[0], &Rv, &Rh, &Tv, &Th);
+                    acc += K0[(2 * j) * LD + i] * Tv + K0[(2 * j + 1) * LD + i] * Th;
                 }
-                double Rv, Rh;
-                fresnel_RvRh(cmk(1.0, 0.0), e0, s.outmu[i >> 1], &Rv, &Rh);
+                interface_RT(frequency, cmk(1.0, 0.0), e0, s.outmu[i >> 1], slab0, s.slab_th[0], &Rv, &Rh, &Tv, &Th);
                 I0 += ((i & 1) ? Rh : Rv) * Idn + s.Ttop[i] * acc * Idn;
             }
             if (atm) I0 = Iup + trans * I0;

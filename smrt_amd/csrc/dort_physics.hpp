@@ -223,17 +223,62 @@ SMRT_DEV void layer_em(int em, int ms, double frequency, double fv, double T, do
 }
 
 // Flat interface, Maezawa & Miyauchi 2009 "rigorous" Fresnel (core/fresnel.py:99-146): power R for V and H.
-SMRT_DEV void fresnel_RvRh(cplx e1, cplx e2, double mu1, double* Rv, double* Rh) {
+// field reflection coefficients and the cosine in medium 2
+SMRT_DEV void fresnel_field(cplx e1, cplx e2, double mu1, cplx* rv, cplx* rh, double* mu2) {
     cplx n1 = csqrt_(e1);
     double kz2 = n1.re * n1.re * (1.0 - mu1 * mu1);
     cplx kyi = cscale(csqrt_(cmk(e1.re - kz2, e1.im)), -1.0);
     cplx kyt = cscale(csqrt_(cmk(e2.re - kz2, e2.im)), -1.0);
-    cplx rh = cdiv(csub(kyi, kyt), cadd(cconj(kyi), kyt));
+    *rh = cdiv(csub(kyi, kyt), cadd(cconj(kyi), kyt));
     cplx num = cmul(cconj(n1), csub(cmul(e2, kyi), cmul(e1, kyt)));
     cplx den = cmul(n1, cadd(cmul(e2, cconj(kyi)), cmul(cconj(e1), kyt)));
-    cplx rv = cdiv(num, den);
+    *rv = cdiv(num, den);
+    *mu2 = -kyt.re / csqrt_(e2).re;
+}
+SMRT_DEV void fresnel_RvRh(cplx e1, cplx e2, double mu1, double* Rv, double* Rh) {
+    cplx rv, rh; double mu2;
+    fresnel_field(e1, e2, mu1, &rv, &rh, &mu2);
     *Rv = cabs2(rv);
     *Rh = cabs2(rh);
+}
+
+// DORT option process_coherent_layers (smrt/interface/coherent_flat.py:60-186): a layer thinner than 3/8 of a wavelength
+// and its two flat interfaces collapsed into ONE interface between medium 1 (incidence, cosine mu1) and medium 2.
+// Field reflection / transmission coefficients of the slab (Tsang I 5.2.10-14) and the cosine in medium 2.
+struct SlabRT { cplx Rv, Rh, Tv, Th; double mu_t; };
+SMRT_DEV SlabRT coherent_slab(double frequency, cplx e1, cplx e2, double mu1, cplx es, double thickness) {
+    cplx r01v, r01h, r1tv, r1th; double mu_1, mu_t;
+    fresnel_field(e1, es, mu1, &r01v, &r01h, &mu_1);
+    fresnel_field(es, e2, mu_1 > 1e-4 ? mu_1 : 1e-4, &r1tv, &r1th, &mu_t);
+    const cplx k1 = cscale(csqrt_(es), 2.0 * kPi * frequency / kCSpeed);
+    const cplx ph = cscale(k1, mu_1 * thickness);                 // complex phase across the slab
+    const double a1 = exp(-ph.im), a2 = a1 * a1;
+    const cplx ex1 = cmk(a1 * cos(ph.re), a1 * sin(ph.re));       // exp(i phase)
+    const cplx ex2 = cmk(a2 * cos(2.0 * ph.re), a2 * sin(2.0 * ph.re));
+    const cplx one = cmk(1.0, 0.0);
+    SlabRT o;
+    const cplx dv = cadd(one, cmul(cmul(r01v, r1tv), ex2)), dh = cadd(one, cmul(cmul(r01h, r1th), ex2));
+    o.Rv = cdiv(cadd(r01v, cmul(r1tv, ex2)), dv);
+    o.Rh = cdiv(cadd(r01h, cmul(r1th, ex2)), dh);
+    o.Tv = cdiv(cmul(cmul(cadd(one, r01v), cadd(one, r1tv)), ex1), dv);
+    o.Th = cdiv(cmul(cmul(cadd(one, r01h), cadd(one, r1th)), ex1), dh);
+    o.mu_t = mu_t;
+    return o;
+}
+// Power reflection and transmission (V, H) of the interface between media 1 and 2, flat (slab_thickness == 0: rigorous
+// Fresnel, T = 1 - R) or coherent (coherent_flat.py:76-147)
+SMRT_DEV void interface_RT(double frequency, cplx e1, cplx e2, double mu1, cplx es, double slab_thickness,
+                           double* Rv, double* Rh, double* Tv, double* Th) {
+    if (!(slab_thickness > 0.0)) {
+        fresnel_RvRh(e1, e2, mu1, Rv, Rh);
+        *Tv = 1.0 - *Rv; *Th = 1.0 - *Rh;
+        return;
+    }
+    const SlabRT q = coherent_slab(frequency, e1, e2, mu1, es, slab_thickness);
+    const double nt = csqrt_(cdiv(e2, e1)).re;
+    *Rv = cabs2(q.Rv); *Rh = cabs2(q.Rh);
+    *Tv = cabs2(q.Tv) * q.mu_t / mu1 / nt;
+    *Th = cabs2(q.Th) * q.mu_t / mu1 * nt;
 }
 
 }  // namespace smrt

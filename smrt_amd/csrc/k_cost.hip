@@ -17,10 +17,11 @@ __global__ __launch_bounds__(NT) void dort_cost_kernel(DevBatch b, double* cost)
     block_sync();
     const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
-    const int L = b.n_layers[si];
+    int L = b.n_layers[si];
     const long long o = (long long)si * b.Lmax;
     const int st = pair_setup<NT>(b, s, b.frequency[fi], L, b.thickness + o, b.frac_volume + o, b.temperature + o, b.p1 + o, b.p2 + o,
                                   b.layer_kind ? b.layer_kind + o : nullptr, gp);
+    if (st == ST_OK) L = s.ints[6];
     if (t == 0) {
         double c = 0.0;
         if (st == ST_OK)

@@ -41,9 +41,6 @@ class DORT(object):
             raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
         if phase_symmetrization:
             raise SMRTError("phase_symmetrization is outside the scope of smrt_amd's DORT")
-        if process_coherent_layers:
-            raise SMRTError("process_coherent_layers is not implemented by smrt_amd's DORT (DESIGN.md 7.3: the removed "
-                            "layers become frequency-dependent Fabry-Perot interfaces)")
         if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
             prune_deep_snowpack = 6
         if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
@@ -59,7 +56,7 @@ class DORT(object):
         self.stream_mode = stream_mode
         self.phase_normalization = phase_normalization
         self.error_handling = error_handling
-        self.process_coherent_layers = False
+        self.process_coherent_layers = bool(process_coherent_layers)
         self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         self.diagonalization_method = diagonalization_method
         self.rayleigh_jeans_approximation = bool(rayleigh_jeans_approximation)
@@ -208,6 +205,9 @@ class DORT(object):
         if not isinstance(emmodel_names, str) and any(not isinstance(e, str) for row in emmodel_names for e in row):
             # at least one emmodel without a device implementation: the whole group is evaluated through the emmodel
             # protocol on the host (the device classes speak it too) and handed to the device as numbers
+            if self.process_coherent_layers:
+                raise SMRTError("process_coherent_layers is not available with emmodels evaluated on the host (the phase "
+                                "matrices are sampled on the streams of the full snowpack)")
             host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
             layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
         elif not (isinstance(emmodel_names, str) and uniform_micro):
@@ -246,7 +246,8 @@ class DORT(object):
                            phase_normalization=self.phase_normalization,
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
-                           layer_kind=layer_kind, host_emmodel=host)
+                           layer_kind=layer_kind, host_emmodel=host,
+                           process_coherent_layers=self.process_coherent_layers)
 
     @staticmethod
     def _ms_code(layer):
@@ -382,16 +383,25 @@ class _Solution:
         sensor, sp = self.sensors[self.sens_idx[i]], self.packs[self.pack_idx[i]]
         out, row = self.outputs[self.group_of[i]], self.row_of[i]
         L = sp.nlayer
+        thickness = sp.layer_thicknesses
+        layers = out.layers[row]
+        if self.solver.process_coherent_layers:   # the layers that were solved: column 4 = streams + 1024 x input index
+            code = layers[:L, 4]
+            kept = int(np.count_nonzero(code > 0))
+            thickness = thickness[(code[:kept] // 1024).astype(int)]
+            layers = layers.copy()
+            layers[:, 4] = layers[:, 4] % 1024
+            L = kept
         outmu = self._reported_streams(sensor, out.streams[row])
         layer_idx = ("layer", np.arange(L))
-        lay = out.layers[row, :L]
+        lay = layers[:L]
         other = {
             "stream_angles": LabeledArray(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
             "effective_permittivity": LabeledArray(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
             "ks": LabeledArray(lay[:, 2].copy(), [layer_idx], name="ks"),
             "ke": LabeledArray(lay[:, 2] + lay[:, 3], [layer_idx], name="ke"),
             "ka": LabeledArray(lay[:, 3].copy(), [layer_idx], name="ka"),
-            "thickness": LabeledArray(sp.layer_thicknesses, [layer_idx], name="thickness"),
+            "thickness": LabeledArray(thickness, [layer_idx], name="thickness"),
         }
         return make_result(sensor, out.values[row], self._coords(sensor), other_data=other)
 
@@ -423,6 +433,12 @@ class _Solution:
         thick = np.full((len(self.packs), Lmax), np.nan)
         for k, sp in enumerate(self.packs):
             thick[k, :sp.nlayer] = sp.packed()[0]
+        thick_rows = thick[self.pack_idx]
+        if self.solver.process_coherent_layers:   # per simulation: the layers that were solved, top first, NaN after them
+            code = np.nan_to_num(lay[:, :, 4])    # streams + 1024 x index in the input (include/smrt_dort.h)
+            kept = code > 0
+            thick_rows = np.where(kept, np.take_along_axis(thick_rows, (code // 1024).astype(np.int64), axis=1), np.nan)
+            lay[~kept] = np.nan
         streams = [self._reported_streams(self.sensors[s], out.streams[r]) for s, r in zip(self.sens_idx, order)] \
             if sensor0.mode == "A" else None
         if streams is None:
@@ -442,7 +458,7 @@ class _Solution:
             "ks": stack(lay[:, :, 2], "ks"),
             "ke": stack(lay[:, :, 2] + lay[:, :, 3], "ke"),
             "ka": stack(lay[:, :, 3], "ka"),
-            "thickness": stack(thick[self.pack_idx], "thickness"),
+            "thickness": stack(thick_rows, "thickness"),
         }
         return make_result(sensor0, data, other_data=other)
 

@@ -100,7 +100,8 @@ def packed_batch_from_fixture(d, freqs=None):
                        d["frequency"][sel], np.deg2rad(d["theta_inc_deg"] if active else d["theta_deg"]),
                        emmodel=emmodel, microstructure=ms, mode="A" if active else "P",
                        n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
-                       prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind)
+                       prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind,
+                       process_coherent_layers=fixture_coherent(d))
 
 
 SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",

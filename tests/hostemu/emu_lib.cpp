@@ -57,7 +57,8 @@ struct Staging {
 template <class Prep, class Jac, class Fin>
 static long run_rounds(DevBatch& d, int order, int nmodes, Staging& sg, Prep prep, Jac jac, Fin fin) {
     long nb = 0;
-    const int rounds = d.prune_tau > 0.0 ? (d.Lmax < 4 ? d.Lmax : 4) : 1;
+    const int rounds = (d.prune_tau > 0.0 && !d.coherent) ? (d.Lmax < 4 ? d.Lmax : 4) : 1;
+    if (d.coherent) for (auto& x : sg.n) x = 0;
     std::vector<int> done((size_t)d.pair_count, 0);
     if (rounds > 1) { for (auto& x : sg.n) x = 0; d.pair_done = done.data(); }
     for (int r = 0; r < rounds; ++r) {
@@ -177,6 +178,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.layer_kind = b->layer_kind;
     d.host_layer = b->host_layer; d.host_streams = b->host_streams; d.host_phase = b->host_phase;
     d.host_modes = active ? b->m_max + 1 : 1; d.host_ne = b->n_max_stream * (active ? 3 : 2);
+    d.coherent = b->process_coherent_layers ? 1 : 0;
     d.sub_kind = b->substrate_kind; d.sub_p1 = b->substrate_p1; d.sub_p2 = b->substrate_p2; d.sub_T = b->substrate_temperature;
     const bool has_atm = b->atm_tb_down != nullptr && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;

@@ -431,3 +431,33 @@ def test_emmodels_without_a_device_implementation_through_the_model():
     # a layer list that mixes a device emmodel with a host one takes the host route as a whole
     mixed = make_model([WrappedIBA, "iba", WrappedIBA], "dort", rtsolver_options=opts).run(sensor, sp)
     np.testing.assert_allclose(mixed.TbV(), native.TbV(), atol=1e-7)
+
+
+def test_process_coherent_layers_through_the_model():
+    """rtsolver_options=dict(process_coherent_layers=True) through make_model()/Model.run() -- with ALL the frequencies
+    of the fixture in one sensor, which the reference itself cannot run (its test on the last layer breaks on arrays,
+    smrt/interface/coherent_flat.py:26): every frequency against the reference's single-frequency runs, and the
+    diagnostics of each frequency list the layers that frequency kept."""
+    from conftest import COHERENT_FIXTURES, model_snowpack_from_fixture
+    from smrt_amd import make_model, sensor_list
+
+    d = load_golden(COHERENT_FIXTURES[0])
+    sp = model_snowpack_from_fixture(d)
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=int(d["opt_n_max_stream"]), process_coherent_layers=True))
+    res = m.run(sensor_list.passive(list(d["frequency"]), list(d["theta_deg"])), sp)
+    for i, f in enumerate(d["frequency"]):
+        np.testing.assert_allclose(np.ravel(res.TbV(frequency=f)), d["result"][i, 0], atol=1e-6)
+        np.testing.assert_allclose(np.ravel(res.TbH(frequency=f)), d["result"][i, 1], atol=1e-6)
+        ks = np.ravel(res.other_data["ks"].sel_data(frequency=f).values) if hasattr(res.other_data["ks"], "sel_data") else None
+    ks = np.asarray(res.other_data["ks"].values)           # (frequency, layer), NaN after the kept layers
+    th = np.asarray(res.other_data["thickness"].values)
+    for i in range(len(d["frequency"])):
+        kept = len(d["f%d_ks" % i])
+        np.testing.assert_allclose(ks[i, :kept], d["f%d_ks" % i], rtol=1e-10)
+        assert np.isnan(ks[i, kept:]).all() and np.isnan(th[i, kept:]).all()
+        assert 0.002 not in th[i, :kept]                    # the 2 mm crust left at every frequency,
+        assert (0.003 in th[i, :kept]) == (i == 2)          # the 3 mm ice lens only below 36.5 GHz
+    # one simulation at a time (the rtsolver protocol) gives the same
+    one = m.run(sensor_list.passive(float(d["frequency"][2]), list(d["theta_deg"])), sp)
+    np.testing.assert_allclose(np.ravel(one.TbV()), d["result"][2, 0], atol=1e-6)
+    assert len(np.ravel(one.other_data["ks"].values)) == len(d["f2_ks"])

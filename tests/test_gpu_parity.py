@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -587,6 +587,57 @@ def test_host_evaluated_emmodels_golden(ctx, name, threads, pipeline):
     for i in range(len(d["frequency"])):
         np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-12)
         np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", COHERENT_FIXTURES)
+@pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
+def test_process_coherent_layers_golden(ctx, name, threads, pipeline):
+    """DORT option process_coherent_layers (smrt/interface/coherent_flat.py) against the reference: per pair the layers
+    thinner than 3/8 of a wavelength -- the crust and the ice lens at the lower frequencies, only the crust at 36.5 GHz --
+    leave the snowpack and become coherent interfaces.  Every kernel shape, passive and active; the diagnostics list the
+    layers that were solved."""
+    d = load_golden(name)
+    out = run_variant(ctx, batch_from_fixture(d), threads, pipeline)
+    assert (out.status == 0).all(), out.status
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
+    else:
+        assert np.abs(out.values - d["result"]).max() < TB_TOL
+    assert np.abs(out.values - d["result_incoherent"]).max() > 1e-4
+    for i in range(len(d["frequency"])):
+        kept = len(d["f%d_ks" % i])
+        code = out.layers[i, :, 4]
+        assert np.count_nonzero(code) == kept < len(d["thickness"])
+        np.testing.assert_allclose(out.layers[i, :kept, 2], d["f%d_ks" % i], rtol=1e-10)
+        # 1024 x the index of the layer in the input rides on the stream count
+        assert 0.002 not in d["thickness"][(code[:kept] // 1024).astype(int)]
+
+
+def test_process_coherent_layers_refusals_and_batches(ctx):
+    """The two cases the reference refuses (coherent_flat.py:26,34) come back as status 6 for the pair concerned only;
+    a batch where some pairs have coherent layers and others none equals the per-pair runs; with prune_deep_snowpack."""
+    from smrt_amd._native import PackedBatch
+
+    thick = np.array([[0.2, 0.3, 0.002],      # the last layer is coherent at 10 GHz
+                      [0.2, 0.002, 0.003],    # ... and here two in a row
+                      [0.2, 0.002, 10.0],     # fine: one lens
+                      [0.2, 0.3, 10.0]])      # no coherent layer at all
+    S = len(thick)
+    mk = lambda **kw: PackedBatch([3] * S, thick, np.full((S, 3), 0.35), np.full((S, 3), 260.0), np.full((S, 3), 1e-4),  # noqa: E731
+                                  None, [10.65e9, 89e9], np.deg2rad([55.0]), n_max_stream=8, **kw)
+    out = ctx.run(mk(process_coherent_layers=True))
+    st = out.status.reshape(2, S)
+    assert list(st[0]) == [6, 6, 0, 0]
+    assert np.isnan(out.values.reshape(2, S, -1)[0, :2]).all()
+    plain = ctx.run(mk())
+    np.testing.assert_array_equal(out.values.reshape(2, S, -1)[0, 3], plain.values.reshape(2, S, -1)[0, 3])
+    assert np.abs(out.values.reshape(2, S, -1)[0, 2] - plain.values.reshape(2, S, -1)[0, 2]).max() > 1e-3
+    # 89 GHz: 2 mm is still coherent (k n d = 0.55 < 2.36), 3 mm too
+    assert st[1, 3] == 0 and st[1, 2] == 0
+    pr = ctx.run(mk(process_coherent_layers=True, prune_deep_snowpack=6.0))
+    ok = (pr.status == 0)
+    assert (ok == (out.status == 0)).all()
+    assert np.abs(pr.values[ok] - out.values[ok]).max() < 0.05   # 10 m of snow: the pruned solve is the same physics
 
 
 def test_prune_rounds_skip_the_layers_below_the_cut(ctx):

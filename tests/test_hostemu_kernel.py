@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -251,3 +251,22 @@ def test_device_ft_even_phase_against_the_oracle(emu, emmodel, micro, npol, m_ma
                                     out.ctypes.data_as(C.POINTER(C.c_double)))
     assert rc == 0
     np.testing.assert_allclose(out, np.asarray(ref), rtol=1e-11, atol=1e-14 * max(np.abs(ref).max(), 1e-300))
+
+
+@pytest.mark.parametrize("name,nt,pipeline,order", [(COHERENT_FIXTURES[0], 64, 1, 0), (COHERENT_FIXTURES[0], 256, 0, 1),
+                                                    (COHERENT_FIXTURES[1], 128, 1, 2)])
+def test_emulated_kernel_process_coherent_layers(emu, name, nt, pipeline, order):
+    """DORT option process_coherent_layers on the device code: the 2 mm crust and the 3 mm ice lens of the fixture are
+    taken out -- both at the lower frequencies, one at 36.5 GHz -- and replaced by coherent interfaces; pipeline and
+    fused kernels, passive and active, against the reference."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        out, st, ref = run_fixture(emu, name, nt=nt, order=order)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    d = load_golden(name)
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out, ref, spread=reference_method_spread(d))
+    else:
+        assert np.abs(out - ref).max() < 1e-6
