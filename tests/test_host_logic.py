@@ -356,9 +356,10 @@ def test_dort_option_validation():
 
     DORT(n_max_stream=64, diagonalization_method="half_rank_eig", error_handling="nan")
     for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=-1), dict(diagonalization_method="foo"),
-                dict(error_handling="ignore"), dict(phase_symmetrization=True), dict(process_coherent_layers=True)):
+                dict(error_handling="ignore"), dict(phase_symmetrization=True)):
         with pytest.raises(SMRTError):
             DORT(**bad)
+    assert DORT(process_coherent_layers=True).process_coherent_layers is True
     # prune_deep_snowpack: True is an optical depth of 6 (smrt/rtsolver/dort.py:176-178); the cache option is a no-op
     assert DORT(prune_deep_snowpack=True).prune_deep_snowpack == 6.0
     assert DORT(prune_deep_snowpack=2.5, diagonalization_cache=True).prune_deep_snowpack == 2.5
