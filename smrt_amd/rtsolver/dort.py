@@ -216,9 +216,12 @@ class DORT(object):
                 em = [emmodel_names] * nl[s] if isinstance(emmodel_names, str) else emmodel_names[s]
                 layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * self._ms_code(lay) for e, lay in zip(em, sp.layers)]
         if host is None:
-            for sp in sps:
-                for lay in sp.layers:
-                    self._ms_code(lay)
+            from ..core.layer import DEVICE_MICROSTRUCTURES
+
+            foreign = set().union(*micro) - set(DEVICE_MICROSTRUCTURES)
+            if foreign:
+                raise SMRTError(f"the microstructure model(s) {sorted(foreign)} have no device implementation: they can only "
+                                "be used with an emmodel evaluated on the host (e.g. rayleigh, prescribed_kskaeps)")
         device_name = "host" if host is not None else (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
             cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
