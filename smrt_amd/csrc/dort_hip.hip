@@ -222,8 +222,16 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if (const char* e = getenv("SMRT_DORT_BIG_MIN_N")) big_min = std::max(64, atoi(e));
     ctx->big = ctx->gmem_path && ctx->split && plan.NMAX > big_min && getenv("SMRT_DORT_NO_BIG_PIPELINE") == nullptr &&
                (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
-    ctx->gmem_split = ctx->big || (ctx->gmem_path && ctx->split && plan.NMAX <= 128 && ctx->jac_in_lds &&
-                      (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds);
+    // 64 < N <= 128: the three-kernel pipeline needs the Jacobi kernel's own LDS matrix and the 16 N doubles of LDS scratch
+    // of the finish kernel's blocked solvers -- NOT the whole-matrix Jacobi buffer of the fused kernel tested above (with 50
+    // layers that plan misses the 160 KB by a few hundred bytes, and the batch must not fall back to the fused kernel,
+    // four times slower, because of it)
+    const bool split128 = ctx->gmem_path && ctx->split && !ctx->big && plan.NMAX <= 128 &&
+        (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds &&
+        (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, 2).total * sizeof(double) <= (size_t)ctx->max_lds &&
+        (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 1).total * sizeof(double) <= (size_t)ctx->max_lds;
+    if (split128) ctx->jac_in_lds = 1;   // what the kernels read as "the finish kernel has its LDS scratch"
+    ctx->gmem_split = ctx->big || split128;
     if (ctx->big) ctx->jac_in_lds = 0;   // prep / finish of the big pipeline keep no Jacobi buffer in LDS
     if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
         const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer

@@ -201,6 +201,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
         if (active) nb = ch == 4 ? run_active<256, 4>(d, order, plan.total, matd) : run_active<256, 6>(d, order, plan.total, matd);
         else nb = ch == 4 ? run_pairs<256, 4>(d, order, plan.total, matd) : run_pairs<256, 6>(d, order, plan.total, matd);
     } else if (gmem && smrt_emu_pipeline && plan.NMAX <= 128 && nt == 256) {
+        d.jac_in_lds = 1;   // like smrt_dort_upload: the finish kernel of this pipeline always has its LDS scratch
         nb = active ? run_split_gmem<256, true>(d, order, plan) : run_split_gmem<256, false>(d, order, plan);
     } else if (active) {
         if (gmem) {

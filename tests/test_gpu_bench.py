@@ -117,3 +117,25 @@ def test_rccl_gather_single_process_communicator():
             ctx.gather([19], root=0)      # counts[own rank] must be the uploaded pair count
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
+    """50 layers x 64 streams (BASELINE configs[2]) must take the three-kernel pipeline on the global workspace, not the
+    fused kernel (four times slower): the choice once hinged on an LDS plan of the FUSED kernel that misses the 160 KB
+    by a few hundred bytes at 50 layers.  Guarded by throughput: > 2000 solves/s on 128 snowpacks x 7 frequencies."""
+    from smrt_amd._native import DortContext, PackedBatch
+
+    S, L = 128, 50
+    rng = np.random.default_rng(3)
+    thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 100.0)], axis=1)
+    freqs = np.array([6.925e9, 7.3e9, 10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
+    batch = PackedBatch([L] * S, thick, rng.uniform(150, 450, (S, L)) / 916.7, rng.uniform(230, 270, (S, L)),
+                        rng.uniform(5e-5, 1.5e-4, (S, L)), np.full((S, L), 0.2), freqs, np.deg2rad([55.0]),
+                        emmodel="dmrt_qca_shortrange", microstructure="sticky_hard_spheres", n_max_stream=64)
+    ctx = DortContext(0)
+    ctx.upload(batch)
+    ctx.launch(); ctx.sync(); ctx.launch(); ctx.sync()
+    rate = batch.n_pairs / ctx.last_kernel_ms() * 1e3
+    assert (ctx.download().status == 0).all()
+    assert rate > 2000.0, rate
