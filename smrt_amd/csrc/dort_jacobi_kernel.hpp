@@ -198,7 +198,8 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
     const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
     p.LDJ = ((rows + 31) / 32) * 32 + SMRT_JACOBI_GS;
-    p.NCOL = ((p.NMAX + 7) / 8) * 8 + 1;                // NB*ceil(N/NB) <= this - 1, plus the idle-slot column
+    // NB * ceil(N / NB) <= this - 1, plus the idle-slot column; NB = 8 column blocks (256 threads), 16 for N > 64 (512)
+    p.NCOL = p.NMAX > 64 ? ((p.NMAX + 15) / 16) * 16 + 1 : ((p.NMAX + 7) / 8) * 8 + 1;
     int o = p.NCOL * p.LDJ;
     p.o_sigma = o; o += p.NMAX + 16;
     p.o_rsig = o; o += p.NMAX + 16; // tracked column norms (padded columns included)
@@ -209,7 +210,7 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
 
 template <int NT, int RPL>
 SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
-    constexpr int JW = (NT / SMRT_LANES >= 4) ? 4 : NT / SMRT_LANES;
+    constexpr int JW = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: 4, or 8 (N > 64)
     constexpr int GS = SMRT_JACOBI_GS;
     constexpr int NB = 2 * JW;
     const int t = tid();

@@ -92,7 +92,8 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     return run_rounds(d, order, nmodes, sg,
         [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); })
                                                   : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
-        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        // (the product launches the Jacobi kernel of this pipeline with 512 threads: k_jacobi.hip)
+        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(512, order, [&]() { dort_jacobi_item<512>(d, sg.st, it, jl.data()); }); },
         [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
                                                   : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
