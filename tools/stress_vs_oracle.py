@@ -3,7 +3,10 @@
 emmodels, stream counts that exercise every kernel path (LDS pipeline, global-workspace pipeline, scalar kernel),
 passive / active, with and without substrate and atmosphere, ragged layer counts -- every pair against the CPU oracle.
 
-    python tools/stress_vs_oracle.py [seed] [prune]      ("prune": also draw a prune_deep_snowpack threshold per case)
+    python tools/stress_vs_oracle.py [seed] [prune|coherent]
+        "prune": also draw a prune_deep_snowpack threshold per case
+        "coherent": process_coherent_layers on, with millimetre-thin layers drawn into the snowpacks (some of them last or
+        in a row: the refusals of the reference must come back as status 6 for exactly those pairs)
 """
 import os, sys, time
 import numpy as np
@@ -14,6 +17,8 @@ from smrt_amd._native import DortContext, PackedBatch
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 with_prune = len(sys.argv) > 2 and sys.argv[2] == "prune"
+with_coherent = len(sys.argv) > 2 and sys.argv[2] == "coherent"
+n_coherent = n_refused = 0
 rng_prune = np.random.default_rng(1000 + (int(sys.argv[1]) if len(sys.argv) > 1 else 1))   # keeps the snowpack stream intact
 n_pruned = 0
 ctx = DortContext(0)
@@ -33,6 +38,9 @@ for mode, n, em, ms in cases:
     nl = rng.integers(1, Lmax + 1, S).astype(np.int32); nl[0] = Lmax
     thick = rng.uniform(0.03, 0.4, (S, Lmax)); 
     for s in range(S): thick[s, nl[s] - 1] = rng.choice([0.5, 100.0])
+    if with_coherent:   # thin crusts / lenses: a few millimetres (coherent at some of the frequencies only)
+        thin = rng_prune.random((S, Lmax)) < 0.3
+        thick = np.where(thin, rng_prune.uniform(0.0005, 0.006, (S, Lmax)), thick)
     dens = rng.uniform(150, 450, (S, Lmax)); temp = rng.uniform(230, 270, (S, Lmax))
     if ms == "exponential":
         p1 = rng.uniform(5e-5, 3e-4, (S, Lmax)); p2 = None
@@ -50,7 +58,8 @@ for mode, n, em, ms in cases:
     if with_prune and n * (3 if mode == "A" else 2) <= 128:   # the option needs a pipeline
         prune = [0.3, 1.0, 3.0, True][int(rng_prune.integers(0, 4))]
     b = PackedBatch(nl, thick, dens / 916.7, temp, p1, p2, freqs, np.deg2rad(theta), emmodel=em, microstructure=ms, mode=mode,
-                    n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm, prune_deep_snowpack=prune)
+                    n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm, prune_deep_snowpack=prune,
+                    process_coherent_layers=with_coherent)
     out = ctx.run(b)
     case_co = case_cx = 0.0; case_ratio = 1.0
     for f in range(len(freqs)):
@@ -65,10 +74,13 @@ for mode, n, em, ms in cases:
             try:
                 det = {}
                 ref = O.solve(sp, float(freqs[f]), theta, emmodel=em, mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2,
-                              method="schur_forcedtriu", substrate=osub, atmosphere=oatm, prune_deep_snowpack=prune, details=det)
+                              method="schur_forcedtriu", substrate=osub, atmosphere=oatm, prune_deep_snowpack=prune, details=det,
+                              process_coherent_layers_=with_coherent)
                 n_pruned += bool(det["pruned_at"]) and min(det["pruned_at"]) < k
+                n_coherent += with_coherent and len(det.get("kept_layers", range(k))) < k
             except O.OracleError as e:
                 assert out.status[p] == e.status, (mode, n, em, out.status[p], e.status)
+                n_refused += e.status == 6
                 continue
             assert out.status[p] == 0, (mode, n, em, ms, f, s, out.status[p])
             n_checked += 1
@@ -89,6 +101,7 @@ for mode, n, em, ms in cases:
                 if ratio > 1e-3: worst_cx = max(worst_cx, e_cx)
     extra = "" if mode == "P" else "  co %.1e  cross(own) %.1e  min cross/co %.1e" % (case_co, case_cx, case_ratio)
     print("%s n=%-3d %-22s %-20s sub=%d atm=%d  ok  (%.0f s)%s" % (mode, n, em, ms, sub is not None, atm is not None, time.time() - t0, extra), flush=True)
+if with_coherent: print("process_coherent_layers: %d of the checked pairs lost at least one layer, %d pairs refused (status 6) by both" % (n_coherent, n_refused))
 if with_prune: print("prune_deep_snowpack drawn per case: %d of the checked pairs were cut above their last layer" % n_pruned)
 print("checked %d pairs: max |dTb| = %.2e K, backscatter max rel (co-pol scale) = %.2e, cross-pol own scale (where cross/co > 1e-3) = %.2e" % (n_checked, worst_tb, worst_co, worst_cx))
 assert worst_tb < 1e-6 and worst_co < 1e-8 and worst_cx < 1e-6
