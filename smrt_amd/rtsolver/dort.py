@@ -39,8 +39,6 @@ class DORT(object):
                  rayleigh_jeans_approximation=False, devices=None, block_threads=0):
         if stream_mode != "most_refringent":
             raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
-        if phase_symmetrization:
-            raise SMRTError("phase_symmetrization is outside the scope of smrt_amd's DORT")
         if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
             prune_deep_snowpack = 6
         if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
@@ -57,6 +55,12 @@ class DORT(object):
         self.phase_normalization = phase_normalization
         self.error_handling = error_handling
         self.process_coherent_layers = bool(process_coherent_layers)
+        # phase_symmetrization (dort.py:104,173; rtsolver_utils.py:743-765) averages the (up, up) / (down, down) and the
+        # (up, down) / (down, up) blocks of the phase matrix.  The device formulation is built on exactly that mirror
+        # symmetry (it only ever forms P(mu, +mu') and P(mu, -mu')), which the device emmodels have to the last bit -- the
+        # reference's own result does not change by one ulp with the option on IBA -- so there it is a no-op; for emmodels
+        # evaluated on the host the averaging is applied when their matrices are packed.
+        self.phase_symmetrization = bool(phase_symmetrization)
         self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
         self.diagonalization_method = diagonalization_method
         self.rayleigh_jeans_approximation = bool(rayleigh_jeans_approximation)
@@ -331,6 +335,13 @@ class DORT(object):
                     # (ps, pi, m, mu_s, mu_i) -> m, (mu_s, ps), (mu_i, pi): the compressed order of core/lib.py:336-347
                     C = np.transpose(ft, (2, 3, 0, 4, 1)).reshape(modes, 2 * n * P, 2 * n * P)
                     nP = n * P
+                    if self.phase_symmetrization:   # rtsolver_utils.py:743-765 (sign -1 between U and V | H for m >= 1)
+                        sgn = np.where(np.arange(nP) % P < 2, 1.0, -1.0)
+                        d = np.ones((modes, 1, 1)) * (sgn[:, None] * sgn[None, :])
+                        d[0] = 1.0 if P == 2 else d[0]
+                        C = C.copy()
+                        C[:, :nP, :nP] = 0.5 * (C[:, :nP, :nP] + d * C[:, nP:, nP:])
+                        C[:, :nP, nP:] = 0.5 * (C[:, :nP, nP:] + d * C[:, nP:, :nP])
                     vh = np.arange(nP)[np.arange(nP) % P < 2]
                     for blk in (C[0][:nP, :nP], C[0][:nP, nP:]):   # the device reads the lower triangles only
                         sub = blk[np.ix_(vh, vh)]

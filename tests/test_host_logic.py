@@ -356,10 +356,11 @@ def test_dort_option_validation():
 
     DORT(n_max_stream=64, diagonalization_method="half_rank_eig", error_handling="nan")
     for bad in (dict(stream_mode="uniform_air"), dict(prune_deep_snowpack=-1), dict(diagonalization_method="foo"),
-                dict(error_handling="ignore"), dict(phase_symmetrization=True)):
+                dict(error_handling="ignore")):
         with pytest.raises(SMRTError):
             DORT(**bad)
     assert DORT(process_coherent_layers=True).process_coherent_layers is True
+    assert DORT(phase_symmetrization=True).phase_symmetrization is True   # a no-op for the device emmodels (see DORT)
     # prune_deep_snowpack: True is an optical depth of 6 (smrt/rtsolver/dort.py:176-178); the cache option is a no-op
     assert DORT(prune_deep_snowpack=True).prune_deep_snowpack == 6.0
     assert DORT(prune_deep_snowpack=2.5, diagonalization_cache=True).prune_deep_snowpack == 2.5
@@ -466,6 +467,18 @@ def test_host_evaluated_emmodels_are_packed_for_the_device():
             P = super().ft_even_phase(mu_s, mu_i, m_max, npol)
             P[0, 0, 0] *= 1.0 + np.asarray(mu_i)[None, :]
             return P
+
+    class Lopsided(Rayleigh):   # down-down block 2 % stronger than up-up: phase_symmetrization averages the two
+        def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):
+            P = super().ft_even_phase(mu_s, mu_i, m_max, npol)
+            h = len(mu_s) // 2
+            P[..., h:, h:] *= 1.02
+            return P
+
+    plain = solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Rayleigh, {})] * 2])
+    lop = DORT(n_max_stream=8, phase_symmetrization=True)._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Lopsided, {})] * 2])
+    np.testing.assert_allclose(lop.host_phase[..., 0, :, :], 1.01 * plain.host_phase[..., 0, :, :], rtol=1e-12)
+    np.testing.assert_allclose(lop.host_phase[..., 1, :, :], plain.host_phase[..., 1, :, :], rtol=1e-12)
 
     for cls, msg in ((Anisotropic, "isotropic"), (NotReciprocal, "reciprocity")):
         with pytest.raises(SMRTError, match=msg):
