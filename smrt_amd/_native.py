@@ -28,7 +28,8 @@ STATUS_MESSAGES = {
     3: "The diagonalization failed in DORT: single scattering albedo >= 1 in a layer (too large grain size for the "
        "emmodel?).",
     4: "The boundary-condition system is singular.",
-    5: "Invalid layer properties (temperature above the freezing point, or fewer than two streams in a layer).",
+    5: "Invalid layer properties (temperature above the freezing point, fewer than two streams in a layer, or -- for an "
+       "emmodel evaluated on the host -- a negative ka / permittivity or a stream count that differs from the device's).",
     6: "process_coherent_layers: the last layer is coherent, or two successive layers are coherent; this is not supported.",
 }
 
