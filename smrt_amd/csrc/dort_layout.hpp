@@ -47,6 +47,10 @@ struct DevBatch {
     // layer_lo = 0 and layer_hi = Lmax.
     int layer_lo, layer_hi;
     const int* pair_done;
+    // Order in which the workgroups of a launch take the pairs of the chunk: dispatch[w] = pair slot of workgroup w (a
+    // permutation of 0 .. pair_count - 1, sorted by estimated cost at upload time), or null: w itself.  Everything else --
+    // outputs, staging items, pair_done -- stays indexed by the pair slot.
+    const int* dispatch;
     double* out;
     int* status;
     double* layer_out;
@@ -73,11 +77,19 @@ SMRT_DEV long long global_pair(const DevBatch& b, long long p) {
     return b.pair_map ? b.pair_map[b.pair_begin + p] : b.pair_begin + p;
 }
 
+// pair slot handled by the w-th workgroup (or grid-stride step) of a launch
+SMRT_DEV long long dispatched_pair(const DevBatch& b, long long w) { return b.dispatch ? (long long)b.dispatch[w] : w; }
+
 // staging item of the blk-th workgroup of a Jacobi launch that covers the layers [layer_lo, layer_hi) of every
-// (pair, azimuth mode): item = (pair * modes + mode) * Lmax + layer
+// (pair, azimuth mode): item = (pair * modes + mode) * Lmax + layer, pairs in dispatch order
 SMRT_DEV long long jacobi_item_of_block(const DevBatch& b, long long blk) {
     const int span = b.layer_hi - b.layer_lo;
-    return (blk / span) * b.Lmax + b.layer_lo + (blk % span);
+    long long row = blk / span;   // pair * modes + mode
+    if (b.dispatch) {
+        const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;
+        row = (long long)b.dispatch[row / nmodes] * nmodes + row % nmodes;
+    }
+    return row * b.Lmax + b.layer_lo + (blk % span);
 }
 
 constexpr double kCSpeed = 299792458.0;

@@ -8,12 +8,12 @@ using namespace smrt;
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_passive_kernel(DevBatch b) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1>(b, (long long)blockIdx.x, smrt_lds);
+    dort_pair_passive<NT, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds);
 }
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_active_kernel(DevBatch b) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, 1>(b, (long long)blockIdx.x, smrt_lds);
+    dort_pair_active<NT, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds);
 }
 
 namespace smrt_launch {

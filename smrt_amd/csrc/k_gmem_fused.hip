@@ -10,7 +10,7 @@ __global__ __launch_bounds__(NT) void dort_passive_kernel_gmem(DevBatch b, doubl
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, CH>(b, p, smrt_lds, mat);
+        dort_pair_passive<NT, CH>(b, dispatched_pair(b, p), smrt_lds, mat);
         __syncthreads();
     }
 }
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NT) void dort_active_kernel_gmem(DevBatch b, double
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, CH>(b, p, smrt_lds, mat);
+        dort_pair_active<NT, CH>(b, dispatched_pair(b, p), smrt_lds, mat);
         __syncthreads();
     }
 }

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        dort_pair_passive<NT, 2, 1>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(NT, SMRT_GMEM_FINISH_WAVES) void dort_finish_kernel
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        dort_pair_passive<NT, 2, 2>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(NT) void dort_active_prep_kernel_gmem(DevBatch b, D
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, 2, 1>(b, p, smrt_lds, mat, &st);
+        dort_pair_active<NT, 2, 1>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NT, SMRT_GMEM_FINISH_WAVES) void dort_active_finish
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, 2, 2>(b, p, smrt_lds, mat, &st);
+        dort_pair_active<NT, 2, 2>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }

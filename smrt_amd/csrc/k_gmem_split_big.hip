@@ -17,7 +17,7 @@ __global__ __launch_bounds__(NT, (MODE == 2 ? SMRT_BIG_FINISH_WAVES : 1)) void d
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_passive<NT, CH, MODE>(b, p, smrt_lds, mat, &st);
+        dort_pair_passive<NT, CH, MODE>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(NT, (MODE == 2 ? SMRT_BIG_FINISH_WAVES : 1)) void d
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
-        dort_pair_active<NT, CH, MODE>(b, p, smrt_lds, mat, &st);
+        dort_pair_active<NT, CH, MODE>(b, dispatched_pair(b, p), smrt_lds, mat, &st);
         __syncthreads();
     }
 }

@@ -8,12 +8,12 @@ using namespace smrt;
 template <int NT>
 __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_prep_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+    dort_pair_active<NT, 1, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
 template <int NT>
 __global__ __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) void dort_active_finish_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_active<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+    dort_pair_active<NT, 1, 3>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
 
 namespace smrt_launch {

@@ -8,20 +8,20 @@ using namespace smrt;
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_prep_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 1>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+    dort_pair_passive<NT, 1, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
 // four N x N matrices in LDS: one workgroup per CU (kept for A/B runs, smrt_dort_set_pipeline(ctx, 2))
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 2>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+    dort_pair_passive<NT, 1, 2>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
 // two LDS slots + F, G in the (dead) staging slots of the item: two workgroups per CU
 // (second launch-bound argument on HIP = wavefronts per SIMD the compiler must leave room for: 2 -> <= 256 VGPRs)
 template <int NT>
 __global__ __launch_bounds__(NT, 2) void dort_finish2_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    dort_pair_passive<NT, 1, 3>(b, (long long)blockIdx.x, smrt_lds, nullptr, &st);
+    dort_pair_passive<NT, 1, 3>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
 
 namespace smrt_launch {
