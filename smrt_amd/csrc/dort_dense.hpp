@@ -354,6 +354,18 @@ SMRT_DEV void gemm_tile(double (&c)[4], int K, int ti, int tj, FA fa, FB fb) {
     for (int k0 = 0; k0 < K; k0 += 4) mfma_f64_16x16x4(fa(ti * 16 + lr, k0 + lk), fb(k0 + lk, tj * 16 + lr), c);
 }
 // store / load an accumulator tile to a column-major matrix (element (r, c) at [c*LD + r]), rows/cols < N only
+// Element (r, c) of a symmetric / lower-triangular N x N matrix.  PK = false: the usual column-major layout with leading
+// dimension LD.  PK = true: only the lower triangle is stored, column after column (column c holds rows c .. LD - 1, LD =
+// the padded order): half the LDS, which is what lets THREE prep workgroups share a CU.  An address above the diagonal
+// maps onto its mirror image (valid memory: reads of it are masked or symmetric, writes must be guarded by the caller).
+template <bool PK>
+SMRT_DEV int sidx(int r, int c, int LD) {
+    if (!PK) return c * LD + r;
+    const int rr = r >= c ? r : c, cc = r >= c ? c : r;
+    return cc * LD - ((cc * (cc - 1)) >> 1) + (rr - cc);
+}
+SMRT_HD int packed_lower_doubles(int n) { return n * (n + 1) / 2; }
+
 template <class F>
 SMRT_DEV void tile_foreach(int ti, int tj, int N, F f) {
     const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
@@ -369,7 +381,7 @@ SMRT_DEV void tile_foreach(int ti, int tj, int N, F f) {
 // reverse_cols: column c of the product is stored as column N-1-c.  The column norms of B = L+^T L- grow with the
 // column index (beta ~ ke / mu, mu descending); the one-sided Jacobi converges in fewer sweeps when the large
 // columns come first (de Rijk), and nothing downstream depends on the order of the eigenpairs.
-template <int NT>
+template <int NT, bool PK = false>   // PK: Lp and Lm in packed lower storage (C is always a full matrix)
 SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int N, int LD, bool reverse_cols = false) {
     const int wave = tid() / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
@@ -383,7 +395,7 @@ SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int
         const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
         for (int k0 = kmin; k0 < N; k0 += 4) {
             const int k = k0 + lk, kc = k < N ? k : N - 1;
-            const double av = Lp[ic * LD + kc], bv = Lm[jc * LD + kc];
+            const double av = Lp[sidx<PK>(kc, ic, LD)], bv = Lm[sidx<PK>(kc, jc, LD)];
             mfma_f64_16x16x4((i < N && k < N && k >= i) ? av : 0.0, (j < N && k < N && k >= j) ? bv : 0.0, c);
         }
         tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[(reverse_cols ? N - 1 - col : col) * LD + row] = c[reg]; });
@@ -938,7 +950,7 @@ SMRT_DEV void r45_rows(double* F, const double* G, const double* Q, double* Wk, 
 // wavefront per matrix with lane = row and the row in registers; the panel below (L_IJ = A_IJ inv(L_JJ)^T) and the
 // trailing update (A_IK -= L_IJ L_KJ^T) are MFMA tile GEMMs.  3 workgroup barriers per block column (12 for N = 64)
 // instead of one per column, and the O(N^3) part runs on the matrix core.
-template <int NT>
+template <int NT, bool PK = false>
 SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int* fail, int N, int LD,
                          double* inv_out = nullptr /* [4][256]: inverses of the diagonal blocks of the first factor */) {
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
@@ -957,7 +969,7 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
             for (int j = 0; j < 16; ++j) {
                 const int gj = b0 + j;
                 const int gic = gi < N ? gi : N - 1, gjc = gj < N ? gj : N - 1;
-                const double v = A[gjc * LD + gic];
+                const double v = A[sidx<PK>(gic, gjc, LD)];
                 row[j] = (gi < N && gj < N) ? v : ((lr == j) ? 1.0 : 0.0);   // identity padding
             }
             bool ok = true;
@@ -977,7 +989,7 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int gj = b0 + j;
-                    if (gi < N && gj < N && j <= lr) A[gj * LD + gi] = row[j];
+                    if (gi < N && gj < N && j <= lr) A[sidx<PK>(gi, gj, LD)] = row[j];
                 }
             }
             // inverse of L_JJ by forward substitution, lane = column of the inverse; L[i][k] = row[k] of lane i
@@ -1013,11 +1025,11 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = 4 * kk + lk, gk = b0 + k, gkc = gk < N ? gk : N - 1;
-                    const double av = A[gkc * LD + ic];
+                    const double av = A[sidx<PK>(ic, gkc, LD)];
                     const double bv = inv[mi * 256 + k * 16 + lr];          // (L^-1)[lr][k] = invT[k][lr]
                     mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, bv, c);
                 }
-                tile_foreach(I, J, N, [&](int reg, int row_, int col) { A[col * LD + row_] = c[reg]; });
+                tile_foreach(I, J, N, [&](int reg, int row_, int col) { A[sidx<PK>(row_, col, LD)] = c[reg]; });
             }
         }
         block_sync();
@@ -1038,10 +1050,10 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int gk = b0 + 4 * kk + lk, gkc = gk < N ? gk : N - 1;
-                    const double av = A[gkc * LD + ic], bv = A[gkc * LD + jc];
+                    const double av = A[sidx<PK>(ic, gkc, LD)], bv = A[sidx<PK>(jc, gkc, LD)];
                     mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, (j < N && gk < N) ? bv : 0.0, c);
                 }
-                tile_foreach(I, K, N, [&](int reg, int row_, int col) { A[col * LD + row_] -= c[reg]; });
+                tile_foreach(I, K, N, [&](int reg, int row_, int col) { if (!PK || row_ >= col) A[sidx<PK>(row_, col, LD)] -= c[reg]; });
             }
         }
         block_sync();

@@ -266,7 +266,9 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
                                    : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
-        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd, 1).total * sizeof(double);
+        // (the LDS-resident passive prep kernel stores its two matrices as packed lower triangles: plan 3)
+        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd,
+                                                (!ctx->gmem_split && !ctx->active) ? 3 : 1).total * sizeof(double);
         ctx->finish2_lds_bytes = ctx->gmem_split
             ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 0 : 2).total * sizeof(double)
             : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd_fin, 2).total * sizeof(double);

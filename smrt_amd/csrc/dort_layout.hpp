@@ -157,11 +157,17 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.nphi = nphi;
     p.ntheta = ntheta;
     p.matrices_in_lds = matrices_in_lds;
+    // slim = 3: the prep kernel of the LDS-resident passive pipeline -- like slim = 1, but its two symmetric matrices are
+    // stored as packed lower triangles (sidx<true>, dort_dense.hpp): 34 KB instead of 67 KB at 32 streams, so that THREE
+    // workgroups share a CU
+    const bool packed = (slim == 3);
+    if (packed) slim = 1;
     const int nmat = slim ? 2 : 4;
-    p.mat_doubles = nmat * p.NMAX * p.LD;
+    const int one = packed ? (p.LD * (p.LD + 1)) / 2 : p.NMAX * p.LD;
+    p.mat_doubles = nmat * one;
     p.scratch_doubles = !matrices_in_lds ? 16 * p.NMAX : 0;
     int o = 0;
-    for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * p.NMAX * p.LD; }
+    for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * one; }
     if (slim == 2) p.o_M[3] = p.NMAX * p.LD;  // the two-slot finish kernel: M0 = X, M3 = R (M1, M2 live in global memory)
     if (matrices_in_lds) o = p.mat_doubles;
     p.slim = slim;

@@ -241,7 +241,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     constexpr int NW = NT / SMRT_LANES;
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
-                                   MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
+                                   MODE == 1 ? (CH == 1 ? 3 : 1) : (MODE == 3 ? 2 : 0),
                                    (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
@@ -258,6 +258,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int LD = plan.LD;
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
+    // the LDS-resident prep kernel keeps X+- / L+- as packed lower triangles (make_plan slim = 3)
+    constexpr bool PK = (MODE == 1 && CH == 1);
 
     const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
@@ -463,18 +465,20 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                     }
                 }
                 const int r0 = 2 * i, c0 = 2 * j;
-                s.M0[c0 * LD + r0] = pvv_p + pvv_m;             s.M1[c0 * LD + r0] = pvv_p - pvv_m;
-                s.M0[(c0 + 1) * LD + r0] = pvh_p + pvh_m;       s.M1[(c0 + 1) * LD + r0] = pvh_p - pvh_m;
-                s.M0[c0 * LD + r0 + 1] = phv_p + phv_m;         s.M1[c0 * LD + r0 + 1] = phv_p - phv_m;
-                s.M0[(c0 + 1) * LD + r0 + 1] = phh_p + phh_m;   s.M1[(c0 + 1) * LD + r0 + 1] = phh_p - phh_m;
+                s.M0[sidx<PK>(r0, c0, LD)] = pvv_p + pvv_m;             s.M1[sidx<PK>(r0, c0, LD)] = pvv_p - pvv_m;
+                if (!PK || i > j) {   // (V, H) of a diagonal stream block lies above the diagonal: its mirror (H, V) is written below
+                    s.M0[sidx<PK>(r0, c0 + 1, LD)] = pvh_p + pvh_m;     s.M1[sidx<PK>(r0, c0 + 1, LD)] = pvh_p - pvh_m;
+                }
+                s.M0[sidx<PK>(r0 + 1, c0, LD)] = phv_p + phv_m;         s.M1[sidx<PK>(r0 + 1, c0, LD)] = phv_p - phv_m;
+                s.M0[sidx<PK>(r0 + 1, c0 + 1, LD)] = phh_p + phh_m;     s.M1[sidx<PK>(r0 + 1, c0 + 1, LD)] = phh_p - phh_m;
             }
         }
         block_sync();
         // -- energy-conserving renormalisation (dort.py:782-819): norm_r = ks / (c sum_c S+[r,c] w_c), c = 1/2
         for (int r = t; r < N; r += NT) {
             double rs = 0.0;
-            for (int c = 0; c <= r; ++c) rs += s.M0[c * LD + r] * s.wrow[c];
-            for (int c = r + 1; c < N; ++c) rs += s.M0[r * LD + c] * s.wrow[c];
+            for (int c = 0; c <= r; ++c) rs += s.M0[sidx<PK>(r, c, LD)] * s.wrow[c];
+            for (int c = r + 1; c < N; ++c) rs += s.M0[sidx<PK>(c, r, LD)] * s.wrow[c];
             double nr = 1.0;
             if (b.normalization != 0 && ks != 0.0) {
                 nr = ks / (0.5 * rs);
@@ -494,13 +498,13 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             if (r >= c) {
                 const double uu = 0.5 * s.u[r] * s.u[c];
                 const double dg = (r == c) ? ke / s.mrow[r] : 0.0;
-                s.M0[c * LD + r] = dg - uu * s.M0[c * LD + r];
-                s.M1[c * LD + r] = dg - uu * s.M1[c * LD + r];
+                s.M0[sidx<PK>(r, c, LD)] = dg - uu * s.M0[sidx<PK>(r, c, LD)];
+                s.M1[sidx<PK>(r, c, LD)] = dg - uu * s.M1[sidx<PK>(r, c, LD)];
             }
         });
         block_sync();
         SMRT_STAGE(SG_CHOL);
-        if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
+        if (!(dense_mfma ? chol2_mfma<NT, PK>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
                                        (MODE == 1 && CH == 1) ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
                       : chol2<NT>(s.M0, s.M1, N, LD))) {
             if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
@@ -508,7 +512,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         SMRT_STAGE(SG_BTL);
         if (MODE == 1) {  // B = L+^T L- straight from the accumulators into the staging area
-            lt_times_l_mfma<NT>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD,
+            lt_times_l_mfma<NT, PK>(s.M0, s.M1, stg->B + (p * (long long)b.Lmax + l) * stg->mat_stride, N, LD,
 #ifdef SMRT_NO_COLUMN_REVERSAL
                                 false);
 #else
@@ -522,7 +526,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (MODE == 1) {  // park L+ and d for the finish kernel (B is already there)
             const long long item = p * (long long)b.Lmax + l;
             double* gL = stg->L + item * stg->mat_stride;
-            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = s.M0[c * LD + r]; });
+            for_2d<NT>(N, N, [&](int r, int c) { gL[c * LD + r] = (PK && r < c) ? 0.0 : s.M0[sidx<PK>(r, c, LD)]; });
             for (int r = t; r < N; r += NT) stg->d[item * stg->vec_stride + r] = s.d[r];
             if (t == 0) stg->n[item] = N;
             block_sync();
@@ -658,6 +662,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
 
     if (MODE == 1) {
         if (t == 0) b.status[p] = ST_OK;
+#ifdef SMRT_STAGE_TIMING
+        SMRT_STAGE(SG_OUT);   // the prep kernel's own stages: slots 0..3 (the finish kernel fills the others)
+        if (t == 0 && b.stage_out) for (int k = 0; k < 4; ++k) b.stage_out[p * 16 + k] = stage_acc[k];
+#endif
         return;
     }
     SMRT_STAGE(SG_OUT);
@@ -710,10 +718,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
 #ifdef SMRT_STAGE_TIMING
     SMRT_STAGE(SG_OUT);
     if (t == 0 && b.stage_out) {
-        for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+        for (int k = (MODE >= 2 ? 4 : 0); k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;   // (0..3: the prep kernel's)
         b.stage_out[p * 16 + 12] = (double)n_sweeps;
         for (int k = 0; k < 3; ++k) b.stage_out[p * 16 + 13 + k] = sub_acc_store[k];
-        b.stage_out[p * 16 + 0] = sub_acc_store[3]; b.stage_out[p * 16 + 1] = sub_acc_store[4]; b.stage_out[p * 16 + 2] = sub_acc_store[5];  // (overrides setup/assemble/cholesky slots in this debug build)
     }
 #endif
 }

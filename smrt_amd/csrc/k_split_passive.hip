@@ -5,8 +5,12 @@
 
 using namespace smrt;
 
+#ifndef SMRT_PREP_WAVES
+#define SMRT_PREP_WAVES 3   // wavefronts per SIMD the prep kernel leaves room for: its LDS plan (two packed lower
+                           // triangles, 45 KB at 32 streams) lets three workgroups share a CU
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void dort_prep_kernel(DevBatch b, DevStage st) {
+__global__ __launch_bounds__(NT, SMRT_PREP_WAVES) void dort_prep_kernel(DevBatch b, DevStage st) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, 1, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }

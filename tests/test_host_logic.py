@@ -413,7 +413,7 @@ def test_kernel_occupancy_as_designed():
         for blk in open(f).read().split(" Function Name: ")[1:]:
             name = blk.split()[0]
             waves[name] = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk).group(1))
-    want = {"dort_finish2_kernelILi256E": 2, "dort_prep_kernelILi256E": 2, "dort_jacobi_kernelILi256E": 4,
+    want = {"dort_finish2_kernelILi256E": 2, "dort_prep_kernelILi256E": 3, "dort_jacobi_kernelILi256E": 4,
             "dort_active_finish_kernelILi256E": 2, "dort_active_prep_kernelILi256E": 2, "dort_finish_kernel_gmemILi256E": 2,
             "dort_active_finish_kernel_gmemILi256E": 2, "dort_passive_big_kernelILi256ELi6ELi2E": 2,
             "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3}
