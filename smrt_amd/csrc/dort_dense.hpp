@@ -972,7 +972,12 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
                 const double v = A[sidx<PK>(gic, gjc, LD)];
                 row[j] = (gi < N && gj < N) ? v : ((lr == j) ? 1.0 : 0.0);   // identity padding
             }
+            // Cholesky of the block and, interleaved with it, the inverse of its factor by forward substitution (lane =
+            // column of the inverse; L[i][m] = row[m] of lane i): row k of L is final after step k, so row k of the inverse
+            // follows at once -- two independent dependency chains in one instruction stream instead of one after the
+            // other -- and 1 / L_kk is the reciprocal square root of the step
             bool ok = true;
+            double x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const double akk = wave_bcast(row[k], k);
@@ -983,6 +988,11 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if (j > k) { const double ljk = wave_bcast(lik, j); row[j] -= lik * ljk; }
+                double acc = (k == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if (m < k) { const double lkm = wave_bcast(row[m], k); acc -= lkm * ((m >= lr) ? x[m] : 0.0); }
+                x[k] = (k >= lr) ? acc * rk : 0.0;
             }
             if (!ok && lane == 0) *fail = 1;
             if (lane < 16) {
@@ -991,17 +1001,6 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
                     const int gj = b0 + j;
                     if (gi < N && gj < N && j <= lr) A[sidx<PK>(gi, gj, LD)] = row[j];
                 }
-            }
-            // inverse of L_JJ by forward substitution, lane = column of the inverse; L[i][k] = row[k] of lane i
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double acc = (i == lr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < i) { const double lik2 = wave_bcast(row[k], i); acc -= lik2 * ((k >= lr) ? x[k] : 0.0); }
-                const double dii = wave_bcast(row[i], i);
-                x[i] = (i >= lr) ? acc * fast_rcp(dii) : 0.0;
             }
             if (lane < 16) {
 #pragma unroll
