@@ -119,21 +119,23 @@ SMRT_DEV double fast_rsqrt(double x) {
     e = __builtin_fma(-h * y, y, 0.5);
     return __builtin_fma(y, e, y);
 }
-// DPP cross-lane move of a double (two 32-bit DPP movs); CTRL is a DPP control word
+// DPP cross-lane move of a double (two 32-bit DPP movs); CTRL is a DPP control word.  mov_dpp, not update_dpp(0, ...):
+// with full row / bank masks every lane is written, and an `old` operand of 0 costs a v_mov_b32 per DPP move (six
+// instructions per 8-lane group sum in the Jacobi step)
 template <int CTRL>
 SMRT_DEV double dpp_move(double v) {
     union { double d; int i[2]; } a, r;
     a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, false);
+    r.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, 0xF, 0xF, false);
     return r.d;
 }
 template <int CTRL>
 SMRT_DEV unsigned long long dpp_move_u64(unsigned long long v) {
     union { unsigned long long u; int i[2]; } a, r;
     a.u = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, false);
+    r.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, 0xF, 0xF, false);
     return r.u;
 }
 SMRT_DEV unsigned long long readlane_u64(unsigned long long v, int lane) {
@@ -170,10 +172,10 @@ SMRT_DEV unsigned wave_bcast_u32(unsigned v, int src_lane) { return (unsigned)__
 // max over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row: four DPP steps
 SMRT_DEV unsigned row16_max_u32(unsigned k) {
     unsigned o;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [1,0,3,2]
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [2,3,0,1]
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;  // row_half_mirror
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;  // row_mirror
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [1,0,3,2]
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;   // quad_perm [2,3,0,1]
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;  // row_half_mirror
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;  // row_mirror
     return k;
 }
 // D = A(16x4) B(4x16) + C on the matrix core, v_mfma_f64_16x16x4_f64.  Lane layout (pinned on gfx950 by
@@ -189,20 +191,20 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
 // row_bcast31 carry the row maxima across (lane 63 ends up with the maximum of all 64), one readlane
 SMRT_DEV unsigned wave_max_u32(unsigned k) {
     unsigned o;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
     o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x142, 0xA, 0xF, false); k = o > k ? o : k;
     o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x143, 0xC, 0xF, false); k = o > k ? o : k;
     return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
 }
 SMRT_DEV unsigned wave_max_u32_rl(unsigned k) {
     unsigned o;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
-    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0xB1, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x4E, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x141, 0xF, 0xF, false); k = o > k ? o : k;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)k, 0x140, 0xF, 0xF, false); k = o > k ? o : k;
     const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)k, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)k, 16),
                    r2 = (unsigned)__builtin_amdgcn_readlane((int)k, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)k, 48);
     const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
