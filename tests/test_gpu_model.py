@@ -448,7 +448,6 @@ def test_process_coherent_layers_through_the_model():
     for i, f in enumerate(d["frequency"]):
         np.testing.assert_allclose(np.ravel(res.TbV(frequency=f)), d["result"][i, 0], atol=1e-6)
         np.testing.assert_allclose(np.ravel(res.TbH(frequency=f)), d["result"][i, 1], atol=1e-6)
-        ks = np.ravel(res.other_data["ks"].sel_data(frequency=f).values) if hasattr(res.other_data["ks"], "sel_data") else None
     ks = np.asarray(res.other_data["ks"].values)           # (frequency, layer), NaN after the kept layers
     th = np.asarray(res.other_data["thickness"].values)
     for i in range(len(d["frequency"])):
