@@ -10,8 +10,11 @@ using namespace smrt;
 #define SMRT_GMEM_FINISH_WAVES 2   // wavefronts per SIMD the finish kernels leave room for
 #endif
 
+#ifndef SMRT_GMEM_PREP_WAVES
+#define SMRT_GMEM_PREP_WAVES 2
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
+__global__ __launch_bounds__(NT, SMRT_GMEM_PREP_WAVES) void dort_prep_kernel_gmem(DevBatch b, DevStage st, double* workspace, long long ws_stride) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     double* mat = workspace + (long long)blockIdx.x * ws_stride;
     for (long long p = blockIdx.x; p < b.pair_count; p += gridDim.x) {
