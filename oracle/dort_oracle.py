@@ -564,6 +564,13 @@ def interface_diagonals(eps, st, npol, substrate=None, slabs=None, frequency=Non
         elif substrate is not None and substrate["kind"] == "flat":  # rtsolver_utils.py:544-547,579-584
             itf["Rbot"].append(flat_reflection(eps[l], substrate["eps"], st.mu[l], npol))
             itf["Tbot"].append(flat_transmission(eps[l], substrate["eps"], st.mu[l], npol))
+        elif substrate is not None and substrate["kind"] == "host":
+            # dense reflection matrices per azimuth mode handed over by the caller (rtsolver_utils.py:567-597,690-707:
+            # specular diagonal + 2 pi | pi x weighted diffuse modes), picked up in dort_mode; no emission terms (active)
+            itf["Rbot"].append(np.zeros((npol, st.n[l])))
+            itf["Tbot"].append(np.zeros((npol, st.n[l])))
+            itf["Rbot_dense"] = substrate["R"]          # list over modes of (n P x n P) arrays
+            itf["Rbot_coh"] = substrate["Rcoh"]         # list over modes of the specular diagonals
         elif substrate is not None and substrate["kind"] == "reflector":
             if npol > 2:
                 raise NotImplementedError("reflector substrate in active mode (reflector.py: not implemented)")
@@ -762,7 +769,11 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
             nc0 = min(len(Tair), N[0])
             b[row_top[0] : row_top[0] + nc0] += (Tair[:, None] * intensity_down)[:nc0]
         # bottom of layer l (eq 18 & 22, dort.py:400-427)
-        _put_block(ab, nband, row_bot[l], j, (Eu - Rbot[:, None] * Ed) * tb[None, :])
+        if l == L - 1 and "Rbot_dense" in itf:   # rough substrate: dense reflection matrix of this mode (diagonal if coherent only)
+            Rmat = np.diag(itf["Rbot_coh"][m]) if coherent_only else np.asarray(itf["Rbot_dense"][m])
+            _put_block(ab, nband, row_bot[l], j, (Eu - Rmat @ Ed) * tb[None, :])
+        else:
+            _put_block(ab, nband, row_bot[l], j, (Eu - Rbot[:, None] * Ed) * tb[None, :])
         if l > 0:
             nc = min(N[l], N[l - 1])
             _put_block(ab, nband, row_bot[l - 1], j, -((Ttop[:, None] * Eu) * tt[None, :])[:nc])

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsm
 
 EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4}
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
-SUBSTRATE_CODES = {"flat": 1, "reflector": 2}
+SUBSTRATE_CODES = {"flat": 1, "reflector": 2, "host": 3}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}
 STATUS_MESSAGES = {
     1: "The eigen-decomposition did not converge in DORT.",
@@ -71,6 +71,8 @@ class SmrtBatch(C.Structure):
         ("host_streams", C.POINTER(C.c_int32)),
         ("host_phase", C.POINTER(C.c_double)),
         ("process_coherent_layers", C.c_int32),
+        ("host_substrate", C.POINTER(C.c_double)),
+        ("host_substrate_coh", C.POINTER(C.c_double)),
     ]
 
 
@@ -129,7 +131,15 @@ class PackedBatch:
             prune_deep_snowpack = 6.0
         s.prune_optical_depth = float(prune_deep_snowpack) if prune_deep_snowpack else 0.0
         s.substrate_kind = 0
-        if substrate is not None:
+        if substrate is not None and substrate[0] == "host":
+            # rough substrate, active mode: ("host", R[F*S][modes][NE][NE], Rcoh[F*S][modes][NE]) -- the dense reflection
+            # matrices of the bottom boundary per azimuth mode and their specular diagonals (include/smrt_dort.h)
+            FS, nm, ne = S * len(self.frequency), int(m_max) + 1, 3 * int(n_max_stream)
+            self.host_substrate = np.ascontiguousarray(np.asarray(substrate[1], np.float64).reshape(FS, nm, ne, ne))
+            self.host_substrate_coh = np.ascontiguousarray(np.asarray(substrate[2], np.float64).reshape(FS, nm, ne))
+            s.substrate_kind = SUBSTRATE_CODES["host"]
+            s.host_substrate, s.host_substrate_coh = _dptr(self.host_substrate), _dptr(self.host_substrate_coh)
+        elif substrate is not None:
             kind, q1, q2, ts = substrate
             F = len(self.frequency)
             self.sub_p1 = np.ascontiguousarray(np.broadcast_to(np.asarray(q1, np.float64), (F, S)))

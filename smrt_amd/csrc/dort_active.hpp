@@ -183,6 +183,9 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 Rt = R3[pol];
             }
         } else
+        if (b.sub_kind == SUB_HOST && j < (int)s.nl[L - 1]) {   // specular part of a rough substrate, from the caller (mode 0)
+            Rt = b.host_substrate_coh[(gp * (long long)(m_max + 1)) * (3 * nmax) + 2 * j + pol];
+        } else
         if (b.sub_kind == SUB_FLAT && j < (int)s.nl[L - 1]) {  // specular reflection of the substrate
             const double rs = s.ri[L - 1] * s.gsin[j];
             double R3[3], T3[3];
@@ -278,6 +281,12 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     else fresnel_RT3(el, ebelow, s.mu[j], R3, T3);
                     for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
                 }
+            }
+            if (MODE != 1 && l == Lk - 1 && Lk == L && b.sub_kind == SUB_HOST) {
+                // rough substrate: the recursion starts from the caller's dense reflection matrix of this mode (smrt_dort.h)
+                const int NE = 3 * nmax;
+                const double* H = b.host_substrate + (gp * (long long)(m_max + 1) + m) * NE * NE;
+                for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = H[r * NE + c]; });
             }
             for (int j = t; j < n; j += NT) {
                 double w;

@@ -302,6 +302,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         if (upload_array(ctx, ctx->d_hostphase, b->host_phase, sizeof(double) * PL * host_modes * 2 * host_ne * host_ne)) return -1;
     }
     const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
+    if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {   // dense reflection matrices of a rough substrate, evaluated by the caller
+        const size_t ne = 3 * (size_t)b->n_max_stream, nm = (size_t)b->m_max + 1;
+        if (upload_array(ctx, ctx->d_sub1, b->host_substrate, sizeof(double) * FS * nm * ne * ne)) return -1;
+        if (upload_array(ctx, ctx->d_sub2, b->host_substrate_coh, sizeof(double) * FS * nm * ne)) return -1;
+    } else
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
         if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;
         if (upload_array(ctx, ctx->d_sub2, b->substrate_p2, sizeof(double) * FS)) return -1;
@@ -347,6 +352,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.coherent = b->process_coherent_layers ? 1 : 0;
     d.sub_kind = b->substrate_kind;
     d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
+    d.host_substrate = (const double*)ctx->d_sub1.p; d.host_substrate_coh = (const double*)ctx->d_sub2.p;   // (SUB_HOST: the same buffers)
     const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? (const double*)ctx->d_atm.p : nullptr;
     d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
@@ -410,7 +416,8 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(temperature), SMRT_OFF(micro_p1), SMRT_OFF(micro_p2), SMRT_OFF(frequency), SMRT_OFF(theta), SMRT_OFF(phi),
         SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
         SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
-        SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers)};
+        SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers),
+        SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

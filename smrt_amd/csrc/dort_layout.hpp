@@ -33,6 +33,8 @@ struct DevBatch {
     const double* host_phase;    // [F * S][Lmax][host_modes][2][host_ne * host_ne]
     int host_modes, host_ne;
     int coherent;  // DORT option process_coherent_layers
+    const double* host_substrate;      // SUB_HOST: [F * S][m_max + 1][NE * NE] dense bottom reflection, NE = 3 n_max_stream
+    const double* host_substrate_coh;  //           [F * S][m_max + 1][NE] its specular diagonal
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]
@@ -101,7 +103,7 @@ constexpr double kPi = 3.14159265358979323846;
 enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3, EM_HOST = 4 };  // 1-3 have a Rayleigh phase matrix; 4: host arrays
 enum { MS_EXP = 0, MS_SHS = 1 };
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5, ST_COHERENT = 6 };
-enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2 };
+enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2, SUB_HOST = 3 };
 
 // ------------------------------------------------------------------------------------------------------------
 // LDS layout (shared by host sizing code and the kernel)

@@ -48,6 +48,11 @@ def fixture_substrate(d, i):
         return None
     T = float(d["substrate_temperature"])
     sub = dict(kind=str(d["substrate_kind"]), temperature=None if np.isnan(T) else T)
+    if sub["kind"] == "host":   # dense reflection matrices per azimuth mode, stored in the fixture (active mode)
+        modes = int(d["opt_m_max"]) + 1
+        sub["R"] = [d["sub_R_m%d" % m] for m in range(modes)]
+        sub["Rcoh"] = [d["sub_Rcoh_m%d" % m] for m in range(modes)]
+        return sub
     if sub["kind"] == "flat":
         sub["eps"] = complex(d["substrate_eps"][i])
     else:
@@ -88,7 +93,16 @@ def packed_batch_from_fixture(d, freqs=None):
     o = fixture_options(d)
     active = str(d["mode"]) == "A"
     substrate = atmosphere = None
-    if "substrate_kind" in d:
+    if "substrate_kind" in d and str(d["substrate_kind"]) == "host":
+        # rough substrate (active): the dense reflection matrices of the fixture, zero-padded to NE = 3 n_max_stream
+        nm, ne = o["m_max"] + 1, 3 * o["n_max_stream"]
+        R, Rc = np.zeros((1, nm, ne, ne)), np.zeros((1, nm, ne))
+        for m in range(nm):
+            k = d["sub_R_m%d" % m].shape[0]
+            R[0, m, :k, :k] = d["sub_R_m%d" % m]
+            Rc[0, m, :k] = d["sub_Rcoh_m%d" % m]
+        substrate = ("host", R, Rc)
+    elif "substrate_kind" in d:
         kind = str(d["substrate_kind"])
         q = d["substrate_eps"][sel] if kind == "flat" else None
         q1 = q.real if kind == "flat" else d["substrate_R"][sel][:, 0]
@@ -135,6 +149,9 @@ HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "p
 
 # DORT option process_coherent_layers: a 2 mm crust and a 3 mm ice lens become coherent interfaces, frequency by frequency
 COHERENT_FIXTURES = ["coherent_L5_n16_passive", "coherent_L5_n12_active"]
+# rough substrates in active mode: the dense reflection matrices of the bottom boundary come with the fixture (evaluated by
+# the reference's geometrical_optics / iem_fung92 substrates) and are handed to the solver as numbers
+ROUGH_SUBSTRATE_FIXTURES = ["rough_go_substrate_L2_n12_active", "rough_iem_substrate_L3_n10_active"]
 
 
 def model_snowpack_from_fixture(d):

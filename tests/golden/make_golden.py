@@ -482,6 +482,58 @@ def main():
             out["result_incoherent"] = np.concatenate([run_new("iba", se, spc, rtsolver_options=opts)["result"] for se in sens])
             save(name, out)
 
+    # (iv-e) rough substrates in active mode (backscatter of snow over rough soil): the DENSE reflection matrix of the bottom
+    # boundary, per azimuth mode, as the reference builds it (rtsolver_utils.py:567-597,690-707: specular diagonal +
+    # 2 pi | pi x the weighted diffuse modes) is stored as an INPUT of the fixture -- smrt_amd takes it from the caller
+    # (SMRT_SUBSTRATE_HOST) and does not restate the interface physics.  (In passive mode the reference raises inside
+    # dort.py:437 for these substrates.)
+    from smrt import make_soil
+    for name, soil_kw, n_str in (
+        ("rough_go_substrate_L2_n12_active", dict(substrate_model="geometrical_optics", mean_square_slope=0.05), 12),
+        ("rough_iem_substrate_L3_n10_active", dict(substrate_model="iem_fung92", roughness_rms=0.004, corr_length=0.05), 10),
+    ):
+        if not wanted(name):
+            continue
+        soil = make_soil(permittivity_model=complex(8.0, 1.0), temperature=268.0, **soil_kw)
+        L = 2 if "L2" in name else 3
+        spq = make_snowpack([0.3, 0.25, 0.8][:L], "exponential", density=[250.0, 300.0, 350.0][:L],
+                            temperature=[258.0, 261.0, 264.0][:L], corr_length=[1e-4, 1.5e-4, 2e-4][:L], substrate=soil)
+        sens = sensor_list.active(13.4e9, [30.0, 40.0])
+        opts = dict(n_max_stream=n_str, m_max=2)
+        SKIP_OLD[0] = False
+        mq = make_model("iba", "dort", rtsolver_options=opts)
+        sims, _ = mq.prepare_simulations(sens, spq, None, "snowpack")
+        sef, spk = list(sims)[0]
+        res = mq.run_single_simulation((sef, spk), None, None)
+        ems = mq.prepare_emmodels(sef, spk)
+        solver = DORT(**opts)
+        solver.init_solve(spk, ems, sef, None)
+        solver.prepare_streams()
+        itf = compute_interface_properties(sef.frequency, spk.interfaces, spk.substrate, solver.effective_permittivity,
+                                           solver.streams, opts["m_max"], 3)
+        out = dict(snowpack_arrays(spk))
+        out.update(emmodel="iba", mode="A", frequency=np.array([float(sef.frequency)]), result=np.asarray(res.data.values)[None],
+                   theta_deg=np.asarray(sens.theta_deg, float), theta_inc_deg=np.asarray(sens.theta_inc_deg, float),
+                   opt_n_max_stream=n_str, opt_m_max=2, substrate_kind="host", substrate_temperature=268.0,
+                   streams_n=np.asarray(solver.streams.n, int))
+        nb = int(solver.streams.n[L - 1])
+        for mode in range(opts["m_max"] + 1):
+            P = 2 if mode == 0 else 3
+            def dense(x):   # ndarray, the reference's diagonal wrapper (smrt_diag) or the scalar 0
+                if hasattr(x, "diagonal") and type(x).__name__ == "smrt_diag":
+                    return np.diag(np.asarray(x.diagonal(), float))
+                x = np.asarray(x, float)
+                return np.zeros((nb * P, nb * P)) if x.ndim == 0 else (np.diag(x) if x.ndim == 1 else x)
+            R = dense(itf.reflection_bottom(L - 1, mode, False))
+            Rc = np.diag(dense(itf.reflection_bottom(L - 1, mode, True))).copy()
+            assert R.shape == (nb * P, nb * P) and Rc.shape == (nb * P,), (name, mode, R.shape, Rc.shape, nb, P)
+            out["sub_R_m%d" % mode] = R
+            out["sub_Rcoh_m%d" % mode] = Rc
+        for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+            out["f0_" + k] = np.asarray(res.other_data[k].values)
+        SKIP_OLD[0] = bool(ONLY)
+        save(name, out)
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

@@ -180,6 +180,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.host_layer = b->host_layer; d.host_streams = b->host_streams; d.host_phase = b->host_phase;
     d.host_modes = active ? b->m_max + 1 : 1; d.host_ne = b->n_max_stream * (active ? 3 : 2);
     d.coherent = b->process_coherent_layers ? 1 : 0;
+    d.host_substrate = b->host_substrate; d.host_substrate_coh = b->host_substrate_coh;
     d.sub_kind = b->substrate_kind; d.sub_p1 = b->substrate_p1; d.sub_p2 = b->substrate_p2; d.sub_T = b->substrate_temperature;
     const bool has_atm = b->atm_tb_down != nullptr && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;

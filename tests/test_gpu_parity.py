@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -638,6 +638,39 @@ def test_process_coherent_layers_refusals_and_batches(ctx):
     ok = (pr.status == 0)
     assert (ok == (out.status == 0)).all()
     assert np.abs(pr.values[ok] - out.values[ok]).max() < 0.05   # 10 m of snow: the pruned solve is the same physics
+
+
+@pytest.mark.parametrize("name", ROUGH_SUBSTRATE_FIXTURES)
+@pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
+def test_rough_substrate_golden(ctx, name, threads, pipeline):
+    """SMRT_SUBSTRATE_HOST -- backscatter of snow over a rough substrate: the dense reflection matrices of the bottom
+    boundary (one per azimuth mode, evaluated by the caller; in the fixtures by the reference's geometrical_optics and
+    iem_fung92 substrates) start the bottom-up recursion.  Every kernel shape, against the reference; refused in passive
+    mode (where the reference itself raises)."""
+    d = load_golden(name)
+    b = batch_from_fixture(d)
+    out = run_variant(ctx, b, threads, pipeline)
+    assert (out.status == 0).all(), out.status
+    assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
+    # sensitivity: without the diffuse part (specular diagonal only) the answer is another one
+    flat = batch_from_fixture(d)
+    flat.host_substrate[:] = 0.0
+    for m in range(flat.host_substrate.shape[1]):
+        k = len(d["sub_Rcoh_m%d" % m])
+        flat.host_substrate[0, m, np.arange(k), np.arange(k)] = d["sub_Rcoh_m%d" % m]
+    other = ctx.run(flat)
+    assert np.abs(other.values[0, :2, :2] / d["result"][0, :2, :2] - 1).max() > 1e-3
+
+
+def test_rough_substrate_is_for_active_mode(ctx):
+    from smrt_amd._native import PackedBatch
+    from smrt_amd.core.error import SMRTError
+
+    ne = 3 * 8
+    b = PackedBatch([1], [[1.0]], [[0.3]], [[260.0]], [[1e-4]], None, [37e9], [0.9], n_max_stream=8, m_max=0, mode="P",
+                    substrate=("host", np.zeros((1, 1, ne, ne)), np.zeros((1, 1, ne))))
+    with pytest.raises(SMRTError, match="active mode only"):
+        ctx.run(b)
 
 
 def test_prune_rounds_skip_the_layers_below_the_cut(ctx):

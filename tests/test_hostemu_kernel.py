@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -270,3 +270,17 @@ def test_emulated_kernel_process_coherent_layers(emu, name, nt, pipeline, order)
         assert_backscatter_close(out, ref, spread=reference_method_spread(d))
     else:
         assert np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,nt,pipeline,order", [(ROUGH_SUBSTRATE_FIXTURES[0], 256, 1, 0), (ROUGH_SUBSTRATE_FIXTURES[1], 64, 0, 1)])
+def test_emulated_kernel_rough_substrate(emu, name, nt, pipeline, order):
+    """SMRT_SUBSTRATE_HOST: the bottom-up recursion of every azimuth mode starts from the dense reflection matrix of a rough
+    substrate handed over by the caller (here: what the reference's geometrical_optics / iem_fung92 substrates gave),
+    pipeline and fused active kernels, against the reference's backscatter."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        out, st, ref = run_fixture(emu, name, nt=nt, order=order)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
                       assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
                       fixture_emmodel, reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
@@ -238,3 +238,14 @@ def test_process_coherent_layers(name):
         else:
             assert np.abs(r - d["result"][i]).max() < TB_TOL
         assert np.abs(r - d["result_incoherent"][i]).max() > (1e-4 if act else 1.0)   # the option matters here
+
+
+@pytest.mark.parametrize("name", ROUGH_SUBSTRATE_FIXTURES)
+def test_rough_substrate_active(name):
+    """Backscatter of snow over a rough substrate (geometrical optics: purely diffuse; IEM: specular + diffuse), with the
+    dense reflection matrices of the bottom boundary taken from the fixture, against the reference."""
+    d = load_golden(name)
+    sp = snowpack_dict(d)
+    r = O.solve(sp, float(d["frequency"][0]), d["theta_deg"], mode="A", theta_inc_deg=d["theta_inc_deg"],
+                method="schur_forcedtriu", substrate=fixture_substrate(d, 0), **fixture_options(d))
+    assert_backscatter_close(r, d["result"][0], spread=reference_method_spread(d)[0])
