@@ -6,10 +6,22 @@ from ..interface.flat import Flat
 from .error import SMRTError
 
 
+def substrate_kind(substrate):
+    """"flat" / "reflector" for the substrates the device evaluates itself, "host" for any other object that speaks the
+    reference's substrate protocol (smrt/core/interface.py:169-240: evaluated in Python, handed to the device as dense
+    reflection matrices, active mode), None for anything else."""
+    kind = getattr(substrate, "device_kind", None)
+    if kind is None and callable(getattr(substrate, "specular_reflection_matrix", None)):
+        kind = "host"
+    return kind
+
+
 class Snowpack:
     def __init__(self, layers=None, interfaces=None, substrate=None, atmosphere=None):
-        if substrate is not None and getattr(substrate, "device_kind", None) is None:
-            raise SMRTError("smrt_amd implements the Flat and Reflector substrates (smrt_amd.substrate)")
+        if substrate is not None and substrate_kind(substrate) is None:
+            raise SMRTError("smrt_amd implements the Flat and Reflector substrates (smrt_amd.substrate); any other substrate "
+                            "must speak the reference's protocol (specular_reflection_matrix, and "
+                            "ft_even_diffuse_reflection_matrix if it is rough): it is then evaluated on the host")
         if atmosphere is not None and not hasattr(atmosphere, "device_params"):
             raise SMRTError("smrt_amd implements the SimpleIsotropicAtmosphere (smrt_amd.atmosphere)")
         self.layers = list(layers) if layers is not None else []
@@ -24,7 +36,7 @@ class Snowpack:
 
     def __add__(self, other):
         """snowpack + substrate (smrt/core/snowpack.py:__add__)."""
-        if getattr(other, "device_kind", None) is not None:
+        if substrate_kind(other) is not None:
             return Snowpack(layers=self.layers, interfaces=self.interfaces, substrate=other, atmosphere=self.atmosphere)
         raise SMRTError("only a substrate can be added to a snowpack in smrt_amd")
 

@@ -18,7 +18,7 @@ import numpy as np
 from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
 from ..core.error import SMRTError
 from ..core.result import LabeledArray, make_result
-from ..core.snowpack import Snowpack
+from ..core.snowpack import Snowpack, substrate_kind
 
 _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
 
@@ -168,7 +168,7 @@ class DORT(object):
             s_code[k] = sensor_keys.setdefault(key, len(sensor_keys))
         p_code = np.empty(len(packs), np.int64)
         for k, sp in enumerate(packs):
-            key = (getattr(sp.substrate, "device_kind", None), id(sp.atmosphere) if sp.atmosphere is not None else None)
+            key = (substrate_kind(sp.substrate), id(sp.atmosphere) if sp.atmosphere is not None else None)
             p_code[k] = pack_keys.setdefault(key, len(pack_keys))
         freq = np.array([float(s.frequency) for s in sensors])
         code = s_code[sens_idx] * len(pack_keys) + p_code[pack_idx]
@@ -237,7 +237,9 @@ class DORT(object):
         mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate
-        if sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
+        if sub0 is not None and substrate_kind(sub0) == "host":
+            substrate = self._substrates_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        elif sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
             q = np.array([[sp.substrate.device_params(f) for sp in sps] for f in freqs])  # (F, S, 2)
             ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
             substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
@@ -255,6 +257,81 @@ class DORT(object):
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
                            layer_kind=layer_kind, host_emmodel=host,
                            process_coherent_layers=self.process_coherent_layers)
+
+    # ---- substrates evaluated on the host (include/smrt_dort.h: SMRT_SUBSTRATE_HOST) -------------------------------
+    @staticmethod
+    def substrate_matrices(substrate, frequency, eps_last, mu, weight, m_max):
+        """Reflection matrices of the bottom boundary as compute_interface_properties builds them for a substrate object
+        (smrt/rtsolver/rtsolver_utils.py:567-597,690-707,728-740): per azimuth mode m, in the compressed order (stream *
+        P + polarisation, P = 2 for mode 0 and 3 above), diag(specular) + (2 pi | pi) x the diffuse mode with the column
+        scaled by mu_i w_i and the row by 1 / mu_s (a diffuse part given as [P, m, n] is diagonal in the streams: scaled by
+        w only).  Returns (list of dense matrices, list of specular diagonals)."""
+        n = len(mu)
+        spec = substrate.specular_reflection_matrix(frequency, eps_last, mu, 3)
+        spec = np.asarray(getattr(spec, "values", spec), float)       # (an smrt_matrix keeps its array in .values)
+        spec = np.zeros((3, n)) if spec.ndim == 0 else spec.reshape(3, n)
+        diff = None
+        if callable(getattr(substrate, "ft_even_diffuse_reflection_matrix", None)):
+            diff = substrate.ft_even_diffuse_reflection_matrix(frequency, eps_last, mu, mu, m_max, 3)
+            diff = np.asarray(getattr(diff, "values", diff), float)
+            diff = None if diff.ndim == 0 else diff
+        dense, coh = [], []
+        for m in range(m_max + 1):
+            P = 2 if m == 0 else 3
+            c = spec[:P].T.reshape(n * P)
+            R = np.diag(c)
+            coef = 2 * np.pi if m == 0 else np.pi
+            if diff is not None and diff.ndim == 5:      # [ps, pi, m, mu_s, mu_i]
+                D = diff[:P, :P, m] * (mu * weight)[None, None, None, :] / mu[None, None, :, None]
+                R = R + coef * np.transpose(D, (2, 0, 3, 1)).reshape(n * P, n * P)
+            elif diff is not None and diff.ndim == 3:    # [p, m, mu]: diagonal in the streams and in the polarisation
+                R = R + coef * np.diag((diff[:P, m] * weight[None, :]).T.reshape(n * P))
+            elif diff is not None:
+                raise SMRTError(f"ft_even_diffuse_reflection_matrix returned an array of {diff.ndim} dimensions")
+            dense.append(R)
+            coh.append(c)
+        return dense, coh
+
+    def _substrates_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """("host", R, Rcoh) of PackedBatch for a group whose snowpacks lie on substrates without a device implementation
+        (rough ones: geometrical optics, IEM, ...).  Needs the streams of every last layer, hence the effective
+        permittivity of every layer: from the host-evaluated emmodels if the group has them, otherwise from a cheap
+        pre-pass of the device emmodels (four streams, layer diagnostics only)."""
+        from .._native import PackedBatch, gauss_legendre_positive
+
+        if sensor0.mode != "A":
+            raise SMRTError("substrates evaluated on the host (rough substrates) are available in active mode only; in "
+                            "passive mode the reference itself fails on them (smrt/rtsolver/dort.py:437)")
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        if host is not None:
+            eps = host[0][..., 2] + 1j * host[0][..., 3]                     # (F, S, Lmax)
+        else:
+            name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
+            probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
+                                microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
+                                phase_normalization="forced", layer_kind=layer_kind)
+            lay = get_context(0).run(probe).layers.reshape(F, S, Lmax, 5)
+            eps = lay[..., 0] + 1j * lay[..., 1]
+        nm, ne = self.m_max + 1, 3 * self.n_max_stream
+        R = np.zeros((F, S, nm, ne, ne))
+        Rc = np.zeros((F, S, nm, ne))
+        gmu, _ = gauss_legendre_positive(self.n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+        for fi, f in enumerate(freqs):
+            for s, sp in enumerate(sps):
+                e = eps[fi, s, :nl[s]]
+                star = max(range(len(e)), key=lambda l: (e[l].real, e[l].imag, -l))
+                rs = np.sqrt(e[star] / e[-1]).real * gsin
+                mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+                w = np.empty_like(mu)                       # streams.py:324-330
+                w[0], w[-1] = 1.0 - 0.5 * (mu[0] + mu[1]), 0.5 * (mu[-2] + mu[-1])
+                w[1:-1] = 0.5 * (mu[:-2] - mu[2:])
+                dense, coh = self.substrate_matrices(sp.substrate, float(f), complex(e[-1]), mu, np.abs(w), self.m_max)
+                for m in range(nm):
+                    k = dense[m].shape[0]
+                    R[fi, s, m, :k, :k] = dense[m]
+                    Rc[fi, s, m, :k] = coh[m]
+        return ("host", R, Rc)
 
     @staticmethod
     def _ms_code(layer):

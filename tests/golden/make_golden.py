@@ -531,6 +531,18 @@ def main():
             out["sub_Rcoh_m%d" % mode] = Rc
         for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
             out["f0_" + k] = np.asarray(res.other_data[k].values)
+        # what the substrate object itself returns on the streams of the last layer (the protocol a host-side substrate
+        # speaks, rtsolver_utils.py:567-597): specular diagonal [3, n] and, if any, the raw diffuse modes [3, 3, m, n, n]
+        mu_b = np.asarray(solver.streams.mu[L - 1], float)
+        eps_b = solver.effective_permittivity[L - 1]
+        out["sub_mu"] = mu_b
+        out["sub_weight"] = np.asarray(solver.streams.weight[L - 1], float)
+        spec = spk.substrate.specular_reflection_matrix(sef.frequency, eps_b, mu_b, 3)
+        spec = np.asarray(getattr(spec, "values", spec), float)
+        out["sub_spec_raw"] = np.zeros((3, nb)) if spec.ndim == 0 else spec.reshape(3, nb)
+        raw = spk.substrate.ft_even_diffuse_reflection_matrix(sef.frequency, eps_b, mu_b, mu_b, opts["m_max"], 3)
+        out["sub_diff_mtype"] = str(getattr(raw, "mtype", "dense5"))
+        out["sub_diff_raw"] = np.asarray(getattr(raw, "values", raw), float)
         SKIP_OLD[0] = bool(ONLY)
         save(name, out)
 

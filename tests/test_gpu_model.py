@@ -460,3 +460,36 @@ def test_process_coherent_layers_through_the_model():
     one = m.run(sensor_list.passive(float(d["frequency"][2]), list(d["theta_deg"])), sp)
     np.testing.assert_allclose(np.ravel(one.TbV()), d["result"][2, 0], atol=1e-6)
     assert len(np.ravel(one.other_data["ks"].values)) == len(d["f2_ks"])
+
+
+def test_rough_substrate_through_the_model():
+    """A substrate object without a device implementation -- here one that answers with what the reference's
+    geometrical_optics / iem_fung92 substrates answered (stored in the fixtures) -- under the snowpack of an active
+    simulation: smrt_amd's rtsolver asks it for its specular and diffuse reflection on the streams of the last layer (which
+    it gets from a cheap pre-pass of the device emmodels), builds the dense bottom reflection of every azimuth mode like
+    compute_interface_properties does and the device starts its recursion from it.  Against the reference's backscatter."""
+    from conftest import ROUGH_SUBSTRATE_FIXTURES, model_snowpack_from_fixture
+    from smrt_amd import make_model, sensor_list
+    from smrt_amd.core.snowpack import Snowpack
+
+    for name in ROUGH_SUBSTRATE_FIXTURES:
+        d = load_golden(name)
+
+        class FromFixture:
+            temperature = 268.0
+
+            def specular_reflection_matrix(self, frequency, eps_1, mu1, npol):
+                np.testing.assert_allclose(mu1, d["sub_mu"], rtol=1e-11)      # the streams the reference had
+                return d["sub_spec_raw"]
+
+            def ft_even_diffuse_reflection_matrix(self, frequency, eps_1, mu_s, mu_i, m_max, npol):
+                return d["sub_diff_raw"]
+
+        sp = model_snowpack_from_fixture(d)
+        sp = Snowpack(layers=sp.layers, substrate=FromFixture())
+        opts = dict(n_max_stream=int(d["opt_n_max_stream"]), m_max=int(d["opt_m_max"]))
+        res = make_model("iba", "dort", rtsolver_options=opts).run(
+            sensor_list.active(float(d["frequency"][0]), list(d["theta_inc_deg"])), sp)
+        fac = 4 * np.pi * np.cos(np.deg2rad(d["theta_inc_deg"]))
+        np.testing.assert_allclose(np.ravel(res.sigmaVV()), fac * d["result"][0, 0, 0], rtol=1e-8)
+        np.testing.assert_allclose(np.ravel(res.sigmaHH()), fac * d["result"][0, 1, 1], rtol=1e-8)

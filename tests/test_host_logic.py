@@ -486,3 +486,38 @@ def test_host_evaluated_emmodels_are_packed_for_the_device():
     # a device emmodel on a microstructure it does not know is refused before anything is launched
     with pytest.raises(SMRTError, match="no device implementation"):
         solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), "iba")
+
+
+def test_host_evaluated_substrates_matrices_and_refusals():
+    """DORT.substrate_matrices (no GPU needed): from what a substrate object returns -- specular diagonal, raw diffuse modes,
+    dense (geometrical optics) or diagonal in the streams (IEM) -- to the reflection matrices of the bottom boundary, equal to
+    the ones the reference built (stored in the fixtures); such a substrate is accepted by Snowpack, refused in passive mode."""
+    from conftest import ROUGH_SUBSTRATE_FIXTURES, load_golden, model_snowpack_from_fixture
+    from smrt_amd.core.snowpack import Snowpack, substrate_kind
+    from smrt_amd.core.sensor import passive
+    from smrt_amd.rtsolver.dort import DORT
+
+    for name in ROUGH_SUBSTRATE_FIXTURES:
+        d = load_golden(name)
+
+        class FromFixture:
+            temperature = 268.0
+
+            def specular_reflection_matrix(self, frequency, eps_1, mu1, npol):
+                np.testing.assert_allclose(mu1, d["sub_mu"], rtol=1e-12)
+                return d["sub_spec_raw"]
+
+            def ft_even_diffuse_reflection_matrix(self, frequency, eps_1, mu_s, mu_i, m_max, npol):
+                return d["sub_diff_raw"]
+
+        dense, coh = DORT.substrate_matrices(FromFixture(), float(d["frequency"][0]), 1.5, d["sub_mu"], d["sub_weight"], 2)
+        for m in range(3):
+            np.testing.assert_allclose(dense[m], d["sub_R_m%d" % m], rtol=1e-13, atol=1e-18)
+            np.testing.assert_allclose(coh[m], d["sub_Rcoh_m%d" % m], rtol=1e-13, atol=1e-18)
+        assert substrate_kind(FromFixture()) == "host"
+        sp = model_snowpack_from_fixture(d)
+        rough = Snowpack(layers=sp.layers, substrate=FromFixture())
+        with pytest.raises(SMRTError, match="active mode only"):
+            DORT(n_max_stream=8)._pack(passive(37e9, 55), [rough], np.array([37e9]), "iba")
+    with pytest.raises(SMRTError, match="protocol"):
+        Snowpack(layers=sp.layers, substrate=object())
