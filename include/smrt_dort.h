@@ -50,7 +50,7 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_SUBSTRATE_NONE 0       /* semi-infinite / transparent (rtsolver_utils.py:548-551,601-603) */
 #define SMRT_SUBSTRATE_FLAT 1       /* Fresnel against a given permittivity (substrate/flat.py) */
 #define SMRT_SUBSTRATE_REFLECTOR 2  /* prescribed specular reflection, emissivity 1 - R (substrate/reflector.py), passive only */
-#define SMRT_SUBSTRATE_HOST 3       /* rough substrate: dense reflection matrices evaluated by the caller, active mode only */
+#define SMRT_SUBSTRATE_HOST 3       /* rough substrate: dense reflection matrices (+ emissivity in passive mode) evaluated by the caller */
 
 /* per-pair status word */
 #define SMRT_OK 0
@@ -132,17 +132,20 @@ typedef struct smrt_batch {
      * the stream count of column 4 so that the caller can tell which layers were kept.  Not combined with SMRT_EM_HOST
      * layers. */
     int32_t process_coherent_layers;
-    /* SMRT_SUBSTRATE_HOST: a rough substrate (smrt/substrate/geometrical_optics.py, iem_fung92*.py, ...) in active mode.
-     * The reflection matrix of the bottom boundary is no longer diagonal; the caller evaluates it with the reference's
-     * own substrate classes exactly as compute_interface_properties does (rtsolver_utils.py:567-597,690-707:
-     * specular_reflection_matrix on the diagonal + 2 pi (mode 0) | pi (mode >= 1) x ft_even_diffuse_reflection_matrix
-     * normalised by mu and the stream weights) on the streams of the LAST layer, and the device starts its bottom-up
-     * recursion from it.  Indexed by the pair p = f * S + s:
-     *   host_substrate     [F * S][m_max + 1][NE * NE], NE = 3 * n_max_stream: reflection_bottom(last layer, mode m),
-     *                      compressed (row = scattered stream * P + polarisation, column = incident; P = 2 for mode 0,
-     *                      3 above), row-major with leading dimension NE; rows / columns below n_last * P are read
-     *   host_substrate_coh [F * S][m_max + 1][NE]: the diagonal of its specular part (coherent-only pass, mode 0 is used)
-     * Not available in passive mode (the reference itself raises there for these substrates, dort.py:437). */
+    /* SMRT_SUBSTRATE_HOST: a rough substrate (smrt/substrate/geometrical_optics.py, iem_fung92*.py, ...).  The reflection
+     * matrix of the bottom boundary is no longer diagonal; the caller evaluates it with the reference's own substrate
+     * classes exactly as compute_interface_properties does (rtsolver_utils.py:567-597,690-707: specular_reflection_matrix
+     * on the diagonal + 2 pi (mode 0) | pi (mode >= 1) x ft_even_diffuse_reflection_matrix normalised by mu and the
+     * stream weights) on the streams of the LAST layer, and the device starts its bottom-up recursion from it.  Indexed
+     * by the pair p = f * S + s; modes = m_max + 1 in active mode, 1 in passive mode; NE = 3 * n_max_stream:
+     *   host_substrate     [F * S][modes][NE * NE]: reflection_bottom(last layer, mode m), compressed (row = scattered
+     *                      stream * P + polarisation, column = incident; P = 2 for mode 0, 3 above), row-major with
+     *                      leading dimension NE; rows / columns below n_last * P are read
+     *   host_substrate_coh [F * S][modes][NE]: active mode: the diagonal of its specular part (coherent-only pass, mode
+     *                      0 is used); passive mode: the emissivity diagonal (substrate.emissivity_matrix,
+     *                      rtsolver_utils.py:533-536), multiplied by B(substrate_temperature[s]) on the device
+     * (The reference runs its purely diffuse substrates -- geometrical_optics -- in active mode only: in passive mode it
+     * raises, dort.py:437; iem_fung92*, geometrical_optics_backscatter run in both.) */
     const double* host_substrate;
     const double* host_substrate_coh;
 } smrt_batch;

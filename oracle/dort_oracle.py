@@ -568,7 +568,8 @@ def interface_diagonals(eps, st, npol, substrate=None, slabs=None, frequency=Non
             # dense reflection matrices per azimuth mode handed over by the caller (rtsolver_utils.py:567-597,690-707:
             # specular diagonal + 2 pi | pi x weighted diffuse modes), picked up in dort_mode; no emission terms (active)
             itf["Rbot"].append(np.zeros((npol, st.n[l])))
-            itf["Tbot"].append(np.zeros((npol, st.n[l])))
+            # passive: the emissivity diagonal (substrate.emissivity_matrix, rtsolver_utils.py:533-536), [npol, n]
+            itf["Tbot"].append(np.asarray(substrate["emissivity"], float) if "emissivity" in substrate else np.zeros((npol, st.n[l])))
             itf["Rbot_dense"] = substrate["R"]          # list over modes of (n P x n P) arrays
             itf["Rbot_coh"] = substrate["Rcoh"]         # list over modes of the specular diagonals
         elif substrate is not None and substrate["kind"] == "reflector":
@@ -778,7 +779,10 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
             nc = min(N[l], N[l - 1])
             _put_block(ab, nband, row_bot[l - 1], j, -((Ttop[:, None] * Eu) * tt[None, :])[:nc])
         if m == 0 and planck_T is not None:
-            b[row_bot[l] : row_bot[l] + N[l]] -= ((1.0 - Rbot) * planck_T[l])[:, None]
+            rb = Rbot   # dense reflection matrix: its row sums (_muleye, dort.py:514-530)
+            if l == L - 1 and "Rbot_dense" in itf:
+                rb = np.asarray(itf["Rbot_dense"][m]).sum(axis=1)
+            b[row_bot[l] : row_bot[l] + N[l]] -= ((1.0 - rb) * planck_T[l])[:, None]
             if l > 0:
                 b[row_bot[l - 1] : row_bot[l - 1] + nc] += (Ttop * planck_T[l])[:nc, None]
             if l == L - 1 and planck_substrate is not None:  # emission of the substrate, dort.py:429-441

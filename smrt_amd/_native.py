@@ -134,11 +134,15 @@ class PackedBatch:
         if substrate is not None and substrate[0] == "host":
             # rough substrate, active mode: ("host", R[F*S][modes][NE][NE], Rcoh[F*S][modes][NE]) -- the dense reflection
             # matrices of the bottom boundary per azimuth mode and their specular diagonals (include/smrt_dort.h)
-            FS, nm, ne = S * len(self.frequency), int(m_max) + 1, 3 * int(n_max_stream)
+            # passive mode: one mode, Rcoh holds the EMISSIVITY diagonal and a fourth element the temperatures [S]
+            FS, nm, ne = S * len(self.frequency), (int(m_max) + 1 if mode == "A" else 1), 3 * int(n_max_stream)
             self.host_substrate = np.ascontiguousarray(np.asarray(substrate[1], np.float64).reshape(FS, nm, ne, ne))
             self.host_substrate_coh = np.ascontiguousarray(np.asarray(substrate[2], np.float64).reshape(FS, nm, ne))
             s.substrate_kind = SUBSTRATE_CODES["host"]
             s.host_substrate, s.host_substrate_coh = _dptr(self.host_substrate), _dptr(self.host_substrate_coh)
+            if len(substrate) > 3:
+                self.sub_T = np.ascontiguousarray(np.nan_to_num(np.broadcast_to(np.asarray(substrate[3], np.float64), (S,)), nan=0.0))
+                s.substrate_temperature = _dptr(self.sub_T)
         elif substrate is not None:
             kind, q1, q2, ts = substrate
             F = len(self.frequency)

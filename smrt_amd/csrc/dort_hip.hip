@@ -303,9 +303,10 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     }
     const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
     if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {   // dense reflection matrices of a rough substrate, evaluated by the caller
-        const size_t ne = 3 * (size_t)b->n_max_stream, nm = (size_t)b->m_max + 1;
+        const size_t ne = 3 * (size_t)b->n_max_stream, nm = ctx->active ? (size_t)b->m_max + 1 : 1;
         if (upload_array(ctx, ctx->d_sub1, b->host_substrate, sizeof(double) * FS * nm * ne * ne)) return -1;
         if (upload_array(ctx, ctx->d_sub2, b->host_substrate_coh, sizeof(double) * FS * nm * ne)) return -1;
+        if (b->substrate_temperature && upload_array(ctx, ctx->d_subT, b->substrate_temperature, sizeof(double) * b->n_snowpacks)) return -1;
     } else
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
         if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;

@@ -76,8 +76,8 @@ inline const char* validate(const smrt_batch* b) {
     if ((b->microstructure == SMRT_MS_STICKY_HARD_SPHERES || b->layer_kind) && !b->micro_p2) return "stickiness array missing";
     if (b->substrate_kind < SMRT_SUBSTRATE_NONE || b->substrate_kind > SMRT_SUBSTRATE_HOST) return "unknown substrate kind";
     if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {
-        if (b->mode != SMRT_MODE_ACTIVE) return "SMRT_SUBSTRATE_HOST (dense substrate reflection from the caller) is for active mode only";
         if (!b->host_substrate || !b->host_substrate_coh) return "SMRT_SUBSTRATE_HOST needs host_substrate and host_substrate_coh";
+        if (b->mode == SMRT_MODE_PASSIVE && !b->substrate_temperature) return "SMRT_SUBSTRATE_HOST in passive mode needs substrate_temperature";
     } else
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE && (!b->substrate_p1 || !b->substrate_p2 || !b->substrate_temperature))
         return "substrate arrays missing";

@@ -361,6 +361,13 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                     interface_RT(frequency, el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), sqrt(1.0 - rs * rs),
                                  cmk(s.slab_re[l + 1], s.slab_im[l + 1]), s.slab_th[l + 1], &Rv, &Rh, &Tv, &Th);
                     Rs = (r & 1) ? Rh : Rv;
+                } else if (b.sub_kind == SUB_HOST) {
+                    // rough substrate evaluated by the caller (smrt_dort.h): dense reflection matrix of mode 0 (its other
+                    // entries are copied below) and the emissivity diagonal
+                    const int NE = 3 * nmax;
+                    Rs = b.host_substrate[gp * (long long)NE * NE + (long long)r * NE + r];
+                    const double Ts = b.sub_T[si];
+                    if (Ts > 0.0) src = b.host_substrate_coh[gp * (long long)NE + r] * (b.rayleigh_jeans ? Ts : planck_radiance(frequency, Ts));
                 } else if (b.sub_kind != SUB_NONE) {
                     const long long gpi = gp;
                     const double q1 = b.sub_p1[gpi], q2 = b.sub_p2[gpi];
@@ -375,6 +382,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 }
                 s.M3[r * LD + r] = Rs;
                 s.svec[r] = src;
+            }
+            if (Lk == L && b.sub_kind == SUB_HOST) {
+                const int NE = 3 * nmax;
+                const double* H = b.host_substrate + gp * (long long)NE * NE;
+                for_2d<NT>(N, N, [&](int r, int c) { if (r != c) s.M3[c * LD + r] = H[r * NE + c]; });
             }
         }
         block_sync();

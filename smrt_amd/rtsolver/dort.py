@@ -260,19 +260,19 @@ class DORT(object):
 
     # ---- substrates evaluated on the host (include/smrt_dort.h: SMRT_SUBSTRATE_HOST) -------------------------------
     @staticmethod
-    def substrate_matrices(substrate, frequency, eps_last, mu, weight, m_max):
+    def substrate_matrices(substrate, frequency, eps_last, mu, weight, m_max, npol=3):
         """Reflection matrices of the bottom boundary as compute_interface_properties builds them for a substrate object
         (smrt/rtsolver/rtsolver_utils.py:567-597,690-707,728-740): per azimuth mode m, in the compressed order (stream *
         P + polarisation, P = 2 for mode 0 and 3 above), diag(specular) + (2 pi | pi) x the diffuse mode with the column
         scaled by mu_i w_i and the row by 1 / mu_s (a diffuse part given as [P, m, n] is diagonal in the streams: scaled by
         w only).  Returns (list of dense matrices, list of specular diagonals)."""
         n = len(mu)
-        spec = substrate.specular_reflection_matrix(frequency, eps_last, mu, 3)
+        spec = substrate.specular_reflection_matrix(frequency, eps_last, mu, npol)
         spec = np.asarray(getattr(spec, "values", spec), float)       # (an smrt_matrix keeps its array in .values)
-        spec = np.zeros((3, n)) if spec.ndim == 0 else spec.reshape(3, n)
+        spec = np.zeros((npol, n)) if spec.ndim == 0 else spec.reshape(npol, n)
         diff = None
         if callable(getattr(substrate, "ft_even_diffuse_reflection_matrix", None)):
-            diff = substrate.ft_even_diffuse_reflection_matrix(frequency, eps_last, mu, mu, m_max, 3)
+            diff = substrate.ft_even_diffuse_reflection_matrix(frequency, eps_last, mu, mu, m_max, npol)
             diff = np.asarray(getattr(diff, "values", diff), float)
             diff = None if diff.ndim == 0 else diff
         dense, coh = [], []
@@ -299,9 +299,7 @@ class DORT(object):
         pre-pass of the device emmodels (four streams, layer diagnostics only)."""
         from .._native import PackedBatch, gauss_legendre_positive
 
-        if sensor0.mode != "A":
-            raise SMRTError("substrates evaluated on the host (rough substrates) are available in active mode only; in "
-                            "passive mode the reference itself fails on them (smrt/rtsolver/dort.py:437)")
+        act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         if host is not None:
             eps = host[0][..., 2] + 1j * host[0][..., 3]                     # (F, S, Lmax)
@@ -312,7 +310,7 @@ class DORT(object):
                                 phase_normalization="forced", layer_kind=layer_kind)
             lay = get_context(0).run(probe).layers.reshape(F, S, Lmax, 5)
             eps = lay[..., 0] + 1j * lay[..., 1]
-        nm, ne = self.m_max + 1, 3 * self.n_max_stream
+        nm, ne = (self.m_max + 1 if act else 1), 3 * self.n_max_stream
         R = np.zeros((F, S, nm, ne, ne))
         Rc = np.zeros((F, S, nm, ne))
         gmu, _ = gauss_legendre_positive(self.n_max_stream)
@@ -326,12 +324,22 @@ class DORT(object):
                 w = np.empty_like(mu)                       # streams.py:324-330
                 w[0], w[-1] = 1.0 - 0.5 * (mu[0] + mu[1]), 0.5 * (mu[-2] + mu[-1])
                 w[1:-1] = 0.5 * (mu[:-2] - mu[2:])
-                dense, coh = self.substrate_matrices(sp.substrate, float(f), complex(e[-1]), mu, np.abs(w), self.m_max)
+                dense, coh = self.substrate_matrices(sp.substrate, float(f), complex(e[-1]), mu, np.abs(w),
+                                                     self.m_max if act else 0, 3 if act else 2)
                 for m in range(nm):
                     k = dense[m].shape[0]
                     R[fi, s, m, :k, :k] = dense[m]
                     Rc[fi, s, m, :k] = coh[m]
-        return ("host", R, Rc)
+                if not act:   # the emissivity diagonal takes the place of the specular one (rtsolver_utils.py:533-536)
+                    if not callable(getattr(sp.substrate, "emissivity_matrix", None)):
+                        raise SMRTError("a substrate evaluated on the host needs an emissivity_matrix method in passive mode")
+                    em = sp.substrate.emissivity_matrix(float(f), complex(e[-1]), mu, 2)
+                    em = np.asarray(getattr(em, "values", em), float)
+                    Rc[fi, s, 0, :2 * len(mu)] = 0.0 if em.ndim == 0 else em.reshape(2, len(mu)).T.reshape(-1)
+        if act:
+            return ("host", R, Rc)
+        return ("host", R, Rc, [sp.substrate.temperature if getattr(sp.substrate, "temperature", None) is not None else 0.0
+                                for sp in sps])
 
     @staticmethod
     def _ms_code(layer):

@@ -49,6 +49,11 @@ def fixture_substrate(d, i):
     T = float(d["substrate_temperature"])
     sub = dict(kind=str(d["substrate_kind"]), temperature=None if np.isnan(T) else T)
     if sub["kind"] == "host":   # dense reflection matrices per azimuth mode, stored in the fixture (active mode)
+        if str(d["mode"]) == "P":   # mode 0 only, plus the emissivity diagonal
+            n = len(d["sub_emis"]) // 2
+            sub["R"], sub["Rcoh"] = [d["sub_R_m0"]], [np.diag(d["sub_R_m0"])]
+            sub["emissivity"] = d["sub_emis"].reshape(n, 2).T
+            return sub
         modes = int(d["opt_m_max"]) + 1
         sub["R"] = [d["sub_R_m%d" % m] for m in range(modes)]
         sub["Rcoh"] = [d["sub_Rcoh_m%d" % m] for m in range(modes)]
@@ -95,13 +100,13 @@ def packed_batch_from_fixture(d, freqs=None):
     substrate = atmosphere = None
     if "substrate_kind" in d and str(d["substrate_kind"]) == "host":
         # rough substrate (active): the dense reflection matrices of the fixture, zero-padded to NE = 3 n_max_stream
-        nm, ne = o["m_max"] + 1, 3 * o["n_max_stream"]
+        nm, ne = (o["m_max"] + 1 if active else 1), 3 * o["n_max_stream"]
         R, Rc = np.zeros((1, nm, ne, ne)), np.zeros((1, nm, ne))
         for m in range(nm):
             k = d["sub_R_m%d" % m].shape[0]
             R[0, m, :k, :k] = d["sub_R_m%d" % m]
-            Rc[0, m, :k] = d["sub_Rcoh_m%d" % m]
-        substrate = ("host", R, Rc)
+            Rc[0, m, :k] = d["sub_Rcoh_m%d" % m] if active else d["sub_emis"]   # passive: the emissivity diagonal
+        substrate = ("host", R, Rc) if active else ("host", R, Rc, [float(d["substrate_temperature"])])
     elif "substrate_kind" in d:
         kind = str(d["substrate_kind"])
         q = d["substrate_eps"][sel] if kind == "flat" else None
@@ -152,6 +157,8 @@ COHERENT_FIXTURES = ["coherent_L5_n16_passive", "coherent_L5_n12_active"]
 # rough substrates in active mode: the dense reflection matrices of the bottom boundary come with the fixture (evaluated by
 # the reference's geometrical_optics / iem_fung92 substrates) and are handed to the solver as numbers
 ROUGH_SUBSTRATE_FIXTURES = ["rough_go_substrate_L2_n12_active", "rough_iem_substrate_L3_n10_active"]
+# ... and the ones the reference runs in passive mode (diagonal in the streams: backscatter-only diffuse parts)
+ROUGH_SUBSTRATE_PASSIVE_FIXTURES = ["rough_iem_substrate_L3_n10_passive", "rough_gob_substrate_L2_n12_passive"]
 
 
 def model_snowpack_from_fixture(d):

@@ -546,6 +546,57 @@ def main():
         SKIP_OLD[0] = bool(ONLY)
         save(name, out)
 
+    # (iv-f) the rough substrates the reference does run in PASSIVE mode (iem_fung92: specular + diagonal diffuse part;
+    # geometrical_optics_backscatter): dense bottom reflection of mode 0 and the emissivity diagonal as fixture inputs
+    for name, soil_kw, n_str in (
+        ("rough_iem_substrate_L3_n10_passive", dict(substrate_model="iem_fung92", roughness_rms=0.004, corr_length=0.05), 10),
+        ("rough_gob_substrate_L2_n12_passive", dict(substrate_model="geometrical_optics_backscatter", mean_square_slope=0.05), 12),
+    ):
+        if not wanted(name):
+            continue
+        soil = make_soil(permittivity_model=complex(8.0, 1.0), temperature=268.0, **soil_kw)
+        L = 2 if "L2" in name else 3
+        spq = make_snowpack([0.3, 0.25, 0.8][:L], "exponential", density=[250.0, 300.0, 350.0][:L],
+                            temperature=[258.0, 261.0, 264.0][:L], corr_length=[1e-4, 1.5e-4, 2e-4][:L], substrate=soil)
+        sens = sensor_list.passive(18.7e9, [40.0, 55.0])
+        opts = dict(n_max_stream=n_str)
+        SKIP_OLD[0] = False
+        mq = make_model("iba", "dort", rtsolver_options=opts)
+        sims, _ = mq.prepare_simulations(sens, spq, None, "snowpack")
+        sef, spk = list(sims)[0]
+        res = mq.run_single_simulation((sef, spk), None, None)
+        ems = mq.prepare_emmodels(sef, spk)
+        solver = DORT(**opts)
+        solver.init_solve(spk, ems, sef, None)
+        solver.prepare_streams()
+        itf = compute_interface_properties(sef.frequency, spk.interfaces, spk.substrate, solver.effective_permittivity,
+                                           solver.streams, 0, 2)
+        nb = int(solver.streams.n[L - 1])
+
+        def dense2(x):
+            if type(x).__name__ == "smrt_diag":
+                return np.diag(np.asarray(x.diagonal(), float))
+            x = np.asarray(x, float)
+            return np.zeros((nb * 2, nb * 2)) if x.ndim == 0 else (np.diag(x) if x.ndim == 1 else x)
+        out = dict(snowpack_arrays(spk))
+        out.update(emmodel="iba", mode="P", frequency=np.array([float(sef.frequency)]), result=np.asarray(res.data.values)[None],
+                   theta_deg=np.asarray(sens.theta_deg, float), opt_n_max_stream=n_str, substrate_kind="host",
+                   substrate_temperature=268.0, streams_n=np.asarray(solver.streams.n, int),
+                   sub_R_m0=dense2(itf.reflection_bottom(L - 1, 0, False)),
+                   sub_emis=np.diag(dense2(itf.transmission_bottom(L - 1, 0, False))).copy())
+        mu_b = np.asarray(solver.streams.mu[L - 1], float)
+        eps_b = solver.effective_permittivity[L - 1]
+        out["sub_mu"], out["sub_weight"] = mu_b, np.asarray(solver.streams.weight[L - 1], float)
+        for key, val in (("sub_spec_raw", spk.substrate.specular_reflection_matrix(sef.frequency, eps_b, mu_b, 2)),
+                         ("sub_emis_raw", spk.substrate.emissivity_matrix(sef.frequency, eps_b, mu_b, 2)),
+                         ("sub_diff_raw", spk.substrate.ft_even_diffuse_reflection_matrix(sef.frequency, eps_b, mu_b, mu_b, 0, 2))):
+            val = np.asarray(getattr(val, "values", val), float)
+            out[key] = np.zeros((2, nb)) if val.ndim == 0 and key != "sub_diff_raw" else val
+        for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+            out["f0_" + k] = np.asarray(res.other_data[k].values)
+        SKIP_OLD[0] = bool(ONLY)
+        save(name, out)
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

@@ -493,3 +493,33 @@ def test_rough_substrate_through_the_model():
         fac = 4 * np.pi * np.cos(np.deg2rad(d["theta_inc_deg"]))
         np.testing.assert_allclose(np.ravel(res.sigmaVV()), fac * d["result"][0, 0, 0], rtol=1e-8)
         np.testing.assert_allclose(np.ravel(res.sigmaHH()), fac * d["result"][0, 1, 1], rtol=1e-8)
+
+
+def test_rough_substrate_passive_through_the_model():
+    """The same host-evaluated substrate route in passive mode (two polarisations, mode 0, emissivity_matrix for the
+    emission of the substrate), on the rough substrates the reference runs there."""
+    from conftest import ROUGH_SUBSTRATE_PASSIVE_FIXTURES, model_snowpack_from_fixture
+    from smrt_amd import make_model, sensor_list
+    from smrt_amd.core.snowpack import Snowpack
+
+    for name in ROUGH_SUBSTRATE_PASSIVE_FIXTURES:
+        d = load_golden(name)
+
+        class FromFixture:
+            temperature = float(d["substrate_temperature"])
+
+            def specular_reflection_matrix(self, frequency, eps_1, mu1, npol):
+                np.testing.assert_allclose(mu1, d["sub_mu"], rtol=1e-11)
+                return d["sub_spec_raw"]
+
+            def ft_even_diffuse_reflection_matrix(self, frequency, eps_1, mu_s, mu_i, m_max, npol):
+                return d["sub_diff_raw"]
+
+            def emissivity_matrix(self, frequency, eps_1, mu1, npol):
+                return d["sub_emis_raw"]
+
+        sp = Snowpack(layers=model_snowpack_from_fixture(d).layers, substrate=FromFixture())
+        res = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=int(d["opt_n_max_stream"]))).run(
+            sensor_list.passive(float(d["frequency"][0]), list(d["theta_deg"])), sp)
+        np.testing.assert_allclose(np.ravel(res.TbV()), d["result"][0, 0], atol=1e-6)
+        np.testing.assert_allclose(np.ravel(res.TbH()), d["result"][0, 1], atol=1e-6)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -662,15 +662,50 @@ def test_rough_substrate_golden(ctx, name, threads, pipeline):
     assert np.abs(other.values[0, :2, :2] / d["result"][0, :2, :2] - 1).max() > 1e-3
 
 
-def test_rough_substrate_is_for_active_mode(ctx):
-    from smrt_amd._native import PackedBatch
-    from smrt_amd.core.error import SMRTError
+@pytest.mark.parametrize("name", ROUGH_SUBSTRATE_PASSIVE_FIXTURES)
+@pytest.mark.parametrize("pipeline", [1, 2, 0])
+def test_rough_substrate_passive_golden(ctx, name, pipeline):
+    """SMRT_SUBSTRATE_HOST in passive mode (the rough substrates the reference runs there: iem_fung92,
+    geometrical_optics_backscatter): reflection matrix of mode 0 and emissivity diagonal from the caller."""
+    d = load_golden(name)
+    ctx.set_pipeline(pipeline)
+    out = ctx.run(batch_from_fixture(d))
+    ctx.set_pipeline(1)
+    assert (out.status == 0).all(), out.status
+    assert np.abs(out.values - d["result"]).max() < TB_TOL
 
-    ne = 3 * 8
-    b = PackedBatch([1], [[1.0]], [[0.3]], [[260.0]], [[1e-4]], None, [37e9], [0.9], n_max_stream=8, m_max=0, mode="P",
-                    substrate=("host", np.zeros((1, 1, ne, ne)), np.zeros((1, 1, ne))))
-    with pytest.raises(SMRTError, match="active mode only"):
-        ctx.run(b)
+
+def test_dense_substrate_passive_against_oracle(ctx):
+    """The reference's passive-capable rough substrates are diagonal in the streams; a DENSE bottom reflection (what a
+    geometrical-optics substrate would give) against the oracle: random snowpacks, a smooth symmetric diffuse kernel on top
+    of a specular diagonal, emissivity = 1 - row sums (energy conserving)."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(11)
+    S, L, n = 3, 4, 12
+    thick = np.concatenate([rng.uniform(0.1, 0.4, (S, L - 1)), np.full((S, 1), 0.6)], axis=1)
+    dens, temp, lc = rng.uniform(200, 400, (S, L)), rng.uniform(245, 268, (S, L)), rng.uniform(8e-5, 2.5e-4, (S, L))
+    freqs, theta = np.array([18.7e9, 36.5e9]), np.array([35.0, 55.0])
+    ne = 3 * n
+    R, E, refs = np.zeros((2, S, 1, ne, ne)), np.zeros((2, S, 1, ne)), []
+    for f in range(2):
+        for s_ in range(S):
+            sp = dict(thickness=thick[s_], density=dens[s_], temperature=temp[s_], microstructure="exponential", corr_length=lc[s_])
+            ems = O.make_layers("iba", float(freqs[f]), sp)
+            st = O.compute_streams(n, np.array([e.eps_eff for e in ems]))
+            nb, mu, w = st.n[-1], st.mu[-1], st.weight[-1]
+            x = np.repeat(mu, 2)
+            Rm = 0.25 * np.exp(-3.0 * (x[:, None] - x[None, :]) ** 2) * np.repeat(mu * w, 2)[None, :] + np.diag(0.2 + 0.3 * (1 - x))
+            em = 1.0 - Rm.sum(axis=1)
+            R[f, s_, 0, :2 * nb, :2 * nb], E[f, s_, 0, :2 * nb] = Rm, em
+            sub = dict(kind="host", temperature=266.0, R=[Rm], Rcoh=[np.diag(Rm)], emissivity=em.reshape(nb, 2).T)
+            refs.append(O.solve(sp, float(freqs[f]), theta, n_max_stream=n, substrate=sub))
+    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad(theta), n_max_stream=n,
+                    substrate=("host", R, E, [266.0] * S))
+    out = ctx.run(b)
+    assert (out.status == 0).all()
+    assert np.abs(out.values - np.array(refs)).max() < TB_TOL
 
 
 def test_prune_rounds_skip_the_layers_below_the_cut(ctx):

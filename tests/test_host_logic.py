@@ -494,7 +494,6 @@ def test_host_evaluated_substrates_matrices_and_refusals():
     the ones the reference built (stored in the fixtures); such a substrate is accepted by Snowpack, refused in passive mode."""
     from conftest import ROUGH_SUBSTRATE_FIXTURES, load_golden, model_snowpack_from_fixture
     from smrt_amd.core.snowpack import Snowpack, substrate_kind
-    from smrt_amd.core.sensor import passive
     from smrt_amd.rtsolver.dort import DORT
 
     for name in ROUGH_SUBSTRATE_FIXTURES:
@@ -516,8 +515,22 @@ def test_host_evaluated_substrates_matrices_and_refusals():
             np.testing.assert_allclose(coh[m], d["sub_Rcoh_m%d" % m], rtol=1e-13, atol=1e-18)
         assert substrate_kind(FromFixture()) == "host"
         sp = model_snowpack_from_fixture(d)
-        rough = Snowpack(layers=sp.layers, substrate=FromFixture())
-        with pytest.raises(SMRTError, match="active mode only"):
-            DORT(n_max_stream=8)._pack(passive(37e9, 55), [rough], np.array([37e9]), "iba")
+        assert Snowpack(layers=sp.layers, substrate=FromFixture()).substrate is not None
+    # passive mode: two polarisations, one mode; the matrices of the fixtures the reference could run
+    from conftest import ROUGH_SUBSTRATE_PASSIVE_FIXTURES
+    for name in ROUGH_SUBSTRATE_PASSIVE_FIXTURES:
+        d = load_golden(name)
+
+        class Passive:
+            def specular_reflection_matrix(self, frequency, eps_1, mu1, npol):
+                assert npol == 2
+                return d["sub_spec_raw"]
+
+            def ft_even_diffuse_reflection_matrix(self, frequency, eps_1, mu_s, mu_i, m_max, npol):
+                assert npol == 2 and m_max == 0
+                return d["sub_diff_raw"]
+
+        dense, _ = DORT.substrate_matrices(Passive(), float(d["frequency"][0]), 1.5, d["sub_mu"], d["sub_weight"], 0, 2)
+        np.testing.assert_allclose(dense[0], d["sub_R_m0"], rtol=1e-13, atol=1e-18)
     with pytest.raises(SMRTError, match="protocol"):
         Snowpack(layers=sp.layers, substrate=object())

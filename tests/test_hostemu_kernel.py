@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -284,3 +284,16 @@ def test_emulated_kernel_rough_substrate(emu, name, nt, pipeline, order):
         C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
     assert (st == 0).all()
     assert_backscatter_close(out, ref, spread=reference_method_spread(load_golden(name)))
+
+
+@pytest.mark.parametrize("name,nt,pipeline", [(ROUGH_SUBSTRATE_PASSIVE_FIXTURES[0], 256, 1), (ROUGH_SUBSTRATE_PASSIVE_FIXTURES[1], 64, 2),
+                                              (ROUGH_SUBSTRATE_PASSIVE_FIXTURES[1], 128, 0)])
+def test_emulated_kernel_rough_substrate_passive(emu, name, nt, pipeline):
+    """SMRT_SUBSTRATE_HOST in passive mode: reflection matrix of mode 0 and emissivity diagonal from the caller."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        out, st, ref = run_fixture(emu, name, nt=nt)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    assert np.abs(out - ref).max() < 1e-6

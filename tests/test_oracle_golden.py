@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
                       assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
                       fixture_emmodel, reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
@@ -249,3 +249,11 @@ def test_rough_substrate_active(name):
     r = O.solve(sp, float(d["frequency"][0]), d["theta_deg"], mode="A", theta_inc_deg=d["theta_inc_deg"],
                 method="schur_forcedtriu", substrate=fixture_substrate(d, 0), **fixture_options(d))
     assert_backscatter_close(r, d["result"][0], spread=reference_method_spread(d)[0])
+
+
+@pytest.mark.parametrize("name", ROUGH_SUBSTRATE_PASSIVE_FIXTURES)
+def test_rough_substrate_passive(name):
+    """The rough substrates the reference runs in passive mode: reflection of mode 0 and emissivity from the fixture."""
+    d = load_golden(name)
+    tb = O.solve(snowpack_dict(d), float(d["frequency"][0]), d["theta_deg"], substrate=fixture_substrate(d, 0), **fixture_options(d))
+    assert np.abs(tb - d["result"][0]).max() < TB_TOL
