@@ -145,7 +145,8 @@ typedef struct smrt_batch {
      *                      0 is used); passive mode: the emissivity diagonal (substrate.emissivity_matrix,
      *                      rtsolver_utils.py:533-536), multiplied by B(substrate_temperature[s]) on the device
      * (The reference runs its purely diffuse substrates -- geometrical_optics -- in active mode only: in passive mode it
-     * raises, dort.py:437; iem_fung92*, geometrical_optics_backscatter run in both.) */
+     * raises, dort.py:437; iem_fung92*, geometrical_optics_backscatter run in both.)  Not combined with
+     * process_coherent_layers. */
     const double* host_substrate;
     const double* host_substrate_coh;
 } smrt_batch;

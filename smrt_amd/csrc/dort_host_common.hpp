@@ -78,6 +78,8 @@ inline const char* validate(const smrt_batch* b) {
     if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {
         if (!b->host_substrate || !b->host_substrate_coh) return "SMRT_SUBSTRATE_HOST needs host_substrate and host_substrate_coh";
         if (b->mode == SMRT_MODE_PASSIVE && !b->substrate_temperature) return "SMRT_SUBSTRATE_HOST in passive mode needs substrate_temperature";
+        if (b->process_coherent_layers)
+            return "process_coherent_layers cannot be combined with SMRT_SUBSTRATE_HOST (its matrices are the caller's, sampled on the streams of the full snowpack)";
     } else
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE && (!b->substrate_p1 || !b->substrate_p2 || !b->substrate_temperature))
         return "substrate arrays missing";

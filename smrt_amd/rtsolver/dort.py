@@ -299,6 +299,9 @@ class DORT(object):
         pre-pass of the device emmodels (four streams, layer diagnostics only)."""
         from .._native import PackedBatch, gauss_legendre_positive
 
+        if self.process_coherent_layers:
+            raise SMRTError("process_coherent_layers is not available with a substrate evaluated on the host (its matrices are "
+                            "sampled on the streams of the full snowpack, which may change when layers are removed)")
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         if host is not None:
