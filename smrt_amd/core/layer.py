@@ -6,9 +6,19 @@ from .error import SMRTError
 from .globalconstants import DENSITY_OF_ICE, DENSITY_OF_WATER, FREEZING_POINT
 
 
+class _Epoch:
+    """Counts the attribute writes on every Layer / Microstructure object: Snowpack's per-run caches (packed columns,
+    microstructure set, per-layer emmodel flag) are valid only while it stands still."""
+    value = 0
+
+
 class Microstructure:
     """Parameters of one of the two supported microstructure models (exponential: corr_length;
     sticky_hard_spheres: radius, stickiness)."""
+
+    def __setattr__(self, key, value):
+        _Epoch.value += 1
+        object.__setattr__(self, key, value)
 
     def __init__(self, name, frac_volume, **params):
         self.name = name
@@ -32,6 +42,15 @@ DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres")
 
 
 class Layer:
+    def __setattr__(self, key, value):
+        """Any change invalidates the snowpacks' caches; a microstructure parameter set on the layer (layer.corr_length =
+        ...) goes to the microstructure object too, which is what the solver reads."""
+        _Epoch.value += 1
+        object.__setattr__(self, key, value)
+        ms = self.__dict__.get("microstructure")
+        if ms is not None and key in MICROSTRUCTURE_ARGS.get(self.__dict__.get("microstructure_model"), ()):
+            setattr(ms, key, float(value))
+
     def __init__(self, thickness, microstructure_model, density, temperature=FREEZING_POINT, medium="snow",
                  liquid_water=None, volumetric_liquid_water=None, salinity=0, emmodel=None, emmodel_options=None,
                  **params):

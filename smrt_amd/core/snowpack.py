@@ -31,6 +31,7 @@ class Snowpack:
         for itf in self.interfaces:
             self._check_interface(itf)
         self._packed = None
+        self._micro = self._overrides = None
         self.substrate = substrate
         self.atmosphere = atmosphere
 
@@ -64,18 +65,38 @@ class Snowpack:
         self._check_interface(interface)
         self.layers.append(layer)
         self.interfaces.append(interface or Flat())
-        self._packed = None
+        self._packed = self._micro = self._overrides = None
 
     def packed(self):
         """The per-layer columns of the device batch for this snowpack -- thickness, ice volume fraction, temperature,
         the two microstructure parameters -- as one (5, n_layers) array, built once (the batching runner stacks these
         rows of many snowpacks instead of walking their layer objects again for every run)."""
-        if self._packed is None or self._packed.shape[1] != len(self.layers):
+        if self._packed is None or not self._fresh("_packed_key"):
             cols = [(lay.thickness, lay.frac_volume, lay.temperature) + lay.microstructure.device_params
                     for lay in self.layers]
             self._packed = np.array(cols, dtype=np.float64).T.reshape(5, len(self.layers))
         return self._packed
 
+    def _fresh(self, slot):
+        """Is the cache `slot` still valid?  Only if no Layer / Microstructure attribute has been written anywhere since
+        it was filled and the layer list holds the same objects."""
+        from .layer import _Epoch
+
+        key = getattr(self, slot, None)
+        ok = key is not None and key[0] == _Epoch.value and key[1] == self.layers
+        if not ok:
+            setattr(self, slot, (_Epoch.value, list(self.layers)))
+        return ok
+
     @property
     def microstructure_models(self):
-        return {lay.microstructure_model for lay in self.layers}
+        if self._micro is None or not self._fresh("_micro_key"):
+            self._micro = {lay.microstructure_model for lay in self.layers}
+        return self._micro
+
+    def has_layer_emmodels(self):
+        """Does any layer carry its own emmodel or emmodel options (smrt/core/model.py:529-582)?  Looked up once per
+        snowpack and layer count: the batching runner asks for every snowpack of every run."""
+        if self._overrides is None or not self._fresh("_overrides_key"):
+            self._overrides = any(getattr(l, "emmodel", None) or getattr(l, "emmodel_options", None) for l in self.layers)
+        return self._overrides

@@ -127,11 +127,20 @@ class DORT(object):
         simple = isinstance(model.emmodel, type)
         checked = set()
         per_pack, distinct = [], set()
+        simple_name = getattr(model.emmodel, "device_name", None) if simple else None
+        simple_options = None
         for sp in plan.snowpacks:
             n = sp.nlayer
-            if simple and not any(getattr(l, "emmodel", None) or getattr(l, "emmodel_options", None) for l in sp.layers):
-                kinds = [model.emmodel] * n                      # the common case, no per-layer look-ups
+            plain = simple and not sp.has_layer_emmodels()
+            if plain and simple_name is not None and simple_options is not None:
+                # the common case -- one device emmodel, no per-layer settings, options already validated: no per-layer work
+                distinct.add(simple_name)
+                per_pack.append([simple_name] * n)
+                continue
+            if plain:
+                kinds = [model.emmodel] * n
                 todo = [(model.emmodel, sp.layers[0])]
+                simple_options = True
             else:
                 kinds = [model.emmodel_of_layer(k, layer, n) for k, layer in enumerate(sp.layers)]
                 todo = list(zip(kinds, sp.layers))

@@ -534,3 +534,23 @@ def test_host_evaluated_substrates_matrices_and_refusals():
         np.testing.assert_allclose(dense[0], d["sub_R_m0"], rtol=1e-13, atol=1e-18)
     with pytest.raises(SMRTError, match="protocol"):
         Snowpack(layers=sp.layers, substrate=object())
+
+
+def test_snowpack_caches_follow_layer_changes():
+    """The batching path caches per snowpack what it needs for every run (packed layer columns, microstructure set,
+    per-layer emmodel flag); changing a layer afterwards -- a temperature for a sensitivity study, a correlation length set
+    on the layer, a layer swapped in the list, an emmodel given to one layer -- must be seen by the next run."""
+    sp = two_layer()
+    a = sp.packed().copy()
+    assert not sp.has_layer_emmodels() and sp.microstructure_models == {"exponential"}
+    sp.layers[0].temperature = 240.0
+    assert sp.packed()[2, 0] == 240.0 and a[2, 0] != 240.0
+    sp.layers[1].corr_length = 3.3e-4                       # forwarded to the microstructure object the solver reads
+    assert sp.packed()[3, 1] == 3.3e-4 and sp.layers[1].microstructure.corr_length == 3.3e-4
+    sp.layers[0].emmodel = "nonscattering"
+    assert sp.has_layer_emmodels()
+    other = two_layer().layers[0]
+    other.thickness = 0.77
+    sp.packed()
+    sp.layers[0] = other                                     # same count, another object
+    assert sp.packed()[0, 0] == 0.77 and not sp.has_layer_emmodels()
