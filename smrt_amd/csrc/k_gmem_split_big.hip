@@ -1,6 +1,7 @@
 // Prep and finish kernels of the three-kernel pipeline for 128 < N <= 384 (BASELINE configs[3]: 128 streams, N = 256 /
 // 384): CH = 4 or 6 row chunks of 64, work matrices and solver scratch in the per-workgroup global workspace, every
 // dense step on the matrix core; the Jacobi kernel in between is dort_jacobi_big_kernel.
+#include <cstdlib>
 #include "dort_ctx.hpp"
 #include "dort_active.hpp"
 
@@ -34,10 +35,10 @@ __global__ __launch_bounds__(NT, (MODE == 2 ? SMRT_BIG_FINISH_WAVES : 1)) void d
 namespace smrt_launch {
 
 template <class K>
-static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, size_t lds) {
+static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, size_t lds, unsigned nt = 256) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, ctx->stream, c, ctx->stage, (double*)ctx->d_work.p, ctx->ws_stride);
     return hipGetLastError();
 }
 
@@ -48,6 +49,15 @@ hipError_t prep_gmem_big(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, b
                    : go(dort_passive_big_kernel<256, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes);
 }
 hipError_t finish_gmem_big(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active, int ch) {
+    // one workgroup of eight wavefronts per CU instead of two of four (see finish_gmem in k_gmem_split.hip): configs[3]
+    // shape 77 -> 86 solves/s (512 and 1024 pairs), passive 128 streams 1910 -> 2690.  SMRT_DORT_BIG_FINISH_256=1: the old shape
+    static const bool wide = getenv("SMRT_DORT_BIG_FINISH_256") == nullptr;
+    if (wide) {
+        if (active) return ch <= 4 ? go(dort_active_big_kernel<512, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes, 512)
+                                   : go(dort_active_big_kernel<512, 6, 2>, ctx, c, grid, ctx->finish2_lds_bytes, 512);
+        return ch <= 4 ? go(dort_passive_big_kernel<512, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes, 512)
+                       : go(dort_passive_big_kernel<512, 6, 2>, ctx, c, grid, ctx->finish2_lds_bytes, 512);
+    }
     if (active) return ch <= 4 ? go(dort_active_big_kernel<256, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes)
                                : go(dort_active_big_kernel<256, 6, 2>, ctx, c, grid, ctx->finish2_lds_bytes);
     return ch <= 4 ? go(dort_passive_big_kernel<256, 4, 2>, ctx, c, grid, ctx->finish2_lds_bytes)
