@@ -94,8 +94,9 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
                                                   : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
         // (the product launches the Jacobi kernel of this pipeline with 512 threads: k_jacobi.hip)
         [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(512, order, [&]() { dort_jacobi_item<512>(d, sg.st, it, jl.data()); }); },
-        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
-                                                  : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
+        // (and the finish kernel with 512 threads too: k_gmem_split.hip)
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(512, order, [&]() { dort_pair_active<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(512, order, [&]() { dort_pair_passive<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
 // 128 < N <= 384: prep / finish with CH row chunks on the global workspace, the blocked Jacobi kernel in between
@@ -112,8 +113,9 @@ static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
                                                   : emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
         [&](long long it) { for (auto& x : jl) x = NAN;
                             return emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, sg.st, it, jl.data()); }); },
-        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); })
-                                                  : emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
+        // (finish kernels of this pipeline: 512 threads in the product, k_gmem_split_big.hip)
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(512, order, [&]() { dort_pair_active<512, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(512, order, [&]() { dort_pair_passive<512, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
 // active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
