@@ -43,6 +43,15 @@ static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, unsigned gri
 }
 
 hipError_t prep_gmem_big(smrt_dort_ctx* ctx, const DevBatch& c, unsigned grid, bool active, int ch) {
+    // eight wavefronts here too (one workgroup per CU either way): configs[3] shape 86.1 -> 89.1 solves/s; on the
+    // 65 ... 128 path the same change loses 1 %.  SMRT_DORT_BIG_PREP_256=1: the old shape
+    static const bool wide = getenv("SMRT_DORT_BIG_PREP_256") == nullptr;
+    if (wide) {
+        if (active) return ch <= 4 ? go(dort_active_big_kernel<512, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes, 512)
+                                   : go(dort_active_big_kernel<512, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes, 512);
+        return ch <= 4 ? go(dort_passive_big_kernel<512, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes, 512)
+                       : go(dort_passive_big_kernel<512, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes, 512);
+    }
     if (active) return ch <= 4 ? go(dort_active_big_kernel<256, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes)
                                : go(dort_active_big_kernel<256, 6, 1>, ctx, c, grid, ctx->prep_lds_bytes);
     return ch <= 4 ? go(dort_passive_big_kernel<256, 4, 1>, ctx, c, grid, ctx->prep_lds_bytes)

@@ -109,8 +109,8 @@ static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
     std::vector<double> jl(jp.total);
     auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };
     return run_rounds(d, order, nmodes, sg,
-        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(256, order, [&]() { dort_pair_active<256, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); })
-                                                  : emu::run_block(256, order, [&]() { dort_pair_passive<256, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
+        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(512, order, [&]() { dort_pair_active<512, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); })
+                                                  : emu::run_block(512, order, [&]() { dort_pair_passive<512, CH, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },   // (512 threads like the product)
         [&](long long it) { for (auto& x : jl) x = NAN;
                             return emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, sg.st, it, jl.data()); }); },
         // (finish kernels of this pipeline: 512 threads in the product, k_gmem_split_big.hip)
