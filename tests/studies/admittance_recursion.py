@@ -1,0 +1,181 @@
+"""Numerical study (NOT a test, not collected by pytest): the pivot-free "admittance" form of the layer recursion that
+the register-resident finish kernel (smrt_amd/csrc/dort_finish_reg.hpp) runs.
+
+State carried bottom-up: the affine relation  delta = -C s + c  between the sum s = I_up + I_dn and the difference
+delta = I_up - I_dn of the intensities at a level (C: N x N "admittance", c: N).  With the symmetric reduction of the
+layer eigenproblem the eigenvector matrices obey  E+^T W E- = -Sigma  (W = D^-2), so both inverses of the
+eigenvector matrices are transposes, and every matrix that has to be inverted is "positive diagonal + (nearly) symmetric
+positive definite": LU WITHOUT pivoting.
+
+    python tests/studies/admittance_recursion.py
+
+prints, per case, max |Tb - oracle| and the element growth of the unpivoted eliminations.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import dort_oracle as O  # noqa: E402
+
+
+def layer_eigen(em, mu, w):
+    """The device's symmetric route in NumPy: A+ = L+^-T B', A- = -L+ U, sigma, d (E+- = d * A+-)."""
+    n = len(mu); P = 2; N = n * P
+    full = np.concatenate((mu, -mu))
+    ft = em.ft_even_phase(mu, full, 0, 2)[:, :, 0]
+    Pc = O.compress(ft)
+    Pp, Pm = Pc[:, :N], Pc[:, N:]
+    wv = np.repeat(w, P); mv = np.repeat(mu, P)
+    c = 0.5
+    ke = em.ks + em.ka
+    if em.ks != 0:
+        rows = c * ((Pp + Pm) * wv[None, :]).sum(axis=1)
+        norm = em.ks / rows
+    else:
+        norm = np.ones(N)
+    sc = np.sqrt(norm * wv)
+    Xp = (ke * np.eye(N) - c * sc[:, None] * (Pp + Pm) * sc[None, :]) / np.sqrt(mv[:, None] * mv[None, :])
+    Xm = (ke * np.eye(N) - c * sc[:, None] * (Pp - Pm) * sc[None, :]) / np.sqrt(mv[:, None] * mv[None, :])
+    Xp = 0.5 * (Xp + Xp.T); Xm = 0.5 * (Xm + Xm.T)
+    Lp = np.linalg.cholesky(Xp); Lm = np.linalg.cholesky(Xm)
+    B = Lp.T @ Lm
+    U, S, _ = np.linalg.svd(B)
+    Bp = U * S[None, :]
+    d = np.sqrt(norm / wv) / np.sqrt(mv)
+    Ap = np.linalg.solve(Lp.T, Bp)
+    Am = -(Lp @ Bp) / S[None, :]
+    return S, Ap, Am, d
+
+
+GROWTH = [1.0]
+
+
+def inv_nopiv(A):
+    """In-place Gauss-Jordan inverse without pivoting (what the kernel does, 16 x 16 blocks there); records growth."""
+    A = A.copy(); n = len(A)
+    a0 = np.abs(A).max()
+    for k in range(n):
+        piv = A[k, k]
+        pinv = 1.0 / piv
+        rowk = A[k, :] * pinv
+        colk = A[:, k].copy()
+        A -= np.outer(colk, rowk)
+        A[k, :] = rowk
+        A[:, k] = -colk * pinv
+        A[k, k] = pinv
+        GROWTH[0] = max(GROWTH[0], np.abs(A).max() / max(a0, 1.0 / a0))
+    return A
+
+
+def solve_pair(sp, frequency, theta_deg, emmodel="iba", n_max_stream=32, substrate=None, atmosphere=None,
+               inverse=inv_nopiv):
+    ems = O.make_layers(emmodel, frequency, sp)
+    eps = np.array([e.eps_eff for e in ems])
+    thick = np.asarray(sp["thickness"], float)
+    st = O.compute_streams(n_max_stream, eps)
+    itf = O.interface_diagonals(eps, st, 2, substrate)
+    L = len(ems)
+    BT = [O.planck(frequency, float(t)) for t in sp["temperature"]]
+    flat = lambda a: O._flatten_pol(a, 0)  # noqa: E731
+    # bottom of the last layer: I_up = R I_dn + src
+    Rs = flat(itf["Rbot"][L - 1])
+    src = np.zeros_like(Rs)
+    if substrate is not None and substrate.get("temperature") is not None:
+        src = flat(itf["Tbot"][L - 1]) * O.planck(frequency, float(substrate["temperature"]))
+    Cdiag = (1.0 - Rs) / (1.0 + Rs)
+    C = np.diag(Cdiag)                 # physical coordinates of the layer the relation is used in
+    c = (Cdiag + 1.0) * src
+    for l in range(L - 1, -1, -1):
+        S, Ap, Am, d = layer_eigen(ems[l], st.mu[l], st.weight[l])
+        N = len(S)
+        t = np.exp(-S * thick[l])
+        Bl = BT[l]
+        Chat = C * (d[None, :] / d[:, None])          # D^-1 C D
+        chat = c / d
+        one_hat = 1.0 / d                              # D^-1 1
+        # (H + Sigma) x1 = -(H - Sigma) t x2 + r,  H = A+^T Chat A+,  r = A+^T (chat - 2 B Chat 1hat)
+        H = Ap.T @ (Chat @ Ap)
+        r = Ap.T @ (chat - 2.0 * Bl * (Chat @ one_hat))
+        Pm_ = inverse(H + np.diag(S))
+        q = Pm_ @ r
+        # M3 = Sigma (1 - t^2) + 2 (Sigma t) P (t Sigma)
+        st_ = S * t
+        M3 = np.diag(S * (1.0 - t * t)) + 2.0 * st_[:, None] * Pm_ * st_[None, :]
+        M3i = inverse(M3)
+        Theta = 2.0 * M3i - np.diag(1.0 / S)
+        Chat_top = Am @ Theta @ Am.T
+        # c' = 2 B C' 1 - 2 E- M3^-1 Sigma t q
+        chat_top = 2.0 * Bl * (Chat_top @ one_hat) - 2.0 * (Am @ (M3i @ (st_ * q)))
+        Ctop = Chat_top * (d[:, None] / d[None, :])   # physical
+        ctop = chat_top * d
+        if l == 0:
+            break
+        # interface with the layer above (general diagonal coefficients)
+        Nu = 2 * st.n[l - 1]
+        nc = min(N, Nu)
+        r2 = flat(itf["Rtop"][l]); t1 = flat(itf["Ttop"][l])
+        r1 = np.ones(N); t2 = np.zeros(N)
+        r1[:nc] = flat(itf["Rbot"][l - 1])[:nc]; t2[:nc] = flat(itf["Tbot"][l - 1])[:nc]
+        t1 = t1.copy(); t1[nc:] = 0.0
+        tt = t1 * t2
+        a_ = 0.5 * (tt + (1 + r1) * (1 - r2))
+        b_ = 0.5 * (tt - (1 + r1) * (1 + r2))
+        c_ = 0.5 * (tt - (1 - r1) * (1 - r2))
+        d_ = 0.5 * (tt + (1 - r1) * (1 + r2))
+        Y = np.diag(a_) - b_[:, None] * Ctop
+        Yi = inverse(Y)
+        Nn = np.diag(c_) - d_[:, None] * Ctop
+        # t2 delta_u = Nn Y^-1 (t2 s_u - b c') + d c'
+        Z = Nn @ Yi
+        Cu = np.zeros((Nu, Nu)); cu = np.zeros(Nu)
+        Cu[:nc, :nc] = -(Z[:nc, :nc] * t2[None, :nc]) / t2[:nc, None]
+        cu[:nc] = ((d_ * ctop - Z @ (b_ * ctop)) [:nc]) / t2[:nc]
+        if Nu > nc:   # streams of the upper layer that do not exist below: I_up = R_bot I_dn (nearly total reflection)
+            rb = flat(itf["Rbot"][l - 1])[nc:]
+            Cu[np.arange(nc, Nu), np.arange(nc, Nu)] = (1.0 - rb) / (1.0 + rb)
+        C, c = Cu, cu
+    # surface: I_dn = r2 I_up + t2 I_sky,  S I_up = (I - C') t2 I_sky + c',  S = (1 - r2) + C' (1 + r2)
+    N0 = len(ctop)
+    r2 = flat(itf["Rtop"][0]); t1 = flat(itf["Ttop"][0])
+    Rair = flat(itf["Rbot_air"]); Tair = flat(itf["Tbot_air"])
+    na = len(Rair)
+    Isky = 0.0
+    if atmosphere is not None:
+        Isky = O.planck(frequency, float(atmosphere["tb_down"]))
+    t2 = np.zeros(N0); t2[:na] = Tair
+    Smat = np.diag(1.0 - r2) + Ctop * (1.0 + r2)[None, :]
+    rhs = ctop + (np.eye(N0) - Ctop) @ (t2 * Isky)
+    Iup = inverse(Smat) @ rhs
+    I0 = Rair * Isky + (t1 * Iup)[:na]
+    if atmosphere is not None:
+        I0 = O.planck(frequency, float(atmosphere["tb_up"])) + atmosphere["transmittance"] * I0
+    tb = O.inverse_planck(frequency, I0).reshape(st.n_air, 2).T
+    return O.interpolate_passive(st.outmu, tb, np.cos(np.deg2rad(np.atleast_1d(theta_deg))))
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    thick, dens, temp, lc = bench.synthetic_snowpacks(1, S=6)
+    worst = 0.0
+    for s in range(6):
+        sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential",
+                  corr_length=lc[s])
+        for f in bench.FREQS:
+            for sub, atm in ((None, None), (dict(kind="flat", eps=5 + 0.5j, temperature=265.0), None),
+                             (dict(kind="reflector", R=(1.0, 0.9), temperature=260.0),
+                              dict(tb_down=30.0, tb_up=20.0, transmittance=0.9))):
+                ref = O.solve(sp, f, [bench.THETA_DEG], n_max_stream=32, substrate=sub, atmosphere=atm)
+                got = solve_pair(sp, f, [bench.THETA_DEG], substrate=sub, atmosphere=atm)
+                e = np.abs(ref - got).max()
+                worst = max(worst, e)
+        print("snowpack", s, "max |dTb| so far %.3e K, growth of the unpivoted eliminations %.3g" % (worst, GROWTH[0]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
