@@ -37,6 +37,9 @@ struct smrt_dort_ctx {
     size_t lds_bytes = 0;
     size_t prep_lds_bytes = 0;
     size_t finish2_lds_bytes = 0;
+    size_t finish_reg_lds_bytes = 0;
+    bool finish_reg = false;    // register-resident finish kernel (passive, N <= 64, Flat interfaces): one wavefront per pair
+    int finish_mode = -1;       // -1: the default choice; 0: never the register-resident finish kernel; 1: whenever supported
     bool finish2 = true;        // two-slot finish kernel (set_pipeline(2) selects the LDS-resident one)
     float last_ms = 0.f;
     double total_ms = 0.0;
@@ -72,6 +75,8 @@ namespace smrt_launch {
 hipError_t prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
 hipError_t finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt, bool two_slot);
 void occupancy_report(smrt_dort_ctx* ctx, int nt);
+// k_finish_reg.hip: the register-resident finish kernel of the same pipeline, one wavefront per pair
+hipError_t finish_reg(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
 // k_jacobi.hip: one workgroup per staging item (pair, [azimuth mode,] layer)
 hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_split_active.hip

@@ -15,6 +15,7 @@
 #include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
 #include "dort_phase_kernel.hpp"
+#include "dort_finish_reg.hpp"      // finish_reg_lds_doubles (device code is inline templates / functions: nothing is instantiated here)
 
 using namespace smrt;
 
@@ -50,6 +51,9 @@ static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long 
 // Jacobi kernels run in up to four ROUNDS over successive layer ranges, top-down, with a small kernel in between that
 // marks the pairs whose cut has been reached: the layers below a cut are never diagonalised (like in the reference),
 // exactly -- the decision uses the same singular values as the finish kernel.
+#ifndef SMRT_FINISH_REG_DEFAULT
+#define SMRT_FINISH_REG_DEFAULT 0   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
+#endif
 static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
     const long long modes = ctx->active ? d.m_max + 1 : 1;
@@ -65,6 +69,7 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     auto finish = [&](const DevBatch& c, unsigned grid) {
         if (ctx->big) return smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
         if (ctx->gmem_split) return smrt_launch::finish_gmem(ctx, c, grid, ctx->active);
+        if (ctx->finish_reg) return smrt_launch::finish_reg(ctx, c);
         return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
     };
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
@@ -153,6 +158,7 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
     if (!ctx) return -1;
     ctx->split = (split != 0);
     ctx->finish2 = (split != 2);
+    ctx->finish_mode = (split == 3) ? 1 : (split == 4 ? 0 : -1);   // 3: register-resident finish wherever supported, 4: never
     ctx->uploaded = false;  // the staging area is sized at upload time
     return 0;
 }
@@ -272,6 +278,16 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->finish2_lds_bytes = ctx->gmem_split
             ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 0 : 2).total * sizeof(double)
             : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd_fin, 2).total * sizeof(double);
+    }
+    // the register-resident finish kernel (one wavefront per pair, dort_finish_reg.hpp): LDS pipeline, passive mode, Flat
+    // interfaces with T = 1 - R (no coherent slabs), no host-evaluated dense substrate
+    {
+        const bool supported = !ctx->gmem_path && ctx->split && ctx->finish2 && !ctx->active && ctx->chunk_pairs > 0 &&
+                               !b->process_coherent_layers && b->substrate_kind != SUB_HOST;
+        int want = ctx->finish_mode;
+        if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
+        ctx->finish_reg = supported && (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
+        ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max, b->n_theta);
     }
     if (b->prune_optical_depth > 0.0) {
         // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:

@@ -58,6 +58,9 @@ SMRT_DEV unsigned row16_max_u32(unsigned k) {
     return k;
 }
 SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f64_16x16x4(a, b, c); }
+// value of lane K of the caller's 16-lane row (lanes 16 g .. 16 g + 15), K a compile-time constant
+template <int K>
+SMRT_DEV double row_bcast16(double v) { return emu::wave_bcast(v, (emu::tid() & 48) | K); }
 SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
 SMRT_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 // sum over aligned groups of GS consecutive lanes (GS power of two <= 64); every lane gets the group total
@@ -130,6 +133,10 @@ SMRT_DEV double dpp_move(double v) {
     r.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], CTRL, 0xF, 0xF, false);
     return r.d;
 }
+// value of lane K of the caller's 16-lane row, K a compile-time constant: DPP row_newbcast (gfx90a and later), two
+// v_mov_b32_dpp, no LDS traffic
+template <int K>
+SMRT_DEV double row_bcast16(double v) { return dpp_move<0x150 + K>(v); }
 template <int CTRL>
 SMRT_DEV unsigned long long dpp_move_u64(unsigned long long v) {
     union { unsigned long long u; int i[2]; } a, r;

@@ -8,11 +8,12 @@
 #include "../../smrt_amd/csrc/dort_active.hpp"
 #include "../../smrt_amd/csrc/dort_host_common.hpp"
 #include "../../smrt_amd/csrc/dort_phase_kernel.hpp"
+#include "../../smrt_amd/csrc/dort_finish_reg.hpp"
 
 using namespace smrt;
 
 // 1: three-kernel pipeline with the two-slot finish kernel (default, like the library), 2: three-kernel pipeline with
-// the LDS-resident finish kernel, 0: fused kernel
+// the LDS-resident finish kernel, 3: ... with the register-resident finish kernel (passive, N <= 64), 0: fused kernel
 extern "C" { int smrt_emu_pipeline = 1; }
 
 template <int NT, int CH>
@@ -136,13 +137,15 @@ static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const L
 template <int NT>
 static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
     Staging sg((size_t)d.pair_count * d.Lmax, plan);
-    std::vector<double> lds(lds_doubles);
+    std::vector<double> lds(lds_doubles + rg::kRegVectors * 64);
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
     return run_rounds(d, order, 1, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
         [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
         [&](long long p) { for (auto& x : lds) x = NAN;
+                           if (smrt_emu_pipeline == 3)   // the register-resident finish kernel: one wavefront per pair
+                               return emu::run_block(64, order, [&]() { dort_pair_passive_reg(d, p, lds.data(), sg.st); });
                            return smrt_emu_pipeline == 2 ? emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &sg.st); })
                                                          : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 3>(d, p, lds.data(), nullptr, &sg.st); }); });
 }
