@@ -176,8 +176,93 @@ SMRT_DEV void invert(Mat& M, int nt, const LaneId& L) {
     }
 }
 
-// ---- vectors live in LDS in natural order (one element per lane for elementwise work); a matrix-vector product reads
-// its operand in "row form" (element 16 tj + c) or "column form" (element 16 ti + 4 r + g) --------------------------
+// ---- products with one operand streamed, results in place (two matrices in registers at most) ----------------------
+// Y <- X^T Y on the leading nt x nt tiles, tile column by tile column (16 doubles of temporaries)
+SMRT_DEV void gemm_tn_inplace(Mat& Y, const Mat& X, int nt) {
+#pragma unroll
+    for (int tj = 0; tj < TM; ++tj) {
+        if (tj < nt) {
+            double acc[TM][4];
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti) {
+                acc[ti][0] = acc[ti][1] = acc[ti][2] = acc[ti][3] = 0.0;
+                if (ti < nt) {
+#pragma unroll
+                    for (int tk = 0; tk < TM; ++tk)
+                        if (tk < nt) tile_tn_acc(acc[ti], X.v[tk][ti], Y.v[tk][tj]);
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+                if (ti < nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Y.v[ti][tj][r] = acc[ti][r];
+                }
+        }
+    }
+}
+// the wavefront's matrix slot in LDS: element (tile ti, tj; register r; lane) at ((4 ti + tj) 4 + r) 64 + lane
+SMRT_DEV void slot_store_tile(double* slot, int ti, int tj, const double (&t)[4], const LaneId& L) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slot[((4 * ti + tj) * 4 + r) * 64 + L.lane] = t[r];
+}
+SMRT_DEV void slot_load_tile(double (&t)[4], const double* slot, int ti, int tj, const LaneId& L) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = slot[((4 * ti + tj) * 4 + r) * 64 + L.lane];
+}
+SMRT_DEV void slot_load(Mat& M, const double* slot, int nt, const LaneId& L) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TM; ++tj)
+            if (ti < nt && tj < nt) slot_load_tile(M.v[ti][tj], slot, ti, tj, L);
+}
+// Z = X^T Y with X in the LDS slot (one tile column of X in registers at a time)
+SMRT_DEV void gemm_tn_slot(Mat& Z, const double* slot, const Mat& Y, int nt, const LaneId& L) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+        if (ti < nt) {
+            double xc[TM][4];
+#pragma unroll
+            for (int tk = 0; tk < TM; ++tk) {
+                xc[tk][0] = xc[tk][1] = xc[tk][2] = xc[tk][3] = 0.0;
+                if (tk < nt) slot_load_tile(xc[tk], slot, tk, ti, L);
+            }
+#pragma unroll
+            for (int tj = 0; tj < TM; ++tj)
+                if (tj < nt) {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int tk = 0; tk < TM; ++tk)
+                        if (tk < nt) tile_tn_acc(acc, xc[tk], Y.v[tk][tj]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Z.v[ti][tj][r] = acc[r];
+                }
+        }
+    }
+}
+// M <- M^T on the leading nt x nt tiles
+SMRT_DEV void transpose_inplace(Mat& M, int nt, const LaneId& L) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < TM; ++tj)
+            if (tj < nt) {
+                double a[4], bq[4];
+                tile_transpose(a, M.v[ti][tj], L);
+                if (tj != ti) {
+                    tile_transpose(bq, M.v[tj][ti], L);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) M.v[ti][tj][r] = bq[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M.v[tj][ti][r] = a[r];
+            }
+}
+
+// ---- vectors: one element per lane in a register for elementwise work; a matrix-vector product or a scaling reads its
+// operand from an LDS exchange vector in "row form" (element 16 tj + c) or "column form" (element 16 ti + 4 r + g) ----
+SMRT_DEV void put(double* x, double v, const LaneId& L) { x[L.lane] = v; }
 // y[i] = sum_j X[i][j] w[j]  -> out (LDS)
 SMRT_DEV void matvec(const Mat& X, const double* w, double* out, int nt, const LaneId& L) {
     double wv[TM];
@@ -218,22 +303,23 @@ SMRT_DEV void matvec_t(const Mat& X, const double* v, double* out, int nt, const
     }
     wave_sync();
 }
-// X[i][j] <- rowf[i] X[i][j] colf[j] + (i == j) diag[i]     (all TM x TM tiles; null pointers: factor 1 / nothing)
-SMRT_DEV void scale_add_diag(Mat& X, const double* rowf, const double* colf, const double* diag, double factor, const LaneId& L) {
+// X[i][j] <- factor rowf[i] X[i][j] colf[j] + (i == j) diag[i] on the leading nt x nt tiles (null pointers: factor 1 / nothing)
+SMRT_DEV void scale_add_diag(Mat& X, const double* rowf, const double* colf, const double* diag, double factor, int nt, const LaneId& L) {
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < TM; ++tj) {
-            const double cf = (colf ? colf[16 * tj + L.c] : 1.0) * factor;
+        for (int tj = 0; tj < TM; ++tj)
+            if (ti < nt && tj < nt) {
+                const double cf = (colf ? colf[16 * tj + L.c] : 1.0) * factor;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ti + 4 * r + L.g;
-                double x = X.v[ti][tj][r] * cf;
-                if (rowf) x *= rowf[row];
-                if (diag && ti == tj && 4 * r + L.g == L.c) x += diag[row];
-                X.v[ti][tj][r] = x;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + L.g;
+                    double x = X.v[ti][tj][r] * cf;
+                    if (rowf) x *= rowf[row];
+                    if (diag && ti == tj && 4 * r + L.g == L.c) x += diag[row];
+                    X.v[ti][tj][r] = x;
+                }
             }
-        }
 }
 
 // tile (ti, tj) of a column-major matrix p (element (r, c) at p[c LD + r]), zero outside N x N
@@ -257,11 +343,22 @@ SMRT_DEV void load_tile_t(double (&t)[4], const double* p, int LD, int N, int ti
     }
 }
 
-constexpr int kRegVectors = 15;   // 64-double LDS vectors of the register-resident finish kernel
+constexpr int kRegVectors = 5;                   // 64-double LDS exchange vectors of the register-resident finish kernel
+constexpr int kSlotDoubles = TM * TM * 4 * 64;   // one 64 x 64 matrix in register layout
 }  // namespace rg
-// LDS doubles of the register-resident finish kernel
-SMRT_HD int finish_reg_lds_doubles(int n_max_stream, int Lmax, int ntheta) {
-    return make_plan(n_max_stream, 2, Lmax, ntheta, 9, 0, 0, 2, 0).total + rg::kRegVectors * 64;
+
+// LDS layout of the register-resident finish kernel: the matrix slot, the exchange vectors, then the tables pair_setup fills
+// (stream tables 3 x n_max_stream, layer tables 15 x Lmax, 8 doubles of flags)
+SMRT_HD int finish_reg_lds_doubles(int n_max_stream, int Lmax) {
+    return rg::kSlotDoubles + rg::kRegVectors * 64 + 3 * n_max_stream + 15 * Lmax + 8;
+}
+
+// reflectivities (V, H) of the Flat interface from medium 1 into medium 2 for the stream whose sine in the most
+// refringent layer is gsin, ri = relative index of medium 1 (streams.py:195-206); T = 1 - R (core/fresnel.py:446-474)
+SMRT_DEV double flat_R(cplx e1, cplx e2, double ri_sin, int pol) {
+    double Rv, Rh;
+    fresnel_RvRh(e1, e2, sqrt(1.0 - ri_sin * ri_sin), &Rv, &Rh);
+    return pol ? Rh : Rv;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -275,11 +372,28 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
     constexpr int NT = 64, P = 2;
     const LaneId Ln = lane_id();
     const int t = Ln.lane;
-    const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, 9, 0, 0, 2, 0);
-    Lds s = carve(lds_base, lds_base, plan);
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
-    const int LD = plan.LD;
+    const int LD = (nmax * P + 1) | 1;   // leading dimension of the staged matrices (make_plan)
+
+    // ---- LDS: matrix slot, exchange vectors, tables
+    double* const slot = lds_base;
+    double* const E0 = lds_base + kSlotDoubles;
+    double* const E1 = E0 + 64;
+    double* const E2 = E0 + 2 * 64;
+    double* const E3 = E0 + 3 * 64;
+    double* const E4 = E0 + 4 * 64;
+    Lds s;
+    {
+        double* v = E0 + kRegVectors * 64;
+        s.gmu = v; s.gsin = v + nmax; s.outmu = v + 2 * nmax; s.mu = s.w = s.muu = nullptr;
+        v += 3 * nmax;
+        const int Lm = b.Lmax;
+        s.eps_re = v; s.eps_im = v + Lm; s.ks = v + 2 * Lm; s.ka = v + 3 * Lm; s.pa = v + 4 * Lm; s.pb = v + 5 * Lm;
+        s.pc = v + 6 * Lm; s.BT = v + 7 * Lm; s.thick = v + 8 * Lm; s.ri = v + 9 * Lm; s.nl = v + 10 * Lm;
+        s.slab_re = v + 11 * Lm; s.slab_im = v + 12 * Lm; s.slab_th = v + 13 * Lm; s.lo = v + 14 * Lm;
+        s.ints = (int*)(v + 15 * Lm);
+    }
 
     const long long gp = global_pair(b, p);
     const int fi = (int)(gp / b.S), si = (int)(gp % b.S);
@@ -325,27 +439,13 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         if (bad != ST_OK) { fail_pair<NT>(b, p, bad, out_stride); return; }
     }
 
-    // LDS vectors (64 doubles each whatever n_max_stream is, natural order, lane e = element e), behind the tables of the plan
-    double* const vec = lds_base + plan.total;
-    double* const v_d = vec;              // row scaling d of the layer (E = D A)
-    double* const v_di = vec + 64;        // 1 / d
-    double* const v_sg = vec + 2 * 64;    // singular values (padding: 1)
-    double* const v_st = vec + 3 * 64;    // sigma t (padding 0)
-    double* const v_c = vec + 4 * 64;     // source c of the relation, physical coordinates
-    double* const v_a = vec + 5 * 64;     // per-layer temporaries
-    double* const v_b = vec + 6 * 64;
-    double* const v_e = vec + 7 * 64;
-    double* const v_f = vec + 8 * 64;
-    double* const v_g = vec + 9 * 64;
-    double* const v_h = vec + 10 * 64;
-    double* const v_i = vec + 11 * 64;
-    double* const v_j = vec + 12 * 64;
-    double* const v_k = vec + 13 * 64;
-    double* const v_tb = vec + 14 * 64;   // brightness temperatures at the air streams
-
-    Mat C, X1, X2;      // C: the relation; X1, X2: work matrices
-    zero(C); zero(X1); zero(X2);
+    Mat X2;   // the matrix that is inverted (H^T + Sigma, M3^T, Y / S); a second one lives only inside a phase
+    zero(X2);
     double n3 = 0.0;
+    // element t of the vectors carried from layer to layer: source c of the relation (physical coordinates of the layer it
+    // is used in) and u = C^ 1^ (C^ itself lies in the LDS slot)
+    double c_e = 0.0, u_e = 0.0;
+    double tb_e = 0.0;
 
     for (int l = Lk - 1; l >= 0; --l) {
         const int n = (int)s.nl[l];
@@ -354,60 +454,56 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         n3 += (double)N * N * N;
         const cplx el = cmk(s.eps_re[l], s.eps_im[l]);
         const double Bl = s.BT[l];
-        const int nu = (l > 0) ? (int)s.nl[l - 1] : n_air;
-        const int Nu = nu * P;
-        const int nc = (N < Nu) ? N : Nu;
         const long long item = p * (long long)b.Lmax + l;
         const double* gL = stg.L + item * stg.mat_stride;
         const double* gB = stg.B + item * stg.mat_stride;
         const double* gI = stg.Linv + item * 1024;
-        const double thick_l = s.thick[l];
+        const bool in_e = t < N;
+        // ---- element t of the vectors of this layer (padding: d = sigma = 1, t = 0)
+        const double d_e = in_e ? stg.d[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
+        const double sg_e = in_e ? stg.sigma[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
+        const double di_e = fast_rcp(d_e);
+        const double nrs_e = -fast_rcp(sg_e);                      // -1 / sigma
+        const double tt_e = in_e ? exp(-sg_e * s.thick[l]) : 0.0;
+        const double st_e = sg_e * tt_e;                           // sigma t
+        const double m3_e = in_e ? sg_e * (1.0 - tt_e * tt_e) : 1.0;
 
-        // ---- element e of the vectors of this layer
-        {
-            const int e = t;
-            const bool in = e < N;
-            const double dd = in ? stg.d[item * stg.vec_stride + (in ? e : 0)] : 1.0;
-            const double sg = in ? stg.sigma[item * stg.vec_stride + (in ? e : 0)] : 1.0;
-            const double tt = in ? exp(-sg * thick_l) : 0.0;
-            v_d[e] = dd; v_di[e] = 1.0 / dd; v_sg[e] = sg; v_st[e] = sg * tt;
-            v_a[e] = in ? sg * (1.0 - tt * tt) : 1.0;    // diagonal of M3
-            v_b[e] = in ? -1.0 / sg : -1.0;              // -1 / sigma
-        }
         if (l == Lk - 1) {
             // what the last layer sees below (rtsolver_utils.py:544-551,579-584,601-603; dort.py:429-441,446-452):
-            // I_up = R I_dn + src  ->  C = (1 - R) / (1 + R), c = (C + 1) src
-            const int r = t;
+            // I_up = R I_dn + src  ->  C = (1 - R) / (1 + R) (diagonal: C^ = C), c = (C + 1) src
             double Rs = 0.0, src = 0.0;
-            if (r < N) {
-                const double rs = s.ri[l] * s.gsin[r >> 1];
-                const double mu_r = sqrt(1.0 - rs * rs);
-                if (Lk < L) {
-                    double Rv, Rh, Tv, Th;
-                    interface_RT(frequency, el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), mu_r,
-                                 cmk(s.slab_re[l + 1], s.slab_im[l + 1]), s.slab_th[l + 1], &Rv, &Rh, &Tv, &Th);
-                    Rs = (r & 1) ? Rh : Rv;
-                } else if (b.sub_kind != SUB_NONE) {
+            if (in_e) {
+                const double rs = s.ri[l] * s.gsin[t >> 1];
+                if (Lk < L) Rs = flat_R(el, cmk(s.eps_re[l + 1], s.eps_im[l + 1]), rs, t & 1);
+                else if (b.sub_kind != SUB_NONE) {
                     const double q1 = b.sub_p1[gp], q2 = b.sub_p2[gp];
-                    if (b.sub_kind == SUB_FLAT) {
-                        double Rv, Rh;
-                        fresnel_RvRh(el, cmk(q1, q2), mu_r, &Rv, &Rh);
-                        Rs = (r & 1) ? Rh : Rv;
-                    } else Rs = (r & 1) ? q2 : q1;
+                    Rs = (b.sub_kind == SUB_FLAT) ? flat_R(el, cmk(q1, q2), rs, t & 1) : ((t & 1) ? q2 : q1);
                     const double Ts = b.sub_T[si];
                     if (Ts > 0.0) src = (1.0 - Rs) * (b.rayleigh_jeans ? Ts : planck_radiance(frequency, Ts));
                 }
             }
-            const double cd = (1.0 - Rs) / (1.0 + Rs);
-            v_k[r] = (r < N) ? cd : 0.0;
-            v_c[r] = (r < N) ? (cd + 1.0) * src : 0.0;
+            const double cd = in_e ? (1.0 - Rs) * fast_rcp(1.0 + Rs) : 0.0;
+            c_e = in_e ? (cd + 1.0) * src : 0.0;
+            u_e = cd * di_e;
+            put(E0, cd, Ln);
             wave_sync();
-            zero(C);
-            scale_add_diag(C, nullptr, nullptr, v_k, 1.0, Ln);
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TM; ++tj)
+                    if (ti < nt && tj < nt) {
+                        double z4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) z4[r] = (ti == tj && 4 * r + Ln.g == Ln.c) ? E0[16 * ti + Ln.c] : 0.0;
+                        slot_store_tile(slot, ti, tj, z4, Ln);
+                    }
+            wave_sync();
         }
-        wave_sync();
 
-        // ---- A+ = L+^-T B' (in X1), blocked back substitution with the diagonal-block inverses of the prep kernel
+        {
+        Mat X1;
+        zero(X1);
+        // ---- A+ = L+^-T B' (X1), blocked back substitution with the diagonal-block inverses of the prep kernel
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
@@ -443,30 +539,20 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     }
             }
         }
-        // ---- C^ = D^-1 C D;  z = c^ - 2 B C^ 1^  (column form, v_e);  T1 = C^^T A+ (X2);  H^T = A+^T T1 (C)
-        scale_add_diag(C, v_di, v_d, nullptr, 1.0, Ln);
-        matvec(C, v_di, v_e, nt, Ln);                                 // u = C^ 1^
-        v_e[t] = v_c[t] * v_di[t] - 2.0 * Bl * v_e[t];                // z
+        // ---- T1 = C^^T A+ (X2; C^ from the slot), r = A+^T z with z = c^ - 2 B C^ 1^, H^T = A+^T T1 (in place, X2)
+        gemm_tn_slot(X2, slot, X1, nt, Ln);
+        put(E0, c_e * di_e - 2.0 * Bl * u_e, Ln);
         wave_sync();
-        gemm_tn(X2, C, X1, nt);
-        matvec_t(X1, v_e, v_f, nt, Ln);                               // r = A+^T z   (row form, v_f)
-        gemm_tn(C, X1, X2, nt);
-        scale_add_diag(C, nullptr, nullptr, v_sg, 1.0, Ln);           // H^T + Sigma
-        invert(C, nt, Ln);                                            // P^T
-        matvec_t(C, v_f, v_e, nt, Ln);                                // q = P r
-        // ---- M3^T = Sigma (1 - t^2) + 2 (Sigma t) P^T (t Sigma), inverse, y = M3^-1 (Sigma t q), Theta^T = 2 M3^-T - Sigma^-1
-        scale_add_diag(C, v_st, v_st, v_a, 2.0, Ln);
-        invert(C, nt, Ln);
-        v_f[t] = v_st[t] * v_e[t];
+        matvec_t(X1, E0, E1, nt, Ln);                                  // r in E1 (natural order)
+        gemm_tn_inplace(X2, X1, nt);
+        // ---- At = A-^T = -Sigma^-1 B'^T L+^T: B' again (X1), L+^T tile by tile, finished columns go to the slot
+        put(E2, nrs_e, Ln);
         wave_sync();
-        matvec_t(C, v_f, v_g, nt, Ln);                                // y (v_g)
-        scale_add_diag(C, nullptr, nullptr, v_b, 2.0, Ln);            // Theta^T
-        // ---- At = A-^T = -Sigma^-1 B'^T L+^T (X1): B' again (X2), L+^T tile by tile
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TM; ++tj)
-                if (ti < nt && tj < nt) load_tile(X2.v[ti][tj], gB, LD, N, ti, tj, Ln);
+                if (ti < nt && tj < nt) load_tile(X1.v[ti][tj], gB, LD, N, ti, tj, Ln);
 #pragma unroll
         for (int tj = 0; tj < TM; ++tj) {
             if (tj < nt) {
@@ -479,146 +565,208 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     load_tile_t(Lt, gL, LD, N, tk, tj, Ln);           // (L+^T)[tk][tj]
 #pragma unroll
                     for (int ti = 0; ti < TM; ++ti)
-                        if (ti < nt) tile_tn_acc(acc[ti], X2.v[tk][ti], Lt);
+                        if (ti < nt) tile_tn_acc(acc[ti], X1.v[tk][ti], Lt);
                 }
 #pragma unroll
                 for (int ti = 0; ti < TM; ++ti)
+                    if (ti < nt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) X1.v[ti][tj][r] = (ti < nt) ? acc[ti][r] : 0.0;
+                        for (int r = 0; r < 4; ++r) acc[ti][r] *= E2[16 * ti + 4 * r + Ln.g];
+                        slot_store_tile(slot, ti, tj, acc[ti], Ln);
+                    }
             }
         }
-        scale_add_diag(X1, v_b, nullptr, nullptr, 1.0, Ln);           // rows times -1 / sigma
-        // ---- C^' = At^T (Theta At): T2 = (Theta^T)^T At (X2), C^' = At^T T2 (C)
-        gemm_tn(X2, C, X1, nt);
-        gemm_tn(C, X1, X2, nt);
-        // c^' = 2 B C^' 1^ - 2 A- y
-        matvec(C, v_di, v_e, nt, Ln);                                 // C^' 1^  (v_e)
-        matvec_t(X1, v_g, v_f, nt, Ln);                               // A- y = At^T y  (v_f)
-        v_c[t] = v_d[t] * (2.0 * Bl * v_e[t] - 2.0 * v_f[t]);         // c' (physical)
         wave_sync();
-        scale_add_diag(C, v_d, v_di, nullptr, 1.0, Ln);               // C' = D C^' D^-1
+        }
 
-        if (l == 0) break;
-        // ---- interface with the layer above: diagonal coefficients per element e (streams paired by index)
-        {
-            const int e = t;
-            double r1 = 1.0, t2 = 0.0, r2 = 0.0, t1 = 0.0, extra = 0.0;
-            const cplx eup = cmk(s.eps_re[l - 1], s.eps_im[l - 1]);
-            const cplx slab = cmk(s.slab_re[l], s.slab_im[l]);
-            if (e < N) {   // from this layer upwards
-                const double rs = s.ri[l] * s.gsin[e >> 1];
-                double Rv, Rh, Tv, Th;
-                interface_RT(frequency, el, eup, sqrt(1.0 - rs * rs), slab, s.slab_th[l], &Rv, &Rh, &Tv, &Th);
-                r2 = (e & 1) ? Rh : Rv;
-                t1 = (e < nc) ? ((e & 1) ? Th : Tv) : 0.0;
-            }
-            if (e < Nu) {  // from the upper layer downwards
-                const double rs = s.ri[l - 1] * s.gsin[e >> 1];
-                double Rv, Rh, Tv, Th;
-                interface_RT(frequency, eup, el, sqrt(1.0 - rs * rs), slab, s.slab_th[l], &Rv, &Rh, &Tv, &Th);
-                const double rb = (e & 1) ? Rh : Rv;
-                if (e < nc) { r1 = rb; t2 = (e & 1) ? Th : Tv; }
-                else extra = (1.0 - rb) / (1.0 + rb);   // a stream that does not exist below: I_up = R I_dn
-            }
-            const bool in = e < N;
-            const double tt2 = t1 * t2;
-            const double ca = 0.5 * (tt2 + (1.0 + r1) * (1.0 - r2));
-            const double cb = 0.5 * (tt2 - (1.0 + r1) * (1.0 + r2));
-            const double cc = 0.5 * (tt2 - (1.0 - r1) * (1.0 - r2));
-            const double cd = 0.5 * (tt2 + (1.0 - r1) * (1.0 + r2));
-            v_a[e] = in ? ca : 1.0;          // Y = a - b C'
-            v_b[e] = in ? -cb : 0.0;
-            v_e[e] = in ? cc : 0.0;          // Nn = c - d C'
-            v_f[e] = in ? -cd : 0.0;
-            v_g[e] = (e < nc) ? t2 : 0.0;
-            v_h[e] = (e < nc) ? -1.0 / t2 : 0.0;
-            v_i[e] = extra;
-            v_j[e] = in ? cb * v_c[e] : 0.0;     // b c'
-            v_k[e] = (e < nc) ? cd * v_c[e] / t2 : 0.0;
-        }
-        wave_sync();
-        // X1 = Y, X2 = Nn
+        // ---- three inversions of X2, one copy of the elimination code (X2 is the only matrix in registers meanwhile)
+        double q_e = 0.0;
+        bool last = false;
+        double cb_e = 0.0, cd_e = 0.0, t2_e = 0.0, it2_e = 0.0, extra_e = 0.0;   // interface coefficients (stage 2 -> post)
+        double r2s_e = 0.0, t1s_e = 0.0, Rair_e = 0.0, Idn = 0.0;               // surface (l == 0)
+        int Nu = 0, nc = 0;
+#if !defined(SMRT_HOST_EMU)
+#pragma nounroll
+#endif
+        for (int stage = 0; stage < 3; ++stage) {
+            if (stage == 0) {
+                put(E2, sg_e, Ln);
+                wave_sync();
+                scale_add_diag(X2, nullptr, nullptr, E2, 1.0, nt, Ln);      // H^T + Sigma
+            } else if (stage == 1) {
+                matvec_t(X2, E1, E0, nt, Ln);                               // q = P r
+                q_e = E0[t];
+                put(E2, st_e, Ln); put(E3, m3_e, Ln);
+                wave_sync();
+                scale_add_diag(X2, E2, E2, E3, 2.0, nt, Ln);                // M3^T
+            } else {
+                put(E0, st_e * q_e, Ln);
+                wave_sync();
+                matvec_t(X2, E0, E1, nt, Ln);                               // y = M3^-1 (Sigma t q), natural order in E1
+                put(E2, nrs_e, Ln);
+                wave_sync();
+                scale_add_diag(X2, nullptr, nullptr, E2, 2.0, nt, Ln);      // Theta^T = 2 M3^-T - Sigma^-1
+                Mat X1;
+                zero(X1);
+                slot_load(X1, slot, nt, Ln);                                // At
+                matvec_t(X1, E1, E0, nt, Ln);                               // A- y = At^T y
+                const double amy_e = E0[t];
+                gemm_tn_inplace(X1, X2, nt);                                // T2 = Theta At
+                slot_load(X2, slot, nt, Ln);
+                gemm_tn_inplace(X1, X2, nt);                                // C^' = At^T T2
+                put(E2, di_e, Ln); put(E3, d_e, Ln);
+                wave_sync();
+                matvec(X1, E2, E0, nt, Ln);                                 // C^' 1^
+                c_e = d_e * (2.0 * Bl * E0[t] - 2.0 * amy_e);               // c' (physical coordinates)
+                scale_add_diag(X1, E3, E2, nullptr, 1.0, nt, Ln);           // C' = D C^' D^-1
+                wave_sync();
+                if (l == 0) {
+                    // surface (dort.py:391-395,484): I_dn = r2 I_up + t2 I_sky just below it;
+                    // S I_up = c' + (I - C') t2 I_sky,  S = (1 - r2) + C' (1 + r2);  I0 = R_air I_sky + t1 I_up
+                    last = true;
+                    const bool atm = (b.atm_down != nullptr);
+                    Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
+                    double Tair = 0.0;
+                    const cplx one = cmk(1.0, 0.0);
+                    if (in_e) { r2s_e = flat_R(el, one, s.ri[0] * s.gsin[t >> 1], t & 1); t1s_e = 1.0 - r2s_e; }
+                    if (t < n_air * P) {
+                        double Rv, Rh;
+                        fresnel_RvRh(one, el, s.outmu[t >> 1], &Rv, &Rh);
+                        Rair_e = (t & 1) ? Rh : Rv; Tair = 1.0 - Rair_e;
+                    }
+                    put(E0, Tair * Idn, Ln);                                // t2 I_sky (0 beyond the air streams)
+                    wave_sync();
+                    matvec(X1, E0, E1, nt, Ln);
+                    const double rhs = in_e ? c_e + E0[t] - E1[t] : 0.0;
+                    wave_sync();
+                    put(E4, rhs, Ln);
+                    put(E2, in_e ? 1.0 + r2s_e : 0.0, Ln); put(E3, in_e ? 1.0 - r2s_e : 1.0, Ln);
+                    wave_sync();
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
+                    for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < TM; ++tj)
+                        for (int tj = 0; tj < TM; ++tj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { X1.v[ti][tj][r] = C.v[ti][tj][r]; X2.v[ti][tj][r] = C.v[ti][tj][r]; }
-        scale_add_diag(X1, v_b, nullptr, v_a, 1.0, Ln);
-        scale_add_diag(X2, v_f, nullptr, v_e, 1.0, Ln);
-        // C <- Nn^T (tile transposes)
+                            for (int r = 0; r < 4; ++r) X2.v[ti][tj][r] = X1.v[ti][tj][r];
+                    scale_add_diag(X2, nullptr, E2, E3, 1.0, nt, Ln);
+                } else {
+                    // interface with the layer above: diagonal coefficients per element (streams paired by index)
+                    Nu = (int)s.nl[l - 1] * P;
+                    nc = (N < Nu) ? N : Nu;
+                    const cplx eup = cmk(s.eps_re[l - 1], s.eps_im[l - 1]);
+                    double r1 = 1.0, t2 = 0.0, r2 = 0.0, t1 = 0.0;
+                    extra_e = 0.0;
+                    if (in_e) {   // from this layer upwards
+                        r2 = flat_R(el, eup, s.ri[l] * s.gsin[t >> 1], t & 1);
+                        t1 = (t < nc) ? 1.0 - r2 : 0.0;
+                    }
+                    if (t < Nu) {  // from the upper layer downwards
+                        const double rb = flat_R(eup, el, s.ri[l - 1] * s.gsin[t >> 1], t & 1);
+                        if (t < nc) { r1 = rb; t2 = 1.0 - rb; }
+                        else extra_e = (1.0 - rb) * fast_rcp(1.0 + rb);   // a stream that does not exist below: I_up = R I_dn
+                    }
+                    const double tt2 = t1 * t2;
+                    const double ca = 0.5 * (tt2 + (1.0 + r1) * (1.0 - r2));
+                    const double cc = 0.5 * (tt2 - (1.0 - r1) * (1.0 - r2));
+                    cb_e = 0.5 * (tt2 - (1.0 + r1) * (1.0 + r2));
+                    cd_e = 0.5 * (tt2 + (1.0 - r1) * (1.0 + r2));
+                    t2_e = (t < nc) ? t2 : 0.0;
+                    it2_e = (t < nc) ? fast_rcp(t2) : 0.0;
+                    // X2 = Y = a - b C',  X1 = Nn = c - d C' and then its transpose
+                    put(E0, in_e ? -cb_e : 0.0, Ln); put(E1, in_e ? ca : 1.0, Ln);
+                    put(E2, in_e ? -cd_e : 0.0, Ln); put(E3, in_e ? cc : 0.0, Ln);
+                    wave_sync();
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
+                    for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < TM; ++tj)
-                if (ti < nt && tj < nt) tile_transpose(C.v[tj][ti], X2.v[ti][tj], Ln);
-        invert(X1, nt, Ln);                                           // Y^-1
-        gemm_tn(X2, C, X1, nt);                                       // Z = Nn Y^-1
-        matvec(X2, v_j, v_e, nt, Ln);                                 // Z (b c')
-        // C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the upper layer's extra streams
+                        for (int tj = 0; tj < TM; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
+                            for (int r = 0; r < 4; ++r) X2.v[ti][tj][r] = X1.v[ti][tj][r];
+                    scale_add_diag(X2, E0, nullptr, E1, 1.0, nt, Ln);
+                    scale_add_diag(X1, E2, nullptr, E3, 1.0, nt, Ln);
+                    transpose_inplace(X1, nt, Ln);
+                    // Nn^T waits in the slot (At is consumed) while Y is inverted
 #pragma unroll
-            for (int tj = 0; tj < TM; ++tj) {
-                const int col = 16 * tj + Ln.c;
-                const double cf = v_g[col];
+                    for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * r + Ln.g;
-                    const bool in = (ti < nt && tj < nt) && row < nc && col < nc;
-                    double x = in ? X2.v[ti][tj][r] * v_h[row] * cf : 0.0;
-                    if (row == col) x += v_i[row];
-                    C.v[ti][tj][r] = x;
+                        for (int tj = 0; tj < TM; ++tj)
+                            if (ti < nt && tj < nt) slot_store_tile(slot, ti, tj, X1.v[ti][tj], Ln);
                 }
+                wave_sync();
             }
-        // c_u = (d c' - Z b c') / t2
-        v_c[t] = (t < nc) ? v_k[t] + v_e[t] * v_h[t] : 0.0;
+            invert(X2, nt, Ln);
+        }
+        if (last) {
+            matvec(X2, E4, E0, nt, Ln);    // I_up just below the surface
+            if (t < n_air * P) {
+                const bool atm = (b.atm_down != nullptr);
+                double I0 = Rair_e * Idn + t1s_e * E0[t];
+                if (atm) I0 = (b.rayleigh_jeans ? b.atm_up[fi] : planck_radiance(frequency, b.atm_up[fi])) + b.atm_trans[fi] * I0;
+                tb_e = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
+            }
+            break;
+        }
+        // ---- Z = Nn Y^-1 (in place, X2);  C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the
+        //      upper layer's extra streams;  c_u = (d c' - Z b c') / t2;  then the hats of the layer above: C^ = D^-1 C D
+        {
+            Mat X1;
+            zero(X1);
+            slot_load(X1, slot, nt, Ln);
+            gemm_tn_inplace(X2, X1, nt);
+        }
+        put(E0, in_e ? cb_e * c_e : 0.0, Ln);
+        wave_sync();
+        matvec(X2, E0, E1, nt, Ln);
+        c_e = (t < nc) ? (cd_e * c_e - E1[t]) * it2_e : 0.0;
+        const int ntu = (Nu + 15) >> 4;
+        const long long item_u = item - 1;
+        const bool in_u = t < Nu;
+        const double du_e = in_u ? stg.d[item_u * stg.vec_stride + (in_u ? t : 0)] : 1.0;
+        const double dui_e = fast_rcp(du_e);
+        wave_sync();
+        put(E2, -it2_e * dui_e, Ln); put(E3, t2_e * du_e, Ln); put(E4, extra_e, Ln); put(E0, dui_e, Ln);
+        wave_sync();
+        {
+            double wv[TM];
+#pragma unroll
+            for (int tj = 0; tj < TM; ++tj) wv[tj] = E0[16 * tj + Ln.c];
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+                if (ti < ntu) {
+                    double urow[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int tj = 0; tj < TM; ++tj)
+                        if (tj < ntu) {
+                            const int col = 16 * tj + Ln.c;
+                            const double cf = E3[col];
+                            double z4[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * ti + 4 * r + Ln.g;
+                                const bool in = (ti < nt && tj < nt) && row < nc && col < nc;
+                                double x = in ? X2.v[ti][tj][r] * E2[row] * cf : 0.0;
+                                if (row == col) x += E4[row];
+                                z4[r] = x;
+                                urow[r] += x * wv[tj];
+                            }
+                            slot_store_tile(slot, ti, tj, z4, Ln);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double a = group_sum<16>(urow[r]);
+                        if (Ln.c == 0) E1[16 * ti + 4 * r + Ln.g] = a;
+                    }
+                }
+        }
+        wave_sync();
+        u_e = in_u ? E1[in_u ? t : 0] : 0.0;
         wave_sync();
     }
 
-    // ---- surface (dort.py:391-395,484): I_dn = r2 I_up + t2 I_sky below it, S I_up = c' + (I - C') t2 I_sky with
-    //      S = (1 - r2) + C' (1 + r2); emerging I0 = R_air I_sky + t1 I_up on the air streams
-    {
-        const int N0 = (int)s.nl[0] * P;
-        const int nt = (N0 + 15) >> 4;
-        const bool atm = (b.atm_down != nullptr);
-        const double Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
-        const double Iup_atm = atm ? (b.rayleigh_jeans ? b.atm_up[fi] : planck_radiance(frequency, b.atm_up[fi])) : 0.0;
-        const double trans = atm ? b.atm_trans[fi] : 1.0;
-        const cplx e0 = cmk(s.eps_re[0], s.eps_im[0]);
-        const cplx slab0 = cmk(s.slab_re[0], s.slab_im[0]);
-        const int e = t;
-        double r2 = 0.0, t1 = 0.0, Rair = 0.0, Tair = 0.0;
-        if (e < N0) {
-            const double rs = s.ri[0] * s.gsin[e >> 1];
-            double Rv, Rh, Tv, Th;
-            interface_RT(frequency, e0, cmk(1.0, 0.0), sqrt(1.0 - rs * rs), slab0, s.slab_th[0], &Rv, &Rh, &Tv, &Th);
-            r2 = (e & 1) ? Rh : Rv; t1 = (e & 1) ? Th : Tv;
-        }
-        if (e < n_air * P) {
-            double Rv, Rh, Tv, Th;
-            interface_RT(frequency, cmk(1.0, 0.0), e0, s.outmu[e >> 1], slab0, s.slab_th[0], &Rv, &Rh, &Tv, &Th);
-            Rair = (e & 1) ? Rh : Rv; Tair = (e & 1) ? Th : Tv;
-        }
-        v_a[e] = (e < N0) ? 1.0 - r2 : 1.0;
-        v_b[e] = (e < N0) ? 1.0 + r2 : 0.0;
-        v_e[e] = Tair * Idn;            // t2 I_sky (0 beyond the air streams)
-        wave_sync();
-        matvec(C, v_e, v_f, nt, Ln);    // C' (t2 I_sky)
-        v_g[e] = (e < N0) ? v_c[e] + v_e[e] - v_f[e] : 0.0;
-        wave_sync();
-        scale_add_diag(C, nullptr, v_b, v_a, 1.0, Ln);
-        invert(C, nt, Ln);
-        matvec(C, v_g, v_f, nt, Ln);    // I_up just below the surface
-        if (e < n_air * P) {
-            double I0 = Rair * Idn + t1 * v_f[e];
-            if (atm) I0 = Iup_atm + trans * I0;
-            v_tb[e] = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
-        }
-    }
+    put(E0, tb_e, Ln);
     block_sync();
     bool bad = false;
-    for (int i = t; i < n_air * P; i += NT) bad = bad || !(fabs(v_tb[i]) < 1e300);   // NaN / inf: a vanishing pivot
+    for (int i = t; i < n_air * P; i += NT) bad = bad || !(fabs(E0[i]) < 1e300);   // NaN / inf: a vanishing pivot
     if (bad) lds_max(&s.ints[0], ST_SINGULAR);
     block_sync();
     if (s.ints[0] != ST_OK) { fail_pair<NT>(b, p, s.ints[0], out_stride); return; }
@@ -627,12 +775,12 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         const double um = cos(b.theta[it]);
         // (rtsolver_utils.py:191-198, see dort_pair_passive)
         double x0, x1, y0, y1;
-        const double top = 0.5 * (v_tb[0] + v_tb[1]);
-        if (um > s.outmu[0] || n_air == 1) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = v_tb[pol]; }
+        const double top = 0.5 * (E0[0] + E0[1]);
+        if (um > s.outmu[0] || n_air == 1) { x0 = 1.0; y0 = top; x1 = s.outmu[0]; y1 = E0[pol]; }
         else {
             int k = 0;
             while (k < n_air - 2 && um < s.outmu[k + 1]) ++k;
-            x0 = s.outmu[k]; y0 = v_tb[2 * k + pol]; x1 = s.outmu[k + 1]; y1 = v_tb[2 * (k + 1) + pol];
+            x0 = s.outmu[k]; y0 = E0[2 * k + pol]; x1 = s.outmu[k + 1]; y1 = E0[2 * (k + 1) + pol];
         }
         b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
     }

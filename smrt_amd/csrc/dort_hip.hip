@@ -287,7 +287,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         int want = ctx->finish_mode;
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
         ctx->finish_reg = supported && (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
-        ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max, b->n_theta);
+        ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
     }
     if (b->prune_optical_depth > 0.0) {
         // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:

@@ -137,7 +137,7 @@ static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const L
 template <int NT>
 static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
     Staging sg((size_t)d.pair_count * d.Lmax, plan);
-    std::vector<double> lds(lds_doubles + rg::kRegVectors * 64);
+    std::vector<double> lds(lds_doubles + finish_reg_lds_doubles(d.n_max_stream, d.Lmax));
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
     return run_rounds(d, order, 1, sg,
