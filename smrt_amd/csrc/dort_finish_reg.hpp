@@ -32,7 +32,6 @@ namespace rg {
 
 constexpr int TM = 4;   // 16 x 16 tiles per side
 struct Mat { double v[TM][TM][4]; };
-struct Tile { double r[4]; };
 
 struct LaneId { int lane, g, c; };
 SMRT_DEV LaneId lane_id() { LaneId L; L.lane = tid() & (SMRT_LANES - 1); L.g = L.lane >> 4; L.c = L.lane & 15; return L; }
@@ -322,25 +321,46 @@ SMRT_DEV void scale_add_diag(Mat& X, const double* rowf, const double* colf, con
             }
 }
 
-// tile (ti, tj) of a column-major matrix p (element (r, c) at p[c LD + r]), zero outside N x N
-SMRT_DEV void load_tile(double (&t)[4], const double* p, int LD, int N, int ti, int tj, const LaneId& L) {
-    const int col = 16 * tj + L.c;
+// Staged matrices are column-major with leading dimension LD (element (r, c) at p[c LD + r]).  A tile load is "uniform
+// base + one 32-bit lane offset": the lane offsets are the same for every tile of a layer (LaneOffsets), the tile offset
+// is scalar arithmetic -- no per-tile 64-bit address registers.  Everything outside N x N reads as zero.
+struct LaneOffsets {
+    unsigned direct;   // c LD + g      lane part of element (16 ti + 4 r + g, 16 tj + c)
+    unsigned transp;   // g LD + c      the same element of the transpose
+    unsigned blk;      // 16 c + g      ... of a 16 x 16 column-major block (diagonal-block inverses)
+    int rl, cl;        // N - g, N - c  row / column bounds of this lane
+};
+SMRT_DEV LaneOffsets lane_offsets(int LD, int N, const LaneId& L) {
+    LaneOffsets o;
+    o.direct = (unsigned)(L.c * LD + L.g); o.transp = (unsigned)(L.g * LD + L.c); o.blk = (unsigned)(16 * L.c + L.g);
+    o.rl = N - L.g; o.cl = N - L.c;
+    return o;
+}
+SMRT_DEV void load_tile(double (&t)[4], const double* p, int LD, int ti, int tj, const LaneOffsets& o) {
+    const bool cin = 16 * tj < o.cl;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + 4 * r + L.g;
-        const bool in = row < N && col < N;
-        t[r] = in ? p[(in ? col : 0) * LD + (in ? row : 0)] : 0.0;
+        const double* q = p + ((16 * tj) * LD + 16 * ti + 4 * r);
+        const bool in = cin && 16 * ti + 4 * r < o.rl;
+        const double v = q[in ? o.direct : 0u];   // (the tile origin is always inside the matrix)
+        t[r] = in ? v : 0.0;
     }
 }
 // tile (ti, tj) of the TRANSPOSE of p
-SMRT_DEV void load_tile_t(double (&t)[4], const double* p, int LD, int N, int ti, int tj, const LaneId& L) {
-    const int col = 16 * tj + L.c;
+SMRT_DEV void load_tile_t(double (&t)[4], const double* p, int LD, int ti, int tj, const LaneOffsets& o) {
+    const bool cin = 16 * tj < o.cl;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 16 * ti + 4 * r + L.g;
-        const bool in = row < N && col < N;
-        t[r] = in ? p[(in ? row : 0) * LD + (in ? col : 0)] : 0.0;
+        const double* q = p + ((16 * ti + 4 * r) * LD + 16 * tj);
+        const bool in = cin && 16 * ti + 4 * r < o.rl;
+        const double v = q[in ? o.transp : 0u];
+        t[r] = in ? v : 0.0;
     }
+}
+// block ti of the [4][256] diagonal-block inverses (identity padded by the prep kernel)
+SMRT_DEV void load_block(double (&t)[4], const double* p, int ti, const LaneOffsets& o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const double* q = p + (ti * 256 + 4 * r); t[r] = q[o.blk]; }
 }
 
 constexpr int kRegVectors = 5;                   // 64-double LDS exchange vectors of the register-resident finish kernel
@@ -374,7 +394,6 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
     const int t = Ln.lane;
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
-    const int LD = (nmax * P + 1) | 1;   // leading dimension of the staged matrices (make_plan)
 
     // ---- LDS: matrix slot, exchange vectors, tables
     double* const slot = lds_base;
@@ -405,7 +424,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
     const double* mp1 = b.p1 + (long long)si * b.Lmax;
     const double* mp2 = b.p2 + (long long)si * b.Lmax;
 
-    if (t < 8) s.ints[t] = 0;
+    if (t < 8) s.ints[t] = (t == 7) ? ((nmax * P + 1) | 1) : 0;   // [7]: leading dimension of the staged matrices (make_plan)
     block_sync();
     {
         const int prev = b.status[p];
@@ -439,13 +458,12 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         if (bad != ST_OK) { fail_pair<NT>(b, p, bad, out_stride); return; }
     }
 
-    Mat X2;   // the matrix that is inverted (H^T + Sigma, M3^T, Y / S); a second one lives only inside a phase
-    zero(X2);
     double n3 = 0.0;
     // element t of the vectors carried from layer to layer: source c of the relation (physical coordinates of the layer it
     // is used in) and u = C^ 1^ (C^ itself lies in the LDS slot)
     double c_e = 0.0, u_e = 0.0;
     double tb_e = 0.0;
+    double* const ws = stg.ws + p * (long long)kSlotDoubles;   // this pair's matrix in global memory (At between its phases)
 
     for (int l = Lk - 1; l >= 0; --l) {
         const int n = (int)s.nl[l];
@@ -500,90 +518,127 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
             wave_sync();
         }
 
+        const int LD = s.ints[7];   // (read per layer from LDS on purpose: keeps the tile offsets out of loop-invariant registers)
+        const LaneOffsets lo = lane_offsets(LD, N, Ln);
+        Mat X2;   // the matrix that is inverted (H^T + Sigma, M3^T, Y / S); the only one in registers meanwhile
         {
-        Mat X1;
-        zero(X1);
-        // ---- A+ = L+^-T B' (X1), blocked back substitution with the diagonal-block inverses of the prep kernel
+            Mat X1;
+            zero(X1);
+            // ---- B' (X1) and L+^T (tile by tile, requested up front: one wavefront per SIMD, nothing else hides the latency)
+            {
+                double LtT[TM][TM][4];   // (L+^T)[tk][tj], tk <= tj
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
+                for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < TM; ++tj)
-                if (ti < nt && tj < nt) load_tile(X1.v[ti][tj], gB, LD, N, ti, tj, Ln);
+                    for (int tj = 0; tj < TM; ++tj)
+                        if (ti < nt && tj < nt) load_tile(X1.v[ti][tj], gB, LD, ti, tj, lo);
 #pragma unroll
-        for (int ti = TM - 1; ti >= 0; --ti) {
-            if (ti < nt) {
+                for (int tj = 0; tj < TM; ++tj)
 #pragma unroll
-                for (int tk = ti + 1; tk < TM; ++tk)
-                    if (tk < nt) {
-                        double Lt[4];
-                        load_tile(Lt, gL, LD, N, tk, ti, Ln);
+                    for (int tk = 0; tk <= tj; ++tk)
+                        if (tj < nt) load_tile_t(LtT[tk][tj], gL, LD, tk, tj, lo);
+                // ---- At = A-^T = -Sigma^-1 B'^T L+^T, column by column, to this pair's matrix in global memory
+                put(E2, nrs_e, Ln);
+                wave_sync();
+#pragma unroll
+                for (int tj = 0; tj < TM; ++tj) {
+                    if (tj < nt) {
+                        double acc[TM][4];
+#pragma unroll
+                        for (int ti = 0; ti < TM; ++ti) acc[ti][0] = acc[ti][1] = acc[ti][2] = acc[ti][3] = 0.0;
+#pragma unroll
+                        for (int tk = 0; tk <= tj; ++tk) {
+#pragma unroll
+                            for (int ti = 0; ti < TM; ++ti)
+                                if (ti < nt) tile_tn_acc(acc[ti], X1.v[tk][ti], LtT[tk][tj]);
+                        }
+#pragma unroll
+                        for (int ti = 0; ti < TM; ++ti)
+                            if (ti < nt) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[ti][r] *= E2[16 * ti + 4 * r + Ln.g];
+                                slot_store_tile(ws, ti, tj, acc[ti], Ln);
+                            }
+                    }
+                }
+            }
+            // ---- A+ = L+^-T B' (in place, X1): blocked back substitution with the diagonal-block inverses of the prep kernel
+            {
+                double Lt[TM][TM][4], Li[TM][4];   // Lt[tk][ti], tk > ti
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti) {
+                    if (ti < nt) load_block(Li[ti], gI, ti, lo);
+#pragma unroll
+                    for (int tk = ti + 1; tk < TM; ++tk)
+                        if (tk < nt) load_tile(Lt[tk][ti], gL, LD, tk, ti, lo);
+                }
+#pragma unroll
+                for (int ti = TM - 1; ti >= 0; --ti) {
+                    if (ti < nt) {
+#pragma unroll
+                        for (int tk = ti + 1; tk < TM; ++tk)
+                            if (tk < nt) {
+#pragma unroll
+                                for (int tj = 0; tj < TM; ++tj)
+                                    if (tj < nt) {
+                                        double u[4];
+                                        tile_tn(u, Lt[tk][ti], X1.v[tk][tj]);
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) X1.v[ti][tj][r] -= u[r];
+                                    }
+                            }
 #pragma unroll
                         for (int tj = 0; tj < TM; ++tj)
                             if (tj < nt) {
                                 double u[4];
-                                tile_tn(u, Lt, X1.v[tk][tj]);
+                                tile_tn(u, Li[ti], X1.v[ti][tj]);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) X1.v[ti][tj][r] -= u[r];
+                                for (int r = 0; r < 4; ++r) X1.v[ti][tj][r] = u[r];
                             }
                     }
-                double Li[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Li[r] = gI[ti * 256 + Ln.c * 16 + 4 * r + Ln.g];
-#pragma unroll
-                for (int tj = 0; tj < TM; ++tj)
-                    if (tj < nt) {
-                        double u[4];
-                        tile_tn(u, Li, X1.v[ti][tj]);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) X1.v[ti][tj][r] = u[r];
-                    }
+                }
             }
-        }
-        // ---- T1 = C^^T A+ (X2; C^ from the slot), r = A+^T z with z = c^ - 2 B C^ 1^, H^T = A+^T T1 (in place, X2)
-        gemm_tn_slot(X2, slot, X1, nt, Ln);
-        put(E0, c_e * di_e - 2.0 * Bl * u_e, Ln);
-        wave_sync();
-        matvec_t(X1, E0, E1, nt, Ln);                                  // r in E1 (natural order)
-        gemm_tn_inplace(X2, X1, nt);
-        // ---- At = A-^T = -Sigma^-1 B'^T L+^T: B' again (X1), L+^T tile by tile, finished columns go to the slot
-        put(E2, nrs_e, Ln);
-        wave_sync();
+            // ---- H^T = A+^T (C^^T A+), column by column (C^ streamed from the slot); r = A+^T z, z = c^ - 2 B C^ 1^
+            zero(X2);
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti)
+            for (int tj = 0; tj < TM; ++tj) {
+                if (tj < nt) {
+                    double t1[TM][4];
 #pragma unroll
-            for (int tj = 0; tj < TM; ++tj)
-                if (ti < nt && tj < nt) load_tile(X1.v[ti][tj], gB, LD, N, ti, tj, Ln);
+                    for (int ti = 0; ti < TM; ++ti) {
+                        t1[ti][0] = t1[ti][1] = t1[ti][2] = t1[ti][3] = 0.0;
+                        if (ti < nt) {
 #pragma unroll
-        for (int tj = 0; tj < TM; ++tj) {
-            if (tj < nt) {
-                double acc[TM][4];
-#pragma unroll
-                for (int ti = 0; ti < TM; ++ti) acc[ti][0] = acc[ti][1] = acc[ti][2] = acc[ti][3] = 0.0;
-#pragma unroll
-                for (int tk = 0; tk <= tj; ++tk) {
-                    double Lt[4];
-                    load_tile_t(Lt, gL, LD, N, tk, tj, Ln);           // (L+^T)[tk][tj]
+                            for (int tk = 0; tk < TM; ++tk)
+                                if (tk < nt) {
+                                    double ct[4];
+                                    slot_load_tile(ct, slot, tk, ti, Ln);
+                                    tile_tn_acc(t1[ti], ct, X1.v[tk][tj]);
+                                }
+                        }
+                    }
 #pragma unroll
                     for (int ti = 0; ti < TM; ++ti)
-                        if (ti < nt) tile_tn_acc(acc[ti], X1.v[tk][ti], Lt);
+                        if (ti < nt) {
+                            double h[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int tk = 0; tk < TM; ++tk)
+                                if (tk < nt) tile_tn_acc(h, X1.v[tk][ti], t1[tk]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) X2.v[ti][tj][r] = h[r];
+                        }
                 }
-#pragma unroll
-                for (int ti = 0; ti < TM; ++ti)
-                    if (ti < nt) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[ti][r] *= E2[16 * ti + 4 * r + Ln.g];
-                        slot_store_tile(slot, ti, tj, acc[ti], Ln);
-                    }
             }
-        }
-        wave_sync();
+            put(E0, c_e * di_e - 2.0 * Bl * u_e, Ln);
+            wave_sync();
+            matvec_t(X1, E0, E1, nt, Ln);                                  // r in E1 (natural order)
         }
 
-        // ---- three inversions of X2, one copy of the elimination code (X2 is the only matrix in registers meanwhile)
+        // ---- three inversions of X2, one copy of the elimination code
         double q_e = 0.0;
         bool last = false;
         double cb_e = 0.0, cd_e = 0.0, t2_e = 0.0, it2_e = 0.0, extra_e = 0.0;   // interface coefficients (stage 2 -> post)
-        double r2s_e = 0.0, t1s_e = 0.0, Rair_e = 0.0, Idn = 0.0;               // surface (l == 0)
+        double t1s_e = 0.0, Rair_e = 0.0, Idn = 0.0;                            // surface (l == 0)
         int Nu = 0, nc = 0;
 #if !defined(SMRT_HOST_EMU)
 #pragma nounroll
@@ -606,29 +661,98 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                 put(E2, nrs_e, Ln);
                 wave_sync();
                 scale_add_diag(X2, nullptr, nullptr, E2, 2.0, nt, Ln);      // Theta^T = 2 M3^-T - Sigma^-1
-                Mat X1;
-                zero(X1);
-                slot_load(X1, slot, nt, Ln);                                // At
-                matvec_t(X1, E1, E0, nt, Ln);                               // A- y = At^T y
+                // T2 = Theta At, column by column from global memory into the slot; A- y = At^T y on the way
+#pragma unroll
+                for (int tj = 0; tj < TM; ++tj) {
+                    if (tj < nt) {
+                        double ac[TM][4];
+                        double amy = 0.0;
+#pragma unroll
+                        for (int tk = 0; tk < TM; ++tk) {
+                            ac[tk][0] = ac[tk][1] = ac[tk][2] = ac[tk][3] = 0.0;
+                            if (tk < nt) {
+                                slot_load_tile(ac[tk], ws, tk, tj, Ln);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) amy += ac[tk][r] * E1[16 * tk + 4 * r + Ln.g];
+                            }
+                        }
+                        amy += shfl_xor(amy, 16);
+                        amy += shfl_xor(amy, 32);
+                        if (Ln.g == 0) E0[16 * tj + Ln.c] = amy;
+#pragma unroll
+                        for (int ti = 0; ti < TM; ++ti)
+                            if (ti < nt) {
+                                double h[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                for (int tk = 0; tk < TM; ++tk)
+                                    if (tk < nt) tile_tn_acc(h, X2.v[tk][ti], ac[tk]);
+                                slot_store_tile(slot, ti, tj, h, Ln);
+                            }
+                    }
+                }
+                wave_sync();
                 const double amy_e = E0[t];
-                gemm_tn_inplace(X1, X2, nt);                                // T2 = Theta At
-                slot_load(X2, slot, nt, Ln);
-                gemm_tn_inplace(X1, X2, nt);                                // C^' = At^T T2
                 put(E2, di_e, Ln); put(E3, d_e, Ln);
                 wave_sync();
-                matvec(X1, E2, E0, nt, Ln);                                 // C^' 1^
+                // C^' = At^T T2 with At in registers (X1), T2 column by column from the slot; C^' 1^ on the way; the
+                // finished column goes back to the slot as C' = D C^' D^-1
+                {
+                    Mat X1;
+                    zero(X1);
+                    slot_load(X1, ws, nt, Ln);
+                    double urow[TM][4];
+#pragma unroll
+                    for (int ti = 0; ti < TM; ++ti) urow[ti][0] = urow[ti][1] = urow[ti][2] = urow[ti][3] = 0.0;
+#pragma unroll
+                    for (int tj = 0; tj < TM; ++tj) {
+                        if (tj < nt) {
+                            double tc[TM][4];
+#pragma unroll
+                            for (int tk = 0; tk < TM; ++tk) {
+                                tc[tk][0] = tc[tk][1] = tc[tk][2] = tc[tk][3] = 0.0;
+                                if (tk < nt) slot_load_tile(tc[tk], slot, tk, tj, Ln);
+                            }
+                            const double dic = E2[16 * tj + Ln.c];
+#pragma unroll
+                            for (int ti = 0; ti < TM; ++ti)
+                                if (ti < nt) {
+                                    double h[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                    for (int tk = 0; tk < TM; ++tk)
+                                        if (tk < nt) tile_tn_acc(h, X1.v[tk][ti], tc[tk]);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        urow[ti][r] += h[r] * dic;
+                                        h[r] *= E3[16 * ti + 4 * r + Ln.g] * dic;
+                                    }
+                                    slot_store_tile(slot, ti, tj, h, Ln);
+                                }
+                        }
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int ti = 0; ti < TM; ++ti)
+                        if (ti < nt) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double a = group_sum<16>(urow[ti][r]);
+                                if (Ln.c == 0) E0[16 * ti + 4 * r + Ln.g] = a;
+                            }
+                        }
+                    wave_sync();
+                }
                 c_e = d_e * (2.0 * Bl * E0[t] - 2.0 * amy_e);               // c' (physical coordinates)
-                scale_add_diag(X1, E3, E2, nullptr, 1.0, nt, Ln);           // C' = D C^' D^-1
                 wave_sync();
+                zero(X2);
                 if (l == 0) {
                     // surface (dort.py:391-395,484): I_dn = r2 I_up + t2 I_sky just below it;
                     // S I_up = c' + (I - C') t2 I_sky,  S = (1 - r2) + C' (1 + r2);  I0 = R_air I_sky + t1 I_up
                     last = true;
                     const bool atm = (b.atm_down != nullptr);
                     Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
-                    double Tair = 0.0;
+                    double Tair = 0.0, r2s = 0.0;
                     const cplx one = cmk(1.0, 0.0);
-                    if (in_e) { r2s_e = flat_R(el, one, s.ri[0] * s.gsin[t >> 1], t & 1); t1s_e = 1.0 - r2s_e; }
+                    if (in_e) { r2s = flat_R(el, one, s.ri[0] * s.gsin[t >> 1], t & 1); t1s_e = 1.0 - r2s; }
                     if (t < n_air * P) {
                         double Rv, Rh;
                         fresnel_RvRh(one, el, s.outmu[t >> 1], &Rv, &Rh);
@@ -636,18 +760,13 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     }
                     put(E0, Tair * Idn, Ln);                                // t2 I_sky (0 beyond the air streams)
                     wave_sync();
-                    matvec(X1, E0, E1, nt, Ln);
+                    slot_load(X2, slot, nt, Ln);                            // C'
+                    matvec(X2, E0, E1, nt, Ln);
                     const double rhs = in_e ? c_e + E0[t] - E1[t] : 0.0;
                     wave_sync();
                     put(E4, rhs, Ln);
-                    put(E2, in_e ? 1.0 + r2s_e : 0.0, Ln); put(E3, in_e ? 1.0 - r2s_e : 1.0, Ln);
+                    put(E2, in_e ? 1.0 + r2s : 0.0, Ln); put(E3, in_e ? 1.0 - r2s : 1.0, Ln);
                     wave_sync();
-#pragma unroll
-                    for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < TM; ++tj)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) X2.v[ti][tj][r] = X1.v[ti][tj][r];
                     scale_add_diag(X2, nullptr, E2, E3, 1.0, nt, Ln);
                 } else {
                     // interface with the layer above: diagonal coefficients per element (streams paired by index)
@@ -672,25 +791,36 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     cd_e = 0.5 * (tt2 + (1.0 - r1) * (1.0 + r2));
                     t2_e = (t < nc) ? t2 : 0.0;
                     it2_e = (t < nc) ? fast_rcp(t2) : 0.0;
-                    // X2 = Y = a - b C',  X1 = Nn = c - d C' and then its transpose
+                    // X2 = Y = a - b C';  Nn = c - d C' goes back to the slot transposed (it waits there while Y is inverted)
                     put(E0, in_e ? -cb_e : 0.0, Ln); put(E1, in_e ? ca : 1.0, Ln);
                     put(E2, in_e ? -cd_e : 0.0, Ln); put(E3, in_e ? cc : 0.0, Ln);
                     wave_sync();
 #pragma unroll
                     for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-                        for (int tj = 0; tj < TM; ++tj)
+                        for (int tj = ti; tj < TM; ++tj)
+                            if (tj < nt) {
+                                double a[4], bq[4], na[4], nb[4], ta[4], tb4[4];
+                                slot_load_tile(a, slot, ti, tj, Ln);
+                                slot_load_tile(bq, slot, tj, ti, Ln);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) X2.v[ti][tj][r] = X1.v[ti][tj][r];
-                    scale_add_diag(X2, E0, nullptr, E1, 1.0, nt, Ln);
-                    scale_add_diag(X1, E2, nullptr, E3, 1.0, nt, Ln);
-                    transpose_inplace(X1, nt, Ln);
-                    // Nn^T waits in the slot (At is consumed) while Y is inverted
-#pragma unroll
-                    for (int ti = 0; ti < TM; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < TM; ++tj)
-                            if (ti < nt && tj < nt) slot_store_tile(slot, ti, tj, X1.v[ti][tj], Ln);
+                                for (int r = 0; r < 4; ++r) {
+                                    const int ra = 16 * ti + 4 * r + Ln.g, rb_ = 16 * tj + 4 * r + Ln.g;
+                                    const bool dg = (4 * r + Ln.g == Ln.c);
+                                    X2.v[ti][tj][r] = a[r] * E0[ra] + ((ti == tj && dg) ? E1[ra] : 0.0);
+                                    na[r] = a[r] * E2[ra] + ((ti == tj && dg) ? E3[ra] : 0.0);
+                                    if (ti != tj) {
+                                        X2.v[tj][ti][r] = bq[r] * E0[rb_];
+                                        nb[r] = bq[r] * E2[rb_];
+                                    }
+                                }
+                                tile_transpose(ta, na, Ln);
+                                if (ti != tj) {
+                                    tile_transpose(tb4, nb, Ln);
+                                    slot_store_tile(slot, ti, tj, tb4, Ln);
+                                }
+                                slot_store_tile(slot, tj, ti, ta, Ln);
+                            }
                 }
                 wave_sync();
             }
@@ -706,60 +836,82 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
             }
             break;
         }
-        // ---- Z = Nn Y^-1 (in place, X2);  C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the
-        //      upper layer's extra streams;  c_u = (d c' - Z b c') / t2;  then the hats of the layer above: C^ = D^-1 C D
-        {
-            Mat X1;
-            zero(X1);
-            slot_load(X1, slot, nt, Ln);
-            gemm_tn_inplace(X2, X1, nt);
-        }
-        put(E0, in_e ? cb_e * c_e : 0.0, Ln);
-        wave_sync();
-        matvec(X2, E0, E1, nt, Ln);
-        c_e = (t < nc) ? (cd_e * c_e - E1[t]) * it2_e : 0.0;
+        // ---- Z = Nn Y^-1, column by column: Nn^T moves from the slot into registers (X1) while Y^-1 takes its place there;
+        //      C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the upper layer's extra streams;
+        //      c_u = (d c' - Z b c') / t2;  the column goes back to the slot in the hats of the layer above, C^ = D^-1 C D
         const int ntu = (Nu + 15) >> 4;
         const long long item_u = item - 1;
         const bool in_u = t < Nu;
         const double du_e = in_u ? stg.d[item_u * stg.vec_stride + (in_u ? t : 0)] : 1.0;
         const double dui_e = fast_rcp(du_e);
         wave_sync();
-        put(E2, -it2_e * dui_e, Ln); put(E3, t2_e * du_e, Ln); put(E4, extra_e, Ln); put(E0, dui_e, Ln);
+        put(E0, in_e ? cb_e * c_e : 0.0, Ln);
+        put(E2, -it2_e * dui_e, Ln); put(E3, t2_e * du_e, Ln); put(E4, extra_e, Ln); put(E1, dui_e, Ln);
         wave_sync();
         {
-            double wv[TM];
-#pragma unroll
-            for (int tj = 0; tj < TM; ++tj) wv[tj] = E0[16 * tj + Ln.c];
+            Mat X1;
+            zero(X1);
 #pragma unroll
             for (int ti = 0; ti < TM; ++ti)
-                if (ti < ntu) {
-                    double urow[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int tj = 0; tj < TM; ++tj)
-                        if (tj < ntu) {
-                            const int col = 16 * tj + Ln.c;
-                            const double cf = E3[col];
-                            double z4[4];
+                for (int tj = 0; tj < TM; ++tj)
+                    if (ti < nt && tj < nt) {
+                        slot_load_tile(X1.v[ti][tj], slot, ti, tj, Ln);
+                        slot_store_tile(slot, ti, tj, X2.v[ti][tj], Ln);
+                    }
+            wave_sync();
+            double zb[TM][4], urow[TM][4];
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti) {
+                zb[ti][0] = zb[ti][1] = zb[ti][2] = zb[ti][3] = 0.0;
+                urow[ti][0] = urow[ti][1] = urow[ti][2] = urow[ti][3] = 0.0;
+            }
+#pragma unroll
+            for (int tj = 0; tj < TM; ++tj) {
+                if (tj < nt || tj < ntu) {
+                    double yc[TM][4];
+#pragma unroll
+                    for (int tk = 0; tk < TM; ++tk) {
+                        yc[tk][0] = yc[tk][1] = yc[tk][2] = yc[tk][3] = 0.0;
+                        if (tk < nt && tj < nt) slot_load_tile(yc[tk], slot, tk, tj, Ln);
+                    }
+                    const int col = 16 * tj + Ln.c;
+                    const double wb = E0[col], cf = E3[col], wu = E1[col];
+#pragma unroll
+                    for (int ti = 0; ti < TM; ++ti)
+                        if (ti < nt || ti < ntu) {
+                            double h[4] = {0.0, 0.0, 0.0, 0.0};
+                            if (ti < nt && tj < nt) {
+#pragma unroll
+                                for (int tk = 0; tk < TM; ++tk)
+                                    if (tk < nt) tile_tn_acc(h, X1.v[tk][ti], yc[tk]);
+                            }
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * ti + 4 * r + Ln.g;
-                                const bool in = (ti < nt && tj < nt) && row < nc && col < nc;
-                                double x = in ? X2.v[ti][tj][r] * E2[row] * cf : 0.0;
+                                zb[ti][r] += h[r] * wb;
+                                double x = (row < nc && col < nc) ? h[r] * E2[row] * cf : 0.0;
                                 if (row == col) x += E4[row];
-                                z4[r] = x;
-                                urow[r] += x * wv[tj];
+                                urow[ti][r] += x * wu;
+                                h[r] = x;
                             }
-                            slot_store_tile(slot, ti, tj, z4, Ln);
+                            if (ti < ntu && tj < ntu) slot_store_tile(slot, ti, tj, h, Ln);
                         }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const double a = group_sum<16>(urow[r]);
-                        if (Ln.c == 0) E1[16 * ti + 4 * r + Ln.g] = a;
-                    }
                 }
+            }
+            wave_sync();
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double a = group_sum<16>(zb[ti][r]);
+                    const double u2 = group_sum<16>(urow[ti][r]);
+                    if (Ln.c == 0) { E0[16 * ti + 4 * r + Ln.g] = a; E1[16 * ti + 4 * r + Ln.g] = u2; }
+                }
+            wave_sync();
         }
-        wave_sync();
-        u_e = in_u ? E1[in_u ? t : 0] : 0.0;
+        c_e = (t < nc) ? (cd_e * c_e - E0[t]) * it2_e : 0.0;
+        u_e = in_u ? E1[t] : 0.0;
         wave_sync();
     }
 

@@ -52,7 +52,7 @@ static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long 
 // marks the pairs whose cut has been reached: the layers below a cut are never diagonalised (like in the reference),
 // exactly -- the decision uses the same singular values as the finish kernel.
 #ifndef SMRT_FINISH_REG_DEFAULT
-#define SMRT_FINISH_REG_DEFAULT 0   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
+#define SMRT_FINISH_REG_DEFAULT 1   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
 #endif
 static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
@@ -142,7 +142,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
-                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti,
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws,
                       &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
@@ -288,6 +288,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
         ctx->finish_reg = supported && (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
         ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
+        ctx->stage.ws = nullptr;
+        if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
+            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * rg::kSlotDoubles));
+            ctx->stage.ws = (double*)ctx->d_regws.p;
+        }
     }
     if (b->prune_optical_depth > 0.0) {
         // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:

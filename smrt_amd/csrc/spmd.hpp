@@ -61,6 +61,14 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f
 // value of lane K of the caller's 16-lane row (lanes 16 g .. 16 g + 15), K a compile-time constant
 template <int K>
 SMRT_DEV double row_bcast16(double v) { return emu::wave_bcast(v, (emu::tid() & 48) | K); }
+// a 16 x 16 tile in MFMA accumulator layout: four doubles per lane (one register tuple on the GPU)
+struct tile4 {
+    double x[4];
+    double& operator[](int i) { return x[i]; }
+    const double& operator[](int i) const { return x[i]; }
+};
+SMRT_DEV tile4 tile_zero() { tile4 t; t.x[0] = t.x[1] = t.x[2] = t.x[3] = 0.0; return t; }
+SMRT_DEV void mfma_tile(double a, double b, tile4& c) { emu::mfma_f64_16x16x4(a, b, c.x); }
 SMRT_DEV double fast_rcp(double x) { return 1.0 / x; }
 SMRT_DEV double fast_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 // sum over aligned groups of GS consecutive lanes (GS power of two <= 64); every lane gets the group total
@@ -194,6 +202,11 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
     cv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cv, 0, 0, 0);
     c[0] = cv[0]; c[1] = cv[1]; c[2] = cv[2]; c[3] = cv[3];
 }
+// a 16 x 16 tile in MFMA accumulator layout: four doubles per lane, kept as ONE 256-bit register tuple (the accumulator
+// operand of v_mfma_f64_16x16x4_f64 as it is; its elements are directly addressable 64-bit sub-registers)
+typedef smrt_v4d tile4;
+SMRT_DEV tile4 tile_zero() { tile4 t = {0.0, 0.0, 0.0, 0.0}; return t; }
+SMRT_DEV void mfma_tile(double a, double b, tile4& c) { c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 // max of a 32-bit key over the wavefront with DPP only: four steps inside the 16-lane rows, then row_bcast15 /
 // row_bcast31 carry the row maxima across (lane 63 ends up with the maximum of all 64), one readlane
 SMRT_DEV unsigned wave_max_u32(unsigned k) {

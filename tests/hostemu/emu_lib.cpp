@@ -46,12 +46,12 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
 // staged item, finish for every pair -- in up to four rounds over successive layer ranges with the pruning marks in
 // between when prune_deep_snowpack is set (the layers below a cut are never staged).
 struct Staging {
-    std::vector<double> L, B, d, sigma, inv;
+    std::vector<double> L, B, d, sigma, inv, ws;
     std::vector<int> n;
     DevStage st;
     Staging(size_t items, const LdsPlan& plan) : L(items * (size_t)plan.NMAX * plan.LD, NAN), B(L.size(), NAN), d(items * plan.NMAX, NAN),
-                                                 sigma(items * plan.NMAX, NAN), inv(items * 1024, NAN), n(items, -1) {
-        st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, inv.data()};
+                                                 sigma(items * plan.NMAX, NAN), inv(items * 1024, NAN), ws(plan.NMAX <= 64 ? items * 4096 : 0, NAN), n(items, -1) {
+        st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, inv.data(), ws.data()};
     }
 };
 
