@@ -357,6 +357,31 @@ SMRT_DEV void load_tile_t(double (&t)[4], const double* p, int LD, int ti, int t
         t[r] = in ? v : 0.0;
     }
 }
+// The same in two passes -- raw loads first (no branch, no use of the data: every request of a phase is in flight before
+// the first wait), masks afterwards.  `have`: the tile exists (uniform); a tile that does not is read at the origin.
+SMRT_DEV void load_tile_raw(double (&t)[4], const double* p, int LD, int ti, int tj, bool have, const LaneOffsets& o) {
+    const bool cin = 16 * tj < o.cl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double* q = p + (have ? ((16 * tj) * LD + 16 * ti + 4 * r) : 0);
+        const bool in = have && cin && 16 * ti + 4 * r < o.rl;
+        t[r] = q[in ? o.direct : 0u];
+    }
+}
+SMRT_DEV void load_tile_t_raw(double (&t)[4], const double* p, int LD, int ti, int tj, bool have, const LaneOffsets& o) {
+    const bool cin = 16 * tj < o.cl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double* q = p + (have ? ((16 * ti + 4 * r) * LD + 16 * tj) : 0);
+        const bool in = have && cin && 16 * ti + 4 * r < o.rl;
+        t[r] = q[in ? o.transp : 0u];
+    }
+}
+SMRT_DEV void mask_tile(double (&t)[4], int ti, int tj, bool have, const LaneOffsets& o) {
+    const bool cin = have && 16 * tj < o.cl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = (cin && 16 * ti + 4 * r < o.rl) ? t[r] : 0.0;
+}
 // block ti of the [4][256] diagonal-block inverses (identity padded by the prep kernel)
 SMRT_DEV void load_block(double (&t)[4], const double* p, int ti, const LaneOffsets& o) {
 #pragma unroll
@@ -380,6 +405,14 @@ SMRT_DEV double flat_R(cplx e1, cplx e2, double ri_sin, int pol) {
     fresnel_RvRh(e1, e2, sqrt(1.0 - ri_sin * ri_sin), &Rv, &Rh);
     return pol ? Rh : Rv;
 }
+
+// Optional phase timing (profiling builds, -DSMRT_REG_TIMING): shader-clock deltas per phase, summed per pair into stage_out
+#ifdef SMRT_REG_TIMING
+#define SMRT_RT(k) do { const long long now_ = cycle_counter(); rt_acc[rt_cur] += (double)(now_ - rt_t0); rt_t0 = now_; rt_cur = (k); } while (0)
+#else
+#define SMRT_RT(k) do {} while (0)
+#endif
+enum { RT_SETUP = 0, RT_VEC, RT_AT, RT_APLUS, RT_HT, RT_INV, RT_ST1, RT_T2, RT_CP, RT_IFACE, RT_POST, RT_SURF, RT_COUNT };
 
 // ------------------------------------------------------------------------------------------------------------
 // the per-pair driver: one wavefront (NT = 64)
@@ -424,6 +457,12 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
     const double* mp1 = b.p1 + (long long)si * b.Lmax;
     const double* mp2 = b.p2 + (long long)si * b.Lmax;
 
+#ifdef SMRT_REG_TIMING
+    double rt_acc[RT_COUNT];
+    for (int k = 0; k < RT_COUNT; ++k) rt_acc[k] = 0.0;
+    long long rt_t0 = cycle_counter();
+    int rt_cur = RT_SETUP;
+#endif
     if (t < 8) s.ints[t] = (t == 7) ? ((nmax * P + 1) | 1) : 0;   // [7]: leading dimension of the staged matrices (make_plan)
     block_sync();
     {
@@ -477,6 +516,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         const double* gB = stg.B + item * stg.mat_stride;
         const double* gI = stg.Linv + item * 1024;
         const bool in_e = t < N;
+        SMRT_RT(RT_VEC);
         // ---- element t of the vectors of this layer (padding: d = sigma = 1, t = 0)
         const double d_e = in_e ? stg.d[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
         const double sg_e = in_e ? stg.sigma[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
@@ -522,21 +562,37 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         const LaneOffsets lo = lane_offsets(LD, N, Ln);
         Mat X2;   // the matrix that is inverted (H^T + Sigma, M3^T, Y / S); the only one in registers meanwhile
         {
+            SMRT_RT(RT_AT);
             Mat X1;
             zero(X1);
             // ---- B' (X1) and L+^T (tile by tile, requested up front: one wavefront per SIMD, nothing else hides the latency)
+            double Lt[TM][TM][4], Li[TM][4];   // Lt[tk][ti], tk > ti: tiles of L+ and the diagonal-block inverses for A+ below
             {
                 double LtT[TM][TM][4];   // (L+^T)[tk][tj], tk <= tj
+                // every request of the two phases first ...
 #pragma unroll
                 for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < TM; ++tj)
-                        if (ti < nt && tj < nt) load_tile(X1.v[ti][tj], gB, LD, ti, tj, lo);
+                    for (int tj = 0; tj < TM; ++tj) load_tile_raw(X1.v[ti][tj], gB, LD, ti, tj, ti < nt && tj < nt, lo);
 #pragma unroll
                 for (int tj = 0; tj < TM; ++tj)
 #pragma unroll
-                    for (int tk = 0; tk <= tj; ++tk)
-                        if (tj < nt) load_tile_t(LtT[tk][tj], gL, LD, tk, tj, lo);
+                    for (int tk = 0; tk <= tj; ++tk) load_tile_t_raw(LtT[tk][tj], gL, LD, tk, tj, tj < nt, lo);
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti) {
+                    load_block(Li[ti], gI, ti < nt ? ti : 0, lo);
+#pragma unroll
+                    for (int tk = ti + 1; tk < TM; ++tk) load_tile_raw(Lt[tk][ti], gL, LD, tk, ti, tk < nt, lo);
+                }
+                // ... then the masks
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TM; ++tj) mask_tile(X1.v[ti][tj], ti, tj, ti < nt && tj < nt, lo);
+#pragma unroll
+                for (int tj = 0; tj < TM; ++tj)
+#pragma unroll
+                    for (int tk = 0; tk <= tj; ++tk) mask_tile(LtT[tk][tj], tk, tj, tj < nt, lo);
                 // ---- At = A-^T = -Sigma^-1 B'^T L+^T, column by column, to this pair's matrix in global memory
                 put(E2, nrs_e, Ln);
                 wave_sync();
@@ -562,16 +618,13 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     }
                 }
             }
+            SMRT_RT(RT_APLUS);
             // ---- A+ = L+^-T B' (in place, X1): blocked back substitution with the diagonal-block inverses of the prep kernel
             {
-                double Lt[TM][TM][4], Li[TM][4];   // Lt[tk][ti], tk > ti
 #pragma unroll
-                for (int ti = 0; ti < TM; ++ti) {
-                    if (ti < nt) load_block(Li[ti], gI, ti, lo);
+                for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-                    for (int tk = ti + 1; tk < TM; ++tk)
-                        if (tk < nt) load_tile(Lt[tk][ti], gL, LD, tk, ti, lo);
-                }
+                    for (int tk = ti + 1; tk < TM; ++tk) mask_tile(Lt[tk][ti], tk, ti, tk < nt, lo);
 #pragma unroll
                 for (int ti = TM - 1; ti >= 0; --ti) {
                     if (ti < nt) {
@@ -598,6 +651,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                     }
                 }
             }
+            SMRT_RT(RT_HT);
             // ---- H^T = A+^T (C^^T A+), column by column (C^ streamed from the slot); r = A+^T z, z = c^ - 2 B C^ 1^
             zero(X2);
 #pragma unroll
@@ -645,16 +699,19 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
 #endif
         for (int stage = 0; stage < 3; ++stage) {
             if (stage == 0) {
+                SMRT_RT(RT_ST1);
                 put(E2, sg_e, Ln);
                 wave_sync();
                 scale_add_diag(X2, nullptr, nullptr, E2, 1.0, nt, Ln);      // H^T + Sigma
             } else if (stage == 1) {
+                SMRT_RT(RT_ST1);
                 matvec_t(X2, E1, E0, nt, Ln);                               // q = P r
                 q_e = E0[t];
                 put(E2, st_e, Ln); put(E3, m3_e, Ln);
                 wave_sync();
                 scale_add_diag(X2, E2, E2, E3, 2.0, nt, Ln);                // M3^T
             } else {
+                SMRT_RT(RT_T2);
                 put(E0, st_e * q_e, Ln);
                 wave_sync();
                 matvec_t(X2, E0, E1, nt, Ln);                               // y = M3^-1 (Sigma t q), natural order in E1
@@ -694,6 +751,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                 const double amy_e = E0[t];
                 put(E2, di_e, Ln); put(E3, d_e, Ln);
                 wave_sync();
+                SMRT_RT(RT_CP);
                 // C^' = At^T T2 with At in registers (X1), T2 column by column from the slot; C^' 1^ on the way; the
                 // finished column goes back to the slot as C' = D C^' D^-1
                 {
@@ -743,6 +801,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                 }
                 c_e = d_e * (2.0 * Bl * E0[t] - 2.0 * amy_e);               // c' (physical coordinates)
                 wave_sync();
+                SMRT_RT(RT_IFACE);
                 zero(X2);
                 if (l == 0) {
                     // surface (dort.py:391-395,484): I_dn = r2 I_up + t2 I_sky just below it;
@@ -824,9 +883,11 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
                 }
                 wave_sync();
             }
+            SMRT_RT(RT_INV);
             invert(X2, nt, Ln);
         }
         if (last) {
+            SMRT_RT(RT_SURF);
             matvec(X2, E4, E0, nt, Ln);    // I_up just below the surface
             if (t < n_air * P) {
                 const bool atm = (b.atm_down != nullptr);
@@ -836,6 +897,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
             }
             break;
         }
+        SMRT_RT(RT_POST);
         // ---- Z = Nn Y^-1, column by column: Nn^T moves from the slot into registers (X1) while Y^-1 takes its place there;
         //      C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the upper layer's extra streams;
         //      c_u = (d c' - Z b c') / t2;  the column goes back to the slot in the hats of the layer above, C^ = D^-1 C D
@@ -937,6 +999,10 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
     }
     if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+#ifdef SMRT_REG_TIMING
+    SMRT_RT(RT_SETUP);
+    if (t == 0 && b.stage_out) for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < RT_COUNT) ? rt_acc[k] : 0.0;
+#endif
 }
 
 }  // namespace smrt
