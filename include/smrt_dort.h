@@ -100,8 +100,10 @@ typedef struct smrt_batch {
     /* DORT option prune_deep_snowpack (dort.py:117-124,176-178,443-452): optical depth (sum over the layers, from the
      * top, of min|beta_l| * thickness_l) beyond which the deeper layers are left out of the solve; the layer in which
      * the threshold is passed keeps its bottom reflection and receives nothing from below.  <= 0 (or NaN): off.
-     * Needs the three-kernel pipeline (the eigenvalues of all the layers are known before the boundary recursion
-     * starts): smrt_dort_upload fails for streams x polarisations > 128 or after smrt_dort_set_pipeline(ctx, 0). */
+     * Needs a three-kernel pipeline (the eigenvalues of all the layers are known before the boundary recursion starts;
+     * every size up to the limit of 384 streams x polarisations has one): smrt_dort_upload fails only after
+     * smrt_dort_set_pipeline(ctx, 0).  The prep and Jacobi kernels then run in up to four rounds over successive layer
+     * ranges, so the layers below a cut are never diagonalised. */
     double prune_optical_depth;
     /* Heterogeneous snowpacks (a list / dict of emmodels in make_model, per-layer microstructure models in make_snowpack;
      * smrt/core/model.py:529-582): [S][Lmax] emmodel + 16 * microstructure of every layer (SMRT_EM_* + 16 * SMRT_MS_*).
@@ -203,12 +205,21 @@ double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 
 /* Pipeline shape.  1 (default) = three kernels -- prep per pair, Jacobi per (pair, layer[, azimuth mode]), finish per
- * pair -- with the factors staged through HBM/L2: on the LDS-resident path (streams x polarisations N <= 64) with the
- * two-slot finish kernel, two workgroups per CU; for 64 < N <= 128 on a per-workgroup global workspace.
- * 2 = the same with the four-matrix LDS finish kernel (one workgroup per CU; N <= 64 passive only, otherwise like 0).
- * 0 = everything fused in one kernel, one workgroup per pair (also what N > 128 always uses; N <= 256 is the limit:
- * n_max_stream <= 128 passive, <= 85 active).  Call before smrt_dort_upload. */
+ * pair -- with the factors staged through HBM/L2, for every size (N = streams x polarisations of the batch maximum):
+ *   N <= 64:        matrices in LDS; finish = the register-resident kernel (one wavefront per pair, four per CU) in
+ *                   passive mode with Flat interfaces, else the two-slot LDS kernel (two workgroups per CU);
+ *   64 < N <= 128:  per-workgroup global workspace, Jacobi kernel on a 128-column LDS matrix;
+ *   128 < N <= 384: global workspace, blocked Jacobi kernel (the limit of this build: n_max_stream <= 192 passive,
+ *                   <= 128 active; smrt_dort_upload fails beyond).
+ * 3 = like 1, the register-resident finish kernel wherever it is supported (what 1 does today); 4 = like 1, never the
+ * register-resident finish kernel (A/B runs); 2 = like 4 with the four-matrix LDS finish kernel (one workgroup per CU;
+ * N <= 64 passive only, otherwise like 0); 0 = everything fused in one kernel, one workgroup per pair (no
+ * prune_deep_snowpack).  Call before smrt_dort_upload.  SMRT_DORT_FINISH_REG=0|1 in the environment overrides 3 / 4. */
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
+
+/* LDS bytes one workgroup (= one wavefront) of the register-resident finish kernel takes for a batch with this
+ * n_max_stream and n_layers_max: four of them share the 160 KB of a CU while this is <= 40 KB. */
+int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max);
 
 /* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */

@@ -250,6 +250,8 @@ def load_library():
     lib.smrt_dort_set_block_threads.restype = C.c_int32
     lib.smrt_dort_set_pipeline.argtypes = [C.c_void_p, C.c_int32]
     lib.smrt_dort_set_pipeline.restype = C.c_int32
+    lib.smrt_dort_finish_reg_lds_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.smrt_dort_finish_reg_lds_bytes.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
     lib.smrt_dort_sum_n3.restype = C.c_double
     lib.smrt_dort_stage_cycles.argtypes = [C.c_void_p, P(C.c_double)]
@@ -287,7 +289,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
-    "smrt_dort_version",
+    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes",
 ]
 
 
@@ -335,8 +337,9 @@ class DortContext:
         self._check(self._lib.smrt_dort_set_block_threads(self._h, int(n)), "smrt_dort_set_block_threads")
 
     def set_pipeline(self, split=1):
-        """1 (default): prep / Jacobi / two-slot finish kernels; 2: the same with the LDS-resident finish kernel;
-        0: one fused kernel per pair."""
+        """1 (default): prep / Jacobi / finish kernels (N <= 64 passive: the register-resident finish kernel); 3: the same,
+        4: never the register-resident finish kernel; 2: the four-matrix LDS finish kernel; 0: one fused kernel per pair
+        (include/smrt_dort.h)."""
         self._check(self._lib.smrt_dort_set_pipeline(self._h, int(split)), "smrt_dort_set_pipeline")
 
     def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1, pairs=None) -> BatchOutput:

@@ -80,15 +80,19 @@ SMRT_DEV void gemm_tn(Mat& Z, const Mat& X, const Mat& Y, int nt) {
 }
 
 // ---- in-register inverse of a 16 x 16 tile, Gauss-Jordan without pivoting ------------------------------------------
-// Step k: row k reaches every lane through the matrix core (a selector matrix picks it out of register k >> 2), column
-// k through DPP row broadcasts; column k is replaced by the unit vector e_k before the rank-one update, which makes the
+// Step k: row k reaches every lane group through two lane-row swaps (v_permlane16_swap / v_permlane32_swap), column k
+// through DPP row broadcasts; column k is replaced by the unit vector e_k before the rank-one update, which makes the
 // in-place update uniform over the tile (Gauss-Jordan inversion in place).
 template <int K>
 SMRT_DEV void inv16_step(double (&d)[4], const LaneId& L) {
     constexpr int r0 = K >> 2, g0 = K & 3;
+#ifdef SMRT_INV16_MFMA_BCAST
     double rk4[4] = {0.0, 0.0, 0.0, 0.0};
     mfma_f64_16x16x4((L.g == g0) ? 1.0 : 0.0, d[r0], rk4);   // every register / lane group: D[K][c]
     double rk = rk4[0];
+#else
+    double rk = rows_bcast<g0>(d[r0]);                       // every lane group: D[K][c]
+#endif
     const double piv = row_bcast16<K>(rk);
     const double pinv = fast_rcp(piv);
     const bool colk = (L.c == K);
@@ -129,16 +133,19 @@ SMRT_DEV void shift_tiles(Mat& M) {
 
 // M <- M^-1 on the leading nt x nt tiles (identity padding inside the last tile), block Gauss-Jordan in place without
 // pivoting; the tiles are rotated after every block step so that the running diagonal block is always tile (0, 0)
-// (one copy of the step code for every block)
+// (one copy of the step code for every block).  Look-ahead: tile (1, 1) -- the next diagonal block -- is updated first
+// and its 16 x 16 elimination (a long dependent chain on the vector unit) is issued behind the matrix-core work of the
+// rest of the step, which runs in its shadow.
 SMRT_DEV void invert(Mat& M, int nt, const LaneId& L) {
+    double D[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[r] = M.v[0][0][r];
+    inv16(D, L);
 #if !defined(SMRT_HOST_EMU)
 #pragma nounroll
 #endif
     for (int step = 0; step < nt; ++step) {
-        double D[4], DT[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D[r] = M.v[0][0][r];
-        inv16(D, L);
+        double DT[4], Dn[4] = {0.0, 0.0, 0.0, 0.0};
         tile_transpose(DT, D, L);
         double R[TM][4];
 #pragma unroll
@@ -159,8 +166,13 @@ SMRT_DEV void invert(Mat& M, int nt, const LaneId& L) {
                         tile_tn(u, LT, R[j]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) M.v[i][j][r] -= u[r];
+                        if (i == 1 && j == 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Dn[r] = M.v[1][1][r];
+                        }
                     }
             }
+        if (step + 1 < nt) inv16(Dn, L);   // (its inputs are ready after the first update above)
 #pragma unroll
         for (int j = 1; j < TM; ++j)
             if (j < nt) {
@@ -172,6 +184,8 @@ SMRT_DEV void invert(Mat& M, int nt, const LaneId& L) {
         if (nt == 4) shift_tiles<4>(M);
         else if (nt == 3) shift_tiles<3>(M);
         else if (nt == 2) shift_tiles<2>(M);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = Dn[r];
     }
 }
 

@@ -5,6 +5,16 @@
 #include <vector>
 #include "../../include/smrt_dort.h"
 
+// Jacobi thresholds of the pipelines in passive mode (squared cosines; the kernels take them as run-time parameters):
+// rotations below SKIP are not applied, a sweep without a rotation above EXIT is the last one.  1.6e-8 K against the
+// oracle on the headline batch (requirement: 1e-6 K); active mode keeps 1e-30 / 1e-22 (dort_jacobi_kernel.hpp).
+#ifndef SMRT_JACOBI_PASSIVE_SKIP_COS2
+#define SMRT_JACOBI_PASSIVE_SKIP_COS2 1e-22
+#endif
+#ifndef SMRT_JACOBI_PASSIVE_EXIT_COS2
+#define SMRT_JACOBI_PASSIVE_EXIT_COS2 1e-12
+#endif
+
 namespace smrt_host {
 
 // Positive nodes (descending) and weights of the Gauss-Legendre rule of order 2n, by Newton iteration on the

@@ -61,6 +61,9 @@ SMRT_DEV void mfma_f64_16x16x4(double a, double b, double (&c)[4]) { emu::mfma_f
 // value of lane K of the caller's 16-lane row (lanes 16 g .. 16 g + 15), K a compile-time constant
 template <int K>
 SMRT_DEV double row_bcast16(double v) { return emu::wave_bcast(v, (emu::tid() & 48) | K); }
+// value of lane 16 G0 + c in every lane 16 g + c (the 16-lane row G0 copied to all four rows), G0 a compile-time constant
+template <int G0>
+SMRT_DEV double rows_bcast(double v) { return emu::wave_bcast(v, 16 * G0 + (emu::tid() & 15)); }
 // a 16 x 16 tile in MFMA accumulator layout: four doubles per lane (one register tuple on the GPU)
 struct tile4 {
     double x[4];
@@ -145,6 +148,21 @@ SMRT_DEV double dpp_move(double v) {
 // v_mov_b32_dpp, no LDS traffic
 template <int K>
 SMRT_DEV double row_bcast16(double v) { return dpp_move<0x150 + K>(v); }
+// value of lane 16 G0 + c in every lane 16 g + c (the 16-lane row G0 copied to all four rows), G0 a compile-time constant:
+// v_permlane16_swap / v_permlane32_swap (gfx950) -- the first makes rows {0, 1} and {2, 3} equal, the second the halves
+template <int G0>
+SMRT_DEV double rows_bcast(double v) {
+    union { double d; unsigned i[2]; } a, r;
+    a.d = v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        auto s16 = __builtin_amdgcn_permlane16_swap(a.i[k], a.i[k], false, false);   // [x0 x0 x2 x2], [x1 x1 x3 x3]
+        const unsigned y = (G0 & 1) ? s16[1] : s16[0];
+        auto s32 = __builtin_amdgcn_permlane32_swap(y, y, false, false);             // [y0 y1 y0 y1], [y2 y3 y2 y3]
+        r.i[k] = (G0 >> 1) ? s32[1] : s32[0];
+    }
+    return r.d;
+}
 template <int CTRL>
 SMRT_DEV unsigned long long dpp_move_u64(unsigned long long v) {
     union { unsigned long long u; int i[2]; } a, r;

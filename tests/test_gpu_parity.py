@@ -630,7 +630,9 @@ def test_process_coherent_layers_refusals_and_batches(ctx):
     assert list(st[0]) == [6, 6, 0, 0]
     assert np.isnan(out.values.reshape(2, S, -1)[0, :2]).all()
     plain = ctx.run(mk())
-    np.testing.assert_array_equal(out.values.reshape(2, S, -1)[0, 3], plain.values.reshape(2, S, -1)[0, 3])
+    # (a batch with process_coherent_layers runs on the two-slot finish kernel, the plain one on the register-resident
+    # kernel: the same system eliminated in a different order)
+    np.testing.assert_allclose(out.values.reshape(2, S, -1)[0, 3], plain.values.reshape(2, S, -1)[0, 3], rtol=0, atol=1e-9)
     assert np.abs(out.values.reshape(2, S, -1)[0, 2] - plain.values.reshape(2, S, -1)[0, 2]).max() > 1e-3
     # 89 GHz: 2 mm is still coherent (k n d = 0.55 < 2.36), 3 mm too
     assert st[1, 3] == 0 and st[1, 2] == 0

@@ -416,11 +416,16 @@ def test_kernel_occupancy_as_designed():
     want = {"dort_finish2_kernelILi256E": 2, "dort_prep_kernelILi256E": 3, "dort_jacobi_kernelILi256E": 4,
             "dort_active_finish_kernelILi256E": 2, "dort_active_prep_kernelILi256E": 2, "dort_finish_kernel_gmemILi256E": 2,
             "dort_active_finish_kernel_gmemILi256E": 2, "dort_passive_big_kernelILi256ELi6ELi2E": 2,
-            "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3}
+            "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3,
+            "dort_finish_reg_kernel": 1}   # one wavefront per SIMD by design: the whole register file
     for key, minimum in want.items():
         hits = [v for k, v in waves.items() if key in k]
         assert hits, key
         assert min(hits) >= minimum, (key, hits)
+    # the register-resident finish kernel must fit four wavefronts in the LDS of a CU at the headline shape (32 streams,
+    # 20 layers): matrix slot + exchange vectors + tables <= 40 KB
+    from smrt_amd import _native
+    assert _native.load_library().smrt_dort_finish_reg_lds_bytes(32, 20) <= 40 * 1024
 
 
 def test_host_evaluated_emmodels_are_packed_for_the_device():

@@ -78,6 +78,38 @@ def test_emulated_kernel_prune_deep_snowpack(emu, name, nt, pipeline):
         assert np.abs(out - ref).max() < 1e-6
 
 
+REG_FIXTURES = ["cfg1_iba_onelayer", "iba_2layer_passive37", "iba_L6_n8_angles", "iba_L3_n16_shallow", "dmrt_L8_n16",
+                "dmrtcp_L5_n12", "mixed_L4_n16_passive", "nonscattering_L3_n10_substrate"] + SUBSTRATE_FIXTURES + PRUNE_FIXTURES
+
+
+@pytest.mark.parametrize("name,order", [(n, i % 3) for i, n in enumerate(dict.fromkeys(REG_FIXTURES))])
+def test_emulated_register_resident_finish_kernel(emu, name, order):
+    """The register-resident finish kernel (one wavefront per pair, pivot-free admittance recursion in MFMA register
+    layout, dort_finish_reg.hpp) behind the same prep and Jacobi kernels: reference fixtures incl. substrates, atmosphere,
+    pruning and heterogeneous snowpacks, in three fiber orders."""
+    d = load_golden(name)
+    if str(d["mode"]) != "P" or "coherent" in name or "rough" in name:
+        pytest.skip("passive, Flat interfaces only")
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 3
+    try:
+        out, st, ref = run_fixture(emu, name, nt=256, order=order)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    assert np.abs(out - ref).max() < 1e-6
+
+
+def test_emulated_register_resident_finish_is_schedule_independent(emu):
+    outs = []
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 3
+    try:
+        for order in (0, 1, 2):
+            outs.append(run_fixture(emu, "iba_L3_n16_substrate_atmosphere", nt=256, order=order)[0])
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_emulated_kernel_is_schedule_independent(emu):
     base, _, _ = run_fixture(emu, "iba_L6_n8_angles", nt=128, order=0)
     for order in (1, 2):
