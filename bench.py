@@ -207,8 +207,10 @@ def main():
     if strong and world > 1:  # equal estimated cost per rank, contiguous slices of the frequency-major list
         ctx.upload(batch)
         bounds = shard_by_cost(ctx.pair_cost(), world)
-        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         counts = np.diff(bounds)
+        if (counts <= 0).any():   # every rank decides the same way (same costs): nobody is left waiting in the gather
+            raise SystemExit("bench.py --scaling strong: %d ranks for %d pairs leaves a rank without work" % (world, batch.n_pairs))
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     else:
         counts = np.full(world, batch.n_pairs, np.int64)
     ctx.upload(batch, lo, hi - lo)  # inputs resident in HBM before the timed region
@@ -237,8 +239,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms_total, n_launch = ctx.total_kernel_ms()
+    per_rank = None
     if use_comm:
         elapsed = float(ctx.allreduce_max([elapsed])[0])   # MAX over ranks
+        # every rank's kernel time and pair count in rank 0's line (a vector with one own entry each, MAX-reduced):
+        # load imbalance shows in the first scaling record
+        mine = np.zeros(2 * world)
+        mine[rank] = kernel_ms_total / max(n_launch, 1)
+        mine[world + rank] = n_pairs
+        allv = ctx.allreduce_max(mine)
+        per_rank = {"kernel_ms": [float(v) for v in allv[:world]], "pairs": [int(v) for v in allv[world:]]}
 
     res = ctx.download()
     n_fail = int((res.status != 0).sum())
@@ -283,6 +293,8 @@ def main():
                 "failed_solves": n_fail,
                 "timed_region": "smrt_dort_launch of the resident batch (+ smrt_dort_gather when N > 1), "
                                 "barrier + stream sync on both sides, max over ranks",
+                "value_is": "the resident-input rate (inputs in HBM when the timed region starts); SURVEY 8(d)'s rate "
+                            "including H2D of the packed inputs and D2H of the results is `pcie_inclusive` of this line",
             },
             "roofline": {
                 "bound": "mfma",
@@ -292,12 +304,15 @@ def main():
                 "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes per pipeline launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                "traffic_source": ("profiles/hbm_traffic.json (round %s; separate rocprofv3 --pmc passes over this command, "
+                                   "tools/pmc_passes.sh -- not measured in this run)" % tj.get("round")) if traffic is not None else None,
                 # the north star also asks for the fraction of the HBM roofline: measured bytes / pipeline time / 8 TB/s
                 "hbm": (None if traffic is None or kernel_ms <= 0 else
                         {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}),
-                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish2_kernel (one launch each per "
-                          "step; kernel_ms is their summed HIP-event time on the launch stream)",
+                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_reg_kernel (one launch each "
+                          "per step; kernel_ms is their summed HIP-event time on the launch stream)",
+                "per_rank": per_rank,
                 "kernel_ms": kernel_ms,
                 "flops_per_launch": flops_per_launch,
                 "note": "FP64 compute roofline: vector FMA and FP64 MFMA share one 78.6 TFLOP/s pipe on gfx950 "

@@ -229,6 +229,44 @@ def oracle_method_spread(sp, frequency, theta_deg, ref, methods=("eig", "half_ra
     return spread
 
 
+# ---- audit of the backscatter bar: every comparison is recorded -- test, element kind, worst achieved
+# relative error, what was allowed there, whether the plain 1e-8 bar had to be widened -- and written at session end to
+# gpurun_out/parity_audit.txt (GPU box: the driver pulls it; the round's table is committed under profiles/).
+# Widening is capped: beyond WIDEN_CAP a comparison fails unless the test is listed in WIDEN_WHITELIST with the spread the
+# reference's own eigensolvers show on that fixture (measured, tests/golden/add_method_spread.py).
+PARITY_AUDIT = []
+WIDEN_CAP = 1e-6
+WIDEN_WHITELIST = {
+    # cross-polarised backscatter of this fixture is a cancellation to ~1e-3 of the modes: the reference's eig / half_rank_eig /
+    # schur answers differ by 7.4e-4 relative there (HV / VH effectively unchecked, co-pol at the plain bar)
+    "iba_shs_active_substrate_conditioning": 3e-3,
+}
+
+
+def _audit_context():
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "?")
+    return cur.split(" (")[0]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY_AUDIT:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        rows = sorted(PARITY_AUDIT, key=lambda r: -r[2])
+        nw = sum(1 for r in rows if r[4])
+        with open(os.path.join(out, "parity_audit.txt"), "w") as fh:
+            fh.write("# backscatter comparisons of this pytest session: %d element kinds, %d of them beyond the plain 1e-8 bar "
+                     "(widened to 3 x the spread of the reference's own eigensolvers, capped at %.0e unless whitelisted)\n"
+                     % (len(rows), nw, WIDEN_CAP))
+            fh.write("# %-100s %-6s %10s %10s %s\n" % ("test", "kind", "achieved", "allowed", "widened"))
+            for t, kind, ach, allowed, widened in rows:
+                fh.write("%-102s %-6s %10.2e %10.2e %s\n" % (t, kind, ach, allowed, "WIDENED" if widened else "-"))
+    except OSError:
+        pass
+
+
 def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=SIGMA_RTOL, spread=None, spread_factor=3.0):
     """r, ref: [..., pol, pol_inc, theta_inc].  EVERY V,H x V,H intensity to 1e-8 relative on its own scale -- the
     north_star's bar -- co- and cross-polarised alike.  `spread` (same shape as ref, from reference_method_spread /
@@ -252,6 +290,19 @@ def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=SIGMA_RTOL, spr
         tol[..., 1, 1, :] = np.maximum(tol[..., 1, 1, :], spread_factor * co)
         tol[..., 0, 1, :] = np.maximum(tol[..., 0, 1, :], spread_factor * cross)
         tol[..., 1, 0, :] = np.maximum(tol[..., 1, 0, :], spread_factor * cross)
+    ctx_name = _audit_context()
+    cap = max([WIDEN_CAP] + [v for k, v in WIDEN_WHITELIST.items() if k in ctx_name])
+    plain = np.empty_like(rel)
+    plain[...] = rtol
+    plain[..., 0, 1, :] = plain[..., 1, 0, :] = cross_rtol
+    assert (tol <= np.maximum(plain, cap)).all(), (
+        "the spread of the reference's own methods would widen the backscatter bar to %.1e (> cap %.0e): add the fixture to "
+        "conftest.WIDEN_WHITELIST with its measured spread if that is what the reference does" % (tol.max(), cap))
+    for kind, idx in (("co", [(0, 0), (1, 1)]), ("cross", [(0, 1), (1, 0)])):
+        a = max(float(rel[..., i, j, :].max()) for i, j in idx)
+        t_ = max(float(tol[..., i, j, :].max()) for i, j in idx)
+        p_ = max(float(plain[..., i, j, :].max()) for i, j in idx)
+        PARITY_AUDIT.append((ctx_name, kind, a, t_, bool(t_ > p_ and a > p_)))
     bad = rel > tol
     assert not bad.any(), "backscatter off by up to %.2e relative (allowed %.2e there)" % (rel[bad].max(), tol[bad].max())
     # third Stokes rows/columns are multiplied by sin(m pi) ~ 1e-16 in backscatter: only their level is meaningful

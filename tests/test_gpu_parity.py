@@ -551,6 +551,67 @@ def test_batches_beyond_one_staging_chunk(ctx):
         assert np.abs(full.values[p] - O.solve(sp, freqs[f], [55.0])).max() < TB_TOL
 
 
+def _embed_fixture_snowpack(d, S, L, rng, k, lo_thick, hi_thick, deep, p1_range):
+    """S random snowpacks of the fixture's shape with the fixture's own snowpack at row k."""
+    sp = snowpack_dict(d)
+    thick = np.concatenate([rng.uniform(lo_thick, hi_thick, (S, L - 1)), np.full((S, 1), deep)], axis=1)
+    fv, temp = rng.uniform(150, 450, (S, L)) / 916.7, rng.uniform(230, 270, (S, L))
+    p1 = rng.uniform(*p1_range, (S, L))
+    thick[k], fv[k], temp[k] = sp["thickness"], sp["frac_volume"], sp["temperature"]
+    p1[k] = sp["corr_length"] if sp["microstructure"] == "exponential" else sp["radius"]
+    return thick, fv, temp, p1
+
+
+def test_cfg3_shape_batch_through_the_pipeline(ctx):
+    """BASELINE configs[2] shape at batch scale: 160 snowpacks x 7 AMSR2 frequencies = 1120 pairs of DMRT-QCA-SR, 50 layers,
+    64 streams on the 64 < N <= 128 pipeline, with the reference fixture's snowpack embedded at row 77 (all seven
+    frequencies against the reference), sub-ranges and a scattered pair list bitwise equal to the full run, every solve ok."""
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden("cfg3_dmrt_L50_n64_amsr2_sp1")
+    sp = snowpack_dict(d)
+    rng = np.random.default_rng(31)
+    S, L, k = 160, 50, 77
+    thick, fv, temp, p1 = _embed_fixture_snowpack(d, S, L, rng, k, 0.05, 0.3, 100.0, (5e-5, 1.5e-4))
+    p2 = np.full((S, L), 0.2)
+    p2[k] = np.broadcast_to(sp["stickiness"], (L,))
+    freqs = np.asarray(d["frequency"], float)
+    b = PackedBatch([L] * S, thick, fv, temp, p1, p2, freqs, np.deg2rad(d["theta_deg"]), emmodel="dmrt_qca_shortrange",
+                    microstructure="sticky_hard_spheres", n_max_stream=64)
+    full = ctx.run(b)
+    assert b.n_pairs == 1120 and (full.status == 0).all()
+    mine = full.values.reshape(len(freqs), S, *full.values.shape[1:])[:, k]
+    assert np.abs(mine - d["result"]).max() < TB_TOL
+    for lo, hi in ((0, 300), (300, 777), (777, 1120)):
+        part = ctx.run(b, pair_begin=lo, pair_count=hi - lo)
+        assert np.array_equal(part.values, full.values[lo:hi])
+    pick = rng.permutation(b.n_pairs)[:500]
+    assert np.array_equal(ctx.run(b, pairs=pick).values, full.values[pick])
+
+
+def test_cfg4_shape_batch_through_staging_chunks(ctx):
+    """BASELINE configs[3] shape at batch scale: 72 snowpacks of IBA active, 30 layers, 128 streams, m_max 2 (N = 256 / 384)
+    on the big pipeline, the reference fixture's snowpack embedded at row 40 (against the reference, backscatter bar of
+    conftest), sub-ranges bitwise equal to the full run, every solve ok."""
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden(BIG_ACTIVE_FIXTURES[0])
+    o = fixture_options(d)
+    rng = np.random.default_rng(41)
+    S, L, k = 72, len(d["thickness"]), 40
+    thick, fv, temp, p1 = _embed_fixture_snowpack(d, S, L, rng, k, 0.02, 0.10, 1000.0, (5e-5, 3e-4))
+    b = PackedBatch([L] * S, thick, fv, temp, p1, None, d["frequency"], np.deg2rad(d["theta_inc_deg"]), emmodel="iba",
+                    microstructure="exponential", mode="A", n_max_stream=o["n_max_stream"], m_max=o["m_max"])
+    full = ctx.run(b)
+    assert (full.status == 0).all()
+    nf = len(d["frequency"])
+    mine = full.values.reshape(nf, S, *full.values.shape[1:])[:, k]
+    assert_backscatter_close(mine, d["result"], spread=reference_method_spread(d))
+    for lo, hi in ((0, 30), (30, 72)):
+        part = ctx.run(b, pair_begin=lo * 1, pair_count=hi - lo)
+        assert np.array_equal(part.values, full.values[lo:hi])
+
+
 @pytest.mark.parametrize("name", MIXED_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):

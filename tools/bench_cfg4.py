@@ -1,8 +1,11 @@
 #!/usr/bin/env python
-"""BASELINE configs[3] shape on one GPU: IBA + DORT active, Sentinel-1 C band, 30 layers, 128 streams (N = 384 for the
-azimuth modes m >= 1), m_max = 2.  Runs on the fused global-workspace kernel with scalar dense steps.
-Usage: python tools/bench_cfg4.py [n_snowpacks]"""
-import os, sys, time
+"""BASELINE configs[3] shape on one GPU: IBA + DORT active, Sentinel-1 C band, 30 layers, 128 streams (N = 256 for mode 0,
+384 for the azimuth modes m >= 1), m_max = 2, on the three-kernel pipeline for N > 128.  Prints ONE JSON
+line shaped like bench.py's: value, roofline with the ACTUAL sum over pairs, modes and layers of N_l^3, failed solves,
+and sigma0_VV of the first pair.  Parity of this shape: tests/test_gpu_parity.py::test_active_full_size_cfg4_shape
+(reference fixtures) and ::test_cfg4_shape_batch_through_staging_chunks.
+   python tools/bench_cfg4.py [n_snowpacks]"""
+import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smrt_amd._native import DortContext, PackedBatch
@@ -16,10 +19,18 @@ b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, [5.405e9], np.deg2
                 microstructure="exponential", mode="A", n_max_stream=128, m_max=2)
 ctx = DortContext(0)
 ctx.upload(b)
-t0 = time.time(); ctx.launch(); ctx.sync(); dt = time.time() - t0
+ctx.launch(); ctx.sync()
+ms = ctx.last_kernel_ms()
 out = ctx.download()
-ok = int((out.status == 0).sum())
+flops = 68.0 * ctx.sum_n3()
+ach = flops / (ms * 1e-3) / 1e12
 vv = 10 * np.log10(4 * np.pi * np.cos(np.deg2rad(theta)) * out.values[0][0, 0])
-print("cfg4 shape: %d pairs (30 layers, 128 streams, m_max 2) in %.1f s = %.1f solves/s, ok %d/%d, kernel %.1f s" % (
-    S, dt, S / dt, ok, S, ctx.last_kernel_ms() / 1e3))
-print("sigma0_VV(dB) of pair 0 at 20..45 deg:", np.round(vv, 3))
+print(json.dumps({
+    "metric": "snowpack x frequency DORT solves/sec (active, 30 layers, 128 streams, m_max 2)", "value": S / ms * 1e3,
+    "unit": "solves/s", "n_gpus": 1, "steps": 1, "ms_per_step": ms, "dtype": "f64", "data": "synthetic",
+    "config": {"workload": "BASELINE configs[3] shape: IBA + DORT active, Sentinel-1 (5.405 GHz, 20..45 deg), 30 layers, "
+                           "128 streams, m_max 2, %d snowpacks, inputs resident" % S,
+               "failed_solves": int((out.status != 0).sum()), "sigma0_VV_dB_pair0": [round(float(v), 4) for v in vv]},
+    "roofline": {"bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+                 "flops_per_launch": flops, "kernel_ms": ms,
+                 "kernel": "active_big prep + jacobi_big + active_big finish (128 < N <= 384 pipeline), summed HIP-event time"}}))

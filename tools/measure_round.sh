@@ -10,7 +10,7 @@ python bench.py > $O/bench_line.json 2> $O/bench_line.err
 ( cd /tmp; rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_line_under_rocprof.json 2> $O/rocprof.err )
 python tools/rocpd_summary.py $(find $O/prof -name "*.db" | head -1) > $O/bench_kernel_stats.txt 2>&1
 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc r2 > $O/pmc_counters.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc r3 > $O/pmc_counters.txt 2>&1
 cp profiles/hbm_traffic.json $O/hbm_traffic.json 2>/dev/null
 {
   echo "# configs[2] shape (DMRT-QCA-SR, 50 layers, 64 streams, 7 AMSR2 frequencies): 64 / 256 / 1024 snowpacks"
