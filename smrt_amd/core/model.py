@@ -150,14 +150,34 @@ class Model(object):
         else:
             self.emmodel = None if emmodel is None else make_emmodel(emmodel)
         self.rtsolver = import_class("rtsolver", rtsolver) if isinstance(rtsolver, str) else rtsolver
-        self.emmodel_options = dict(emmodel_options or {})
+        self.emmodel_options = self._checked_options(emmodel_options)
         self.rtsolver_options = dict(rtsolver_options or {})
 
     def set_rtsolver_options(self, options=None, **kwargs):
         self.rtsolver_options = self._merged(self.rtsolver_options, options, kwargs)
 
     def set_emmodel_options(self, options=None, **kwargs):
-        self.emmodel_options = self._merged(self.emmodel_options, options, kwargs)
+        if is_sequence(options):
+            if kwargs:
+                raise SMRTError("keyword options cannot be combined with a per-layer list of emmodel options")
+            self.emmodel_options = self._checked_options(options)
+            return
+        current = self.emmodel_options if isinstance(self.emmodel_options, Mapping) else {}
+        self.emmodel_options = self._merged(current, options, kwargs)
+
+    @staticmethod
+    def _checked_options(options):
+        """The three forms of smrt/core/model.py:556-569: one dict for every layer, a sequence of dicts (one per layer),
+        or -- with a dict of emmodels -- a dict of dicts keyed by the medium (recognised when it is used)."""
+        if options is None:
+            return {}
+        if is_sequence(options):
+            if not all(isinstance(o, Mapping) for o in options):
+                raise SMRTError("a sequence of emmodel_options must hold one Mapping (eg. dict) per layer")
+            return [dict(o) for o in options]
+        if not isinstance(options, Mapping):
+            raise SMRTError("emmodel_options must be a Mapping (eg. dict) or a sequence of them, one per layer")
+        return dict(options)
 
     @staticmethod
     def _merged(current, options, kwargs):
@@ -261,15 +281,27 @@ class Model(object):
             raise SMRTError("no emmodel: give one to make_model or to every layer")
         return chosen
 
-    def emmodel_options_of_layer(self, layer):
+    def emmodel_options_of_layer(self, layer, index=None, n_layers=None):
+        """The options of one layer's emmodel, in the reference's order (smrt/core/model.py:556-569): the entry of a
+        per-layer sequence, the per-medium dict of dicts that goes with a dict of emmodels, else the layer's own
+        options or the model-wide dict."""
+        opts = self.emmodel_options
+        if isinstance(opts, list):
+            if index is None or n_layers is None or len(opts) != n_layers:
+                raise SMRTError("the list of emmodel_options must have the same length as the number of layers")
+            return opts[index]
+        if isinstance(self.emmodel, dict) and opts and all(isinstance(o, Mapping) for o in opts.values()):
+            if layer.medium not in opts:
+                raise SMRTError(f"no emmodel_options are given for the medium '{layer.medium}'")
+            return dict(opts[layer.medium])
         own = getattr(layer, "emmodel_options", None)
-        return own if own else self.emmodel_options
+        return own if own else opts
 
     def prepare_emmodels(self, sensor, snowpack):
         """One emmodel instance per layer."""
         n = snowpack.nlayer
         return [make_emmodel_instance(self.emmodel_of_layer(k, layer, n), sensor, layer,
-                                      **self.emmodel_options_of_layer(layer))
+                                      **self.emmodel_options_of_layer(layer, k, n))
                 for k, layer in enumerate(snowpack.layers)]
 
     def make_rtsolver_instance(self):

@@ -71,32 +71,36 @@ class Snowpack:
         """The per-layer columns of the device batch for this snowpack -- thickness, ice volume fraction, temperature,
         the two microstructure parameters -- as one (5, n_layers) array, built once (the batching runner stacks these
         rows of many snowpacks instead of walking their layer objects again for every run)."""
-        if self._packed is None or not self._fresh("_packed_key"):
+        fresh = self._fresh("_packed_key")
+        if self._packed is None or not fresh:
             cols = [(lay.thickness, lay.frac_volume, lay.temperature) + lay.microstructure.device_params
                     for lay in self.layers]
             self._packed = np.array(cols, dtype=np.float64).T.reshape(5, len(self.layers))
         return self._packed
 
     def _fresh(self, slot):
-        """Is the cache `slot` still valid?  Only if no Layer / Microstructure attribute has been written anywhere since
-        it was filled and the layer list holds the same objects."""
-        from .layer import _Epoch
-
-        key = getattr(self, slot, None)
-        ok = key is not None and key[0] == _Epoch.value and key[1] == self.layers
+        """Is the cache `slot` still valid?  Only if the layer list holds the same objects and none of them (nor its
+        microstructure object) has been written to since the cache was filled: every Layer / Microstructure counts its
+        own writes, so building or changing OTHER snowpacks' layers does not invalidate this one.  Called on every use
+        (it also records the state the cache is being filled for)."""
+        state = tuple((id(lay), lay.__dict__.get("_version", 0), lay.microstructure.__dict__.get("_version", 0))
+                      for lay in self.layers)
+        ok = getattr(self, slot, None) == state
         if not ok:
-            setattr(self, slot, (_Epoch.value, list(self.layers)))
+            setattr(self, slot, state)
         return ok
 
     @property
     def microstructure_models(self):
-        if self._micro is None or not self._fresh("_micro_key"):
+        fresh = self._fresh("_micro_key")
+        if self._micro is None or not fresh:
             self._micro = {lay.microstructure_model for lay in self.layers}
         return self._micro
 
     def has_layer_emmodels(self):
         """Does any layer carry its own emmodel or emmodel options (smrt/core/model.py:529-582)?  Looked up once per
         snowpack and layer count: the batching runner asks for every snowpack of every run."""
-        if self._overrides is None or not self._fresh("_overrides_key"):
+        fresh = self._fresh("_overrides_key")
+        if self._overrides is None or not fresh:
             self._overrides = any(getattr(l, "emmodel", None) or getattr(l, "emmodel_options", None) for l in self.layers)
         return self._overrides

@@ -6,6 +6,12 @@ import numpy as np
 from ..core.error import SMRTError
 
 
+# (emmodel, microstructure, frac_volume, temperature, p1, p2, frequency) -> eps / ks / ka as the device computes them: one
+# tiny launch per distinct layer state and frequency, not one per emmodel INSTANCE (the sequential runner makes an
+# instance per layer and simulation)
+_PROPS_CACHE = {}
+
+
 class _DeviceEMModel:
     device_name = None
 
@@ -25,13 +31,21 @@ class _DeviceEMModel:
             from ..rtsolver.dort import get_context
 
             p1, p2 = self.layer.microstructure.device_params
+            key = (self.device_name, self.layer.microstructure_model, float(self.layer.frac_volume),
+                   float(self.layer.temperature), p1, p2, self.frequency)
+            if key in _PROPS_CACHE:
+                self._props = _PROPS_CACHE[key]
+                return self._props
             batch = PackedBatch([1], [100.0], [self.layer.frac_volume], [self.layer.temperature], [p1], [p2],
                                 [self.frequency], [0.0], emmodel=self.device_name,
                                 microstructure=self.layer.microstructure_model, n_max_stream=4,
                                 phase_normalization="forced")
-            out = get_context(0).run(batch)   # the shared, cached context of GPU 0 (serialised by its lock)
+            out = get_context().run(batch)   # the shared, cached context of this process's default GPU (serialised by its lock)
             lay = out.layers[0, 0]
             self._props = dict(eps=complex(lay[0], lay[1]), ks=float(lay[2]), ka=float(lay[3]))
+            if len(_PROPS_CACHE) > 65536:
+                _PROPS_CACHE.clear()
+            _PROPS_CACHE[key] = self._props
         return self._props
 
     def effective_permittivity(self):
@@ -63,7 +77,7 @@ class _DeviceEMModel:
         if np.any(np.asarray(mu_i) == 1) and npol > 2:
             raise SMRTError("Phase matrix signs for sine elements of mode m = 2 incorrect")
         p1, p2 = self.layer.microstructure.device_params
-        return get_context(0).ft_even_phase(self.device_name, self.layer.microstructure_model, self.frequency,
+        return get_context().ft_even_phase(self.device_name, self.layer.microstructure_model, self.frequency,
                                             self.layer.frac_volume, self.layer.temperature, p1,
                                             p2, mu_s, mu_i, m_max, npol)
 

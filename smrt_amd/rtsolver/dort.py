@@ -16,7 +16,7 @@ import threading
 import numpy as np
 
 from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
-from ..core.error import SMRTError
+from ..core.error import SMRTError, smrt_warn
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack, substrate_kind
 
@@ -45,6 +45,12 @@ class DORT(object):
             raise SMRTError("prune_deep_snowpack must be None, True or a positive optical depth")
         if diagonalization_method not in _DIAG_METHODS:
             raise SMRTError(f"Unknown method '{diagonalization_method}' to diagonalize the matrix")
+        if diagonalization_method != "schur_forcedtriu":
+            # not silently: 'stamnes88' in the reference differs from its other methods by up to ~1 K
+            # (smrt/test/test_integration_iba.py atol table); the device has ONE route, equal to the default to 1e-8 K
+            smrt_warn(f"diagonalization_method='{diagonalization_method}' is ignored: smrt_amd's DORT always diagonalises with "
+                      "its own symmetric reduction (Cholesky x 2 + one-sided Jacobi), which reproduces the reference's "
+                      "default 'schur_forcedtriu'" + (" -- NOT the 'stamnes88' variant" if diagonalization_method == "stamnes88" else ""))
         if error_handling not in ("exception", "nan"):
             raise SMRTError("error_handling must be 'exception' or 'nan'")
         if phase_normalization not in (True, False, "auto", "forced"):
@@ -131,7 +137,7 @@ class DORT(object):
         simple_options = None
         for sp in plan.snowpacks:
             n = sp.nlayer
-            plain = simple and not sp.has_layer_emmodels()
+            plain = simple and not sp.has_layer_emmodels() and not isinstance(model.emmodel_options, list)
             if plain and simple_name is not None and simple_options is not None:
                 # the common case -- one device emmodel, no per-layer settings, options already validated: no per-layer work
                 distinct.add(simple_name)
@@ -139,20 +145,20 @@ class DORT(object):
                 continue
             if plain:
                 kinds = [model.emmodel] * n
-                todo = [(model.emmodel, sp.layers[0])]
+                todo = [(model.emmodel, sp.layers[0], 0)]
                 simple_options = True
             else:
                 kinds = [model.emmodel_of_layer(k, layer, n) for k, layer in enumerate(sp.layers)]
-                todo = list(zip(kinds, sp.layers))
-            for kind, layer in todo:
-                options = model.emmodel_options_of_layer(layer)
+                todo = [(kind, layer, k) for k, (kind, layer) in enumerate(zip(kinds, sp.layers))]
+            for kind, layer, k in todo:
+                options = model.emmodel_options_of_layer(layer, k, n)
                 key = (kind, tuple(sorted(options.items())))
                 if key not in checked:
                     checked.add(key)
                     kind(plan.sensors[0], layer, **options)     # validates the options against the class
             # a class without a device implementation is evaluated on the host, layer by layer (_evaluate_on_host)
-            names = [getattr(k, "device_name", None) or (k, model.emmodel_options_of_layer(layer))
-                     for k, layer in zip(kinds, sp.layers)]
+            names = [getattr(kd, "device_name", None) or (kd, model.emmodel_options_of_layer(layer, k, n))
+                     for k, (kd, layer) in enumerate(zip(kinds, sp.layers))]
             distinct.update(n if isinstance(n, str) else "host" for n in names)
             per_pack.append(names)
         return distinct.pop() if len(distinct) == 1 and "host" not in distinct else per_pack
@@ -320,7 +326,13 @@ class DORT(object):
             probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
                                 microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
                                 phase_normalization="forced", layer_kind=layer_kind)
-            lay = get_context(0).run(probe).layers.reshape(F, S, Lmax, 5)
+            # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
+            res = get_context((self.devices or [default_device()])[0]).run(probe)
+            bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless
+            if len(bad):
+                raise SMRTError("the layer electromagnetics of pair %d are not computable (status 5): cannot place the "
+                                "streams of the substrate matrices" % int(bad[0]))
+            lay = res.layers.reshape(F, S, Lmax, 5)
             eps = lay[..., 0] + 1j * lay[..., 1]
         nm, ne = (self.m_max + 1 if act else 1), 3 * self.n_max_stream
         R = np.zeros((F, S, nm, ne, ne))
@@ -579,8 +591,26 @@ _ctx_cache = {}
 _ctx_lock = threading.Lock()
 
 
-def get_context(device):
-    """The cached context of a GPU (created on first use; its calls are serialised by DortContext.lock)."""
+def default_device():
+    """The GPU the helpers outside a solver run use (emmodel accessors, ft_even_phase): SMRT_DORT_DEVICE, else this
+    process's LOCAL_RANK in a one-process-per-GPU launch, else 0 -- never blindly GPU 0."""
+    import os
+
+    for key in ("SMRT_DORT_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v.strip().isdigit():
+            from .._native import device_count
+
+            n = device_count()
+            return int(v) % n if n > 0 else int(v)
+    return 0
+
+
+def get_context(device=None):
+    """The cached context of a GPU (created on first use; its calls are serialised by DortContext.lock); None: the
+    default device of this process (default_device)."""
+    if device is None:
+        device = default_device()
     with _ctx_lock:
         if device not in _ctx_cache:
             _ctx_cache[device] = DortContext(device)

@@ -26,8 +26,12 @@ def shard_bounds(n_items, world_size):
 
 
 def _token():
-    """What both sides must agree on before a payload is handed over (keeps strangers and stale servers apart)."""
-    key = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "WORLD_SIZE"))
+    """What both sides must agree on before a payload is handed over (keeps stale servers and other jobs apart).  The
+    launcher's variables are not secret: on a network where strangers can reach MASTER_ADDR, export the same random
+    SMRT_DORT_JOB_SECRET to every rank (the launcher's environment) and it becomes part of the token -- a peer that does
+    not know it is never handed the RCCL id and never counts as a rank."""
+    key = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "WORLD_SIZE",
+                                                    "SMRT_DORT_JOB_SECRET"))
     return hashlib.sha256(key.encode()).digest()[:16]
 
 

@@ -541,6 +541,57 @@ def test_host_evaluated_substrates_matrices_and_refusals():
         Snowpack(layers=sp.layers, substrate=object())
 
 
+def test_layer_density_is_read_only_and_update_keeps_the_layer_consistent():
+    """`layer.density = x` used to be accepted and ignored (frac_volume lives on the microstructure object).
+    Like the reference (smrt/inputs/make_medium.py:355-359) the three attributes frac_volume derives from are read-only
+    once the layer exists; update(density=...) recomputes the ice volume fraction and the snowpack's packed columns."""
+    from smrt_amd.core.error import SMRTError
+
+    sp = two_layer()
+    before = sp.packed().copy()
+    for attr in ("density", "liquid_water", "volumetric_liquid_water"):
+        with pytest.raises(SMRTError, match="read-only"):
+            setattr(sp.layers[0], attr, 400.0)
+    assert np.array_equal(sp.packed(), before)
+    sp.layers[0].update(density=400.0)
+    assert sp.layers[0].density == 400.0 and abs(sp.layers[0].frac_volume - 400.0 / 916.7) < 1e-12
+    assert abs(sp.packed()[1, 0] - 400.0 / 916.7) < 1e-12 and sp.packed()[1, 0] != before[1, 0]
+    with pytest.raises(SMRTError, match="wet"):
+        sp.layers[0].update(liquid_water=0.1)
+    # the caches of one snowpack do not care about layers built or changed elsewhere
+    filled = sp.packed()
+    other = two_layer()
+    other.layers[0].temperature = 200.0
+    assert sp.packed() is filled
+
+
+def test_emmodel_options_forms_and_diagonalization_warning():
+    """The three forms of emmodel options of smrt/core/model.py:556-569 (one dict, a sequence with one dict per layer, a
+    dict of dicts keyed by the medium next to a dict of emmodels) are resolved per layer or refused -- never mis-applied;
+    a diagonalization_method other than the default is announced as ignored."""
+    import warnings
+
+    from smrt_amd import make_model
+    from smrt_amd.core.error import SMRTError, SMRTWarning
+    from smrt_amd.rtsolver.dort import DORT
+
+    sp = two_layer()
+    m = make_model("iba", "dort", emmodel_options=[dict(dense_snow_correction=None), {}])
+    assert m.emmodel_options_of_layer(sp.layers[0], 0, 2) == dict(dense_snow_correction=None)
+    assert m.emmodel_options_of_layer(sp.layers[1], 1, 2) == {}
+    with pytest.raises(SMRTError, match="same length"):
+        m.emmodel_options_of_layer(sp.layers[0], 0, 3)
+    with pytest.raises(SMRTError, match="Mapping"):
+        make_model("iba", "dort", emmodel_options=[1, 2])
+    md = make_model({"snow": "iba"}, "dort", emmodel_options={"snow": dict(dense_snow_correction=None)})
+    assert md.emmodel_options_of_layer(sp.layers[0], 0, 2) == dict(dense_snow_correction=None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        DORT(diagonalization_method="stamnes88")
+        DORT()
+    assert len(w) == 1 and issubclass(w[0].category, SMRTWarning) and "stamnes88" in str(w[0].message)
+
+
 def test_snowpack_caches_follow_layer_changes():
     """The batching path caches per snowpack what it needs for every run (packed layer columns, microstructure set,
     per-layer emmodel flag); changing a layer afterwards -- a temperature for a sensitivity study, a correlation length set
