@@ -279,6 +279,15 @@ int32_t smrt_dort_comm_destroy(smrt_dort_ctx* ctx);
 int32_t smrt_dort_gather(smrt_dort_ctx* ctx, int32_t root, const int64_t* counts, double* out, int32_t* status);
 int32_t smrt_dort_comm_allreduce_max(smrt_dort_ctx* ctx, double* values, int32_t n);
 
+/* The transfers smrt_dort_gather issues, as data (host arithmetic only -- no GPU, no communicator): on `root` one receive
+ * per other rank that has rows, the rows of rank r landing at row offset counts[0] + ... + counts[r - 1] of the gathered
+ * buffer (own rows are copied to *own_offset_rows); on any other rank one send of its counts[rank] rows.  Returns the
+ * number of transfers (ops beyond `capacity` are counted, not written), -1 on invalid arguments; *total_rows = sum of
+ * counts.  What the multi-rank CPU tests check with 2..8 ranks, unequal and empty shards and any root. */
+typedef struct smrt_gather_op { int32_t peer; int32_t reserved; int64_t offset_rows; int64_t rows; } smrt_gather_op;
+int32_t smrt_dort_gather_plan(int32_t world, int32_t root, int32_t rank, const int64_t* counts, smrt_gather_op* ops,
+                              int32_t capacity, int64_t* own_offset_rows, int64_t* total_rows);
+
 /* Self-description of the ABI for foreign-function bindings: out[0] = sizeof(smrt_batch), out[1..] = byte offset of
  * every field of smrt_batch in declaration order.  Returns the number of entries of the full description (fields + 1);
  * at most `capacity` of them are written (out may be NULL to query the count).  A binding checks its own struct

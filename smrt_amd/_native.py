@@ -250,6 +250,9 @@ def load_library():
     lib.smrt_dort_set_block_threads.restype = C.c_int32
     lib.smrt_dort_set_pipeline.argtypes = [C.c_void_p, C.c_int32]
     lib.smrt_dort_set_pipeline.restype = C.c_int32
+    lib.smrt_dort_gather_plan.argtypes = [C.c_int32, C.c_int32, C.c_int32, P(C.c_int64), C.c_void_p, C.c_int32,
+                                          P(C.c_int64), P(C.c_int64)]
+    lib.smrt_dort_gather_plan.restype = C.c_int32
     lib.smrt_dort_finish_reg_lds_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.smrt_dort_finish_reg_lds_bytes.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
@@ -289,7 +292,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
-    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes",
+    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_gather_plan",
 ]
 
 
@@ -474,6 +477,25 @@ class DortContext:
 
     def sum_n3(self):
         return float(self._lib.smrt_dort_sum_n3(self._h))
+
+
+class GatherOp(C.Structure):
+    """smrt_gather_op of include/smrt_dort.h."""
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_int32), ("offset_rows", C.c_int64), ("rows", C.c_int64)]
+
+
+def gather_plan(world, root, rank, counts):
+    """The transfers smrt_dort_gather issues on `rank` (smrt_dort_gather_plan: host arithmetic, needs no GPU):
+    ([(peer, offset_rows, rows), ...], own_offset_rows, total_rows)."""
+    lib = load_library()
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    ops = (GatherOp * max(int(world), 1))()
+    own, total = C.c_int64(0), C.c_int64(0)
+    n = lib.smrt_dort_gather_plan(int(world), int(root), int(rank), counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  C.cast(ops, C.c_void_p), int(world), C.byref(own), C.byref(total))
+    if n < 0:
+        raise SMRTError("smrt_dort_gather_plan: invalid arguments")
+    return [(o.peer, o.offset_rows, o.rows) for o in ops[:n]], own.value, total.value
 
 
 def device_count():

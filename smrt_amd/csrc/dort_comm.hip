@@ -9,6 +9,7 @@
 
 #include "../../include/smrt_dort.h"
 #include "dort_ctx.hpp"
+#include "dort_host_common.hpp"
 
 namespace {
 
@@ -139,32 +140,32 @@ int32_t smrt_dort_gather(smrt_dort_ctx* ctx, int32_t root, const int64_t* counts
     HIPCHK(hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     const size_t stride = (size_t)ctx->out_stride;
+    // the transfers come from smrt_dort_gather_plan (host arithmetic, tested with 2..8 ranks on the CPU)
+    std::vector<smrt_gather_op> ops((size_t)world);
+    int64_t own_off = 0, total = 0;
+    const int n_ops = smrt_host::gather_plan(world, root, rank, counts, ops.data(), world, &own_off, &total);
+    if (n_ops < 0) { ctx->err = "negative count"; return -1; }
     if (rank != root) {
         NCCLCHK(R.GroupStart());
-        NCCLCHK(R.Send(ctx->dev.out, (size_t)counts[rank] * stride, ncclDouble, root, comm, ctx->stream));
-        NCCLCHK(R.Send(ctx->dev.status, (size_t)counts[rank], ncclInt32, root, comm, ctx->stream));
+        for (int k = 0; k < n_ops; ++k) {
+            NCCLCHK(R.Send(ctx->dev.out, (size_t)ops[k].rows * stride, ncclDouble, ops[k].peer, comm, ctx->stream));
+            NCCLCHK(R.Send(ctx->dev.status, (size_t)ops[k].rows, ncclInt32, ops[k].peer, comm, ctx->stream));
+        }
         NCCLCHK(R.GroupEnd());
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return 0;
     }
-    int64_t total = 0;
-    for (int r = 0; r < world; ++r) { if (counts[r] < 0) { ctx->err = "negative count"; return -1; } total += counts[r]; }
     HIPCHK(ctx->d_gather_out.reserve(sizeof(double) * (size_t)total * stride));
     HIPCHK(ctx->d_gather_status.reserve(sizeof(int32_t) * (size_t)total));
     double* gout = (double*)ctx->d_gather_out.p;
     int32_t* gst = (int32_t*)ctx->d_gather_status.p;
     NCCLCHK(R.GroupStart());
-    int64_t off = 0;
-    for (int r = 0; r < world; ++r) {
-        if (r != root && counts[r] > 0) {
-            NCCLCHK(R.Recv(gout + (size_t)off * stride, (size_t)counts[r] * stride, ncclDouble, r, comm, ctx->stream));
-            NCCLCHK(R.Recv(gst + off, (size_t)counts[r], ncclInt32, r, comm, ctx->stream));
-        }
-        off += counts[r];
+    for (int k = 0; k < n_ops; ++k) {
+        NCCLCHK(R.Recv(gout + (size_t)ops[k].offset_rows * stride, (size_t)ops[k].rows * stride, ncclDouble, ops[k].peer, comm, ctx->stream));
+        NCCLCHK(R.Recv(gst + ops[k].offset_rows, (size_t)ops[k].rows, ncclInt32, ops[k].peer, comm, ctx->stream));
     }
     NCCLCHK(R.GroupEnd());
-    off = 0;
-    for (int r = 0; r < root; ++r) off += counts[r];
+    const int64_t off = own_off;
     HIPCHK(hipMemcpyAsync(gout + (size_t)off * stride, ctx->dev.out, sizeof(double) * (size_t)counts[root] * stride,
                           hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(gst + off, ctx->dev.status, sizeof(int32_t) * (size_t)counts[root], hipMemcpyDeviceToDevice, ctx->stream));
@@ -172,6 +173,11 @@ int32_t smrt_dort_gather(smrt_dort_ctx* ctx, int32_t root, const int64_t* counts
     if (status) HIPCHK(hipMemcpyAsync(status, gst, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int32_t smrt_dort_gather_plan(int32_t world, int32_t root, int32_t rank, const int64_t* counts, smrt_gather_op* ops,
+                              int32_t capacity, int64_t* own_offset_rows, int64_t* total_rows) {
+    return smrt_host::gather_plan(world, root, rank, counts, ops, capacity < 0 ? 0 : capacity, own_offset_rows, total_rows);
 }
 
 int32_t smrt_dort_comm_allreduce_max(smrt_dort_ctx* ctx, double* values, int32_t n) {

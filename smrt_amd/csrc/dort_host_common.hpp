@@ -17,6 +17,41 @@
 
 namespace smrt_host {
 
+// The transfers of smrt_dort_gather as data, so that the offset / count arithmetic can be tested with any number of ranks
+// on a machine with one GPU or none (tests/test_multirank_cpu.py): on the root one receive per other rank that has rows
+// (the rows of rank r land at row offset sum(counts[0..r)) of the gathered buffer, own rows copied to own_offset), on
+// every other rank one send of its counts[rank] rows (none when it has no rows).  Returns the number of ops, -1 on
+// invalid arguments.
+inline int gather_plan(int world, int root, int rank, const int64_t* counts, smrt_gather_op* ops, int capacity,
+                       int64_t* own_offset_rows, int64_t* total_rows) {
+    if (world < 1 || root < 0 || root >= world || rank < 0 || rank >= world || !counts) return -1;
+    int64_t total = 0, own = 0;
+    for (int r = 0; r < world; ++r) {
+        if (counts[r] < 0) return -1;
+        if (r == rank) own = total;
+        total += counts[r];
+    }
+    if (own_offset_rows) *own_offset_rows = (rank == root) ? own : 0;
+    if (total_rows) *total_rows = total;
+    int n = 0;
+    if (rank != root) {
+        if (counts[rank] > 0) {
+            if (ops && n < capacity) { ops[n].peer = root; ops[n].offset_rows = 0; ops[n].rows = counts[rank]; }
+            ++n;
+        }
+        return n;
+    }
+    int64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+        if (r != root && counts[r] > 0) {
+            if (ops && n < capacity) { ops[n].peer = r; ops[n].offset_rows = off; ops[n].rows = counts[r]; }
+            ++n;
+        }
+        off += counts[r];
+    }
+    return n;
+}
+
 // Positive nodes (descending) and weights of the Gauss-Legendre rule of order 2n, by Newton iteration on the
 // three-term recurrence (what scipy.special.roots_legendre provides to smrt/rtsolver/streams.py:300-313).
 inline void gauss_legendre_positive(int n, double* mu, double* weight) {

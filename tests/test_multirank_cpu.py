@@ -24,7 +24,7 @@ def _make_batch():
                        rng.uniform(5e-5, 3e-4, (S, L)), None, [18.7e9, 36.5e9, 89e9], np.deg2rad([55.0]), n_max_stream=8)
 
 
-def _emu_run(batch, lo, n):
+def _emu_run(batch, lo, n, want_cost=False):
     from smrt_amd._native import SmrtBatch
 
     lib = C.CDLL(EMU_LIB)
@@ -33,10 +33,12 @@ def _emu_run(batch, lo, n):
                                  P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_long)]
     out = np.empty((n,) + batch.out_shape())
     st = np.empty(n, np.int32)
+    n3 = np.zeros(n)
     rc = lib.smrt_emu_run(C.byref(batch.struct), lo, n, 64, 0, out.ctypes.data_as(P(C.c_double)),
-                          st.ctypes.data_as(P(C.c_int32)), None, None, None, None)
+                          st.ctypes.data_as(P(C.c_int32)), None, None, n3.ctypes.data_as(P(C.c_double)) if want_cost else None,
+                          None)
     assert rc == 0
-    return out, st
+    return (out, st, n3) if want_cost else (out, st)
 
 
 def _worker(rank, world, port, tmpdir):
@@ -45,20 +47,40 @@ def _worker(rank, world, port, tmpdir):
     import torch
     import torch.distributed as dist
 
-    from smrt_amd.runner.distributed import gather_to_root, shard_bounds
+    from smrt_amd._native import gather_plan
+    from smrt_amd.rtsolver.dort import shard_by_cost
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     batch = _make_batch()
-    b = shard_bounds(batch.n_pairs, world)
-    out, st = _emu_run(batch, int(b[rank]), int(b[rank + 1] - b[rank]))
-    v, s = gather_to_root(dist, torch.from_numpy(out), torch.from_numpy(st), dst=0)
+    # what the product shards by (smrt_dort_pair_cost: sum over the layers of N_l^3), here from the emulated solve of the
+    # whole batch; the slices are unequal in length
+    full, fst, cost = _emu_run(batch, 0, batch.n_pairs, want_cost=True)
+    b = shard_by_cost(cost, world)
+    counts = np.diff(b)
+    out, st = _emu_run(batch, int(b[rank]), int(counts[rank]))
+    # the product's collective is grouped send / recv following smrt_dort_gather_plan (dort_comm.hip): the SAME plan drives
+    # gloo send / recv here, with the root that is not rank 0 so that the own-offset arithmetic matters
+    root = world - 1
+    ops, own_off, total = gather_plan(world, root, rank, counts)
+    stride = int(np.prod(batch.out_shape()))
+    if rank != root:
+        for peer, _, rows in ops:
+            dist.send(torch.from_numpy(out.reshape(-1, stride)[:rows].copy()), dst=peer)
+            dist.send(torch.from_numpy(st[:rows].copy()), dst=peer)
+    else:
+        gv = torch.zeros((total, stride), dtype=torch.float64)
+        gs = torch.full((total,), -1, dtype=torch.int32)
+        for peer, off, rows in ops:
+            dist.recv(gv[off:off + rows], src=peer)
+            dist.recv(gs[off:off + rows], src=peer)
+        gv[own_off:own_off + counts[root]] = torch.from_numpy(out.reshape(-1, stride))
+        gs[own_off:own_off + counts[root]] = torch.from_numpy(st)
+        ok = (np.array_equal(gv.numpy().reshape(full.shape), full) and np.array_equal(gs.numpy(), fst) and (fst == 0).all()
+              and len(set(counts.tolist())) > 1)
+        open(os.path.join(tmpdir, "result.txt"), "w").write("OK" if ok else "MISMATCH %s" % counts)
     dist.barrier()
-    if rank == 0:
-        full, fst = _emu_run(batch, 0, batch.n_pairs)
-        ok = np.array_equal(v.numpy(), full) and np.array_equal(s.numpy(), fst) and (fst == 0).all()
-        open(os.path.join(tmpdir, "result.txt"), "w").write("OK" if ok else "MISMATCH")
     dist.destroy_process_group()
 
 
@@ -70,6 +92,41 @@ def test_shard_bounds():
     b = shard_bounds(9, 2)
     assert list(b) == [0, 4, 9]
     assert list(shard_bounds(3, 8)) == [0, 0, 0, 1, 1, 1, 2, 2, 3] or shard_bounds(3, 8)[-1] == 3
+
+
+def test_gather_plan_offsets_for_any_world_root_and_shard_sizes():
+    """smrt_dort_gather_plan (the arithmetic smrt_dort_gather runs on, dort_comm.hip): simulate its transfers for 2..8
+    ranks, every root, unequal and EMPTY shards -- the gathered buffer must be the rank-ordered concatenation."""
+    from smrt_amd._native import gather_plan
+
+    rng = np.random.default_rng(7)
+    for world in range(1, 9):
+        for trial in range(6):
+            counts = rng.integers(0, 7, world)
+            if trial == 0:
+                counts[:] = 3
+            rows = [np.arange(c) + 100 * r for r, c in enumerate(counts)]
+            want = np.concatenate(rows) if world else np.array([])
+            for root in range(world):
+                got = np.full(int(counts.sum()), -1)
+                sends = {}
+                for rank in range(world):
+                    ops, own, total = gather_plan(world, root, rank, counts)
+                    assert total == counts.sum()
+                    if rank == root:
+                        got[own:own + counts[root]] = rows[root]
+                        recvs = ops
+                    else:
+                        assert len(ops) == (1 if counts[rank] > 0 else 0)
+                        for peer, off, n in ops:
+                            assert peer == root and off == 0 and n == counts[rank]
+                            sends[rank] = rows[rank][:n]
+                assert sorted(p for p, _, _ in recvs) == sorted(sends)   # every send has its receive: nobody blocks
+                for peer, off, n in recvs:
+                    got[off:off + n] = sends[peer]
+                assert np.array_equal(got, want)
+    with pytest.raises(Exception):
+        gather_plan(2, 0, 0, [1, -1])
 
 
 def test_two_ranks_gloo_gather(tmp_path):

@@ -30,6 +30,8 @@ def ctype_of(decl):
         return "C.c_char_p"
     if base == "smrt_batch":
         return "C.POINTER(SmrtBatch)"
+    if base == "smrt_gather_op":   # {int32 peer, int32 reserved, int64 offset_rows, int64 rows}: passed as an opaque array
+        return "C.c_void_p"
     c = SCALARS[base]
     for _ in range(stars):
         c = "C.POINTER(%s)" % c
