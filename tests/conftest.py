@@ -201,13 +201,16 @@ BIG_ACTIVE_FIXTURES = ["cfg4_iba_active_L30_n128_sp0", "cfg4_iba_active_L30_n128
 SIGMA_RTOL = 1e-8  # backscatter, relative (BASELINE.json north_star)
 
 
+METHOD_RESULT_KEYS = ("result_eig", "result_half_rank_eig", "result_rerun")
+
+
 def reference_method_spread(d):
     """Element-wise spread of the reference's own answers over its diagonalisation methods (stored in the active
     fixtures by tests/golden/add_method_spread.py as result_<method>); zeros when the fixture holds none."""
     ref = np.asarray(d["result"])
     spread = np.zeros_like(ref)
-    for k in d:
-        if k.startswith("result_"):
+    for k in METHOD_RESULT_KEYS:   # (NOT every "result_*" key: result_incoherent of the coherent fixtures is another physics)
+        if k in d:
             spread = np.maximum(spread, np.abs(np.asarray(d[k]) - ref))
     return spread
 
@@ -240,6 +243,7 @@ WIDEN_WHITELIST = {
     # cross-polarised backscatter of this fixture is a cancellation to ~1e-3 of the modes: the reference's eig / half_rank_eig /
     # schur answers differ by 7.4e-4 relative there (HV / VH effectively unchecked, co-pol at the plain bar)
     "iba_shs_active_substrate_conditioning": 3e-3,
+    "test_active_substrate_dominated_pair": 3e-3,   # (the GPU test on that fixture)
 }
 
 

@@ -693,7 +693,7 @@ def test_process_coherent_layers_refusals_and_batches(ctx):
     plain = ctx.run(mk())
     # (a batch with process_coherent_layers runs on the two-slot finish kernel, the plain one on the register-resident
     # kernel: the same system eliminated in a different order)
-    np.testing.assert_allclose(out.values.reshape(2, S, -1)[0, 3], plain.values.reshape(2, S, -1)[0, 3], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out.values.reshape(2, S, -1)[0, 3], plain.values.reshape(2, S, -1)[0, 3], rtol=0, atol=1e-7)
     assert np.abs(out.values.reshape(2, S, -1)[0, 2] - plain.values.reshape(2, S, -1)[0, 2]).max() > 1e-3
     # 89 GHz: 2 mm is still coherent (k n d = 0.55 < 2.36), 3 mm too
     assert st[1, 3] == 0 and st[1, 2] == 0
