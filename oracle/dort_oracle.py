@@ -745,6 +745,19 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
     R = intensity_down.shape[1]
     b = np.zeros((ntot, R))
     optical_depth = 0.0
+    dense_itf = itf.get("dense", {})   # rough interfaces: {i: matrices of the interface on top of layer i (0: the surface)}
+
+    def imat(i, kind, diag):
+        """Matrix `kind` (Rtop / Ttop of layer i, Rbot / Tbot of the layer above it, or of the air side for i = 0) of
+        interface i: the caller's dense matrix of this mode for a rough interface (its specular diagonal in the coherent
+        pass), else the Flat diagonal `diag` (rtsolver_utils.py:473-642,690-707)."""
+        if i in dense_itf:
+            return np.asarray(dense_itf[i][kind + ("_coh" if coherent_only else "")][m], float)
+        return np.diag(diag)
+
+    def rowsum(M):   # _muleye (dort.py:514-530): action on the isotropic black-body field
+        return np.asarray(M).sum(axis=1)
+
     for l in range(L):
         beta, Eu, Ed = layers_eig[l].solve(m, coherent_only)
         tt = np.exp(-np.maximum(beta, 0.0) * thickness[l])  # reference at the bottom (dort.py:339)
@@ -757,34 +770,40 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
         if l == 0:
             Eu0, tt0 = Eu, tt
         # top of layer l (eq 17 & 19, dort.py:364-395)
-        _put_block(ab, nband, row_top[l], j, (Ed - Rtop[:, None] * Eu) * tt[None, :])
+        RtopM = imat(l, "Rtop", Rtop)
+        _put_block(ab, nband, row_top[l], j, (Ed - RtopM @ Eu) * tt[None, :])
         if l < L - 1:
-            nc = min(N[l], N[l + 1])
-            _put_block(ab, nband, row_top[l + 1], j, -((Tbot[:, None] * Ed) * tb[None, :])[:nc])
+            TbotM = imat(l + 1, "Tbot", Tbot)      # (rows: streams of layer l + 1 for a dense matrix, of layer l for a diagonal)
+            nc = min(TbotM.shape[0], N[l + 1])
+            _put_block(ab, nband, row_top[l + 1], j, -((TbotM @ Ed) * tb[None, :])[:nc])
         if m == 0 and planck_T is not None:
-            b[row_top[l] : row_top[l] + N[l]] -= ((1.0 - Rtop) * planck_T[l])[:, None]
+            b[row_top[l] : row_top[l] + N[l]] -= ((1.0 - rowsum(RtopM)) * planck_T[l])[:, None]
             if l < L - 1:
-                b[row_top[l + 1] : row_top[l + 1] + nc] += (Tbot * planck_T[l])[:nc, None]
+                b[row_top[l + 1] : row_top[l + 1] + nc] += (rowsum(TbotM) * planck_T[l])[:nc, None]
         if l == 0:
-            Tair = _flatten_pol(itf["Tbot_air"], m)
-            nc0 = min(len(Tair), N[0])
-            b[row_top[0] : row_top[0] + nc0] += (Tair[:, None] * intensity_down)[:nc0]
+            TairM = imat(0, "Tbot", _flatten_pol(itf["Tbot_air"], m))
+            nc0 = min(TairM.shape[0], N[0])
+            b[row_top[0] : row_top[0] + nc0] += (TairM @ intensity_down)[:nc0]
         # bottom of layer l (eq 18 & 22, dort.py:400-427)
         if l == L - 1 and "Rbot_dense" in itf:   # rough substrate: dense reflection matrix of this mode (diagonal if coherent only)
             Rmat = np.diag(itf["Rbot_coh"][m]) if coherent_only else np.asarray(itf["Rbot_dense"][m])
             _put_block(ab, nband, row_bot[l], j, (Eu - Rmat @ Ed) * tb[None, :])
         else:
-            _put_block(ab, nband, row_bot[l], j, (Eu - Rbot[:, None] * Ed) * tb[None, :])
+            RbotM = imat(l + 1, "Rbot", Rbot) if l < L - 1 else np.diag(Rbot)
+            _put_block(ab, nband, row_bot[l], j, (Eu - RbotM @ Ed) * tb[None, :])
         if l > 0:
-            nc = min(N[l], N[l - 1])
-            _put_block(ab, nband, row_bot[l - 1], j, -((Ttop[:, None] * Eu) * tt[None, :])[:nc])
+            TtopM = imat(l, "Ttop", Ttop)
+            nc = min(TtopM.shape[0], N[l - 1])
+            _put_block(ab, nband, row_bot[l - 1], j, -((TtopM @ Eu) * tt[None, :])[:nc])
         if m == 0 and planck_T is not None:
             rb = Rbot   # dense reflection matrix: its row sums (_muleye, dort.py:514-530)
             if l == L - 1 and "Rbot_dense" in itf:
                 rb = np.asarray(itf["Rbot_dense"][m]).sum(axis=1)
+            elif l < L - 1:
+                rb = rowsum(imat(l + 1, "Rbot", Rbot))
             b[row_bot[l] : row_bot[l] + N[l]] -= ((1.0 - rb) * planck_T[l])[:, None]
             if l > 0:
-                b[row_bot[l - 1] : row_bot[l - 1] + nc] += (Ttop * planck_T[l])[:nc, None]
+                b[row_bot[l - 1] : row_bot[l - 1] + nc] += (rowsum(TtopM) * planck_T[l])[:nc, None]
             if l == L - 1 and planck_substrate is not None:  # emission of the substrate, dort.py:429-441
                 b[row_bot[l] : row_bot[l] + N[l]] += (Tbot * planck_substrate)[:, None]
         optical_depth += np.min(np.abs(beta)) * thickness[l]  # dort.py:444
@@ -800,9 +819,9 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
     I1 = Eu0 @ (tt0[:, None] * x0)  # dort.py:476
     if m == 0 and planck_T is not None:
         I1 = I1 + planck_T[0]
-    Rair = _flatten_pol(itf["Rbot_air"], m)
-    Ttop0 = _flatten_pol(itf["Ttop"][0], m)
-    I0 = Rair[:, None] * intensity_down + (Ttop0[:, None] * I1)[: st.n_air * P]  # dort.py:484
+    RairM = imat(0, "Rbot", _flatten_pol(itf["Rbot_air"], m))
+    Ttop0M = imat(0, "Ttop", _flatten_pol(itf["Ttop"][0], m))
+    I0 = RairM @ intensity_down + (Ttop0M @ I1)[: st.n_air * P]  # dort.py:484
     return (I0, x0) if return_x0 else I0
 
 
@@ -811,8 +830,12 @@ def dort_mode(m, layers_eig, st, itf, thickness, planck_T, intensity_down, coher
 # ----------------------------------------------------------------------------------------------------------------
 def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None, phi=np.pi, n_max_stream=32,
           m_max=2, method="half_rank_eig", phase_normalization=True, rayleigh_jeans=False, details=None,
-          substrate=None, atmosphere=None, prune_deep_snowpack=None, process_coherent_layers_=False):
-    """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces.
+          substrate=None, atmosphere=None, prune_deep_snowpack=None, process_coherent_layers_=False, interfaces=None):
+    """DORT.solve (smrt/rtsolver/dort.py:189-261) for Flat interfaces -- or rough ones handed over as matrices:
+    interfaces = {i: {"Rtop": [per azimuth mode], "Ttop": [...], "Rbot": [...], "Tbot": [...], and the same keys + "_coh"
+    (specular parts, for the coherent pass of active mode)}} for the interface on top of layer i (0: the surface), every
+    matrix as compute_interface_properties combines it (rtsolver_utils.py:473-642,690-707: specular diagonal + 2 pi | pi x
+    the normalised diffuse mode); Rtop / Ttop belong to layer i looking up, Rbot / Tbot to the medium above looking down.
 
     process_coherent_layers_: DORT option process_coherent_layers (dort.py:110,156,203; rtsolver_utils.py:349-365).
 
@@ -848,6 +871,8 @@ def solve(sp, frequency, theta_deg, emmodel="iba", mode="P", theta_inc_deg=None,
     npol = 3 if active else 2
     mm = m_max if active else 0
     itf = interface_diagonals(eps, st, npol, substrate, slabs, frequency)
+    if interfaces:
+        itf["dense"] = dict(interfaces)
     leig = [LayerEigen(ems[l], st.mu[l], st.weight[l], mm, npol, method, phase_normalization)
             for l in range(len(ems))]
     if details is not None:

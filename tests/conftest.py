@@ -161,6 +161,22 @@ ROUGH_SUBSTRATE_FIXTURES = ["rough_go_substrate_L2_n12_active", "rough_iem_subst
 ROUGH_SUBSTRATE_PASSIVE_FIXTURES = ["rough_iem_substrate_L3_n10_passive", "rough_gob_substrate_L2_n12_passive"]
 
 
+ROUGH_INTERFACE_FIXTURES = ["rough_iem_surface_L3_n10_passive", "rough_iem_inner_L3_n10_passive",
+                            "rough_go_surface_L3_n10_active", "rough_iem_inner_L3_n10_active"]
+
+
+def fixture_interfaces(d):
+    """{i: {"Rtop": [per mode], "Ttop": ..., "Rbot": ..., "Tbot": ..., + "_coh"}} of a rough-interface fixture: the dense
+    matrices of the interface on top of layer i as the reference combined them (inputs of the fixture)."""
+    out = {}
+    nm = (int(d["opt_m_max"]) + 1) if str(d["mode"]) == "A" else 1
+    for i in np.atleast_1d(d["rough_interface"]):
+        i = int(i)
+        out[i] = {kind + tag: [d["itf%d_%s%s_m%d" % (i, kind, tag, m)] for m in range(nm)]
+                  for kind in ("Rtop", "Ttop", "Rbot", "Tbot") for tag in ("", "_coh")}
+    return out
+
+
 def model_snowpack_from_fixture(d):
     """smrt_amd's own Snowpack object for a (uniform-microstructure) fixture, with the layer attributes the
     prescribed_kskaeps emmodel reads when the fixture holds them."""

@@ -597,6 +597,99 @@ def main():
         SKIP_OLD[0] = bool(ONLY)
         save(name, out)
 
+    # (iv-g) ROUGH INTERFACES at the surface / between layers (rtsolver_utils.py:473-642, interface/iem_fung92.py,
+    # interface/geometrical_optics.py): like the rough substrates, the interface physics stays with the caller -- the
+    # fixtures hold, per rough interface i (on top of layer i, 0 = the surface) and azimuth mode, the four dense matrices
+    # the reference combines (Rtop / Ttop of layer i looking up, Rbot / Tbot of the medium above looking down; and their
+    # specular-only versions of the coherent pass) as INPUTS, plus what the interface object itself returned on the stream
+    # grids (the protocol a host-side interface speaks).  Passive: iem_fung92 (geometrical_optics does not conserve energy
+    # in passive mode -- the reference itself warns); active: both.
+    from smrt import make_interface
+    from smrt.interface.flat import Flat as RefFlat
+    for name, iname, ikw, where, mode_, n_str in (
+        ("rough_iem_surface_L3_n10_passive", "iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 0, "P", 10),
+        ("rough_iem_inner_L3_n10_passive", "iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 2, "P", 10),
+        ("rough_go_surface_L3_n10_active", "geometrical_optics", dict(mean_square_slope=0.03), 0, "A", 10),
+        ("rough_iem_inner_L3_n10_active", "iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 2, "A", 10),
+    ):
+        if not wanted(name):
+            continue
+        rough = make_interface(iname, **ikw)
+        ilist = [RefFlat, RefFlat, RefFlat]
+        ilist[where] = rough
+        spq = make_snowpack([0.3, 0.25, 100.0], "exponential", density=[250.0, 300.0, 350.0], temperature=[258.0, 261.0, 264.0],
+                            corr_length=[1e-4, 1.5e-4, 2e-4], interface=ilist)
+        act = mode_ == "A"
+        sens = sensor_list.active(13.4e9, [30.0, 40.0]) if act else sensor_list.passive(18.7e9, [40.0, 55.0])
+        opts = dict(n_max_stream=n_str, m_max=2) if act else dict(n_max_stream=n_str)
+        SKIP_OLD[0] = False
+        mq = make_model("iba", "dort", rtsolver_options=opts)
+        sims, _ = mq.prepare_simulations(sens, spq, None, "snowpack")
+        sef, spk = list(sims)[0]
+        res = mq.run_single_simulation((sef, spk), None, None)
+        ems = mq.prepare_emmodels(sef, spk)
+        solver = DORT(**opts)
+        solver.init_solve(spk, ems, sef, None)
+        solver.prepare_streams()
+        m_max, npol = (2, 3) if act else (0, 2)
+        itf = compute_interface_properties(sef.frequency, spk.interfaces, spk.substrate, solver.effective_permittivity,
+                                           solver.streams, m_max, npol)
+        st = solver.streams
+        n_low = int(st.n[where])
+        n_up = int(st.n[where - 1]) if where > 0 else int(len(st.outmu))
+        out = dict(snowpack_arrays(spk))
+        out.update(emmodel="iba", mode=mode_, frequency=np.array([float(sef.frequency)]), result=np.asarray(res.data.values)[None],
+                   theta_deg=np.asarray(sens.theta_deg, float), opt_n_max_stream=n_str, streams_n=np.asarray(st.n, int),
+                   rough_interface=np.array([where]))
+        if act:
+            out.update(theta_inc_deg=np.asarray(sens.theta_inc_deg, float), opt_m_max=2)
+
+        def densify(x, rows, cols):
+            if type(x).__name__ == "smrt_diag":
+                x = np.asarray(x.diagonal(), float)
+            x = np.asarray(getattr(x, "values", x), float)
+            if x.ndim == 0:
+                return np.zeros((rows, cols))
+            return np.diag(x) if x.ndim == 1 else x
+        up_idx = where - 1 if where > 0 else -1
+        for m in range(m_max + 1):
+            P = 2 if m == 0 else 3
+            for coh in (False, True):
+                tag = "_coh" if coh else ""
+                out["itf%d_Rtop%s_m%d" % (where, tag, m)] = densify(itf.reflection_top(where, m, coh), n_low * P, n_low * P)
+                out["itf%d_Ttop%s_m%d" % (where, tag, m)] = densify(itf.transmission_top(where, m, coh), n_low * P, n_low * P)
+                out["itf%d_Rbot%s_m%d" % (where, tag, m)] = densify(itf.reflection_bottom(up_idx, m, coh), n_up * P, n_up * P)
+                out["itf%d_Tbot%s_m%d" % (where, tag, m)] = densify(itf.transmission_bottom(up_idx, m, coh), n_up * P, n_up * P)
+        # the protocol outputs of the interface object on the grids compute_interface_properties uses (rtsolver_utils.py:
+        # 476-642; NB its mu_t of the upward diffuse transmission is streams.mu[layer - 1] only for layer > 1)
+        eps = solver.effective_permittivity
+        e_l, e_u = eps[where], (eps[where - 1] if where > 0 else 1)
+        mu_l = np.asarray(st.mu[where], float)
+        mu_u = np.asarray(st.mu[where - 1], float) if where > 0 else np.asarray(st.outmu, float)
+        mu_t_up = np.asarray(st.mu[where - 1], float) if where > 1 else np.asarray(st.outmu, float)
+        w_l = np.asarray(st.weight[where], float)
+        w_u = np.asarray(st.weight[where - 1], float) if where > 0 else np.asarray(st.outweight, float)
+        out.update(itf_mu_low=mu_l, itf_mu_up=mu_u, itf_mu_t_up=mu_t_up, itf_w_low=w_l, itf_w_up=w_u,
+                   itf_eps_low=np.array([complex(e_l)]), itf_eps_up=np.array([complex(e_u)]))
+        raw = dict(
+            spec_up=rough.specular_reflection_matrix(sef.frequency, e_l, e_u, mu_l, npol),
+            spec_dn=rough.specular_reflection_matrix(sef.frequency, e_u, e_l, mu_u, npol),
+            ctr_up=rough.coherent_transmission_matrix(sef.frequency, e_l, e_u, mu_l, npol),
+            ctr_dn=rough.coherent_transmission_matrix(sef.frequency, e_u, e_l, mu_u, npol))
+        if hasattr(rough, "ft_even_diffuse_reflection_matrix"):
+            raw.update(drf_up=rough.ft_even_diffuse_reflection_matrix(sef.frequency, e_l, e_u, mu_l, mu_l, m_max, npol),
+                       drf_dn=rough.ft_even_diffuse_reflection_matrix(sef.frequency, e_u, e_l, mu_u, mu_u, m_max, npol))
+        if hasattr(rough, "ft_even_diffuse_transmission_matrix"):   # (iem_fung92 has no diffuse transmission)
+            raw.update(dtr_up=rough.ft_even_diffuse_transmission_matrix(sef.frequency, e_l, e_u, mu_t_up, mu_l, m_max, npol),
+                       dtr_dn=rough.ft_even_diffuse_transmission_matrix(sef.frequency, e_u, e_l, mu_l, mu_u, m_max, npol))
+        for k, v in raw.items():
+            out["itf_raw_" + k + "_mtype"] = str(getattr(v, "mtype", "none"))
+            out["itf_raw_" + k] = np.asarray(getattr(v, "values", v), float)
+        for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+            out["f0_" + k] = np.asarray(res.other_data[k].values)
+        SKIP_OLD[0] = bool(ONLY)
+        save(name, out)
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

@@ -257,3 +257,27 @@ def test_rough_substrate_passive(name):
     d = load_golden(name)
     tb = O.solve(snowpack_dict(d), float(d["frequency"][0]), d["theta_deg"], substrate=fixture_substrate(d, 0), **fixture_options(d))
     assert np.abs(tb - d["result"][0]).max() < TB_TOL
+
+
+@pytest.mark.parametrize("name", __import__("conftest").ROUGH_INTERFACE_FIXTURES)
+def test_rough_interfaces_against_the_reference(name):
+    """Rough interfaces at the surface and between layers (smrt/rtsolver/rtsolver_utils.py:473-642, dort.py:356-441): the
+    dense reflection / transmission matrices of the interface -- inputs of the fixture, as the reference combined them
+    from its iem_fung92 / geometrical_optics interface objects -- enter the boundary system like in the reference (row
+    sums on the thermal terms, truncation to the common streams)."""
+    from conftest import fixture_interfaces
+
+    d = load_golden(name)
+    sp, o = snowpack_dict(d), fixture_options(d)
+    itf = fixture_interfaces(d)
+    f = float(d["frequency"][0])
+    if str(d["mode"]) == "A":
+        r = O.solve(sp, f, d["theta_deg"], mode="A", theta_inc_deg=d["theta_inc_deg"], interfaces=itf,
+                    method="schur_forcedtriu", **o)
+        assert_backscatter_close(r, d["result"][0])
+        flat = O.solve(sp, f, d["theta_deg"], mode="A", theta_inc_deg=d["theta_inc_deg"], method="schur_forcedtriu", **o)
+        assert (np.abs(flat - d["result"][0])[:2, :2] / np.abs(d["result"][0][:2, :2])).max() > 1e-3   # it matters
+    else:
+        r = O.solve(sp, f, d["theta_deg"], interfaces=itf, **o)
+        assert np.abs(r - d["result"][0]).max() < TB_TOL
+        assert np.abs(O.solve(sp, f, d["theta_deg"], **o) - d["result"][0]).max() > 1e-2
