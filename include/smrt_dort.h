@@ -151,6 +151,31 @@ typedef struct smrt_batch {
      * process_coherent_layers. */
     const double* host_substrate;
     const double* host_substrate_coh;
+    /* SMRT_INTERFACE_HOST: rough interfaces at the surface or between layers (smrt/interface/iem_fung92.py,
+     * geometrical_optics.py, ...; smrt/rtsolver/rtsolver_utils.py:473-642).  Their reflection / transmission matrices are
+     * dense in the streams; the caller evaluates them with the reference's own interface classes exactly as
+     * compute_interface_properties combines them (specular / coherent part on the diagonal + 2 pi (mode 0) | pi (mode >= 1)
+     * x the diffuse mode normalised by mu and the stream weights) and the device composes each of them with the
+     * reflection matrix of everything below (one N x N solve and two products per rough interface and mode).
+     *   host_interface_slot [F * S][n_layers_max] int32: -1 = the interface ON TOP of this layer is Flat (Fresnel on the
+     *                       device); k >= 0 = it is rough and slot k of host_interface holds it (layer 0: the surface);
+     *   host_interface      [F * S][host_interface_slots][modes][4][NE * NE], modes = m_max + 1 in active mode, 1 in passive
+     *                       mode, NE = 3 * n_max_stream, row-major with leading dimension NE, compressed order (stream * P +
+     *                       polarisation; P = 2 for mode 0, 3 above), zero outside the streams that exist:
+     *                         [0] Rtop  reflection_top(layer):       rows and columns = streams of the layer
+     *                         [1] Ttop  transmission_top(layer):     rows = streams of the medium above, columns = of the layer
+     *                         [2] Rbot  reflection_bottom(above):    rows and columns = streams of the medium above
+     *                         [3] Tbot  transmission_bottom(above):  rows = streams of the layer, columns = of the medium above
+     *                       (a purely specular transmission is diagonal and is cut to the common streams, like the
+     *                       reference does, dort.py:372-376,409-414);
+     *   host_interface_coh  [F * S][host_interface_slots][4][NE]: the diagonals of the specular-only versions of the same
+     *                       four for mode 0 (index 2 * stream + polarisation): the coherent pass of active mode.
+     * NULL host_interface_slot: every interface is Flat.  Not combined with process_coherent_layers; the interface under
+     * the last layer kept by prune_deep_snowpack is taken as Flat. */
+    const int32_t* host_interface_slot;
+    const double* host_interface;
+    const double* host_interface_coh;
+    int32_t host_interface_slots;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

@@ -73,6 +73,10 @@ class SmrtBatch(C.Structure):
         ("process_coherent_layers", C.c_int32),
         ("host_substrate", C.POINTER(C.c_double)),
         ("host_substrate_coh", C.POINTER(C.c_double)),
+        ("host_interface_slot", C.POINTER(C.c_int32)),
+        ("host_interface", C.POINTER(C.c_double)),
+        ("host_interface_coh", C.POINTER(C.c_double)),
+        ("host_interface_slots", C.c_int32),
     ]
 
 
@@ -87,13 +91,16 @@ class PackedBatch:
     def __init__(self, n_layers, thickness, frac_volume, temperature, micro_p1, micro_p2, frequency, theta,
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
-                 prune_deep_snowpack=None, layer_kind=None, host_emmodel=None, process_coherent_layers=False):
+                 prune_deep_snowpack=None, layer_kind=None, host_emmodel=None, process_coherent_layers=False,
+                 host_interfaces=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
         prune_deep_snowpack: None / False, True (= 6, smrt/rtsolver/dort.py:176-177) or the optical depth itself.
         layer_kind: None, or [S][Lmax] integer codes EM_CODES[emmodel] + 16 * MS_CODES[microstructure] for snowpacks
         that mix emmodels / microstructure models (smrt/core/model.py:529-582).
+        host_interfaces: None, or (slot[F*S][Lmax] int (-1: Flat), matrices[F*S][slots][modes][4][NE][NE],
+        coh[F*S][slots][4][NE]) for rough interfaces evaluated by the caller (include/smrt_dort.h: SMRT_INTERFACE_HOST).
         host_emmodel: None, or (host_layer[F*S][Lmax][4], host_streams[F*S][Lmax], host_phase[F*S][Lmax][modes][2][NE][NE])
         for the layers of kind "host" (emmodels evaluated by the caller, include/smrt_dort.h)."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
@@ -169,6 +176,16 @@ class PackedBatch:
             s.host_layer, s.host_phase = _dptr(self.host_layer), _dptr(self.host_phase)
             s.host_streams = self.host_streams.ctypes.data_as(C.POINTER(C.c_int32))
         s.process_coherent_layers = 1 if process_coherent_layers else 0
+        if host_interfaces is not None:
+            FS, nm, ne = S * len(self.frequency), (int(m_max) + 1 if mode == "A" else 1), 3 * int(n_max_stream)
+            slot = np.asarray(host_interfaces[0], dtype=np.int32).reshape(FS, Lmax)
+            nslots = int(np.asarray(host_interfaces[1]).size // (FS * nm * 4 * ne * ne))
+            self.host_interface_slot = np.ascontiguousarray(slot)
+            self.host_interface = np.ascontiguousarray(np.asarray(host_interfaces[1], np.float64).reshape(FS, nslots, nm, 4, ne, ne))
+            self.host_interface_coh = np.ascontiguousarray(np.asarray(host_interfaces[2], np.float64).reshape(FS, nslots, 4, ne))
+            s.host_interface_slot = self.host_interface_slot.ctypes.data_as(C.POINTER(C.c_int32))
+            s.host_interface, s.host_interface_coh = _dptr(self.host_interface), _dptr(self.host_interface_coh)
+            s.host_interface_slots = nslots
         self.struct = s
 
     @property

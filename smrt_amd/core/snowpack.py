@@ -58,8 +58,16 @@ class Snowpack:
 
     @staticmethod
     def _check_interface(interface):
-        if interface is not None and not isinstance(interface, Flat):
-            raise SMRTError("only Flat interfaces are in the scope of smrt_amd")
+        """Flat (Fresnel on the device), or any object that speaks the reference's interface protocol
+        (smrt/core/interface.py; specular_reflection_matrix + coherent_transmission_matrix, and the ft_even_diffuse_*
+        matrices if it is rough): it is evaluated in Python and handed to the device as dense matrices."""
+        if interface is None or isinstance(interface, Flat):
+            return
+        if not (callable(getattr(interface, "specular_reflection_matrix", None)) and
+                callable(getattr(interface, "coherent_transmission_matrix", None))):
+            raise SMRTError("an interface must be Flat or speak the reference's interface protocol (specular_reflection_matrix, "
+                            "coherent_transmission_matrix, and ft_even_diffuse_reflection_matrix / "
+                            "ft_even_diffuse_transmission_matrix if it is rough): it is then evaluated on the host")
 
     def append(self, layer, interface=None):
         self._check_interface(interface)

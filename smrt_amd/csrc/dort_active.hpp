@@ -198,11 +198,15 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             const cplx eup = (l > 0) ? cmk(s.eps_re[l - 1], s.eps_im[l - 1]) : cmk(1.0, 0.0);
             K = 0.0;
             double Tt = 0.0;
+            // a rough interface on top of this layer: its specular parts come from the caller (smrt_dort.h)
+            const int hsc = host_interface_slot(b, gp, (int)s.lo[l]);
+            const double* hspec = (hsc >= 0) ? host_interface_specular(b, gp, hsc) : nullptr;
             if (j < n) {
                 const double rs = s.ri[l] * s.gsin[j];
                 const double mu = sqrt(1.0 - rs * rs);
                 double R3[3], T3[3];
                 fresnel_RT3(el, eup, mu, R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
+                if (hspec) { R3[pol] = hspec[2 * j + pol]; T3[pol] = hspec[3 * nmax + 2 * j + pol]; }
                 const double tt = exp(-(s.ks[l] + s.ka[l]) * s.thick[l] / mu);
                 const double y = tt * tt * Rt;
                 K = y / (1.0 - R3[pol] * y);
@@ -215,12 +219,20 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double muu = sqrt(1.0 - rs * rs);
                     double R3[3], T3[3];
                     fresnel_RT3(eup, el, muu, R3, T3, frequency, cmk(s.slab_re[l], s.slab_im[l]), s.slab_th[l]);
+                    if (hspec) { R3[pol] = hspec[2 * 3 * nmax + 2 * j + pol]; T3[pol] = hspec[3 * 3 * nmax + 2 * j + pol]; }
                     Rt = R3[pol] + Tt * K * T3[pol];
                 } else Rt = 0.0;
             } else Ttop0 = Tt;
         }
         double Ra[3], Ta[3];
         fresnel_RT3(cmk(1.0, 0.0), cmk(s.eps_re[0], s.eps_im[0]), s.outmu[j], Ra, Ta, frequency, cmk(s.slab_re[0], s.slab_im[0]), s.slab_th[0]);
+        {
+            const int hs0 = host_interface_slot(b, gp, (int)s.lo[0]);
+            if (hs0 >= 0) {
+                const double* hspec = host_interface_specular(b, gp, hs0);
+                Ra[pol] = hspec[2 * 3 * nmax + 2 * j + pol]; Ta[pol] = hspec[3 * 3 * nmax + 2 * j + pol];
+            }
+        }
         coh[pol * NI + jn] = Ra[pol] + Ttop0 * K * Ta[pol];
     }
     block_sync();
@@ -313,6 +325,13 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     for (int q = 0; q < P; ++q) { s.Rbu[P * j + q] = R3[q]; s.Tbu[P * j + q] = T3[q]; }
                 }
 
+            // a rough interface on top of this layer (evaluated by the caller): transparent top for the layer step, the
+            // interface is composed afterwards (dort_interface_dense.hpp)
+            const int hs = (MODE != 1) ? host_interface_slot(b, gp, (int)s.lo[l]) : -1;
+            if (hs >= 0) {
+                block_sync();
+                for (int r = t; r < N; r += NT) { s.Rtop[r] = 0.0; s.Ttop[r] = 1.0; s.Rbu[r] = 0.0; s.Tbu[r] = 1.0; }
+            }
             if (MODE < 2) {
             // -- phase matrix of mode m: S+ = P(mu,+mu') + P(mu,-mu') D -> M0, S- = P(+) - P(-) D -> M1, lower
             //    triangle (rows = scattered stream/polarisation, columns = incident); D = -1 on the U columns
@@ -535,15 +554,22 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             if (!gj_solve<NT, true, CH>(F, Wk, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }
-            if (l > 0) {
-                const int nc = (N < Nu) ? N : Nu;
-                for_2d<NT>(Nu, Nu, [&](int i, int j) {
+            if (l > 0 || hs >= 0) {
+                const int Nue = (hs >= 0) ? N : Nu;
+                const int nc = (N < Nue) ? N : Nue;
+                for_2d<NT>(Nue, Nue, [&](int i, int j) {
                     double v = (i == j) ? s.Rbu[i] : 0.0;
                     if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
                     s.M3[j * LD + i] = v;
                 });
                 block_sync();
-            } else {
+                if (hs >= 0) {   // composed with the caller's matrices of this azimuth mode: the reflection matrix the medium above sees
+                    const int Nabove = (l > 0) ? Nu : n_air * P;
+                    if (!interface_dense_step<NT>(host_interface_matrices(b, gp, hs, m, m_max + 1), 3 * nmax, K, s.M3, nullptr, nullptr,
+                                                  s.gj, N, Nabove, LD, false)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+                }
+            }
+            if (l == 0) {
                 // -- read the backscatter of this mode off the reflection matrix of the whole snowpack
                 //    (dort.py:228-259): I0up = [Rbot_air + Ttop_0 K_0 Tbot_air] intensity_0 at the incident streams
                 const double cm = cos((double)m * b.phi), sm = sin((double)m * b.phi);
@@ -560,6 +586,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     const double power = ((m == 0) ? 1.0 : 2.0) / (2.0 * kPi * w);
                     const int r = P * j + po, c = P * j + pi;
                     double v = ((po == pi) ? Ra[po] : 0.0) + s.Ttop[r] * K[c * LD + r] * Ta[pi];
+                    if (hs >= 0) v = s.M3[c * LD + r];   // rough surface: R_air + T_top X T_air, composed above
                     v *= power;
                     if (po < 2 && pi < 2 && po == pi) v -= coh[po * NI + jn] * ((m == 0) ? 1.0 : 2.0) / (2.0 * kPi * w);
                     if (m > 0) v *= (po < 2) ? cm : sm;

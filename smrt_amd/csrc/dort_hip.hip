@@ -142,7 +142,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
-                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws,
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws, &ctx->d_itfslot, &ctx->d_itf, &ctx->d_itfcoh,
                       &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
@@ -287,7 +287,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     // interfaces with T = 1 - R (no coherent slabs), no host-evaluated dense substrate
     {
         const bool supported = !ctx->gmem_path && ctx->split && ctx->finish2 && !ctx->active && ctx->chunk_pairs > 0 &&
-                               !b->process_coherent_layers && b->substrate_kind != SUB_HOST;
+                               !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
         int want = ctx->finish_mode;
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
         ctx->finish_reg = supported && (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
@@ -327,6 +327,12 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         if (upload_array(ctx, ctx->d_hostphase, b->host_phase, sizeof(double) * PL * host_modes * 2 * host_ne * host_ne)) return -1;
     }
     const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
+    if (b->host_interface_slot) {   // rough interfaces evaluated by the caller
+        const size_t ne = 3 * (size_t)b->n_max_stream, nm = ctx->active ? (size_t)b->m_max + 1 : 1, ns = (size_t)b->host_interface_slots;
+        if (upload_array(ctx, ctx->d_itfslot, b->host_interface_slot, sizeof(int32_t) * FS * b->n_layers_max)) return -1;
+        if (upload_array(ctx, ctx->d_itf, b->host_interface, sizeof(double) * FS * ns * nm * 4 * ne * ne)) return -1;
+        if (upload_array(ctx, ctx->d_itfcoh, b->host_interface_coh, sizeof(double) * FS * ns * 4 * ne)) return -1;
+    }
     if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {   // dense reflection matrices of a rough substrate, evaluated by the caller
         const size_t ne = 3 * (size_t)b->n_max_stream, nm = ctx->active ? (size_t)b->m_max + 1 : 1;
         if (upload_array(ctx, ctx->d_sub1, b->host_substrate, sizeof(double) * FS * nm * ne * ne)) return -1;
@@ -378,6 +384,10 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.coherent = b->process_coherent_layers ? 1 : 0;
     d.sub_kind = b->substrate_kind;
     d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
+    d.host_itf_slot = b->host_interface_slot ? (const int*)ctx->d_itfslot.p : nullptr;
+    d.host_itf = b->host_interface_slot ? (const double*)ctx->d_itf.p : nullptr;
+    d.host_itf_coh = b->host_interface_slot ? (const double*)ctx->d_itfcoh.p : nullptr;
+    d.host_itf_slots = b->host_interface_slot ? b->host_interface_slots : 0;
     d.host_substrate = (const double*)ctx->d_sub1.p; d.host_substrate_coh = (const double*)ctx->d_sub2.p;   // (SUB_HOST: the same buffers)
     const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? (const double*)ctx->d_atm.p : nullptr;
@@ -444,7 +454,8 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
         SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
         SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers),
-        SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh)};
+        SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh), SMRT_OFF(host_interface_slot), SMRT_OFF(host_interface),
+        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

@@ -130,6 +130,14 @@ inline const char* validate(const smrt_batch* b) {
         return "substrate arrays missing";
     if (b->substrate_kind == SMRT_SUBSTRATE_REFLECTOR && b->mode == SMRT_MODE_ACTIVE)
         return "the reflector substrate has no third Stokes component: passive mode only (smrt/substrate/reflector.py)";
+    if (b->host_interface_slot) {
+        if (!b->host_interface || !b->host_interface_coh || b->host_interface_slots < 1)
+            return "host_interface_slot needs host_interface, host_interface_coh and host_interface_slots >= 1";
+        if (b->process_coherent_layers) return "process_coherent_layers cannot be combined with interfaces evaluated by the caller";
+        const long long n = (long long)b->n_frequencies * b->n_snowpacks * b->n_layers_max;
+        for (long long i = 0; i < n; ++i)
+            if (b->host_interface_slot[i] < -1 || b->host_interface_slot[i] >= b->host_interface_slots) return "host_interface_slot entry out of range";
+    }
     if ((b->atm_tb_down != nullptr) != (b->atm_tb_up != nullptr) || (b->atm_tb_down != nullptr) != (b->atm_transmittance != nullptr))
         return "atmosphere arrays must be given together";
     return nullptr;

@@ -35,6 +35,11 @@ struct DevBatch {
     int coherent;  // DORT option process_coherent_layers
     const double* host_substrate;      // SUB_HOST: [F * S][m_max + 1][NE * NE] dense bottom reflection, NE = 3 n_max_stream
     const double* host_substrate_coh;  //           [F * S][m_max + 1][NE] its specular diagonal
+    // rough interfaces evaluated by the caller (smrt_dort.h: SMRT_INTERFACE_HOST), indexed by the global pair
+    const int* host_itf_slot;          // [F * S][Lmax], -1: Flat; or null
+    const double* host_itf;            // [F * S][slots][modes][4][NE * NE]
+    const double* host_itf_coh;        // [F * S][slots][4][NE]
+    int host_itf_slots;
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <string.h>
 #include "dort_gauss_jordan.hpp"
+#include "dort_interface_dense.hpp"
 
 namespace smrt {
 
@@ -328,6 +329,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (t == 0) { stg->n[p * (long long)b.Lmax + l] = -code; s.ints[0] = ST_OK; }
         block_sync();
     };
+    bool rough_surface = false;   // the surface is a rough interface: R~ (air side) and s are in M3 / svec after the loop
     // ---- bottom-up over the layers -------------------------------------------------------------------------
     if (MODE == 1 && b.pair_done && b.pair_done[p]) return;   // the cut of this pair lies above this round's layers (uniform)
     for (int l = Lk - 1; l >= 0; --l) {
@@ -418,6 +420,13 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 s.Tbu[2 * j] = Tv; s.Tbu[2 * j + 1] = Th;
             }
 
+        // a rough interface on top of this layer (evaluated by the caller): the layer step runs with a transparent top and
+        // the interface is composed afterwards (dort_interface_dense.hpp)
+        const int hs = (MODE != 1) ? host_interface_slot(b, gp, (int)s.lo[l]) : -1;
+        if (hs >= 0) {
+            block_sync();
+            for (int r = t; r < N; r += NT) { s.Rtop[r] = 0.0; s.Ttop[r] = 1.0; s.Rbu[r] = 0.0; s.Tbu[r] = 1.0; }
+        }
         SMRT_STAGE(SG_ASSEMBLE);
         if (MODE < 2) {
         // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
@@ -659,17 +668,25 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             s.up[i] = acc;
         }
         block_sync();
-        if (l > 0) {
-            // reflection matrix and source seen from the bottom of layer l-1 (streams paired by index)
-            const int nc = (N < Nu) ? N : Nu;
-            for_2d<NT>(Nu, Nu, [&](int i, int j) {
+        if (l > 0 || hs >= 0) {
+            // reflection matrix and source seen from the bottom of layer l-1 (streams paired by index); under a rough
+            // interface first as if the layer above had the same streams and no interface ...
+            const int Nue = (hs >= 0) ? N : Nu;
+            const int nc = (N < Nue) ? N : Nue;
+            for_2d<NT>(Nue, Nue, [&](int i, int j) {
                 double v = (i == j) ? s.Rbu[i] : 0.0;
                 if (i < nc && j < nc) v += s.Ttop[i] * K[j * LD + i] * s.Tbu[j];
                 s.M3[j * LD + i] = v;
             });
-            for (int i = t; i < Nu; i += NT) s.svec[i] = (i < nc) ? s.Ttop[i] * s.up[i] : 0.0;
+            for (int i = t; i < Nue; i += NT) s.svec[i] = (i < nc) ? s.Ttop[i] * s.up[i] : 0.0;
             block_sync();
+            if (hs >= 0) {   // ... then composed with the caller's matrices: R~ and s as the medium above (layer l - 1 or the air) sees them
+                const int Nabove = (l > 0) ? Nu : n_air * P;
+                if (!interface_dense_step<NT>(host_interface_matrices(b, gp, hs, 0, 1), 3 * nmax, K, s.M3, s.up, s.svec, s.gj,
+                                              N, Nabove, LD, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
+            }
         }
+        rough_surface = (l == 0 && hs >= 0);
     }
 
     if (MODE == 1) {
@@ -694,6 +711,11 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         const cplx e0 = cmk(s.eps_re[0], s.eps_im[0]);
         for (int i = t; i < n_air * P; i += NT) {
             double I0 = s.Ttop[i] * s.up[i];  // dort.py:484
+            if (rough_surface) {   // I0 = R~_air I_sky + s with the composed matrices (dense R_air, T_top, T_air inside)
+                double acc = 0.0;
+                for (int j = 0; j < n_air * P; ++j) acc += s.M3[j * LD + i];
+                I0 = acc * Idn + s.svec[i];
+            } else
             if (atm && Idn != 0.0) {
                 double acc = 0.0;
                 const cplx slab0 = cmk(s.slab_re[0], s.slab_im[0]);

@@ -37,16 +37,26 @@ def make_snowpack(thickness, microstructure_model, density, interface=None, surf
     _check_size(density, n, "density")
     for k, v in kwargs.items():
         _check_size(v, n, k)
-    for itf in (interface, surface):
-        if itf is not None and not (isinstance(itf, Flat) or itf in ("flat", Flat)):
-            raise SMRTError("only Flat interfaces are in the scope of smrt_amd")
+    def as_interface(itf):   # None / "flat" / the Flat class or an instance / an object with the reference's interface protocol
+        if itf is None or itf == "flat" or itf is Flat:
+            return Flat()
+        if isinstance(itf, str):
+            raise SMRTError(f"interface '{itf}' has no implementation in smrt_amd: pass Flat or an interface OBJECT with the "
+                            "reference's protocol (e.g. smrt's iem_fung92 / geometrical_optics instance); it is evaluated on "
+                            "the host")
+        return itf() if isinstance(itf, type) else itf
+
+    if isinstance(interface, (list, tuple)):
+        _check_size(interface, n, "interface")
     sp = Snowpack(substrate=substrate, atmosphere=atmosphere)
     for i, dz in enumerate(thickness):
         if dz <= 0:
             continue
         layer = make_snow_layer(dz, _get(microstructure_model, i), density=_get(density, i),
                                 **{k: _get(v, i) for k, v in kwargs.items()})
-        sp.append(layer, interface=Flat())
+        # (one interface per layer, on top of it; `surface` replaces the first one, smrt/inputs/make_medium.py:127-133)
+        itf = surface if (surface is not None and sp.nlayer == 0) else (_get(interface, i) if isinstance(interface, (list, tuple)) else interface)
+        sp.append(layer, interface=as_interface(itf))
     if sp.nlayer == 0:
         raise SMRTError("a snowpack needs at least one layer with a positive thickness")
     return sp

@@ -19,6 +19,7 @@ from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, de
 from ..core.error import SMRTError, smrt_warn
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack, substrate_kind
+from ..interface.flat import Flat
 
 _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
 
@@ -258,6 +259,9 @@ class DORT(object):
             q = np.array([[sp.substrate.device_params(f) for sp in sps] for f in freqs])  # (F, S, 2)
             ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
             substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
+        host_interfaces = None
+        if any(not isinstance(itf, Flat) for sp in sps for itf in sp.interfaces):
+            host_interfaces = self._interfaces_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
         atm0 = sps[0].atmosphere
         if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)
             a = np.array([atm0.device_params(f) for f in freqs])  # (F, 3)
@@ -271,7 +275,153 @@ class DORT(object):
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
                            layer_kind=layer_kind, host_emmodel=host,
-                           process_coherent_layers=self.process_coherent_layers)
+                           process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces)
+
+    def _layer_permittivities(self, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """Effective permittivity of every layer, (F, S, Lmax): from the host-evaluated emmodels if the group has them,
+        otherwise from a cheap pre-pass of the device emmodels (four streams, layer diagnostics only) -- what the streams
+        of matrices evaluated on the host (rough substrates / interfaces) are placed with."""
+        from .._native import PackedBatch
+
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        if host is not None:
+            return host[0][..., 2] + 1j * host[0][..., 3]
+        name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
+        probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
+                            microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
+                            phase_normalization="forced", layer_kind=layer_kind)
+        # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
+        res = get_context((self.devices or [default_device()])[0]).run(probe)
+        bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless
+        if len(bad):
+            raise SMRTError("the layer electromagnetics of pair %d are not computable (status 5): cannot place the "
+                            "streams of the matrices evaluated on the host" % int(bad[0]))
+        lay = res.layers.reshape(F, S, Lmax, 5)
+        return lay[..., 0] + 1j * lay[..., 1]
+
+    # ---- rough interfaces evaluated on the host (include/smrt_dort.h: SMRT_INTERFACE_HOST) --------------------------
+    @staticmethod
+    def _streams_of(eps_layers, n_max_stream):
+        """mu and weights of every layer and of the air for one (snowpack, frequency): streams.py:136-223,300-330."""
+        from .._native import gauss_legendre_positive
+
+        gmu, _ = gauss_legendre_positive(n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+        e = np.asarray(eps_layers, complex)
+        star = max(range(len(e)), key=lambda l: (e[l].real, e[l].imag, -l))
+
+        def weights(mu, absolute):
+            w = np.empty_like(mu)
+            w[0], w[-1] = 1.0 - 0.5 * (mu[0] + mu[1]), 0.5 * (mu[-2] + mu[-1])
+            w[1:-1] = 0.5 * (mu[:-2] - mu[2:])
+            return np.abs(w) if absolute else w
+        mus, ws = [], []
+        for el in list(e) + [1.0 + 0j]:
+            rs = np.sqrt(e[star] / el).real * gsin
+            mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+            mus.append(mu)
+            ws.append(weights(mu, absolute=len(mus) <= len(e)))
+        return mus[:-1], ws[:-1], mus[-1], ws[-1]
+
+    @staticmethod
+    def interface_matrices(interface, frequency, eps_low, eps_up, mu_low, mu_up, mu_t_up, w_low, w_up, m_max, npol):
+        """The four matrices of a rough interface between a layer (eps_low, streams mu_low / weights w_low) and the medium
+        above it (eps_up, mu_up / w_up) as compute_interface_properties combines them (smrt/rtsolver/rtsolver_utils.py:
+        473-642,690-707,728-740): per azimuth mode m, in the compressed order (stream * P + polarisation, P = 2 for mode 0,
+        3 above),  specular / coherent part on the diagonal + (2 pi | pi) x the diffuse mode with the column scaled by
+        mu_i w_i and the row by 1 / mu_s (a diffuse part given as [P, m, n] is diagonal in the streams).  The diffuse
+        transmissions carry the ratio of the real permittivities (incident / transmitted side).  mu_t_up: the cosines the
+        reference evaluates the upward diffuse transmission on (streams.mu[layer - 1] for layer > 1, the air streams
+        otherwise, rtsolver_utils.py:510).  Returns (list over modes of {"Rtop", "Ttop", "Rbot", "Tbot"},
+        {"Rtop", ...: specular diagonal of mode 0})."""
+        def raw(method, *args):
+            f = getattr(interface, method, None)
+            if not callable(f):
+                return None
+            v = f(frequency, *args)
+            v = np.asarray(getattr(v, "values", v), float)
+            return None if v.ndim == 0 else v
+
+        def diag_of(spec, n, P):
+            return np.zeros(n * P) if spec is None else spec.reshape(npol, n)[:P].T.reshape(n * P)
+
+        def combined(spec, diff, m, mu_st, mu_i, w_i, scale, same):
+            P = 2 if m == 0 else 3
+            coef = 2 * np.pi if m == 0 else np.pi
+            M = np.diag(diag_of(spec, len(mu_i), P))
+            if diff is None:
+                return M
+            if diff.ndim == 5:      # [ps, pi, m, mu_st, mu_i]
+                D = diff[:P, :P, m] * scale * (mu_i * w_i)[None, None, None, :] / mu_st[None, None, :, None]
+                D = np.transpose(D, (2, 0, 3, 1)).reshape(len(mu_st) * P, len(mu_i) * P)
+                if M.shape != D.shape:   # rectangular transmission: the specular part sits on the common streams
+                    Mr = np.zeros_like(D)
+                    k = min(D.shape[0], M.shape[0])
+                    Mr[:k, :k] = M[:k, :k]
+                    M = Mr
+                return M + coef * D
+            if diff.ndim == 3:      # [p, m, mu]: diagonal in the streams and in the polarisation
+                fac = w_i if same else mu_i * w_i / mu_st
+                return M + coef * np.diag((diff[:P, m] * scale * fac[None, :]).T.reshape(len(mu_i) * P))
+            raise SMRTError("unsupported layout of a diffuse interface matrix (expected [p, p, m, mu_s, mu_i] or [p, m, mu])")
+
+        spec_up = raw("specular_reflection_matrix", eps_low, eps_up, mu_low, npol)
+        spec_dn = raw("specular_reflection_matrix", eps_up, eps_low, mu_up, npol)
+        ctr_up = raw("coherent_transmission_matrix", eps_low, eps_up, mu_low, npol)
+        ctr_dn = raw("coherent_transmission_matrix", eps_up, eps_low, mu_up, npol)
+        drf_up = raw("ft_even_diffuse_reflection_matrix", eps_low, eps_up, mu_low, mu_low, m_max, npol)
+        drf_dn = raw("ft_even_diffuse_reflection_matrix", eps_up, eps_low, mu_up, mu_up, m_max, npol)
+        dtr_up = raw("ft_even_diffuse_transmission_matrix", eps_low, eps_up, mu_t_up, mu_low, m_max, npol)
+        dtr_dn = raw("ft_even_diffuse_transmission_matrix", eps_up, eps_low, mu_low, mu_up, m_max, npol)
+        r_up, r_dn = complex(eps_low).real / complex(eps_up).real, complex(eps_up).real / complex(eps_low).real
+        modes = []
+        for m in range(m_max + 1):
+            modes.append(dict(Rtop=combined(spec_up, drf_up, m, mu_low, mu_low, w_low, 1.0, True),
+                              Ttop=combined(ctr_up, dtr_up, m, mu_t_up, mu_low, w_low, r_up, False),
+                              Rbot=combined(spec_dn, drf_dn, m, mu_up, mu_up, w_up, 1.0, True),
+                              Tbot=combined(ctr_dn, dtr_dn, m, mu_low, mu_up, w_up, r_dn, False)))
+        coh = dict(Rtop=diag_of(spec_up, len(mu_low), 2), Ttop=diag_of(ctr_up, len(mu_low), 2),
+                   Rbot=diag_of(spec_dn, len(mu_up), 2), Tbot=diag_of(ctr_dn, len(mu_up), 2))
+        return modes, coh
+
+    def _interfaces_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """(slot, matrices, specular diagonals) of PackedBatch(host_interfaces=...) for a group with rough interfaces: every
+        interface object that is not Flat is evaluated through the reference's interface protocol on the streams of the
+        two media it separates."""
+        if self.process_coherent_layers:
+            raise SMRTError("process_coherent_layers is not available with interfaces evaluated on the host")
+        act = sensor0.mode == "A"
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        nm, ne, npol = (self.m_max + 1 if act else 1), 3 * self.n_max_stream, (3 if act else 2)
+        rough = [[i for i, itf in enumerate(sp.interfaces) if not isinstance(itf, Flat)] for sp in sps]
+        nslots = max(1, max(len(r) for r in rough))
+        slot = -np.ones((F, S, Lmax), np.int32)
+        M = np.zeros((F, S, nslots, nm, 4, ne, ne))
+        C = np.zeros((F, S, nslots, 4, ne))
+        for fi, f in enumerate(freqs):
+            for s, sp in enumerate(sps):
+                if not rough[s]:
+                    continue
+                e = eps[fi, s, :nl[s]]
+                mus, ws, outmu, outw = self._streams_of(e, self.n_max_stream)
+                for k, i in enumerate(rough[s]):
+                    mu_up, w_up, e_up = (mus[i - 1], ws[i - 1], complex(e[i - 1])) if i > 0 else (outmu, outw, 1.0)
+                    mu_t = mus[i - 1] if i > 1 else outmu      # (the reference's choice, rtsolver_utils.py:510)
+                    modes, coh = self.interface_matrices(sp.interfaces[i], float(f), complex(e[i]), e_up, mus[i], mu_up, mu_t,
+                                                         ws[i], w_up, self.m_max if act else 0, npol)
+                    slot[fi, s, i] = k
+                    for m in range(nm):
+                        P = 2 if m == 0 else 3
+                        n_low, n_up = len(mus[i]) * P, len(mu_up) * P
+                        for q, (kind, rows) in enumerate((("Rtop", n_low), ("Ttop", n_up), ("Rbot", n_up), ("Tbot", n_low))):
+                            A = modes[m][kind]
+                            r = min(A.shape[0], rows)     # cut to the common streams like dort.py:372-376,409-414
+                            M[fi, s, k, m, q, :r, :A.shape[1]] = A[:r]
+                    for q, (kind, rows) in enumerate((("Rtop", None), ("Ttop", len(mu_up) * 2), ("Rbot", None), ("Tbot", len(mus[i]) * 2))):
+                        c = coh[kind] if rows is None else coh[kind][:rows]
+                        C[fi, s, k, q, :len(c)] = c
+        return slot, M, C
 
     # ---- substrates evaluated on the host (include/smrt_dort.h: SMRT_SUBSTRATE_HOST) -------------------------------
     @staticmethod
@@ -319,21 +469,7 @@ class DORT(object):
                             "sampled on the streams of the full snowpack, which may change when layers are removed)")
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
-        if host is not None:
-            eps = host[0][..., 2] + 1j * host[0][..., 3]                     # (F, S, Lmax)
-        else:
-            name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
-            probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
-                                microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
-                                phase_normalization="forced", layer_kind=layer_kind)
-            # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
-            res = get_context((self.devices or [default_device()])[0]).run(probe)
-            bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless
-            if len(bad):
-                raise SMRTError("the layer electromagnetics of pair %d are not computable (status 5): cannot place the "
-                                "streams of the substrate matrices" % int(bad[0]))
-            lay = res.layers.reshape(F, S, Lmax, 5)
-            eps = lay[..., 0] + 1j * lay[..., 1]
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
         nm, ne = (self.m_max + 1 if act else 1), 3 * self.n_max_stream
         R = np.zeros((F, S, nm, ne, ne))
         Rc = np.zeros((F, S, nm, ne))

@@ -120,7 +120,11 @@ def packed_batch_from_fixture(d, freqs=None):
                        emmodel=emmodel, microstructure=ms, mode="A" if active else "P",
                        n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
                        prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind,
-                       process_coherent_layers=fixture_coherent(d))
+                       process_coherent_layers=fixture_coherent(d),
+                       host_interfaces=(pack_host_interfaces([fixture_interfaces(d)] * len(np.atleast_1d(d["frequency"][sel])),
+                                                             len(sp["thickness"]), o["n_max_stream"],
+                                                             (o["m_max"] + 1) if active else 1)
+                                        if "rough_interface" in d else None))
 
 
 SUBSTRATE_FIXTURES = ["iba_L3_n16_flat_substrate", "iba_L3_n16_substrate_atmosphere", "dmrt_L4_n12_reflector",
@@ -175,6 +179,66 @@ def fixture_interfaces(d):
         out[i] = {kind + tag: [d["itf%d_%s%s_m%d" % (i, kind, tag, m)] for m in range(nm)]
                   for kind in ("Rtop", "Ttop", "Rbot", "Tbot") for tag in ("", "_coh")}
     return out
+
+
+class ReplayInterface:
+    """An interface object speaking the reference's protocol (smrt/core/interface.py) that replays what the reference's
+    own iem_fung92 / geometrical_optics object returned on the stream grids of a rough-interface fixture (itf_raw_*): lets
+    the host-side evaluation (DORT.interface_matrices, Model.run) be tested without restating the interface physics."""
+
+    def __init__(self, d):
+        self.d = d
+        self.eps_low = complex(d["itf_eps_low"][0])
+        if "itf_raw_drf_up" in d:
+            self.ft_even_diffuse_reflection_matrix = self._drf
+        if "itf_raw_dtr_up" in d:
+            self.ft_even_diffuse_transmission_matrix = self._dtr
+
+    def _side(self, eps_1):
+        return "up" if abs(complex(eps_1) - self.eps_low) < 1e-9 * abs(self.eps_low) else "dn"
+
+    def _get(self, key, n_last):
+        v = self.d["itf_raw_" + key]
+        assert v.ndim == 0 or v.shape[-1] == n_last, (key, v.shape, n_last)
+        return v
+
+    def specular_reflection_matrix(self, frequency, eps_1, eps_2, mu1, npol):
+        return self._get("spec_" + self._side(eps_1), len(mu1))
+
+    def coherent_transmission_matrix(self, frequency, eps_1, eps_2, mu1, npol):
+        return self._get("ctr_" + self._side(eps_1), len(mu1))
+
+    def _drf(self, frequency, eps_1, eps_2, mu_s, mu_i, m_max, npol):
+        return self._get("drf_" + self._side(eps_1), len(mu_i))
+
+    def _dtr(self, frequency, eps_1, eps_2, mu_s, mu_i, m_max, npol):
+        return self._get("dtr_" + self._side(eps_1), len(mu_i))
+
+
+def pack_host_interfaces(per_pair, n_layers_max, n_max_stream, n_modes):
+    """The (slot, matrices, coh) triple of PackedBatch(host_interfaces=...) from, per pair, a dict {i: dense dict} as
+    fixture_interfaces returns it: zero-padded NE x NE blocks, transmissions cut to the common streams when they come as
+    the square diagonal form (include/smrt_dort.h)."""
+    ne = 3 * n_max_stream
+    nslots = max(1, max(len(x) for x in per_pair))
+    slot = -np.ones((len(per_pair), n_layers_max), np.int32)
+    M = np.zeros((len(per_pair), nslots, n_modes, 4, ne, ne))
+    coh = np.zeros((len(per_pair), nslots, 4, ne))
+    for p, itfs in enumerate(per_pair):
+        for k, (i, e) in enumerate(sorted(itfs.items())):
+            slot[p, i] = k
+            for m in range(n_modes):
+                P = 2 if m == 0 else 3
+                n_low, n_up = e["Rtop"][m].shape[0], e["Rbot"][m].shape[0]
+                for q, (kind, rows) in enumerate((("Rtop", n_low), ("Ttop", n_up), ("Rbot", n_up), ("Tbot", n_low))):
+                    A = np.asarray(e[kind][m], float)
+                    r = min(A.shape[0], rows)
+                    M[p, k, m, q, :r, :A.shape[1]] = A[:r]
+                    if m == 0:
+                        c = np.diag(np.asarray(e[kind + "_coh"][0], float))
+                        nd = min(len(c), rows) if kind in ("Ttop", "Tbot") else len(c)
+                        coh[p, k, q, :nd] = c[:nd]
+    return slot, M, coh
 
 
 def model_snowpack_from_fixture(d):

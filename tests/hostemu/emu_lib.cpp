@@ -144,7 +144,7 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
         [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
         [&](long long p) { for (auto& x : lds) x = NAN;
-                           if (smrt_emu_pipeline == 3)   // the register-resident finish kernel: one wavefront per pair
+                           if (smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the register-resident finish kernel: one wavefront per pair (where the library uses it)
                                return emu::run_block(64, order, [&]() { dort_pair_passive_reg(d, p, lds.data(), sg.st); });
                            return smrt_emu_pipeline == 2 ? emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &sg.st); })
                                                          : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 3>(d, p, lds.data(), nullptr, &sg.st); }); });
@@ -186,6 +186,8 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.host_modes = active ? b->m_max + 1 : 1; d.host_ne = b->n_max_stream * (active ? 3 : 2);
     d.coherent = b->process_coherent_layers ? 1 : 0;
     d.host_substrate = b->host_substrate; d.host_substrate_coh = b->host_substrate_coh;
+    d.host_itf_slot = b->host_interface_slot; d.host_itf = b->host_interface; d.host_itf_coh = b->host_interface_coh;
+    d.host_itf_slots = b->host_interface_slot ? b->host_interface_slots : 0;
     d.sub_kind = b->substrate_kind; d.sub_p1 = b->substrate_p1; d.sub_p2 = b->substrate_p2; d.sub_T = b->substrate_temperature;
     const bool has_atm = b->atm_tb_down != nullptr && b->mode == SMRT_MODE_PASSIVE;
     d.atm_down = has_atm ? b->atm_tb_down : nullptr; d.atm_up = has_atm ? b->atm_tb_up : nullptr;

@@ -495,6 +495,38 @@ def test_rough_substrate_through_the_model():
         np.testing.assert_allclose(np.ravel(res.sigmaHH()), fac * d["result"][0, 1, 1], rtol=1e-8)
 
 
+def test_rough_interfaces_through_the_model():
+    """Interface objects without a device implementation -- here ones that answer with what the reference's iem_fung92 /
+    geometrical_optics interfaces answered (stored in the fixtures) -- at the surface or between two layers, through
+    make_snowpack(interface=[...]) and Model.run: the rtsolver places the streams (pre-pass of the device emmodels), asks the
+    object for its specular / coherent and diffuse matrices, combines them like compute_interface_properties and the
+    device composes the dense interface with the layers below.  Against the reference, passive and active."""
+    from conftest import ROUGH_INTERFACE_FIXTURES, ReplayInterface, snowpack_dict
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.interface.flat import Flat
+
+    for name in ROUGH_INTERFACE_FIXTURES:
+        d = load_golden(name)
+        sp = snowpack_dict(d)
+        i = int(d["rough_interface"][0])
+        itf = [Flat()] * len(sp["thickness"])
+        itf[i] = ReplayInterface(d)
+        pack = make_snowpack(sp["thickness"], "exponential", density=sp["density"], temperature=sp["temperature"],
+                             corr_length=sp["corr_length"], interface=itf)
+        f = float(d["frequency"][0])
+        if str(d["mode"]) == "A":
+            opts = dict(n_max_stream=int(d["opt_n_max_stream"]), m_max=int(d["opt_m_max"]))
+            res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.active(f, list(d["theta_inc_deg"])), pack)
+            fac = 4 * np.pi * np.cos(np.deg2rad(d["theta_inc_deg"]))
+            np.testing.assert_allclose(np.ravel(res.sigmaVV()), fac * d["result"][0, 0, 0], rtol=1e-8)
+            np.testing.assert_allclose(np.ravel(res.sigmaHH()), fac * d["result"][0, 1, 1], rtol=1e-8)
+        else:
+            opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+            res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.passive(f, list(d["theta_deg"])), pack)
+            np.testing.assert_allclose(np.ravel(res.TbV()), d["result"][0, 0], atol=1e-6)
+            np.testing.assert_allclose(np.ravel(res.TbH()), d["result"][0, 1], atol=1e-6)
+
+
 def test_rough_substrate_passive_through_the_model():
     """The same host-evaluated substrate route in passive mode (two polarisations, mode 0, emissivity_matrix for the
     emission of the substrate), on the rough substrates the reference runs there."""

@@ -703,6 +703,45 @@ def test_process_coherent_layers_refusals_and_batches(ctx):
     assert np.abs(pr.values[ok] - out.values[ok]).max() < 0.05   # 10 m of snow: the pruned solve is the same physics
 
 
+@pytest.mark.parametrize("name", __import__("conftest").ROUGH_INTERFACE_FIXTURES)
+@pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS + [(256, 2)])
+def test_rough_interfaces_golden(ctx, name, threads, pipeline):
+    """SMRT_INTERFACE_HOST: rough interfaces at the surface and between layers (smrt/rtsolver/rtsolver_utils.py:473-642;
+    iem_fung92 and geometrical_optics of the reference), their dense matrices per azimuth mode handed over by the caller
+    (here: inputs of the reference fixtures) and composed on the device with the reflection matrix of everything below
+    (dort_interface_dense.hpp) -- passive and active, on every kernel shape, against the reference."""
+    d = load_golden(name)
+    out = run_variant(ctx, batch_from_fixture(d), threads, pipeline)
+    assert (out.status == 0).all(), out.status
+    if str(d["mode"]) == "A":
+        assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
+    else:
+        assert np.abs(out.values - d["result"]).max() < TB_TOL
+
+
+def test_rough_interfaces_in_a_batch_with_flat_ones(ctx):
+    """A batch where only some pairs have a rough interface: those equal their one-pair runs, the others the plain Flat
+    run (the slot table is per pair and layer)."""
+    from conftest import fixture_interfaces, pack_host_interfaces
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden("rough_iem_inner_L3_n10_passive")
+    sp = snowpack_dict(d)
+    o = fixture_options(d)
+    S, L = 3, len(sp["thickness"])
+    rep = lambda a: np.tile(np.asarray(a, float), (S, 1))  # noqa: E731
+    itfs = [{}, fixture_interfaces(d), {}]
+    mk = lambda hi: PackedBatch([L] * S, rep(sp["thickness"]), rep(sp["frac_volume"]), rep(sp["temperature"]),  # noqa: E731
+                                rep(sp["corr_length"]), None, d["frequency"], np.deg2rad(d["theta_deg"]),
+                                n_max_stream=o["n_max_stream"], host_interfaces=hi)
+    mixed = ctx.run(mk(pack_host_interfaces(itfs, L, o["n_max_stream"], 1)))
+    flat = ctx.run(mk(None))
+    assert (mixed.status == 0).all()
+    assert np.abs(mixed.values[1] - d["result"][0]).max() < TB_TOL
+    assert np.abs(mixed.values[0] - flat.values[0]).max() < 1e-7 and np.abs(mixed.values[2] - flat.values[2]).max() < 1e-7
+    assert np.abs(mixed.values[1] - flat.values[1]).max() > 1e-2
+
+
 @pytest.mark.parametrize("name", ROUGH_SUBSTRATE_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_rough_substrate_golden(ctx, name, threads, pipeline):

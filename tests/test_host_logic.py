@@ -137,7 +137,7 @@ def test_emmodel_configuration_is_honoured_on_the_batch_path():
     mf = make_model(Foreign, "dort")
     assert DORT.emmodel_names(mf, mf.plan(sensor_list.amsre("37V"), [sp])) == [[(Foreign, {}), (Foreign, {})]]
     with pytest.raises(SMRTError):
-        Snowpack(layers=sp.layers, interfaces=["rough", "rough"])   # interfaces are validated by the constructor too
+        Snowpack(layers=sp.layers, interfaces=["rough", "rough"])   # interfaces are validated by the constructor too (protocol objects pass)
 
 
 def test_ctypes_struct_matches_the_library():
@@ -590,6 +590,40 @@ def test_emmodel_options_forms_and_diagonalization_warning():
         DORT(diagonalization_method="stamnes88")
         DORT()
     assert len(w) == 1 and issubclass(w[0].category, SMRTWarning) and "stamnes88" in str(w[0].message)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").ROUGH_INTERFACE_FIXTURES)
+def test_host_evaluated_interfaces_matrices(name):
+    """DORT.interface_matrices (no GPU needed): from what an interface object with the reference's protocol returns on the
+    stream grids -- here the replayed outputs of the reference's own iem_fung92 / geometrical_optics objects -- to the four
+    combined matrices per azimuth mode that compute_interface_properties builds (rtsolver_utils.py:473-642): equal to the
+    reference's matrices stored in the fixture; and the streams placed on the host equal the reference's."""
+    from conftest import ReplayInterface, fixture_interfaces, load_golden
+    from smrt_amd.rtsolver.dort import DORT
+
+    d = load_golden(name)
+    act = str(d["mode"]) == "A"
+    i = int(d["rough_interface"][0])
+    m_max, npol = (int(d["opt_m_max"]), 3) if act else (0, 2)
+    eps = d["f0_effective_permittivity"]
+    mus, ws, outmu, outw = DORT._streams_of(eps, int(d["opt_n_max_stream"]))
+    assert [len(m) for m in mus] == list(d["streams_n"])
+    np.testing.assert_allclose(mus[i], d["itf_mu_low"], rtol=1e-13)
+    np.testing.assert_allclose(ws[i], d["itf_w_low"], rtol=1e-12)
+    mu_up, w_up = (mus[i - 1], ws[i - 1]) if i > 0 else (outmu, outw)
+    np.testing.assert_allclose(mu_up, d["itf_mu_up"], rtol=1e-13)
+    np.testing.assert_allclose(w_up, d["itf_w_up"], rtol=1e-12)
+    modes, coh = DORT.interface_matrices(ReplayInterface(d), float(d["frequency"][0]), complex(d["itf_eps_low"][0]),
+                                         complex(d["itf_eps_up"][0]), d["itf_mu_low"], d["itf_mu_up"], d["itf_mu_t_up"],
+                                         d["itf_w_low"], d["itf_w_up"], m_max, npol)
+    want = fixture_interfaces(d)[i]
+    for m in range(m_max + 1):
+        for kind in ("Rtop", "Ttop", "Rbot", "Tbot"):
+            A, B = modes[m][kind], np.asarray(want[kind][m])
+            assert A.shape == B.shape, (kind, m, A.shape, B.shape)
+            np.testing.assert_allclose(A, B, rtol=1e-13, atol=1e-300)
+    for kind in ("Rtop", "Ttop", "Rbot", "Tbot"):
+        np.testing.assert_allclose(coh[kind], np.diag(np.asarray(want[kind + "_coh"][0])), rtol=1e-13, atol=1e-300)
 
 
 def test_snowpack_caches_follow_layer_changes():

@@ -110,6 +110,23 @@ def test_emulated_register_resident_finish_is_schedule_independent(emu):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("name,nt,pipeline,order", [("rough_iem_surface_L3_n10_passive", 256, 1, 0), ("rough_iem_inner_L3_n10_passive", 64, 0, 1),
+                                                    ("rough_go_surface_L3_n10_active", 256, 1, 2), ("rough_iem_inner_L3_n10_active", 64, 0, 0)])
+def test_emulated_kernel_rough_interfaces(emu, name, nt, pipeline, order):
+    """SMRT_INTERFACE_HOST on the device code: dense interface matrices (inputs of the reference fixtures) composed with the
+    layers below, passive and active, pipeline and fused kernels."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        out, st, ref = run_fixture(emu, name, nt=nt, order=order)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    if "active" in name:
+        assert_backscatter_close(out, ref)
+    else:
+        assert np.abs(out - ref).max() < 1e-6
+
+
 def test_emulated_kernel_is_schedule_independent(emu):
     base, _, _ = run_fixture(emu, "iba_L6_n8_angles", nt=128, order=0)
     for order in (1, 2):
