@@ -86,6 +86,12 @@ class IBA(_DeviceEMModel):
     device_name = "iba"
 
     def __init__(self, sensor, layer, dense_snow_correction=None):
-        if dense_snow_correction not in (None, False):
-            raise SMRTError("dense_snow_correction is outside the scope of smrt_amd's IBA")
+        # dense_snow_correction="auto" (smrt/emmodel/iba.py:85-105) inverts the medium -- air inclusions in ice -- for layers
+        # whose ice volume fraction exceeds 0.5 and leaves every other layer alone: accepted, a no-op below 0.5; the
+        # inverted medium itself has no device implementation
+        if dense_snow_correction not in (None, False, "auto"):
+            raise SMRTError(f"unknown dense_snow_correction '{dense_snow_correction}' (None or 'auto')")
+        if dense_snow_correction == "auto" and layer.frac_volume > 0.5:
+            raise SMRTError("dense_snow_correction='auto' on a layer with frac_volume > 0.5: the inverted medium (air "
+                            "inclusions in ice) has no device implementation in smrt_amd")
         super().__init__(sensor, layer)

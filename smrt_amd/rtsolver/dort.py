@@ -138,7 +138,8 @@ class DORT(object):
         simple_options = None
         for sp in plan.snowpacks:
             n = sp.nlayer
-            plain = simple and not sp.has_layer_emmodels() and not isinstance(model.emmodel_options, list)
+            plain = (simple and not sp.has_layer_emmodels() and not isinstance(model.emmodel_options, list)
+                     and model.emmodel_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
             if plain and simple_name is not None and simple_options is not None:
                 # the common case -- one device emmodel, no per-layer settings, options already validated: no per-layer work
                 distinct.add(simple_name)
@@ -153,7 +154,7 @@ class DORT(object):
                 todo = [(kind, layer, k) for k, (kind, layer) in enumerate(zip(kinds, sp.layers))]
             for kind, layer, k in todo:
                 options = model.emmodel_options_of_layer(layer, k, n)
-                key = (kind, tuple(sorted(options.items())))
+                key = (kind, tuple(sorted(options.items())), options.get("dense_snow_correction") == "auto" and layer.frac_volume > 0.5)
                 if key not in checked:
                     checked.add(key)
                     kind(plan.sensors[0], layer, **options)     # validates the options against the class
