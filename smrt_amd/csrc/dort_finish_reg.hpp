@@ -106,11 +106,46 @@ SMRT_DEV void inv16_step(double (&d)[4], const LaneId& L) {
         d[r] = old - m * rk;
     }
 }
+// Two columns per step (K even): the 2 x 2 pivot block P = D[K..K+1][K..K+1] is inverted in closed form and rows / columns
+// K, K + 1 are eliminated together -- the same in-place Gauss-Jordan with the unit-vector trick, with HALF the dependent
+// chains (row broadcast -> pivot -> reciprocal -> multipliers -> update).  Measured: no gain (see inv16), so not the default.  det P > 0 for the matrices of the recursion (positive definite symmetric
+// part), like the 1 x 1 pivots.
+template <int K>
+SMRT_DEV void inv16_step2(double (&d)[4], const LaneId& L) {
+    constexpr int r0 = K >> 2, g0 = K & 3;   // rows K, K + 1: register r0, lane rows g0 and g0 + 1
+    double rk0 = rows_bcast<g0>(d[r0]);      // D[K][c]
+    double rk1 = rows_bcast<g0 + 1>(d[r0]);  // D[K + 1][c]
+    const double pa = row_bcast16<K>(rk0), pb = row_bcast16<K + 1>(rk0);
+    const double pc = row_bcast16<K>(rk1), pd = row_bcast16<K + 1>(rk1);
+    const double idet = fast_rcp(pa * pd - pb * pc);
+    const double i00 = pd * idet, i01 = -pb * idet, i10 = -pc * idet, i11 = pa * idet;   // P^-1
+    const bool c0 = (L.c == K), c1 = (L.c == K + 1);
+    rk0 = c0 ? 1.0 : (c1 ? 0.0 : rk0);       // rows K, K + 1 with the columns K, K + 1 replaced by the identity
+    rk1 = c0 ? 0.0 : (c1 ? 1.0 : rk1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double f0 = row_bcast16<K>(d[r]), f1 = row_bcast16<K + 1>(d[r]);   // D[4 r + g][K], [K + 1]
+        double m0 = f0 * i00 + f1 * i10, m1 = f0 * i01 + f1 * i11;                 // [f0 f1] P^-1
+        double e = 0.0;                                                             // entry of the unit columns in this row
+        if (r == r0) {                                                              // rows K, K + 1: I - P^-1
+            if (L.g == g0) { m0 = 1.0 - i00; m1 = -i01; e = c0 ? 1.0 : 0.0; }
+            if (L.g == g0 + 1) { m0 = -i10; m1 = 1.0 - i11; e = c1 ? 1.0 : 0.0; }
+        }
+        const double old = (c0 || c1) ? e : d[r];
+        d[r] = old - m0 * rk0 - m1 * rk1;
+    }
+}
 SMRT_DEV void inv16(double (&d)[4], const LaneId& L) {
+#ifndef SMRT_INV16_TWO_COLUMNS   // (two columns per step: same instruction count, same time -- 42.5 vs 42.3 ms per step: the
+                                  // elimination is issue bound, not latency bound; kept as an opt-in build)
     inv16_step<0>(d, L); inv16_step<1>(d, L); inv16_step<2>(d, L); inv16_step<3>(d, L);
     inv16_step<4>(d, L); inv16_step<5>(d, L); inv16_step<6>(d, L); inv16_step<7>(d, L);
     inv16_step<8>(d, L); inv16_step<9>(d, L); inv16_step<10>(d, L); inv16_step<11>(d, L);
     inv16_step<12>(d, L); inv16_step<13>(d, L); inv16_step<14>(d, L); inv16_step<15>(d, L);
+#else
+    inv16_step2<0>(d, L); inv16_step2<2>(d, L); inv16_step2<4>(d, L); inv16_step2<6>(d, L);
+    inv16_step2<8>(d, L); inv16_step2<10>(d, L); inv16_step2<12>(d, L); inv16_step2<14>(d, L);
+#endif
 }
 
 // cyclic shift of the leading NTT x NTT tiles: new[i][j] = old[(i + 1) % NTT][(j + 1) % NTT]

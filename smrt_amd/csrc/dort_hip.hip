@@ -290,8 +290,10 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
                                !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
         int want = ctx->finish_mode;
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
-        ctx->finish_reg = supported && (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
         ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
+        // (its per-layer tables grow with n_layers_max: beyond the LDS of a workgroup the two-slot kernel takes over)
+        ctx->finish_reg = supported && ctx->finish_reg_lds_bytes <= (size_t)64 * 1024 &&
+                          (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
         ctx->stage.ws = nullptr;
         if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
             HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * rg::kSlotDoubles));
