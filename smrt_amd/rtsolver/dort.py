@@ -39,7 +39,11 @@ class DORT(object):
                  prune_deep_snowpack=None, diagonalization_method="schur_forcedtriu", diagonalization_cache=False,
                  rayleigh_jeans_approximation=False, devices=None, block_threads=0):
         if stream_mode != "most_refringent":
-            raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only")
+            # the reference's two other modes do not run in the reference either: "uniform_air" always fails the
+            # assertion at smrt/rtsolver/streams.py:288 (np.size of a scalar stream count is 1, never > 2), "air" is
+            # announced as untested there (streams.py:164-175)
+            raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only (the reference's "
+                            "'uniform_air' raises an AssertionError for every snowpack, its 'air' is untested code)")
         if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
             prune_deep_snowpack = 6
         if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
