@@ -35,6 +35,10 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_EM_DMRT_QCACP_SHORTRANGE 2
 #define SMRT_EM_NONSCATTERING 3
 #define SMRT_EM_HOST 4   /* any other emmodel, evaluated by the caller: see smrt_batch.host_layer / host_phase */
+/* IBA with dense_snow_correction="auto" on a layer of more than half ice (smrt/emmodel/iba.py:95-96 ->
+ * smrt/core/layer.py:186-201): air inclusions in an ice background.  The layer's frac_volume entry is then the volume
+ * fraction of the INCLUSIONS, i.e. 1 - (ice fraction), exactly what the reference's inverted layer carries. */
+#define SMRT_EM_IBA_INVERTED 5
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1

@@ -127,13 +127,19 @@ class IBALayer(LayerEM):
 
     kind = "iba"
 
+    dense_snow_correction = None
+
     def __init__(self, frequency, frac_volume, temperature, microstructure, **mp):
         self.frequency = frequency
-        self.f = frac_volume
         self.k0 = 2.0 * np.pi * frequency / C_SPEED
         e0 = 1.0
         eps = ice_permittivity_maetzler06(frequency, temperature)
         self.eps_ice = eps
+        if frac_volume > 0.5 and self.dense_snow_correction == "auto":
+            # iba.py:95-96 -> core/layer.py:186-201, microstructure_model/autocorrelation.py:146-153: the inverted
+            # medium -- same autocorrelation family with frac_volume -> 1 - frac_volume, permittivities swapped
+            frac_volume, e0, eps = 1.0 - frac_volume, eps, e0
+        self.f = frac_volume
         self.eps_eff = polder_van_santen_spheres(frac_volume, e0, eps)  # emmodel/common.py:269-289
         if microstructure == "exponential":
             lc = mp["corr_length"]
@@ -164,6 +170,12 @@ class IBALayer(LayerEM):
     def ft_even_phase(self, mu_s, mu_i, m_max, npol):
         nsamples = int(2 ** np.ceil(4 + np.log(m_max + 1) / np.log(2)))  # emmodel/common.py:401-414
         return ft_even_matrix(lambda dphi: self.phase(mu_s, mu_i, dphi, npol), m_max, nsamples, npol)
+
+
+class IBADenseAutoLayer(IBALayer):
+    """IBA with emmodel_options=dict(dense_snow_correction="auto") (iba.py:85-105)."""
+
+    dense_snow_correction = "auto"
 
 
 class DMRTQCAShortRangeLayer(LayerEM):
@@ -389,7 +401,7 @@ def rayleigh_ft_even_phase(ks, mu_s, mu_i, m_max, npol):
 def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
-    classes = {"iba": IBALayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
+    classes = {"iba": IBALayer, "iba_dense_auto": IBADenseAutoLayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
                "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer,
                "rayleigh": RayleighLayer, "prescribed_kskaeps": PrescribedLayer}
     L = len(sp["thickness"])

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMRT_DORT_LIB: an alternative build of the same library (profiling / ablation builds made by tools/), never a fallback
 LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
-EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4}
+EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4,
+            "iba_inverted": 5}   # include/smrt_dort.h: SMRT_EM_*
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1}
 SUBSTRATE_CODES = {"flat": 1, "reflector": 2, "host": 3}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}

@@ -544,7 +544,7 @@ int32_t smrt_dort_ft_even_phase(smrt_dort_ctx* ctx, int32_t emmodel, int32_t mic
         ctx->err = "invalid ft_even_phase request";
         return -1;
     }
-    if (emmodel < SMRT_EM_IBA || emmodel > SMRT_EM_NONSCATTERING ||
+    if (emmodel < SMRT_EM_IBA || (emmodel > SMRT_EM_NONSCATTERING && emmodel != SMRT_EM_IBA_INVERTED) ||
         (microstructure != SMRT_MS_EXPONENTIAL && microstructure != SMRT_MS_STICKY_HARD_SPHERES)) {
         ctx->err = "unknown emmodel / microstructure";
         return -1;

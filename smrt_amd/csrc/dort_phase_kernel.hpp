@@ -34,7 +34,7 @@ SMRT_DEV void ft_even_phase_entry(const PhaseRequest& q, int is, int ii) {
         for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) e[a][c] = 0.0;
         if (q.em == EM_NONSCAT) {
             // null phase matrix
-        } else if (q.em != EM_IBA) {   // Rayleigh closed forms times 1.5 ks (pa); the minus on the (V|H, U) column: :121-124
+        } else if (q.em != EM_IBA && q.em != EM_IBA_INV) {   // Rayleigh closed forms times 1.5 ks (pa); the minus on the (V|H, U) column: :121-124
             const double a2 = mi * mi, x2 = x * x;
             if (m == 0) {
                 e[0][0] = pa * (0.5 * a2 * x2 + (1.0 - a2) * (1.0 - x2));

@@ -112,18 +112,23 @@ SMRT_DEV void layer_em(int em, int ms, double frequency, double fv, double T, do
     cplx es = ice_permittivity(frequency, T);
     if (T > kFreezing) *bad = 1;
     double k0 = 2.0 * kPi * frequency / kCSpeed;
-    if (em == EM_IBA) {
-        // Polder-van Santen, spheres: 2x^2 + bx - eps e0 = 0 (generic_mixing_formula.py:117-145), e0 = 1
-        cplx bq = csub(csub(es, cmk(2.0, 0.0)), cscale(csub(es, cmk(1.0, 0.0)), 3.0 * fv));
-        cplx disc = cadd(cmul(bq, bq), cscale(es, 8.0));
+    if (em == EM_IBA || em == EM_IBA_INV) {
+        // EM_IBA_INV: IBA's dense_snow_correction="auto" on a layer with more than half ice (iba.py:95-96,
+        // core/layer.py:186-201): air inclusions (e1 = 1) in an ice background (e0 = ice); fv is then the AIR fraction,
+        // which is what the caller passes for such a layer (smrt_dort.h)
+        const cplx e0 = em == EM_IBA ? cmk(1.0, 0.0) : es, e1 = em == EM_IBA ? es : cmk(1.0, 0.0);
+        const cplx de = csub(e1, e0);
+        // Polder-van Santen, spheres: 2x^2 + bx - e1 e0 = 0 (generic_mixing_formula.py:117-145)
+        cplx bq = csub(csub(e1, cscale(e0, 2.0)), cscale(de, 3.0 * fv));
+        cplx disc = cadd(cmul(bq, bq), cscale(cmul(e1, e0), 8.0));
         cplx ee = cscale(csub(csqrt_(disc), bq), 0.25);
         if (ee.im < -1e-10) *bad = 1;
         *eps_eff = ee;
         // mean squared field ratio with depolarisation factors 1/3 (iba.py:152-162)
-        cplx app = cadd(cscale(ee, 2.0 / 3.0), cmk(1.0 / 3.0, 0.0));
-        cplx den = cadd(app, cscale(csub(es, cmk(1.0, 0.0)), 1.0 / 3.0));
+        cplx app = cadd(cscale(ee, 2.0 / 3.0), cscale(e0, 1.0 / 3.0));
+        cplx den = cadd(app, cscale(de, 1.0 / 3.0));
         double y2 = cabs2(cdiv(app, den));
-        double coeff = (1.0 / (4.0 * kPi)) * cabs2(csub(es, cmk(1.0, 0.0))) * y2 * (k0 * k0) * (k0 * k0);
+        double coeff = (1.0 / (4.0 * kPi)) * cabs2(de) * y2 * (k0 * k0) * (k0 * k0);
         cplx sq = csqrt_(ee);
         *ka = 2.0 * k0 * sq.im;  // iba.py:265
         // ks: Romberg on 65 samples of mu = 1 - j/32 (iba.py:176-226; scipy.integrate.romb), |sqrt(eps)| here

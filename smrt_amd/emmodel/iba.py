@@ -24,6 +24,14 @@ class _DeviceEMModel:
         self.npol = 2 if sensor.mode == "P" else 3
         self.options = options
         self._props = None
+        self._device_name = self.device_name_for(layer, options)
+        # the volume fraction of the INCLUSIONS: the air of an inverted medium (smrt/core/layer.py:186-201)
+        self._frac_volume = float(1.0 - layer.frac_volume if self._device_name == "iba_inverted" else layer.frac_volume)
+
+    @classmethod
+    def device_name_for(cls, layer, options):
+        """The device emmodel of one layer under these options (the class attribute, unless an option changes the medium)."""
+        return cls.device_name
 
     def _device_properties(self):
         if self._props is None:
@@ -31,13 +39,13 @@ class _DeviceEMModel:
             from ..rtsolver.dort import get_context
 
             p1, p2 = self.layer.microstructure.device_params
-            key = (self.device_name, self.layer.microstructure_model, float(self.layer.frac_volume),
+            key = (self._device_name, self.layer.microstructure_model, self._frac_volume,
                    float(self.layer.temperature), p1, p2, self.frequency)
             if key in _PROPS_CACHE:
                 self._props = _PROPS_CACHE[key]
                 return self._props
-            batch = PackedBatch([1], [100.0], [self.layer.frac_volume], [self.layer.temperature], [p1], [p2],
-                                [self.frequency], [0.0], emmodel=self.device_name,
+            batch = PackedBatch([1], [100.0], [self._frac_volume], [self.layer.temperature], [p1], [p2],
+                                [self.frequency], [0.0], emmodel=self._device_name,
                                 microstructure=self.layer.microstructure_model, n_max_stream=4,
                                 phase_normalization="forced")
             out = get_context().run(batch)   # the shared, cached context of this process's default GPU (serialised by its lock)
@@ -77,8 +85,8 @@ class _DeviceEMModel:
         if np.any(np.asarray(mu_i) == 1) and npol > 2:
             raise SMRTError("Phase matrix signs for sine elements of mode m = 2 incorrect")
         p1, p2 = self.layer.microstructure.device_params
-        return get_context().ft_even_phase(self.device_name, self.layer.microstructure_model, self.frequency,
-                                            self.layer.frac_volume, self.layer.temperature, p1,
+        return get_context().ft_even_phase(self._device_name, self.layer.microstructure_model, self.frequency,
+                                            self._frac_volume, self.layer.temperature, p1,
                                             p2, mu_s, mu_i, m_max, npol)
 
 
@@ -86,12 +94,15 @@ class IBA(_DeviceEMModel):
     device_name = "iba"
 
     def __init__(self, sensor, layer, dense_snow_correction=None):
-        # dense_snow_correction="auto" (smrt/emmodel/iba.py:85-105) inverts the medium -- air inclusions in ice -- for layers
-        # whose ice volume fraction exceeds 0.5 and leaves every other layer alone: accepted, a no-op below 0.5; the
-        # inverted medium itself has no device implementation
+        # dense_snow_correction="auto" (smrt/emmodel/iba.py:85-105) inverts the medium -- air inclusions in an ice
+        # background -- for layers whose ice volume fraction exceeds 0.5 and leaves every other layer alone; the device
+        # has both media (include/smrt_dort.h: SMRT_EM_IBA_INVERTED)
         if dense_snow_correction not in (None, False, "auto"):
             raise SMRTError(f"unknown dense_snow_correction '{dense_snow_correction}' (None or 'auto')")
-        if dense_snow_correction == "auto" and layer.frac_volume > 0.5:
-            raise SMRTError("dense_snow_correction='auto' on a layer with frac_volume > 0.5: the inverted medium (air "
-                            "inclusions in ice) has no device implementation in smrt_amd")
-        super().__init__(sensor, layer)
+        super().__init__(sensor, layer, dense_snow_correction=dense_snow_correction)
+        self.frac_volume = self._frac_volume   # what the reference's instance exposes (iba.py:98-99)
+
+    @classmethod
+    def device_name_for(cls, layer, options):
+        inverted = options.get("dense_snow_correction") == "auto" and layer.frac_volume > 0.5
+        return "iba_inverted" if inverted else cls.device_name

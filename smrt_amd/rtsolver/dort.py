@@ -86,7 +86,8 @@ class DORT(object):
         if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
             snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
                                 atmosphere=atmosphere)
-        entries = [getattr(type(e), "device_name", None) or e for e in emmodels]   # instances: evaluated on the host
+        # device-backed instances by the device emmodel of their layer; any other instance is evaluated on the host
+        entries = [getattr(e, "_device_name", None) or getattr(type(e), "device_name", None) or e for e in emmodels]
         return self.solve_batch([(sensor, snowpack)], [entries])[0]
 
     # ---- batched entry points ------------------------------------------------------------------------------------
@@ -163,7 +164,8 @@ class DORT(object):
                     checked.add(key)
                     kind(plan.sensors[0], layer, **options)     # validates the options against the class
             # a class without a device implementation is evaluated on the host, layer by layer (_evaluate_on_host)
-            names = [getattr(kd, "device_name", None) or (kd, model.emmodel_options_of_layer(layer, k, n))
+            names = [kd.device_name_for(layer, model.emmodel_options_of_layer(layer, k, n))
+                     if getattr(kd, "device_name", None) else (kd, model.emmodel_options_of_layer(layer, k, n))
                      for k, (kd, layer) in enumerate(zip(kinds, sp.layers))]
             distinct.update(n if isinstance(n, str) else "host" for n in names)
             per_pack.append(names)
@@ -255,6 +257,13 @@ class DORT(object):
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
             for s, sp in enumerate(sps):
                 cols[:, s, :nl[s]] = sp.packed()
+        if layer_kind is not None and host is None:
+            # IBA on the inverted medium (dense_snow_correction="auto" above half ice): the device takes the volume
+            # fraction of the inclusions, the air (include/smrt_dort.h: SMRT_EM_IBA_INVERTED)
+            inverted = (layer_kind & 15) == EM_CODES["iba_inverted"]
+            cols[1][inverted] = 1.0 - cols[1][inverted]
+        elif device_name == "iba_inverted":   # every layer of the batch
+            cols[1] = 1.0 - cols[1]
         mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate

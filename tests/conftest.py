@@ -82,6 +82,10 @@ def packed_batch_from_fixture(d, freqs=None):
     ms = sp["microstructure"]
     layer_kind = None
     emmodel = str(d["emmodel"]) if np.ndim(d["emmodel"]) == 0 else [str(e) for e in d["emmodel"]]
+    if emmodel == "iba_dense_auto":   # what the product's host side does with that option (rtsolver/dort.py:_pack)
+        dense = np.asarray(sp["frac_volume"]) > 0.5
+        emmodel = ["iba_inverted" if x else "iba" for x in dense]
+        sp["frac_volume"] = np.where(dense, 1.0 - np.asarray(sp["frac_volume"]), sp["frac_volume"])
     if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
         L = len(sp["thickness"])
         msl = ms if isinstance(ms, list) else [ms] * L
@@ -153,6 +157,8 @@ PRUNE_ACTIVE_FIXTURES = ["iba_active_L6_n10_prune"]
 MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
 # emmodels without a device implementation (evaluated on the host, SMRT_EM_HOST): the reference's rayleigh on
 # independent spheres, passive and active, and prescribed_kskaeps on a homogeneous microstructure
+# IBA with emmodel_options=dict(dense_snow_correction="auto"): layers above half ice on the inverted medium (air in ice)
+DENSE_AUTO_FIXTURES = ["iba_dense_auto_L5_n12", "iba_dense_auto_shs_active_L3_n8"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 
 

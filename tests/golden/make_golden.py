@@ -70,12 +70,16 @@ def snowpack_arrays(sp):
     return out
 
 
-def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_layers=(0,)):
+def run_case(emmodel, sensor, sp, rtsolver_options=None, stages=False, stage_layers=(0,), emmodel_options=None,
+             emmodel_label=None):
     """Run the reference for every (frequency) configuration of `sensor` on snowpack `sp`."""
     if ONLY and SKIP_OLD[0]:
         return {}
     rtsolver_options = dict(rtsolver_options or {})
-    m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options)   # emmodel: a name, or a list (one per layer)
+    # emmodel: a name, or a list (one per layer)
+    m = make_model(emmodel, "dort", rtsolver_options=rtsolver_options, emmodel_options=emmodel_options or {})
+    if emmodel_label is not None:   # the name under which the oracle / the tests know (emmodel, emmodel_options)
+        emmodel = emmodel_label
     sims, dims = m.prepare_simulations(sensor, sp, None, "snowpack")
     sims = list(sims)
     out = dict(snowpack_arrays(sp))
@@ -689,6 +693,24 @@ def main():
             out["f0_" + k] = np.asarray(res.other_data[k].values)
         SKIP_OLD[0] = bool(ONLY)
         save(name, out)
+
+    # (iv-h) IBA with emmodel_options=dict(dense_snow_correction="auto") (smrt/emmodel/iba.py:85-105): layers above half ice
+    # are modelled as air inclusions in ice (core/layer.py:186-201), the others are left alone.  Firn / ice-lens like
+    # densities next to ordinary snow, both microstructure models, passive and active.
+    if wanted("iba_dense_auto_L5_n12"):
+        spx = make_snowpack([0.15, 0.3, 0.2, 0.5, 100.0], "exponential", density=[300, 550, 700, 850, 400],
+                            temperature=[255, 258, 260, 262, 265], corr_length=[1e-4, 2.5e-4, 3e-4, 2e-4, 1.5e-4])
+        save("iba_dense_auto_L5_n12", run_new("iba", passive([18.7e9, 36.5e9, 89e9], [30, 55]), spx,
+                                               rtsolver_options=dict(n_max_stream=12), stages=True, stage_layers=(2,),
+                                               emmodel_options=dict(dense_snow_correction="auto"),
+                                               emmodel_label="iba_dense_auto"))
+    if wanted("iba_dense_auto_shs_active_L3_n8"):
+        spx = make_snowpack([0.2, 0.4, 1000.0], "sticky_hard_spheres", density=[600, 350, 800], temperature=[258, 262, 266],
+                            radius=[2e-4, 1.5e-4, 2.5e-4], stickiness=0.3)
+        save("iba_dense_auto_shs_active_L3_n8", run_new("iba", active(13.4e9, [30, 45]), spx,
+                                                         rtsolver_options=dict(n_max_stream=8, m_max=2),
+                                                         emmodel_options=dict(dense_snow_correction="auto"),
+                                                         emmodel_label="iba_dense_auto"))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import assert_backscatter_close, load_golden, reference_method_spread
 
 pytestmark = pytest.mark.gpu
 
@@ -336,6 +336,39 @@ def test_heterogeneous_snowpacks_through_the_model():
     sp2.layers[1].emmodel = "dmrt_qca_shortrange"
     res2 = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16)).run(sensor, sp2)
     assert np.array_equal(res2.data.values, res.data.values[:, 0])
+
+
+def test_iba_dense_snow_correction_through_the_model():
+    """emmodel_options=dict(dense_snow_correction="auto") (smrt/emmodel/iba.py:85-105): layers above half ice are solved
+    on the inverted medium -- batch runner, sequential runner, the emmodel instance's own accessors -- against the
+    reference fixtures (firn / ice-lens densities between ordinary snow layers; exponential passive, SHS active)."""
+    from smrt_amd import make_model, make_snowpack, sensor_list
+    from smrt_amd.emmodel.iba import IBA
+    from smrt_amd.runner.sequential_runner import SequentialRunner
+
+    d = load_golden("iba_dense_auto_L5_n12")
+    sp = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                       corr_length=d["corr_length"])
+    opts = dict(emmodel_options=dict(dense_snow_correction="auto"), rtsolver_options=dict(n_max_stream=12))
+    m = make_model("iba", "dort", **opts)
+    sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+    res = m.run(sensor, [sp, sp])
+    assert np.abs(res.data.values[:, 0] - d["result"]).max() < 1e-6
+    seq = m.run(sensor, sp, runner=SequentialRunner())
+    assert np.array_equal(seq.data.values, res.data.values[:, 0])
+    np.testing.assert_allclose(np.asarray(seq.other_data["ks"].values)[0].ravel(), d["f0_ks"], rtol=1e-11)
+    # without the option the dense layers keep ice inclusions in air: a different answer (the option is not a no-op here)
+    plain = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=12)).run(sensor, sp)
+    assert np.abs(plain.data.values - d["result"]).max() > 0.5
+    e = IBA(sensor_list.passive(float(d["frequency"][1]), 55), sp.layers[3], dense_snow_correction="auto")
+    assert abs(e.frac_volume - (1.0 - sp.layers[3].frac_volume)) < 1e-15      # iba.py:98-99: the inverted layer's
+    np.testing.assert_allclose([e._ks, e.ka], [d["f1_ks"][3], d["f1_ka"][3]], rtol=1e-10)
+    da = load_golden("iba_dense_auto_shs_active_L3_n8")
+    spa = make_snowpack(da["thickness"], "sticky_hard_spheres", density=da["density"], temperature=da["temperature"],
+                        radius=da["radius"], stickiness=da["stickiness"])
+    ma = make_model("iba", "dort", emmodel_options=dict(dense_snow_correction="auto"), rtsolver_options=dict(n_max_stream=8, m_max=2))
+    ra = ma.run(sensor_list.active(float(da["frequency"][0]), list(da["theta_inc_deg"])), spa)
+    assert_backscatter_close(ra.data.values, da["result"][0], spread=reference_method_spread(da)[0])
 
 
 def test_emmodel_ft_even_phase_on_the_device():

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -612,11 +612,12 @@ def test_cfg4_shape_batch_through_staging_chunks(ctx):
         assert np.array_equal(part.values, full.values[lo:hi])
 
 
-@pytest.mark.parametrize("name", MIXED_FIXTURES)
+@pytest.mark.parametrize("name", MIXED_FIXTURES + DENSE_AUTO_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
     """smrt_batch.layer_kind: one emmodel per layer (IBA / DMRT QCA short range / non-scattering) over layers mixing the
-    exponential and sticky-hard-spheres microstructure models, passive and active, against the reference."""
+    exponential and sticky-hard-spheres microstructure models, passive and active, against the reference.  Also IBA on
+    the inverted medium (SMRT_EM_IBA_INVERTED: the reference's dense_snow_correction="auto" above half ice)."""
     d = load_golden(name)
     out = run_variant(ctx, batch_from_fixture(d), threads, pipeline)
     assert (out.status == 0).all(), out.status

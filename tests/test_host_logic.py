@@ -120,11 +120,10 @@ def test_emmodel_configuration_is_honoured_on_the_batch_path():
     assert DORT.emmodel_names(m, plan) == "iba"           # "auto" is a no-op below frac_volume 0.5 (smrt/emmodel/iba.py:85-105)
     dense = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
                              Layer(10.0, "exponential", 600, 250.0, corr_length=5e-5)])   # frac_volume 0.65: needs the inversion
-    plan_d = m.plan(sensor_list.amsre("37V"), [dense])
-    with pytest.raises(SMRTError, match="inverted medium"):
-        DORT.emmodel_names(m, plan_d)
-    with pytest.raises(SMRTError, match="inverted medium"):
-        m.prepare_emmodels(plan_d.sensors[0], dense)      # the per-simulation route says the same
+    plan_d = m.plan(sensor_list.amsre("37V"), [dense, sp])
+    # above half ice the layer goes to the device's inverted medium (SMRT_EM_IBA_INVERTED), layer by layer
+    assert DORT.emmodel_names(m, plan_d) == [["iba", "iba_inverted"], ["iba", "iba"]]
+    assert DORT.emmodel_names(make_model("iba", "dort"), plan_d) == "iba"   # without the option: plain IBA, as in the reference
     with pytest.raises(SMRTError, match="dense_snow_correction"):
         make_model("iba", "dort", emmodel_options=dict(dense_snow_correction="yes")).prepare_emmodels(plan.sensors[0], sp)
     mixed = Snowpack(layers=[Layer(0.1, "exponential", 200, 250.0, corr_length=5e-5),
