@@ -945,9 +945,49 @@ SMRT_DEV void r45_rows(double* F, const double* G, const double* Q, double* Wk, 
     block_sync();
 }
 
+// ---- Cholesky of one 16 x 16 block in registers ---------------------------------------------------------------
+// a: the symmetric positive definite block (both triangles) in MFMA accumulator layout -- lane 16 g + c, register r holds
+// element (4 r + g, c); w: the identity on entry.  On return the lower triangle of a is L (a = L L^T) and w = L^-1 (lower
+// triangular); whatever sits above the diagonals is meaningless.  Right-looking, one column per step: row K reaches the
+// four lane rows through v_permlane16/32_swap, column K and the pivot through DPP row broadcasts -- no LDS, no
+// v_readlane; the row operations of the step (scale row K by 1 / L_KK, subtract L_iK times it from the rows below) are
+// applied to w at once, so the inverse of the factor comes out of the same 16 steps (two independent dependency chains
+// in one instruction stream).  ok goes false (uniformly) on a pivot that is not positive.
+template <int K>
+SMRT_DEV void chol16_step(double (&a)[4], double (&w)[4], bool& ok, int g, int c) {
+    constexpr int r0 = K >> 2, g0 = K & 3;
+    const double rowk = rows_bcast<g0>(a[r0]);      // A[K][c] = A[c][K] (the trailing matrix is kept symmetric)
+    const double wrow = rows_bcast<g0>(w[r0]);      // W[K][c]
+    const double akk = row_bcast16<K>(rowk);
+    if (!(akk > 0.0)) ok = false;
+    const double rk = fast_rsqrt(ok ? akk : 1.0);
+    const double ljk = (c > K) ? rowk * rk : 0.0;   // L[c][K] for the columns still to be eliminated (finished columns stay)
+    const double wk = wrow * rk;                    // row K of the inverse: final
+    // rows 4 r + g: registers r < r0 hold finished rows only (nothing to do, known at compile time), registers r > r0 rows
+    // below K; only register r0 mixes the three cases (lane rows g < g0, g == g0, g > g0)
+#pragma unroll
+    for (int r = r0; r < 4; ++r) {
+        const double lik = row_bcast16<K>(a[r]) * rk;   // L[i][K] for i >= K
+        a[r] = (c == K) ? lik : a[r] - lik * ljk;
+        if (r > r0) w[r] -= lik * wk;
+        else {
+            // one fused multiply-add for the three cases: the multiplier of row K itself is L_KK - 1, which turns
+            // W[K][c] into W[K][c] - (L_KK - 1) W[K][c] / L_KK = W[K][c] / L_KK
+            const double m = (g > g0) ? lik : ((g == g0) ? lik - 1.0 : 0.0);
+            w[r] -= m * wk;
+        }
+    }
+}
+SMRT_DEV void chol16_reg(double (&a)[4], double (&w)[4], bool& ok, int g, int c) {
+    chol16_step<0>(a, w, ok, g, c); chol16_step<1>(a, w, ok, g, c); chol16_step<2>(a, w, ok, g, c); chol16_step<3>(a, w, ok, g, c);
+    chol16_step<4>(a, w, ok, g, c); chol16_step<5>(a, w, ok, g, c); chol16_step<6>(a, w, ok, g, c); chol16_step<7>(a, w, ok, g, c);
+    chol16_step<8>(a, w, ok, g, c); chol16_step<9>(a, w, ok, g, c); chol16_step<10>(a, w, ok, g, c); chol16_step<11>(a, w, ok, g, c);
+    chol16_step<12>(a, w, ok, g, c); chol16_step<13>(a, w, ok, g, c); chol16_step<14>(a, w, ok, g, c); chol16_step<15>(a, w, ok, g, c);
+}
+
 // ---- blocked Cholesky of two SPD matrices side by side on the matrix core (N <= 64) --------------------------
-// Right-looking with 16-column blocks: the 16x16 diagonal block is factorised (and its inverse formed) by one
-// wavefront per matrix with lane = row and the row in registers; the panel below (L_IJ = A_IJ inv(L_JJ)^T) and the
+// Right-looking with 16-column blocks: the 16x16 diagonal block is factorised (and the inverse of its factor formed) by
+// one wavefront per matrix entirely in registers (chol16_reg); the panel below (L_IJ = A_IJ inv(L_JJ)^T) and the
 // trailing update (A_IK -= L_IJ L_KJ^T) are MFMA tile GEMMs.  3 workgroup barriers per block column (12 for N = 64)
 // instead of one per column, and the O(N^3) part runs on the matrix core.
 template <int NT, bool PK = false>
@@ -963,52 +1003,27 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
         // (a) diagonal block: L_JJ and its inverse
         for (int mi = wave; mi < 2; mi += NW) {
             double* A = mi ? A1 : A0;
-            double row[16];
-            const int gi = b0 + lr;                      // lanes 16..63 mirror lanes 0..15 (harmless duplicates)
+            // the tile in registers in MFMA accumulator layout (lane 16 g + c, register r: element (4 r + g, c)), identity
+            // padding; both triangles are filled from the stored lower one (chol16_reg keeps the trailing part symmetric)
+            double a[4], w[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int gj = b0 + j;
-                const int gic = gi < N ? gi : N - 1, gjc = gj < N ? gj : N - 1;
-                const double v = A[sidx<PK>(gic, gjc, LD)];
-                row[j] = (gi < N && gj < N) ? v : ((lr == j) ? 1.0 : 0.0);   // identity padding
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
+                const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
+                const double v = A[sidx<PK>(hi < N ? hi : N - 1, lo < N ? lo : N - 1, LD)];
+                a[r] = (hi < N) ? v : ((i == lr) ? 1.0 : 0.0);
+                w[r] = (i == lr) ? 1.0 : 0.0;
             }
-            // Cholesky of the block and, interleaved with it, the inverse of its factor by forward substitution (lane =
-            // column of the inverse; L[i][m] = row[m] of lane i): row k of L is final after step k, so row k of the inverse
-            // follows at once -- two independent dependency chains in one instruction stream instead of one after the
-            // other -- and 1 / L_kk is the reciprocal square root of the step
             bool ok = true;
-            double x[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double akk = wave_bcast(row[k], k);
-                if (!(akk > 0.0)) ok = false;
-                const double rk = fast_rsqrt(ok ? akk : 1.0);
-                const double lik = row[k] * rk;             // L[i][k] for i >= k (lane k: sqrt(akk))
-                row[k] = lik;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (j > k) { const double ljk = wave_bcast(lik, j); row[j] -= lik * ljk; }
-                double acc = (k == lr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int m = 0; m < 16; ++m)
-                    if (m < k) { const double lkm = wave_bcast(row[m], k); acc -= lkm * ((m >= lr) ? x[m] : 0.0); }
-                x[k] = (k >= lr) ? acc * rk : 0.0;
-            }
+            chol16_reg(a, w, ok, lk, lr);
             if (!ok && lane == 0) *fail = 1;
-            if (lane < 16) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int gj = b0 + j;
-                    if (gi < N && gj < N && j <= lr) A[sidx<PK>(gi, gj, LD)] = row[j];
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) inv[mi * 256 + lr * 16 + i] = x[i];   // (L^-1)[i][j = lr]
-                if (mi == 0 && inv_out) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) inv_out[J * 256 + lr * 16 + i] = x[i];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
+                if (gi < N && gj < N && lr <= i) A[sidx<PK>(gi, gj, LD)] = a[r];
+                const double wv = (lr <= i) ? w[r] : 0.0;     // (L^-1)[i][j = lr]
+                inv[mi * 256 + lr * 16 + i] = wv;
+                if (mi == 0 && inv_out) inv_out[J * 256 + lr * 16 + i] = wv;
             }
         }
         block_sync();

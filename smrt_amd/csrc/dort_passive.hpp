@@ -467,23 +467,30 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                         const double c = s.cphi[k], s2 = s.s2phi[k], wk = s.wphi[k];
                         double ct_p = mm + sisj * c;       // cos(scattering angle), mu' = +mu_j
                         double ct_m = -mm + sisj * c;      // mu' = -mu_j
-                        ct_p = ct_p > 1.0 ? 1.0 : (ct_p < -1.0 ? -1.0 : ct_p);
-                        ct_m = ct_m > 1.0 ? 1.0 : (ct_m < -1.0 ? -1.0 : ct_m);
+                        // (only these two bounds can be crossed, by rounding, at mu = mu': cos(ti - tj) and -cos(ti - tj);
+                        // the other two are +-cos(ti + tj) with ti + tj < pi)
+                        ct_p = ct_p > 1.0 ? 1.0 : ct_p;
+                        ct_m = ct_m < -1.0 ? -1.0 : ct_m;
                         double Cp, Cm;
                         if (ms_l == MS_EXP) {
+                            // pa wk / dp^2 and pa wk / dm^2 with ONE reciprocal (quarter rate, plus its Newton steps)
                             const double dp = 1.0 + pb * (1.0 - ct_p), dm = 1.0 + pb * (1.0 - ct_m);
-                            Cp = pa * fast_rcp(dp * dp); Cm = pa * fast_rcp(dm * dm);   // 1 / (dp dm)^2 without the IEEE division
+                            const double dp2 = dp * dp, dm2 = dm * dm;
+                            const double q = (pa * wk) * fast_rcp(dp2 * dm2);
+                            Cp = dm2 * q; Cm = dp2 * q;
                         } else {
-                            Cp = pa * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
-                            Cm = pa * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
+                            Cp = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
+                            Cm = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
                         }
-                        Cp *= wk; Cm *= wk;
                         const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
                         pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;
-                        pvh_p += s2 * a2 * Cp; pvh_m += s2 * a2 * Cm;
-                        phv_p += s2 * b2 * Cp; phv_m += s2 * b2 * Cm;
-                        phh_p += c * c * Cp; phh_m += c * c * Cm;
+                        const double s2p = s2 * Cp, s2m = s2 * Cm;          // (a2, b2 are applied once, after the loop)
+                        pvh_p += s2p; pvh_m += s2m;
+                        const double c2 = c * c;
+                        phh_p += c2 * Cp; phh_m += c2 * Cm;
                     }
+                    phv_p = b2 * pvh_p; phv_m = b2 * pvh_m;
+                    pvh_p *= a2; pvh_m *= a2;
                 }
                 const int r0 = 2 * i, c0 = 2 * j;
                 s.M0[sidx<PK>(r0, c0, LD)] = pvv_p + pvv_m;             s.M1[sidx<PK>(r0, c0, LD)] = pvv_p - pvv_m;
