@@ -393,10 +393,14 @@ SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int
         const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
         const int i = ti * 16 + lr, j = tj * 16 + lr;
         const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+        // column bases hoisted out of the k loop: element (k, col) of a lower triangle sits at base(col) + k for k >= col
+        // (rows above the diagonal are masked, their address only has to be valid: k is clamped to the diagonal)
+        const int abase = sidx<PK>(ic, ic, LD) - ic, bbase = sidx<PK>(jc, jc, LD) - jc;
         for (int k0 = kmin; k0 < N; k0 += 4) {
             const int k = k0 + lk, kc = k < N ? k : N - 1;
-            const double av = Lp[sidx<PK>(kc, ic, LD)], bv = Lm[sidx<PK>(kc, jc, LD)];
-            mfma_f64_16x16x4((i < N && k < N && k >= i) ? av : 0.0, (j < N && k < N && k >= j) ? bv : 0.0, c);
+            const double av = Lp[abase + (kc > ic ? kc : ic)], bv = Lm[bbase + (kc > jc ? kc : jc)];
+            const bool kin = k < N;
+            mfma_f64_16x16x4((kin && k >= i) ? av : 0.0, (kin && k >= j) ? bv : 0.0, c);   // (k >= i, k < N imply i < N)
         }
         tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[(reverse_cols ? N - 1 - col : col) * LD + row] = c[reg]; });
     }
