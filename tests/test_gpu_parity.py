@@ -24,10 +24,12 @@ def batch_from_fixture(d, freqs=None):
     return packed_batch_from_fixture(d, freqs)
 
 
-# The kernel shapes a batch can run through: (workgroup threads, pipeline).  Pipeline 1 = prep / Jacobi / two-slot
-# finish (the default), 0 = one fused kernel per pair; 64 threads = one wavefront per workgroup (every wavefront-level
+# The kernel shapes a batch can run through: (workgroup threads, pipeline).  Pipeline 1 = prep / Jacobi / finish (the
+# default: the register-resident finish kernel wherever it applies -- passive, N <= 64, Flat interfaces -- the two-slot
+# finish kernel elsewhere), 4 = the same with the two-slot finish kernel everywhere (so that it stays covered on the
+# passive fixtures), 0 = one fused kernel per pair; 64 threads = one wavefront per workgroup (every wavefront-level
 # assumption of the device code is exercised without a second wavefront to hide it).
-KERNEL_VARIANTS = [(256, 1), (64, 1), (256, 0), (64, 0)]
+KERNEL_VARIANTS = [(256, 1), (64, 1), (256, 0), (64, 0), (256, 4)]
 
 
 def run_variant(ctx, batch, threads, pipeline):
