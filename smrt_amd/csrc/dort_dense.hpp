@@ -1002,35 +1002,58 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
     const int RT = (N + 15) >> 4;
     if (t == 0) *fail = 0;
     block_sync();
+    // (a) diagonal block J of matrix mi: L_JJ and its inverse, one wavefront, in registers
+    auto diag = [&](int J, int mi) {
+        const int b0 = J * 16;
+        double* A = mi ? A1 : A0;
+        // the tile in registers in MFMA accumulator layout (lane 16 g + c, register r: element (4 r + g, c)), identity
+        // padding; both triangles are filled from the stored lower one (chol16_reg keeps the trailing part symmetric)
+        double a[4], w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
+            const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
+            const double v = A[sidx<PK>(hi < N ? hi : N - 1, lo < N ? lo : N - 1, LD)];
+            a[r] = (hi < N) ? v : ((i == lr) ? 1.0 : 0.0);
+            w[r] = (i == lr) ? 1.0 : 0.0;
+        }
+        bool ok = true;
+        chol16_reg(a, w, ok, lk, lr);
+        if (!ok && lane == 0) *fail = 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
+            if (gi < N && gj < N && lr <= i) A[sidx<PK>(gi, gj, LD)] = a[r];
+            const double wv = (lr <= i) ? w[r] : 0.0;     // (L^-1)[i][j = lr]
+            inv[mi * 256 + lr * 16 + i] = wv;
+            if (mi == 0 && inv_out) inv_out[J * 256 + lr * 16 + i] = wv;
+        }
+    };
+    // (c) one tile of the trailing update A_IK -= L_IJ L_KJ^T, I >= K > J
+    auto trailing_tile = [&](int J, int mi, int I, int K) {
+        const int b0 = J * 16;
+        double* A = mi ? A1 : A0;
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
+        const int i = I * 16 + lr, ic = i < N ? i : N - 1;
+        const int j = K * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int gk = b0 + 4 * kk + lk, gkc = gk < N ? gk : N - 1;
+            const double av = A[sidx<PK>(ic, gkc, LD)], bv = A[sidx<PK>(jc, gkc, LD)];
+            mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, (j < N && gk < N) ? bv : 0.0, c);
+        }
+        tile_foreach(I, K, N, [&](int reg, int row_, int col) { if (!PK || row_ >= col) A[sidx<PK>(row_, col, LD)] -= c[reg]; });
+    };
+    // Look-ahead (four or more wavefronts): the pair of wavefronts that factorises the diagonal blocks takes tile
+    // (J + 1, J + 1) of the trailing update first and goes straight on to block J + 1, while the other wavefronts do the
+    // rest of the update -- the long dependent chain of the next diagonal block no longer waits behind a barrier with
+    // half the workgroup idle.
+    constexpr bool AHEAD = NW >= 4;
     for (int J = 0; J < RT; ++J) {
         const int b0 = J * 16;
-        // (a) diagonal block: L_JJ and its inverse
-        for (int mi = wave; mi < 2; mi += NW) {
-            double* A = mi ? A1 : A0;
-            // the tile in registers in MFMA accumulator layout (lane 16 g + c, register r: element (4 r + g, c)), identity
-            // padding; both triangles are filled from the stored lower one (chol16_reg keeps the trailing part symmetric)
-            double a[4], w[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
-                const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
-                const double v = A[sidx<PK>(hi < N ? hi : N - 1, lo < N ? lo : N - 1, LD)];
-                a[r] = (hi < N) ? v : ((i == lr) ? 1.0 : 0.0);
-                w[r] = (i == lr) ? 1.0 : 0.0;
-            }
-            bool ok = true;
-            chol16_reg(a, w, ok, lk, lr);
-            if (!ok && lane == 0) *fail = 1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * r + lk, gi = b0 + i, gj = b0 + lr;
-                if (gi < N && gj < N && lr <= i) A[sidx<PK>(gi, gj, LD)] = a[r];
-                const double wv = (lr <= i) ? w[r] : 0.0;     // (L^-1)[i][j = lr]
-                inv[mi * 256 + lr * 16 + i] = wv;
-                if (mi == 0 && inv_out) inv_out[J * 256 + lr * 16 + i] = wv;
-            }
-        }
-        block_sync();
+        if (!AHEAD || J == 0)
+            for (int mi = wave; mi < 2; mi += NW) diag(J, mi);
+        block_sync();             // (with look-ahead and J > 0: the barrier behind the trailing update of block J - 1)
         if (*fail) return false;  // uniform
         // (b) panel below the diagonal block: L_IJ = A_IJ inv(L_JJ)^T
         {
@@ -1051,31 +1074,37 @@ SMRT_DEV bool chol2_mfma(double* A0, double* A1, double* inv /* [2][256] */, int
             }
         }
         block_sync();
-        // (c) trailing update A_IK -= L_IJ L_KJ^T, I >= K > J
+        // (c) trailing update
         {
             const int nb = RT - 1 - J;
             const int ntri = nb * (nb + 1) / 2;
-            for (int tix = wave; tix < 2 * ntri; tix += NW) {
-                const int mi = tix & 1;
-                int q = tix >> 1, Ir = 0;
-                while ((Ir + 1) * (Ir + 2) / 2 <= q) ++Ir;
-                const int Kr = q - Ir * (Ir + 1) / 2;
-                const int I = J + 1 + Ir, K = J + 1 + Kr;
-                double* A = mi ? A1 : A0;
-                double c[4] = {0.0, 0.0, 0.0, 0.0};
-                const int i = I * 16 + lr, ic = i < N ? i : N - 1;
-                const int j = K * 16 + lr, jc = j < N ? j : N - 1;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int gk = b0 + 4 * kk + lk, gkc = gk < N ? gk : N - 1;
-                    const double av = A[sidx<PK>(ic, gkc, LD)], bv = A[sidx<PK>(jc, gkc, LD)];
-                    mfma_f64_16x16x4((i < N && gk < N) ? av : 0.0, (j < N && gk < N) ? bv : 0.0, c);
+            if (AHEAD && nb > 0) {
+                if (wave < 2) {
+                    trailing_tile(J, wave, J + 1, J + 1);
+                    wave_sync_lds();       // the block is read back in another lane mapping
+                    diag(J + 1, wave);
+                } else {
+                    for (int tix = wave - 2; tix < 2 * (ntri - 1); tix += NW - 2) {
+                        const int mi = tix & 1;
+                        int q = (tix >> 1) + 1, Ir = 0;      // (q = 0 is the tile the other two wavefronts took)
+                        while ((Ir + 1) * (Ir + 2) / 2 <= q) ++Ir;
+                        const int Kr = q - Ir * (Ir + 1) / 2;
+                        trailing_tile(J, mi, J + 1 + Ir, J + 1 + Kr);
+                    }
                 }
-                tile_foreach(I, K, N, [&](int reg, int row_, int col) { if (!PK || row_ >= col) A[sidx<PK>(row_, col, LD)] -= c[reg]; });
+            } else {
+                for (int tix = wave; tix < 2 * ntri; tix += NW) {
+                    const int mi = tix & 1;
+                    int q = tix >> 1, Ir = 0;
+                    while ((Ir + 1) * (Ir + 2) / 2 <= q) ++Ir;
+                    const int Kr = q - Ir * (Ir + 1) / 2;
+                    trailing_tile(J, mi, J + 1 + Ir, J + 1 + Kr);
+                }
             }
         }
-        block_sync();
+        if (!AHEAD) block_sync();   // (with look-ahead the barrier at the top of the next iteration does it)
     }
+    if (AHEAD) block_sync();
     return true;
 }
 
