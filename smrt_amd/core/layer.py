@@ -7,6 +7,9 @@ from .globalconstants import DENSITY_OF_ICE, DENSITY_OF_WATER, FREEZING_POINT
 
 
 READ_ONLY_AFTER_INIT = ("density", "liquid_water", "volumetric_liquid_water")   # smrt/inputs/make_medium.py:355-359
+# count of writes to ANY Layer / Microstructure object of the process: while it stands still, no snowpack cache can have
+# gone stale through an attribute write (Snowpack._fresh then skips its per-layer comparison)
+WRITES = [0]
 
 
 class Microstructure:
@@ -16,7 +19,7 @@ class Microstructure:
     def __setattr__(self, key, value):
         # every write bumps the object's own version: Snowpack's per-run caches (packed columns, microstructure set,
         # per-layer emmodel flag) compare the versions of THEIR layers, nobody else's
-        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
         object.__setattr__(self, key, value)
 
     def __init__(self, name, frac_volume, **params):
@@ -50,7 +53,7 @@ class Layer:
         if key in READ_ONLY_AFTER_INIT and self.__dict__.get("_constructed"):
             raise SMRTError(f"The attribute '{key}' is read-only, setting it would make the layer inconsistent "
                             "(frac_volume derives from it). Use the update method instead: layer.update(density=...).")
-        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
         object.__setattr__(self, key, value)
         ms = self.__dict__.get("microstructure")
         if ms is not None and key in MICROSTRUCTURE_ARGS.get(self.__dict__.get("microstructure_model"), ()):
@@ -109,7 +112,7 @@ class Layer:
             if not (0 <= frac_volume <= 1.01):
                 raise SMRTError(f"the frac_volume of ice in snow is {frac_volume} but must be between 0 and 1.")
             object.__setattr__(self, "density", density)
-            object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+            object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
             self.microstructure.frac_volume = min(frac_volume, 1.0)
         for k in ("liquid_water", "volumetric_liquid_water"):
             kwargs.pop(k, None)

@@ -4,6 +4,7 @@ import numpy as np
 
 from ..interface.flat import Flat
 from .error import SMRTError
+from .layer import WRITES as LAYER_WRITES
 
 
 def substrate_kind(substrate):
@@ -91,11 +92,16 @@ class Snowpack:
         microstructure object) has been written to since the cache was filled: every Layer / Microstructure counts its
         own writes, so building or changing OTHER snowpacks' layers does not invalidate this one.  Called on every use
         (it also records the state the cache is being filled for)."""
+        writes = LAYER_WRITES[0]
+        seen = getattr(self, slot, None)
+        # fast path: no Layer / Microstructure of the process has been written to since this cache was checked, and the
+        # list holds the same objects in the same order (list equality: identity first, element by element, in C)
+        if seen is not None and seen[0] == writes and seen[1] == self.layers:
+            return True
         state = tuple((id(lay), lay.__dict__.get("_version", 0), lay.microstructure.__dict__.get("_version", 0))
                       for lay in self.layers)
-        ok = getattr(self, slot, None) == state
-        if not ok:
-            setattr(self, slot, state)
+        ok = seen is not None and seen[2] == state
+        setattr(self, slot, (writes, list(self.layers), state))
         return ok
 
     @property
