@@ -81,8 +81,8 @@ SMRT_DEV void gemm_tn(Mat& Z, const Mat& X, const Mat& Y, int nt) {
 
 // ---- in-register inverse of a 16 x 16 tile, Gauss-Jordan without pivoting ------------------------------------------
 // Step k: row k reaches every lane group through two lane-row swaps (v_permlane16_swap / v_permlane32_swap), column k
-// through DPP row broadcasts; column k is replaced by the unit vector e_k before the rank-one update, which makes the
-// in-place update uniform over the tile (Gauss-Jordan inversion in place).
+// through DPP row broadcasts; the in-place update (Gauss-Jordan inversion in place) is one fused multiply-add per register,
+// uniform over the tile, column k included.
 template <int K>
 SMRT_DEV void inv16_step(double (&d)[4], const LaneId& L) {
     constexpr int r0 = K >> 2, g0 = K & 3;
@@ -95,15 +95,17 @@ SMRT_DEV void inv16_step(double (&d)[4], const LaneId& L) {
 #endif
     const double piv = row_bcast16<K>(rk);
     const double pinv = fast_rcp(piv);
-    const bool colk = (L.c == K);
-    rk = colk ? 1.0 : rk;
+    // column K itself takes part in the same fused multiply-add as every other column: with piv + 1 in its place in the
+    // pivot row, D[i][K] - m_i (piv + 1) = -m_i (m_i = D[i][K] / piv), and for the pivot row, whose multiplier is
+    // 1 - 1 / piv, piv - (1 - 1 / piv)(piv + 1) = 1 / piv: no select per register.  (The cancellation costs |piv| ulps
+    // of relative accuracy in that column: 1e-13 for the largest pivots of the recursion.)
+    rk = (L.c == K) ? piv + 1.0 : rk;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double f = row_bcast16<K>(d[r]);           // D[4 r + g][K]
         double m = f * pinv;
         if (r == r0) m = (L.g == g0) ? (1.0 - pinv) : m;  // row K itself: new = old - (1 - pinv) old = old pinv
-        const double old = colk ? ((r == r0 && L.g == g0) ? 1.0 : 0.0) : d[r];
-        d[r] = old - m * rk;
+        d[r] -= m * rk;
     }
 }
 // Two columns per step (K even): the 2 x 2 pivot block P = D[K..K+1][K..K+1] is inverted in closed form and rows / columns
