@@ -390,8 +390,15 @@ def test_emmodel_ft_even_phase_on_the_device():
              (DMRT_QCA_ShortRange, "dmrt_qca_shortrange",
               make_snowpack([1.0], "sticky_hard_spheres", density=[300], temperature=[262], radius=[1.5e-4], stickiness=[0.25]),
               dict(microstructure="sticky_hard_spheres", radius=[1.5e-4], stickiness=[0.25]))]
+    # ... and IBA on the inverted medium (dense_snow_correction="auto" above half ice), both microstructure models
+    dense = lambda **kw: (lambda sensor, layer: IBA(sensor, layer, dense_snow_correction="auto"))   # noqa: E731
+    cases += [(dense(), "iba_dense_auto", make_snowpack([1.0], "exponential", density=[700], temperature=[262], corr_length=[2e-4]),
+               dict(microstructure="exponential", corr_length=[2e-4])),
+              (dense(), "iba_dense_auto",
+               make_snowpack([1.0], "sticky_hard_spheres", density=[700], temperature=[262], radius=[1.5e-4], stickiness=[0.25]),
+               dict(microstructure="sticky_hard_spheres", radius=[1.5e-4], stickiness=[0.25]))]
     for cls, name, sp, osp in cases:
-        layer = O.make_layers(name, 36.5e9, dict(thickness=[1.0], density=[300.0], temperature=[262.0], **osp))[0]
+        layer = O.make_layers(name, 36.5e9, dict(thickness=[1.0], density=[float(sp.layers[0].density)], temperature=[262.0], **osp))[0]
         em_a = cls(sensor_list.active(36.5e9, 40), sp.layers[0])
         got = em_a.ft_even_phase(mu_full, mu_full, 2)
         assert got.shape == (3, 3, 3, 8, 8)
