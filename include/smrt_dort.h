@@ -135,8 +135,11 @@ typedef struct smrt_batch {
      * non-zero = per pair, every layer with k0 Re(sqrt(eps_eff)) thickness < 3 pi / 4 at the pair's frequency is taken
      * out of the snowpack and becomes a coherent (Fabry-Perot) interface on top of the layer below it; layer_out then
      * holds the remaining layers, top first, and zeros after them, with 1024 x (index of the layer in the input) added to
-     * the stream count of column 4 so that the caller can tell which layers were kept.  Not combined with SMRT_EM_HOST
-     * layers. */
+     * the stream count of column 4 so that the caller can tell which layers were kept.  With SMRT_EM_HOST layers the
+     * host_* arrays stay indexed by the layer's position in the INPUT; host_streams / host_phase of a layer that stays
+     * must then be sampled on the streams of the REDUCED snowpack (the caller applies the same criterion to its own
+     * permittivities: the most refringent layer is searched among the layers that stay), entries of layers that leave are
+     * not read apart from the permittivity. */
     int32_t process_coherent_layers;
     /* SMRT_SUBSTRATE_HOST: a rough substrate (smrt/substrate/geometrical_optics.py, iem_fung92*.py, ...).  The reflection
      * matrix of the bottom boundary is no longer diagonal; the caller evaluates it with the reference's own substrate

@@ -352,7 +352,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) { pp[a][c] = 0.0; pm[a][c] = 0.0; }
                     if (em_l == EM_HOST) {  // mode m of the caller's ft_even_phase(mu, +-mu'), compressed (smrt_dort.h)
                         const int NE = b.host_ne;
-                        const double* hp = b.host_phase + ((gp * b.Lmax + l) * (long long)b.host_modes + m) * 2 * NE * NE;
+                        const double* hp = b.host_phase + ((gp * b.Lmax + lo) * (long long)b.host_modes + m) * 2 * NE * NE;
                         const double* hm = hp + (long long)NE * NE;
                         for (int a = 0; a < P; ++a)
                             for (int c = 0; c < P; ++c) {

@@ -112,8 +112,6 @@ inline const char* validate(const smrt_batch* b) {
             }
     if (host_layers && (!b->host_layer || !b->host_streams || !b->host_phase))
         return "layers of kind SMRT_EM_HOST need host_layer, host_streams and host_phase";
-    if (host_layers && b->process_coherent_layers)
-        return "process_coherent_layers cannot be combined with layers of kind SMRT_EM_HOST (their streams are the caller's)";
     if (b->mode != SMRT_MODE_PASSIVE && b->mode != SMRT_MODE_ACTIVE) return "unknown mode";
     if (!b->n_layers || !b->thickness || !b->frac_volume || !b->temperature || !b->micro_p1 || !b->frequency ||
         !b->theta)

@@ -119,7 +119,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
         if ((kind & 15) == EM_HOST) {   // evaluated by the caller (smrt_batch.host_layer)
             if (b.host_layer) {
-                const double* h = b.host_layer + (gp * b.Lmax + l) * 4;   // (not combined with process_coherent_layers)
+                const double* h = b.host_layer + (gp * b.Lmax + l) * 4;   // (l: still the index in the input arrays here)
                 ks = h[0]; ka = h[1]; ee = cmk(h[2], h[3]);
                 if (!(ka >= 0.0) || !(ee.re > 0.0)) bad = 1;
             } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
@@ -189,7 +189,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
             s.ri[l] = ri; s.nl[l] = (double)n;
             if (n < 2) lds_max(&s.ints[0], ST_INPUT);
             // the phase matrix of a host-evaluated layer was sampled on the caller's streams: same count or nothing
-            if (((int)s.pc[l] & 15) == EM_HOST && !(b.host_streams && b.host_phase && b.host_streams[gp * b.Lmax + l] == n))
+            if (((int)s.pc[l] & 15) == EM_HOST && !(b.host_streams && b.host_phase && b.host_streams[gp * b.Lmax + (int)s.lo[l]] == n))
                 lds_max(&s.ints[0], ST_INPUT);
         }
         if (t == NT - 1) {
@@ -446,7 +446,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 double pvv_p, pvh_p, phv_p, phh_p, pvv_m, pvh_m, phv_m, phh_m;
                 if (em_l == EM_HOST) {  // mode 0 of the caller's ft_even_phase(mu, +-mu'), compressed (smrt_dort.h)
                     const int NE = b.host_ne;
-                    const double* hp = b.host_phase + ((gp * b.Lmax + l) * (long long)b.host_modes) * 2 * NE * NE;
+                    const double* hp = b.host_phase + ((gp * b.Lmax + lo) * (long long)b.host_modes) * 2 * NE * NE;   // lo: the layer's index in the input
                     const double* hm = hp + (long long)NE * NE;
                     const int r0 = 2 * i, c0 = 2 * j;
                     pvv_p = hp[r0 * NE + c0]; pvh_p = hp[r0 * NE + c0 + 1];

@@ -17,6 +17,7 @@ import numpy as np
 
 from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
 from ..core.error import SMRTError, smrt_warn
+from ..core.globalconstants import C_SPEED
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack, substrate_kind
 from ..interface.flat import Flat
@@ -232,9 +233,6 @@ class DORT(object):
         if not isinstance(emmodel_names, str) and any(not isinstance(e, str) for row in emmodel_names for e in row):
             # at least one emmodel without a device implementation: the whole group is evaluated through the emmodel
             # protocol on the host (the device classes speak it too) and handed to the device as numbers
-            if self.process_coherent_layers:
-                raise SMRTError("process_coherent_layers is not available with emmodels evaluated on the host (the phase "
-                                "matrices are sampled on the streams of the full snowpack)")
             host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
             layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
         elif not (isinstance(emmodel_names, str) and uniform_micro):
@@ -576,8 +574,20 @@ class DORT(object):
             for s, sp in enumerate(sps):
                 ems = [instance(entries[s][l], sensor, layer) for l, layer in enumerate(sp.layers)]
                 eps = np.array([complex(em.effective_permittivity()) for em in ems])
-                star = max(range(len(eps)), key=lambda l: (eps[l].real, eps[l].imag, -l))   # np.argmax on complex
-                for l, em in enumerate(ems):
+                stay = list(range(len(eps)))
+                if self.process_coherent_layers:
+                    # the layers the device will take out at this frequency (interface/coherent_flat.py:16-57, k0 Re(n) d
+                    # < 3 pi / 4): the streams of the others are those of the REDUCED snowpack.  (Where the reference
+                    # refuses -- the last layer or two in a row -- the device answers status 6 whatever is put here.)
+                    k0 = 2.0 * np.pi * float(f) / C_SPEED
+                    stay = [l for l, lay in enumerate(sp.layers) if not k0 * np.sqrt(eps[l]).real * lay.thickness < 0.75 * np.pi]
+                    for l in set(range(len(eps))) - set(stay):
+                        hl[fi, s, l, 2:] = eps[l].real, eps[l].imag
+                    if not stay:
+                        continue
+                star = max(stay, key=lambda l: (eps[l].real, eps[l].imag, -l))   # np.argmax on complex
+                for l in stay:
+                    em = ems[l]
                     rs = np.sqrt(eps[star] / eps[l]).real * gsin
                     mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
                     n = len(mu)

@@ -160,6 +160,9 @@ MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
 # IBA with emmodel_options=dict(dense_snow_correction="auto"): layers above half ice on the inverted medium (air in ice)
 DENSE_AUTO_FIXTURES = ["iba_dense_auto_L5_n12", "iba_dense_auto_shs_active_L3_n8"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
+# ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
+# snowpack (a 3 mm and a 6 mm layer leave at these frequencies)
+COHERENT_HOST_FIXTURES = ["rayleigh_coherent_L5_n12_passive", "rayleigh_coherent_L5_n10_active"]
 
 
 # DORT option process_coherent_layers: a 2 mm crust and a 3 mm ice lens become coherent interfaces, frequency by frequency
@@ -270,7 +273,7 @@ def host_batch_from_fixture(d):
     from smrt_amd.rtsolver.dort import DORT
 
     o = fixture_options(d)
-    solver = DORT(n_max_stream=o["n_max_stream"], m_max=o["m_max"])
+    solver = DORT(n_max_stream=o["n_max_stream"], m_max=o["m_max"], process_coherent_layers=fixture_coherent(d))
     sp = model_snowpack_from_fixture(d)
     act = str(d["mode"]) == "A"
     f0 = float(d["frequency"][0])

@@ -486,6 +486,26 @@ def main():
             out["result_incoherent"] = np.concatenate([run_new("iba", se, spc, rtsolver_options=opts)["result"] for se in sens])
             save(name, out)
 
+    # (iv-d2) process_coherent_layers together with an emmodel that has no device implementation (the reference's rayleigh on
+    # independent spheres): the phase matrices of the kept layers live on the streams of the REDUCED snowpack.  The 3 mm
+    # lens is coherent at both frequencies, the 6 mm layer only at 10.65 GHz.
+    for name, sens, opts in (
+        ("rayleigh_coherent_L5_n12_passive", [sensor_list.passive(f, [40.0, 55.0]) for f in (10.65e9, 18.7e9)], dict(n_max_stream=12)),
+        ("rayleigh_coherent_L5_n10_active", [sensor_list.active(f, [30.0, 45.0]) for f in (13.4e9,)], dict(n_max_stream=10, m_max=2)),
+    ):
+        if wanted(name):
+            spc = make_snowpack([0.2, 0.003, 0.3, 0.006, 100.0], "independent_sphere", density=[150.0, 800.0, 220.0, 500.0, 300.0],
+                                temperature=[255.0, 258.0, 260.0, 262.0, 266.0], radius=[2.0e-4, 1.0e-4, 3.0e-4, 1.5e-4, 2.5e-4])
+            parts = [run_new("rayleigh", se, spc, rtsolver_options=dict(opts, process_coherent_layers=True)) for se in sens]
+            out = dict(parts[0])
+            out["frequency"] = np.concatenate([p_["frequency"] for p_ in parts])
+            out["result"] = np.concatenate([p_["result"] for p_ in parts])
+            for i, p_ in enumerate(parts):
+                for k in ("stream_angles", "effective_permittivity", "ks", "ke", "ka"):
+                    out["f%d_%s" % (i, k)] = p_["f0_" + k]
+            out["result_incoherent"] = np.concatenate([run_new("rayleigh", se, spc, rtsolver_options=opts)["result"] for se in sens])
+            save(name, out)
+
     # (iv-e) rough substrates in active mode (backscatter of snow over rough soil): the DENSE reflection matrix of the bottom
     # boundary, per azimuth mode, as the reference builds it (rtsolver_utils.py:567-597,690-707: specular diagonal +
     # 2 pi | pi x the weighted diffuse modes) is stored as an INPUT of the fixture -- smrt_amd takes it from the caller

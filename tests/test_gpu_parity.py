@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -633,7 +633,7 @@ def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
         np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-10, atol=1e-300)
 
 
-@pytest.mark.parametrize("name", HOST_EMMODEL_FIXTURES)
+@pytest.mark.parametrize("name", HOST_EMMODEL_FIXTURES + COHERENT_HOST_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_host_evaluated_emmodels_golden(ctx, name, threads, pipeline):
     """SMRT_EM_HOST: emmodels without a device implementation (the reference's rayleigh on independent spheres,
@@ -647,10 +647,13 @@ def test_host_evaluated_emmodels_golden(ctx, name, threads, pipeline):
         assert_backscatter_close(out.values, d["result"], spread=reference_method_spread(d))
     else:
         assert np.abs(out.values - d["result"]).max() < TB_TOL
-    L = len(d["thickness"])
     for i in range(len(d["frequency"])):
+        L = len(d["f%d_ks" % i])      # (with process_coherent_layers: the layers that stayed, top first)
         np.testing.assert_allclose(out.layers[i, :L, 2], d["f%d_ks" % i], rtol=1e-12)
         np.testing.assert_allclose(out.layers[i, :L, 3], d["f%d_ka" % i], rtol=1e-12)
+    if name in COHERENT_HOST_FIXTURES:   # together with process_coherent_layers: the option matters and layers did leave
+        assert np.abs(out.values - d["result_incoherent"]).max() > (1e-6 if str(d["mode"]) == "A" else 1e-2)
+        assert all(np.count_nonzero(out.layers[i, :, 4]) == len(d["f%d_ks" % i]) < len(d["thickness"]) for i in range(len(d["frequency"])))
 
 
 @pytest.mark.parametrize("name", COHERENT_FIXTURES)

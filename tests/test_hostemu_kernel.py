@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (COHERENT_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -249,7 +249,8 @@ def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
 
 
 @pytest.mark.parametrize("name,nt,order", [(HOST_EMMODEL_FIXTURES[0], 64, 0), (HOST_EMMODEL_FIXTURES[1], 256, 1),
-                                           (HOST_EMMODEL_FIXTURES[2], 128, 2)])
+                                           (HOST_EMMODEL_FIXTURES[2], 128, 2), (COHERENT_HOST_FIXTURES[0], 256, 0),
+                                           (COHERENT_HOST_FIXTURES[1], 64, 1)])
 def test_emulated_kernel_with_host_evaluated_emmodels(emu, name, nt, order):
     """Emmodels without a device implementation (the reference's rayleigh and prescribed_kskaeps): the product
     evaluates the emmodel protocol on the host (DORT._evaluate_on_host), the device code takes ks / ka / permittivity /

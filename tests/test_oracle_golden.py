@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, COHERENT_HOST_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
                       assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
                       fixture_emmodel, reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
@@ -229,7 +229,7 @@ def test_heterogeneous_snowpacks(name):
             assert np.abs(r - d["result"][i]).max() < TB_TOL
 
 
-@pytest.mark.parametrize("name", COHERENT_FIXTURES)
+@pytest.mark.parametrize("name", COHERENT_FIXTURES + COHERENT_HOST_FIXTURES)
 def test_process_coherent_layers(name):
     """DORT option process_coherent_layers (smrt/interface/coherent_flat.py): the layers removed -- a different set at
     each frequency --, the Fabry-Perot interface that replaces them, passive and active, against the reference."""
@@ -239,14 +239,16 @@ def test_process_coherent_layers(name):
     kw = dict(mode="A", theta_inc_deg=d["theta_inc_deg"], method="schur_forcedtriu") if act else {}
     for i, f in enumerate(d["frequency"]):
         det = {}
-        r = O.solve(sp, float(f), d["theta_deg"], process_coherent_layers_=True, details=det, **kw, **fixture_options(d))
+        r = O.solve(sp, float(f), d["theta_deg"], emmodel=fixture_emmodel(d), process_coherent_layers_=True, details=det, **kw,
+                    **fixture_options(d))
         assert len(det["kept_layers"]) == len(d["f%d_ks" % i]) < len(d["thickness"])
         np.testing.assert_allclose([e.ks for e in det["ems"]], d["f%d_ks" % i], rtol=1e-10)
         if act:
             assert_backscatter_close(r, d["result"][i])
         else:
             assert np.abs(r - d["result"][i]).max() < TB_TOL
-        assert np.abs(r - d["result_incoherent"][i]).max() > (1e-4 if act else 1.0)   # the option matters here
+        # the option matters here (less on the independent-sphere snowpack of the host-emmodel fixtures: 0.01-0.09 K)
+        assert np.abs(r - d["result_incoherent"][i]).max() > (1e-6 if act else 1.0 if name in COHERENT_FIXTURES else 5e-3)
 
 
 @pytest.mark.parametrize("name", ROUGH_SUBSTRATE_FIXTURES)
