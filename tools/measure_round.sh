@@ -22,8 +22,8 @@ cp profiles/hbm_traffic.json $O/hbm_traffic.json 2>/dev/null
   python tools/bench_active.py 2>&1 | tail -n 6
 } > $O/other_configs.txt 2>&1
 {
-  for s in 1 2 3; do python tools/stress_vs_oracle.py $s 2>&1 | tail -n 1; done
-  for s in 11 12; do python tools/stress_vs_oracle.py $s prune 2>&1 | tail -n 2; done
+  for s in 1 2 3 4 5 6; do python tools/stress_vs_oracle.py $s 2>&1 | tail -n 1; done
+  for s in 11 12 13; do python tools/stress_vs_oracle.py $s prune 2>&1 | tail -n 2; done
   for s in 51 52 53 54; do python tools/stress_vs_oracle.py $s coherent 2>&1 | tail -n 2; done
 } > $O/stress_vs_oracle.txt 2>&1
 ls -la $O
