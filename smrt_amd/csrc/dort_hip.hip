@@ -402,8 +402,9 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     // a rotation above exit2 is the last one (dort_jacobi_kernel.hpp).  SMRT_DORT_JACOBI_SKIP2 / _EXIT2 override them
     // for experiments.  Passive mode, measured on the headline batch against the oracle (profiles/r3_jacobi_thresholds.txt):
     // 1e-26 / 1e-15 -> 1.4e-10 K, 1e-22 / 1e-12 -> 1.6e-8 K (2.6 % faster), 1e-20 / 1e-10 -> 2.4e-7 K; the requirement is 1e-6 K.
-    d.jacobi_skip2 = ctx->active ? 1e-30 : SMRT_JACOBI_PASSIVE_SKIP_COS2;
-    d.jacobi_exit2 = ctx->active ? 1e-22 : SMRT_JACOBI_PASSIVE_EXIT_COS2;
+    // The register-resident finish kernel needs the tighter pair on weakly scattering media (dort_host_common.hpp).
+    d.jacobi_skip2 = ctx->active ? 1e-30 : (ctx->finish_reg ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);
+    d.jacobi_exit2 = ctx->active ? 1e-22 : (ctx->finish_reg ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
     if (const char* e = getenv("SMRT_DORT_JACOBI_SKIP2")) d.jacobi_skip2 = atof(e);
     if (const char* e = getenv("SMRT_DORT_JACOBI_EXIT2")) d.jacobi_exit2 = atof(e);
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;

@@ -6,13 +6,26 @@
 #include "../../include/smrt_dort.h"
 
 // Jacobi thresholds of the pipelines in passive mode (squared cosines; the kernels take them as run-time parameters):
-// rotations below SKIP are not applied, a sweep without a rotation above EXIT is the last one.  1.6e-8 K against the
-// oracle on the headline batch (requirement: 1e-6 K); active mode keeps 1e-30 / 1e-22 (dort_jacobi_kernel.hpp).
+// rotations below SKIP are not applied, a sweep without a rotation above EXIT is the last one.  Active mode keeps
+// 1e-30 / 1e-22 (dort_jacobi_kernel.hpp).  Two sets:
+//  * the pipelines that solve with the eigenvector matrices as they come (two-slot / global-workspace / big finish kernels)
+//    tolerate columns of B' that are orthogonal to 1e-6 only: 1e-22 / 1e-12, 2e-8 K against the oracle;
+//  * the register-resident finish kernel uses the orthogonality itself (the inverses of the eigenvector matrices are their
+//    transposes): with 1e-22 / 1e-12 it is at 1.6e-8 K on the headline batch but loses up to 2.4e-4 K on weakly
+//    scattering media (1.4 GHz: nearly degenerate singular values) -- tools/stress_reg_extremes.py, 860 hard pairs:
+//    1e-24 / 1e-14 -> 2.6e-6 K, 1e-26 / 1e-15 -> 1.3e-7 K (+1.1 ms per headline step), 1e-28 / 1e-16 -> 1.9e-8 K (+1.5 ms).
+//    The requirement is 1e-6 K.
 #ifndef SMRT_JACOBI_PASSIVE_SKIP_COS2
 #define SMRT_JACOBI_PASSIVE_SKIP_COS2 1e-22
 #endif
 #ifndef SMRT_JACOBI_PASSIVE_EXIT_COS2
 #define SMRT_JACOBI_PASSIVE_EXIT_COS2 1e-12
+#endif
+#ifndef SMRT_JACOBI_REG_SKIP_COS2
+#define SMRT_JACOBI_REG_SKIP_COS2 1e-26
+#endif
+#ifndef SMRT_JACOBI_REG_EXIT_COS2
+#define SMRT_JACOBI_REG_EXIT_COS2 1e-15
 #endif
 
 namespace smrt_host {

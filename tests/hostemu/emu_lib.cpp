@@ -194,8 +194,10 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
     d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
-    d.jacobi_skip2 = active ? 1e-30 : SMRT_JACOBI_PASSIVE_SKIP_COS2;   // like smrt_dort_upload
-    d.jacobi_exit2 = active ? 1e-22 : SMRT_JACOBI_PASSIVE_EXIT_COS2;
+    const bool reg_thr = !active && smrt_emu_pipeline == 3 && b->n_max_stream * 2 <= 64 && !b->host_interface_slot &&
+                         !b->process_coherent_layers && b->substrate_kind != SUB_HOST;   // where the register-resident finish kernel runs
+    d.jacobi_skip2 = active ? 1e-30 : (reg_thr ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);   // like smrt_dort_upload
+    d.jacobi_exit2 = active ? 1e-22 : (reg_thr ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
     d.out = out; d.status = status; d.layer_out = layer_out; d.stream_out = stream_out; d.n3_out = n3_out; d.stage_out = nullptr;
     long nb;
     if (gmem && plan.NMAX > 128 && smrt_emu_pipeline) {   // the big pipeline (blocked Jacobi kernel)
