@@ -3,7 +3,8 @@
 against the CPU oracle: layers from 0.1 mm to 100 m, ice volume fractions 0.05 ... 0.49, correlation lengths up to the
 30 % renormalisation limit, 1.4 ... 183 GHz, 4 ... 32 streams, with and without a substrate / atmosphere.  Pairs the
 oracle refuses must come back with the same status.
-    python tools/stress_reg_extremes.py [seed] [n_cases]"""
+    python tools/stress_reg_extremes.py [seed] [n_cases] [big | deep]
+        "big": 40 / 64 streams (the global-workspace pipeline);  "deep": up to 45 layers"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,13 +17,13 @@ from smrt_amd._native import DortContext, PackedBatch
 WORST_TWO = [0.0]   # the same pairs through the two-slot finish kernel (set_pipeline(4)), filled by run()
 
 
-def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32)):
+def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_layers=8):
   """(max |dTb| in K, pairs checked, pairs refused by both, status mismatches) of `n_cases` random hard cases."""
   rng = np.random.default_rng(seed)
   worst, checked, refused, mism = 0.0, 0, 0, 0
   WORST_TWO[0] = 0.0
   for case in range(n_cases):
-      S, L = 6, int(rng.integers(1, 9))
+      S, L = 6, int(rng.integers(1, max_layers + 1))
       n_str = int(rng.choice(list(streams)))
       thick = 10.0 ** rng.uniform(-4, 0.5, (S, L)); thick[:, -1] = rng.choice([0.3, 100.0], S)
       fv = rng.uniform(0.05, 0.49, (S, L)); temp = rng.uniform(200, 272.9, (S, L))
@@ -71,6 +72,8 @@ if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     big = len(sys.argv) > 3 and sys.argv[3] == "big"     # 40 / 64 streams: the global-workspace pipeline (both runs are that one)
-    worst, checked, refused, mism = run(seed, n_cases, DortContext(0), streams=(40, 64) if big else (4, 7, 12, 16, 24, 32))
+    deep = len(sys.argv) > 3 and sys.argv[3] == "deep"   # up to 45 layers
+    worst, checked, refused, mism = run(seed, n_cases, DortContext(0), streams=(40, 64) if big else (4, 7, 12, 16, 24, 32),
+                                        max_layers=45 if deep else 8)
     print("seed %d: %d pairs checked, max |dTb| = %.2e K (two-slot / global-workspace finish kernel on the same pairs: %.2e K); %d refused by "
           "both (renormalisation / albedo); %d status mismatches" % (seed, checked, worst, WORST_TWO[0], refused, mism))
