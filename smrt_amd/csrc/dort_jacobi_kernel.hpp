@@ -8,6 +8,13 @@
 
 namespace smrt {
 
+#ifndef SMRT_JACOBI_GS
+#define SMRT_JACOBI_GS 8     // lanes per column pair in the Jacobi kernel
+#endif
+#ifndef SMRT_JACOBI_NT
+#define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
+#endif
+
 // ---- zero-padded Jacobi step for the split pipeline ----------------------------------------------------------
 // The matrix is padded with zero rows/columns up to CP = NB*m columns and RPL*GS rows, so no lane ever needs a
 // validity test or a masked load (a zero column never rotates: g = 0).  Column norms are tracked in LDS (a rotation
@@ -49,17 +56,29 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
     }
 }
 
+// Wavefronts that rotate block pairs for an N-column item: 64 / GS = 8 column pairs per wavefront and step, so one
+// wavefront per 16 columns keeps every lane group busy (NB = 2 JW column blocks of m = ceil(N / NB) <= 8 columns).  With
+// the fixed four wavefronts of the first versions a 42 ... 48-column item (60 % of the headline batch) left a quarter
+// of every wavefront rotating the padding column.
+SMRT_HD int jacobi_waves(int N, int jw_max) {
+#ifdef SMRT_JACOBI_ALL_WAVES   // ablation build (tools/build_variant.py): the fixed wavefront count of the first versions
+    return jw_max;
+#endif
+    const int w = (N + 2 * (SMRT_LANES / SMRT_JACOBI_GS) - 1) / (2 * (SMRT_LANES / SMRT_JACOBI_GS));
+    return w < 1 ? 1 : (w > jw_max ? jw_max : w);
+}
+
 // Two-level ordering as jacobi_onesided, on a zero-padded LDS matrix (rows < RPL*GS <= LD, columns < NB*m).
 // skip2 / exit2: squared-cosine thresholds below which a rotation is skipped / does not count against convergence.
 // Passive brightness temperatures (1e-6 K of ~250 K) tolerate 1e-26 / 1e-15; the backscatter is a small difference
 // of intensities (coherent part subtracted, azimuth modes cancelling in cross-pol), so active mode uses 1e-30 / 1e-22
 // (5e-10 -> 2e-11 relative error on the fixtures, about a third of a sweep more).
-template <int NT, int JW, int GS, int RPL>
-SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nrm, int* flag,
+template <int NT, int GS, int RPL>
+SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nrm, int* flag, int JW,
                             double skip2 = SMRT_JACOBI_SKIP_COS2, double exit2 = SMRT_JACOBI_EXIT_COS2) {
     const int t = tid();
     const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
-    constexpr int NB = 2 * JW;
+    const int NB = 2 * JW;
     constexpr int SLOTS = SMRT_LANES / GS;
     const int slot = lane / GS, sub = lane % GS;
     const int m = (N + NB - 1) / NB;
@@ -184,12 +203,6 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
 // pairs a 32-lane group rotates together are ADJACENT columns (8 lanes each), so consecutive columns must start 8
 // bank slots apart to be conflict-free (with the odd LD of the other kernels they overlapped: 41 % of the LDS cycles
 // of this kernel were bank conflicts, profiles/r1f_pmc_counters.txt).
-#ifndef SMRT_JACOBI_GS
-#define SMRT_JACOBI_GS 8     // lanes per column pair in the Jacobi kernel
-#endif
-#ifndef SMRT_JACOBI_NT
-#define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
-#endif
 struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
 SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     JacobiPlan p;
@@ -198,8 +211,16 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
     // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
     const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
     p.LDJ = ((rows + 31) / 32) * 32 + SMRT_JACOBI_GS;
-    // NB * ceil(N / NB) <= this - 1, plus the idle-slot column; NB = 8 column blocks (256 threads), 16 for N > 64 (512)
-    p.NCOL = p.NMAX > 64 ? ((p.NMAX + 15) / 16) * 16 + 1 : ((p.NMAX + 7) / 8) * 8 + 1;
+    // NB * ceil(N / NB) <= this - 1 for every N <= NMAX and its NB = 2 * jacobi_waves(N) column blocks (the padded column
+    // count grows with N inside a wavefront count and reaches 16 JW at its upper end, so NMAX decides), for workgroups of
+    // four and of eight wavefronts (k_jacobi.hip launches either on 64 < N <= 128); plus the idle-slot column
+    int cpmax = 0;
+    for (int jw_max = 4; jw_max <= 8; jw_max += 4) {
+        const int nb = 2 * jacobi_waves(p.NMAX, jw_max);
+        const int cp = nb * ((p.NMAX + nb - 1) / nb);
+        if (cp > cpmax) cpmax = cp;
+    }
+    p.NCOL = cpmax + 1;
     int o = p.NCOL * p.LDJ;
     p.o_sigma = o; o += p.NMAX + 16;
     p.o_rsig = o; o += p.NMAX + 16; // tracked column norms (padded columns included)
@@ -210,9 +231,8 @@ SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
 
 template <int NT, int RPL>
 SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
-    constexpr int JW = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: 4, or 8 (N > 64)
+    constexpr int JWMAX = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: at most 4, or 8 (N > 64)
     constexpr int GS = SMRT_JACOBI_GS;
-    constexpr int NB = 2 * JW;
     const int t = tid();
     const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
     const long long p = item / ((long long)b.Lmax * nmodes);
@@ -232,12 +252,14 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     double* gB = stg.B + item * stg.mat_stride;
     // load B and zero the padding: rows N..RPL*GS-1 of every used column, columns N..CP (CP = NB*m, plus the idle
     // slot column CP itself)
+    const int JW = jacobi_waves(N, JWMAX);
+    const int NB = 2 * JW;
     const int m = (N + NB - 1) / NB;
     const int CP = NB * m;
     for_2d<NT>(RPL * GS, CP + 1, [&](int r, int c) { M[c * LDJ + r] = (r < N && c < N) ? gB[c * LD + r] : 0.0; });
     if (t == 0) ints[0] = 0;
     block_sync();
-    const bool ok = jacobi_padded<NT, JW, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], b.jacobi_skip2, b.jacobi_exit2);
+    const bool ok = jacobi_padded<NT, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], JW, b.jacobi_skip2, b.jacobi_exit2);
     if (!ok) { if (t == 0) stg.n[item] = -ST_EIGEN; return; }   // per layer, like the prep kernel's failures
 #ifdef SMRT_GJ_FAST_PANEL
     // eigenpairs out in ascending order of the singular value -- the order of the streams in the no-scattering limit,
