@@ -15,6 +15,29 @@ namespace smrt {
 #define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
 #endif
 
+// Rotation that annihilates the inner product g of two columns with squared norms a, b (dd = b - a):
+// t = sign(dd) 2g / (|dd| + sqrt(dd^2 + 4 g^2)), c = 1 / sqrt(1 + t^2), s = c t.  From the third sweep on almost every
+// rotation is a small one, and the parameters sit on the sequential chain of the kernel: for g^2 < 1e-8 dd^2 the series
+// t = (g / dd)(1 - (g / dd)^2), c = 1 - t^2 / 2, s = c t (relative errors 2e-16, 4e-17, 4e-17) replaces two of the
+// three reciprocal (square root)s and their Newton steps.
+#ifndef SMRT_JACOBI_SMALL_ANGLE
+#define SMRT_JACOBI_SMALL_ANGLE 1e-8
+#endif
+SMRT_DEV void jacobi_rotation(double gg, double g2, double dd, double& tt, double& c, double& sn) {
+    if (g2 < SMRT_JACOBI_SMALL_ANGLE * (dd * dd)) {
+        const double t0 = gg * fast_rcp1(dd);
+        tt = t0 - t0 * (t0 * t0);
+        c = 1.0 - 0.5 * (tt * tt);
+        sn = c * tt;
+    } else {
+        const double hh = dd * dd + 4.0 * g2;
+        const double h = hh * fast_rsqrt1(hh);
+        tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);
+        c = fast_rsqrt(1.0 + tt * tt);
+        sn = c * tt;
+    }
+}
+
 // ---- zero-padded Jacobi step for the split pipeline ----------------------------------------------------------
 // The matrix is padded with zero rows/columns up to CP = NB*m columns and RPL*GS rows, so no lane ever needs a
 // validity test or a masked load (a zero column never rotates: g = 0).  Column norms are tracked in LDS (a rotation
@@ -38,10 +61,8 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
     const double g2 = gg * gg, ab = a * bb;
     if (g2 > skip2 * ab) {
         const double dd = bb - a;
-        const double hh = dd * dd + 4.0 * g2;
-        const double h = hh * fast_rsqrt1(hh);
-        const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);
-        const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
+        double tt, c, sn;
+        jacobi_rotation(gg, g2, dd, tt, c, sn);
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int r = sub + i * GS;
@@ -156,10 +177,8 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                     const double g2 = gg * gg, ab = a * bb;
                     if (g2 > skip2 * ab) {
                         const double dd = bb - a;
-                        const double hh = dd * dd + 4.0 * g2;
-                        const double h = hh * fast_rsqrt1(hh);
-                        const double tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);
-                        const double c = fast_rsqrt(1.0 + tt * tt), sn = c * tt;
+                        double tt, c, sn;
+                        jacobi_rotation(gg, g2, dd, tt, c, sn);
 #pragma unroll
                         for (int i = 0; i < RPL; ++i) {
                             const double xn = c * x[i] - sn * y[i];
