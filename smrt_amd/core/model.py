@@ -71,6 +71,51 @@ def make_model(emmodel=None, rtsolver=None, emmodel_options=None, rtsolver_optio
     return Model(emmodel, rtsolver, emmodel_options=emmodel_options, rtsolver_options=rtsolver_options)
 
 
+# ---- which emmodel, with which options, for which layer ------------------------------------------------------------
+# Free functions of (model.emmodel, model.emmodel_options): they serve smrt_amd's Model and -- through
+# rtsolver/dort.py:DORT.emmodel_names -- a Model of the reference package handed to HipBatchRunner by its own `run`.
+def select_emmodel(emmodel, index, layer, n_layers, make=None):
+    """The emmodel class for one layer: from the per-layer list, the per-medium dict, the layer's own attribute or the
+    model-wide class, in the reference's order of precedence (smrt/core/model.py:529-554).  `make`: the make_emmodel
+    that resolves a layer's own emmodel given by name (default: smrt_amd's)."""
+    make = make or make_emmodel
+    own = getattr(layer, "emmodel", None)
+    if is_sequence(emmodel):
+        if len(emmodel) != n_layers:
+            raise SMRTError("the list of emmodels must have the same length as the number of layers")
+        chosen = emmodel[index]
+    elif isinstance(emmodel, Mapping):
+        if layer.medium not in emmodel:
+            raise SMRTError(f"no emmodel is given for the medium '{layer.medium}'")
+        chosen = emmodel[layer.medium]
+    else:
+        if own is not None:
+            return make(own)
+        chosen = emmodel
+    if own is not None:
+        smrt_warn("a layer defines its own emmodel but the model was given a list / dict of emmodels: the layer's "
+                  "emmodel is ignored")
+    if chosen is None:
+        raise SMRTError("no emmodel: give one to make_model or to every layer")
+    return chosen
+
+
+def select_emmodel_options(emmodel, options, layer, index=None, n_layers=None):
+    """The options of one layer's emmodel, in the reference's order (smrt/core/model.py:556-569): the entry of a
+    per-layer sequence, the per-medium dict of dicts that goes with a dict of emmodels, else the layer's own options or
+    the model-wide dict."""
+    if is_sequence(options):
+        if index is None or n_layers is None or len(options) != n_layers:
+            raise SMRTError("the list of emmodel_options must have the same length as the number of layers")
+        return options[index]
+    if isinstance(emmodel, Mapping) and options and all(isinstance(o, Mapping) for o in options.values()):
+        if layer.medium not in options:
+            raise SMRTError(f"no emmodel_options are given for the medium '{layer.medium}'")
+        return dict(options[layer.medium])
+    own = getattr(layer, "emmodel_options", None)
+    return own if own else options
+
+
 # ---- the flattened grid ------------------------------------------------------------------------------------------
 @dataclass
 class SimulationPlan:
@@ -259,43 +304,12 @@ class Model(object):
 
     # ---- one simulation (the unit a generic runner maps over) ----------------------------------------------------
     def emmodel_of_layer(self, index, layer, n_layers):
-        """The emmodel class for one layer: from the per-layer list, the per-medium dict, the layer's own attribute or
-        the model-wide class, in the reference's order of precedence (smrt/core/model.py:529-582)."""
-        if isinstance(self.emmodel, list):
-            if len(self.emmodel) != n_layers:
-                raise SMRTError("the list of emmodels must have the same length as the number of layers")
-            chosen = self.emmodel[index]
-        elif isinstance(self.emmodel, dict):
-            if layer.medium not in self.emmodel:
-                raise SMRTError(f"no emmodel is given for the medium '{layer.medium}'")
-            chosen = self.emmodel[layer.medium]
-        else:
-            own = getattr(layer, "emmodel", None)
-            if own is not None:
-                return make_emmodel(own)
-            chosen = self.emmodel
-        if getattr(layer, "emmodel", None) is not None and not isinstance(self.emmodel, type):
-            smrt_warn("a layer defines its own emmodel but the model was given a list / dict of emmodels: the layer's "
-                      "emmodel is ignored")
-        if chosen is None:
-            raise SMRTError("no emmodel: give one to make_model or to every layer")
-        return chosen
+        """The emmodel class for one layer (`select_emmodel` on this model's configuration)."""
+        return select_emmodel(self.emmodel, index, layer, n_layers)
 
     def emmodel_options_of_layer(self, layer, index=None, n_layers=None):
-        """The options of one layer's emmodel, in the reference's order (smrt/core/model.py:556-569): the entry of a
-        per-layer sequence, the per-medium dict of dicts that goes with a dict of emmodels, else the layer's own
-        options or the model-wide dict."""
-        opts = self.emmodel_options
-        if isinstance(opts, list):
-            if index is None or n_layers is None or len(opts) != n_layers:
-                raise SMRTError("the list of emmodel_options must have the same length as the number of layers")
-            return opts[index]
-        if isinstance(self.emmodel, dict) and opts and all(isinstance(o, Mapping) for o in opts.values()):
-            if layer.medium not in opts:
-                raise SMRTError(f"no emmodel_options are given for the medium '{layer.medium}'")
-            return dict(opts[layer.medium])
-        own = getattr(layer, "emmodel_options", None)
-        return own if own else opts
+        """The options of one layer's emmodel (`select_emmodel_options` on this model's configuration)."""
+        return select_emmodel_options(self.emmodel, self.emmodel_options, layer, index, n_layers)
 
     def prepare_emmodels(self, sensor, snowpack):
         """One emmodel instance per layer."""

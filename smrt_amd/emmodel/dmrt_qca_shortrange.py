@@ -9,6 +9,6 @@ class DMRT_QCA_ShortRange(_DeviceEMModel):
     def __init__(self, sensor, layer, dense_snow_correction="auto"):
         if dense_snow_correction != "auto":
             raise SMRTError("smrt_amd's DMRT_QCA_ShortRange implements dense_snow_correction='auto' only")
-        if layer.microstructure_model != "sticky_hard_spheres":
+        super().__init__(sensor, layer)   # (a layer of the reference package is adopted there: self.layer)
+        if self.layer.microstructure_model != "sticky_hard_spheres":
             raise SMRTError("DMRT_QCA_ShortRange is only compatible with SHS microstructure model")
-        super().__init__(sensor, layer)

@@ -10,6 +10,6 @@ class DMRT_QCACP_ShortRange(_DeviceEMModel):
     def __init__(self, sensor, layer, dense_snow_correction="auto"):
         if dense_snow_correction != "auto":
             raise SMRTError("smrt_amd's DMRT_QCACP_ShortRange implements dense_snow_correction='auto' only")
-        if layer.microstructure_model != "sticky_hard_spheres":
+        super().__init__(sensor, layer)   # (a layer of the reference package is adopted there: self.layer)
+        if self.layer.microstructure_model != "sticky_hard_spheres":
             raise SMRTError("DMRT_QCACP_ShortRange is only compatible with SHS microstructure model")
-        super().__init__(sensor, layer)

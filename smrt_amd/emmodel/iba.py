@@ -19,6 +19,14 @@ class _DeviceEMModel:
         if np.ndim(sensor.frequency) != 0:
             raise SMRTError("an emmodel instance needs a single-frequency sensor")
         self.sensor = sensor
+        if not hasattr(layer.microstructure, "device_params"):
+            # a layer object of the reference package (its Model.prepare_emmodels instantiates this class with it,
+            # smrt/core/model.py:571-582): read through core/foreign.py; what the device cannot compute is refused
+            from ..core.foreign import AdoptedLayer
+
+            layer = AdoptedLayer(layer)
+            if layer.device_refusal:
+                raise SMRTError(f"the device emmodel {type(self).__name__} cannot compute this layer: {layer.device_refusal}")
         self.layer = layer
         self.frequency = float(sensor.frequency)
         self.npol = 2 if sensor.mode == "P" else 3

@@ -18,6 +18,7 @@ import numpy as np
 from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
 from ..core.error import SMRTError, smrt_warn
 from ..core.globalconstants import C_SPEED
+from ..core.foreign import result_factory
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack, substrate_kind
 from ..interface.flat import Flat
@@ -84,11 +85,17 @@ class DORT(object):
         """One (snowpack, sensor configuration).  `emmodels`: the per-layer instances made by Model.prepare_emmodels;
         they must be smrt_amd's device-backed classes, all of one kind (the device recomputes their numbers from the
         layer properties)."""
+        from ..core.foreign import adopt_atmosphere, adopt_snowpack, entry_of_instance
+
+        snowpack = adopt_snowpack(snowpack)     # the reference's own Snowpack (smrt/core/model.py:609-615) or smrt_amd's
         if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
             snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
-                                atmosphere=atmosphere)
-        # device-backed instances by the device emmodel of their layer; any other instance is evaluated on the host
-        entries = [getattr(e, "_device_name", None) or getattr(type(e), "device_name", None) or e for e in emmodels]
+                                atmosphere=adopt_atmosphere(atmosphere))
+        if len(emmodels) != snowpack.nlayer:
+            raise SMRTError("one emmodel per layer is needed")
+        # device-backed instances (and the reference's instances the device reproduces) by the device emmodel of their
+        # layer; any other instance is evaluated on the host
+        entries = [entry_of_instance(e, layer) for e, layer in zip(emmodels, snowpack.layers)]
         return self.solve_batch([(sensor, snowpack)], [entries])[0]
 
     # ---- batched entry points ------------------------------------------------------------------------------------
@@ -102,11 +109,15 @@ class DORT(object):
 
     def solve_batch(self, simulations, emmodel):
         """simulations: sequence of (single-frequency sensor, snowpack).  One Result per simulation, in order.
-        emmodel: one emmodel class for every layer, or -- aligned with the distinct snowpacks in order of first
-        appearance -- a list of per-layer lists of device names for snowpacks that mix emmodels."""
+        emmodel: one emmodel class (or device emmodel name) for every layer, or -- aligned with the distinct snowpacks in
+        order of first appearance -- a list of per-layer lists of entries (device name, (class, options) pair or ready
+        instance) for snowpacks that mix emmodels.  The snowpacks may be the reference's own objects (core/foreign.py)."""
+        from ..core.foreign import adopt_snowpack
+
         sensors, packs, si, pi = [], [], [], []
-        seen_s, seen_p = {}, {}
+        seen_s, seen_p, memo = {}, {}, {}
         for sensor, sp in simulations:
+            sp = adopt_snowpack(sp, memo)
             si.append(seen_s.setdefault(id(sensor), len(sensors)))
             if si[-1] == len(sensors):
                 sensors.append(sensor)
@@ -115,7 +126,7 @@ class DORT(object):
                 packs.append(sp)
         if not si:
             return []
-        names = emmodel if isinstance(emmodel, list) else self._device_name(emmodel)
+        names = emmodel if isinstance(emmodel, (list, str)) else self._device_name(emmodel)
         sol = self._solve_indexed(sensors, packs, np.asarray(si), np.asarray(pi), names)
         return [sol.result(i) for i in range(len(si))]
 
@@ -136,38 +147,53 @@ class DORT(object):
         through Model.prepare_emmodels (per-layer overrides, lists / dicts of emmodels and emmodel options are honoured
         or refused, never dropped): one device name when all the layers of all the snowpacks share it, otherwise a list
         (per snowpack) of lists (per layer).  One instance is made per distinct (class, options) pair, which validates
-        the options against the class."""
-        simple = isinstance(model.emmodel, type)
+        the options against the class.  `model` is smrt_amd's Model or the reference's (only its public attributes
+        `emmodel` and `emmodel_options` are read, smrt/core/model.py:254-283); the snowpacks of the plan are smrt_amd's
+        or adopted ones (core/foreign.py)."""
+        from ..core.foreign import device_entry, is_native, model_make_emmodel
+        from ..core.model import is_sequence, select_emmodel, select_emmodel_options
+
+        emmodel, all_options = model.emmodel, model.emmodel_options
+        make = None if is_native(model) else model_make_emmodel(model)
+        simple = isinstance(emmodel, type)
         checked = set()
         per_pack, distinct = [], set()
-        simple_name = getattr(model.emmodel, "device_name", None) if simple else None
+        simple_name = getattr(emmodel, "device_name", None) if simple else None
         simple_options = None
         for sp in plan.snowpacks:
             n = sp.nlayer
-            plain = (simple and not sp.has_layer_emmodels() and not isinstance(model.emmodel_options, list)
-                     and model.emmodel_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
-            if plain and simple_name is not None and simple_options is not None:
-                # the common case -- one device emmodel, no per-layer settings, options already validated: no per-layer work
+            plain = (simple and not sp.has_layer_emmodels() and not is_sequence(all_options)
+                     and all_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
+            if plain and simple_name is not None and simple_options is not None and not hasattr(sp, "source"):
+                # the common case -- one device emmodel, no per-layer settings, options already validated, smrt_amd's own
+                # layers (nothing the device could not compute): no per-layer work
                 distinct.add(simple_name)
                 per_pack.append([simple_name] * n)
                 continue
             if plain:
-                kinds = [model.emmodel] * n
-                todo = [(model.emmodel, sp.layers[0], 0)]
+                kinds = [emmodel] * n
+                options = [all_options] * n
+                todo = [0]
                 simple_options = True
             else:
-                kinds = [model.emmodel_of_layer(k, layer, n) for k, layer in enumerate(sp.layers)]
-                todo = [(kind, layer, k) for k, (kind, layer) in enumerate(zip(kinds, sp.layers))]
-            for kind, layer, k in todo:
-                options = model.emmodel_options_of_layer(layer, k, n)
-                key = (kind, tuple(sorted(options.items())), options.get("dense_snow_correction") == "auto" and layer.frac_volume > 0.5)
+                kinds = [select_emmodel(emmodel, k, layer, n, make) for k, layer in enumerate(sp.layers)]
+                options = [select_emmodel_options(emmodel, all_options, layer, k, n) for k, layer in enumerate(sp.layers)]
+                todo = range(n)
+            for k in todo:
+                kind, layer, opts = kinds[k], sp.layers[k], options[k]
+                key = (kind, tuple(sorted(opts.items())), opts.get("dense_snow_correction") == "auto" and layer.frac_volume > 0.5)
                 if key not in checked:
                     checked.add(key)
-                    kind(plan.sensors[0], layer, **options)     # validates the options against the class
+                    # validates the options against the class (a class of the reference sees the reference's layer)
+                    kind(plan.sensors[0], layer if is_native(kind) else getattr(layer, "source", layer), **opts)
             # a class without a device implementation is evaluated on the host, layer by layer (_evaluate_on_host)
-            names = [kd.device_name_for(layer, model.emmodel_options_of_layer(layer, k, n))
-                     if getattr(kd, "device_name", None) else (kd, model.emmodel_options_of_layer(layer, k, n))
-                     for k, (kd, layer) in enumerate(zip(kinds, sp.layers))]
+            names = [device_entry(kd, opts, layer) for kd, opts, layer in zip(kinds, options, sp.layers)]
+            if any(not isinstance(e, str) for e in names):
+                # the snowpack goes to the host route as a whole: a layer whose class of the REFERENCE package was mapped
+                # to a device emmodel is evaluated by that class as well (one implementation per snowpack, and no device
+                # round trip per layer through smrt_amd's descriptor)
+                names = [(kd, dict(opts)) if isinstance(e, str) and not getattr(kd, "device_name", None) else e
+                         for e, kd, opts in zip(names, kinds, options)]
             distinct.update(n if isinstance(n, str) else "host" for n in names)
             per_pack.append(names)
         return distinct.pop() if len(distinct) == 1 and "host" not in distinct else per_pack
@@ -192,7 +218,8 @@ class DORT(object):
             s_code[k] = sensor_keys.setdefault(key, len(sensor_keys))
         p_code = np.empty(len(packs), np.int64)
         for k, sp in enumerate(packs):
-            key = (substrate_kind(sp.substrate), id(sp.atmosphere) if sp.atmosphere is not None else None)
+            on_host = not isinstance(emmodel_names, str) and any(not isinstance(e, str) for e in emmodel_names[k])
+            key = (substrate_kind(sp.substrate), id(sp.atmosphere) if sp.atmosphere is not None else None, on_host)
             p_code[k] = pack_keys.setdefault(key, len(pack_keys))
         freq = np.array([float(s.frequency) for s in sensors])
         code = s_code[sens_idx] * len(pack_keys) + p_code[pack_idx]
@@ -535,6 +562,7 @@ class DORT(object):
         import copy
 
         from .._native import gauss_legendre_positive
+        from ..core.foreign import is_native
         from ..core.plugin import import_class
 
         mode = sensor0.mode
@@ -555,13 +583,19 @@ class DORT(object):
 
         def instance(entry, sensor, layer):
             if isinstance(entry, str):
+                # a device emmodel inside a group that is evaluated on the host: its descriptor class speaks the protocol
+                # too ("iba_inverted" is IBA under dense_snow_correction="auto", the only option the device names carry)
+                if entry == "iba_inverted":
+                    return import_class("emmodel", "iba")(sensor, layer, dense_snow_correction="auto")
                 return import_class("emmodel", entry)(sensor, layer)
             if isinstance(entry, tuple):
-                return entry[0](sensor, layer, **entry[1])
+                # a class of the reference package is given the reference's own layer object (core/foreign.py)
+                target = layer if is_native(entry[0]) else getattr(layer, "source", layer)
+                return entry[0](sensor, target, **entry[1])
             return entry
 
         def scalar(value, what):
-            a = np.asarray(value, float).ravel()
+            a = np.asarray(getattr(value, "values", value), float).ravel()   # (an smrt_matrix keeps its array in .values)
             if a.size == 0 or not np.allclose(a, a[0], rtol=1e-12, atol=0.0):
                 raise SMRTError(f"smrt_amd's DORT needs an isotropic {what} (one number per layer)")
             return float(a[0])
@@ -598,7 +632,8 @@ class DORT(object):
                     if hl[fi, s, l, 0] == 0.0 or n == 0:
                         continue
                     full = np.concatenate((mu, -mu))
-                    ft = np.asarray(em.ft_even_phase(full, full, m_arg, npol=P), float)
+                    ft = em.ft_even_phase(full, full, m_arg, npol=P)
+                    ft = np.asarray(getattr(ft, "values", ft), float)
                     if ft.shape != (P, P, modes, 2 * n, 2 * n):
                         raise SMRTError(f"ft_even_phase returned the shape {ft.shape}, expected {(P, P, modes, 2 * n, 2 * n)}")
                     # (ps, pi, m, mu_s, mu_i) -> m, (mu_s, ps), (mu_i, pi): the compressed order of core/lib.py:336-347
@@ -678,15 +713,17 @@ class _Solution:
         outmu = self._reported_streams(sensor, out.streams[row])
         layer_idx = ("layer", np.arange(L))
         lay = layers[:L]
+        # smrt_amd's Result, or the caller's own when the sensor belongs to the reference package (core/foreign.py)
+        make, labelled = result_factory(sensor)
         other = {
-            "stream_angles": LabeledArray(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
-            "effective_permittivity": LabeledArray(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
-            "ks": LabeledArray(lay[:, 2].copy(), [layer_idx], name="ks"),
-            "ke": LabeledArray(lay[:, 2] + lay[:, 3], [layer_idx], name="ke"),
-            "ka": LabeledArray(lay[:, 3].copy(), [layer_idx], name="ka"),
-            "thickness": LabeledArray(thickness, [layer_idx], name="thickness"),
+            "stream_angles": labelled(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
+            "effective_permittivity": labelled(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
+            "ks": labelled(lay[:, 2].copy(), [layer_idx], name="ks"),
+            "ke": labelled(lay[:, 2] + lay[:, 3], [layer_idx], name="ke"),
+            "ka": labelled(lay[:, 3].copy(), [layer_idx], name="ka"),
+            "thickness": labelled(np.asarray(thickness, float), [layer_idx], name="thickness"),
         }
-        return make_result(sensor, out.values[row], self._coords(sensor), other_data=other)
+        return make(sensor, out.values[row], self._coords(sensor), other_data=other)
 
     def stacked_result(self, plan):
         """All simulations as ONE Result whose leading dimensions are the plan's -- built from the output arrays by

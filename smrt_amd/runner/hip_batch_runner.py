@@ -10,8 +10,13 @@ Two ways in:
   list becomes one device batch per GPU and one Result per item comes back, in order.
 
 Either way the emmodel configuration of the model is honoured the way the per-simulation route honours it: per-layer
-emmodels and emmodel options go through `Model.emmodel_of_layer` / `emmodel_options_of_layer` and the emmodel class
-validates the options; what the device path cannot do raises SMRTError instead of being ignored."""
+emmodels and emmodel options go through `select_emmodel` / `select_emmodel_options` (core/model.py) and the emmodel
+class validates the options; what the device path cannot do raises SMRTError instead of being ignored.
+
+The second way is also how the REFERENCE's own `Model.run(..., runner=HipBatchRunner())` arrives: `function.__self__`
+is then smrt's Model, the snowpacks and sensors are smrt's objects and the results go back as smrt's Result (so that
+its `concat_results` nests them) -- core/foreign.py reads those objects, INTEGRATION.md section 1 shows the call and
+tests/test_reference_binding.py executes it."""
 import inspect
 
 from ..core.error import SMRTError
@@ -60,14 +65,16 @@ class HipBatchRunner(object):
         rtsolver = self._rtsolver(model)
         if not hasattr(rtsolver, "solve_batch"):
             raise SMRTError("HipBatchRunner needs an rtsolver with a solve_batch method (smrt_amd.rtsolver.dort.DORT)")
+        from ..core.foreign import adopt_snowpack
         from ..core.model import SimulationPlan  # the same emmodel checks as run_plan
         import numpy as np
 
-        simulations = [simul for simul, _, _ in args]
+        # the reference's own Snowpack objects (its Model.run hands them over as they are, smrt/core/model.py:395-398) are
+        # read through their public attributes once per distinct snowpack; smrt_amd's own pass through untouched
+        memo = {}
+        simulations = [(sensor, adopt_snowpack(sp, memo)) for (sensor, sp), _, _ in args]
         sensors = list({id(s): s for s, _ in simulations}.values())
         packs = list({id(p): p for _, p in simulations}.values())
         probe = SimulationPlan(sensors, packs, np.zeros(0, int), np.zeros(0, int))
         emmodel = rtsolver.emmodel_names(model, probe) if hasattr(rtsolver, "emmodel_names") else model.emmodel
-        if isinstance(emmodel, str):   # uniform: solve_batch takes the class (any layer's will do)
-            emmodel = model.emmodel_of_layer(0, packs[0].layers[0], packs[0].nlayer)
         return rtsolver.solve_batch(simulations, emmodel)

@@ -400,3 +400,99 @@ def assert_backscatter_close(r, ref, rtol=SIGMA_RTOL, cross_rtol=SIGMA_RTOL, spr
     assert not bad.any(), "backscatter off by up to %.2e relative (allowed %.2e there)" % (rel[bad].max(), tol[bad].max())
     # third Stokes rows/columns are multiplied by sin(m pi) ~ 1e-16 in backscatter: only their level is meaningful
     assert np.abs(r[..., 2, :, :]).max() <= 10 * np.abs(ref[..., 2, :, :]).max() + 1e-30
+
+
+# ---- stand-ins for the reference's objects (tests/golden/reference_objects.json, made by make_binding_dump.py) --------
+def _undump(v):
+    if isinstance(v, dict) and "complex" in v:
+        return complex(*v["complex"])
+    if isinstance(v, dict) and "dict" in v:
+        return {(tuple(k) if isinstance(k, list) else k): _undump(x) for k, x in v["dict"]}
+    if isinstance(v, list):
+        return [_undump(x) for x in v]
+    return v
+
+
+_STANDIN_CLASSES = {}
+
+
+def standin_class(module, name, **members):
+    """A class that carries the reference class's identity (module, name) and nothing of its code."""
+    key = (module, name)
+    if key not in _STANDIN_CLASSES:
+        _STANDIN_CLASSES[key] = type(name, (), dict(__module__=module, **members))
+    return _STANDIN_CLASSES[key]
+
+
+def _standin(cls_id, **attrs):
+    obj = standin_class(*cls_id)()
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+def standins_from_dump(case):
+    """(model, simulations, snowpacks, expected results) of one case of reference_objects.json: objects with the classes'
+    names, modules and public attributes of the reference's -- what its `Model.run` would hand to a runner -- and none of
+    its behaviour beyond `substrate.permittivity(frequency)` (a table) and a constructor for the emmodel class."""
+    def function(module, name):
+        def f(*a, **k):
+            raise AssertionError("a stand-in permittivity function is never evaluated")
+        f.__module__, f.__name__ = module, name
+        return f
+
+    def layer(d):
+        ms = _standin(d["microstructure"]["cls"], **{k: _undump(v) for k, v in d["microstructure"]["attrs"].items()})
+        pm = tuple(function(*p["function"]) if isinstance(p, dict) and "function" in p else _undump(p) for p in d["permittivity_model"])
+        return _standin(d["cls"], microstructure=ms, microstructure_model=type(ms), permittivity_model=pm,
+                        frac_volume=d["frac_volume"], **{k: _undump(v) for k, v in d["attrs"].items()})
+
+    def substrate(d):
+        if d is None:
+            return None
+        table = None if d["permittivity"] is None else {f: _undump(e) for f, e in d["permittivity"]}
+        cls = standin_class(*d["cls"], permittivity=lambda self, frequency: self._table[frequency],
+                            specular_reflection_matrix=lambda self, *a: None)
+        obj = cls()
+        obj.temperature, obj._table = d["temperature"], table
+        obj.specular_reflection = _undump(d["specular_reflection"])
+        return obj
+
+    def snowpack(d):
+        layers = [layer(x) for x in d["layers"]]
+        sp = _standin(d["cls"], layers=layers, interfaces=[standin_class(*c)() for c in d["interfaces"]],
+                      substrate=substrate(d["substrate"]),
+                      atmosphere=None if d["atmosphere"] is None else
+                      _standin(d["atmosphere"]["cls"], **{k: _undump(v) for k, v in d["atmosphere"]["attrs"].items()}))
+        type(sp).nlayer = property(lambda self: len(self.layers))
+        type(sp).layer_thicknesses = property(lambda self: [lay.thickness for lay in self.layers])
+        return sp
+
+    def sensor(d):
+        attrs = {k: _undump(v) for k, v in d["attrs"].items()}
+        for k in ("theta_deg", "theta", "theta_inc_deg", "theta_inc"):
+            attrs[k] = None if attrs[k] is None else np.asarray(attrs[k], float)
+        return _standin(d["cls"], mode=d["mode"], **attrs)
+
+    def emmodel_init(self, sensor, layer, **options):
+        self.options = options
+
+    md = case["model"]
+    emmodel = standin_class(*md["emmodel"], __init__=emmodel_init)
+    model_cls = standin_class(*md["cls"], run_single_simulation=lambda self, simulation, atmosphere, parallel_computation: None)
+    model = model_cls()
+    from smrt_amd.rtsolver.dort import DORT
+
+    model.emmodel, model.emmodel_options = emmodel, _undump(md["emmodel_options"])
+    model.rtsolver, model.rtsolver_options = DORT, _undump(md["rtsolver_options"])
+    sensors = [sensor(s) for s in case["sensors"]]
+    packs = [snowpack(s) for s in case["snowpacks"]]
+    sims = [(sensors[i], packs[j]) for i, j in case["simulations"]]
+    return model, sims, packs, [np.asarray(r) for r in case["results"]]
+
+
+def load_reference_objects():
+    import json
+
+    with open(os.path.join(GOLDEN, "reference_objects.json")) as f:
+        return {c["name"]: c for c in json.load(f)["cases"]}

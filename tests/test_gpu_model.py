@@ -596,3 +596,39 @@ def test_rough_substrate_passive_through_the_model():
             sensor_list.passive(float(d["frequency"][0]), list(d["theta_deg"])), sp)
         np.testing.assert_allclose(np.ravel(res.TbV()), d["result"][0, 0], atol=1e-6)
         np.testing.assert_allclose(np.ravel(res.TbH()), d["result"][0, 1], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["headline_shape_two_snowpacks", "flat_substrate_and_atmosphere", "dmrt_on_a_reflector",
+                                  "active_dense_auto"])
+def test_reference_shaped_objects_through_the_runner(name):
+    """What the reference's `Model.run(..., runner=HipBatchRunner())` hands over (smrt/core/model.py:395-398), replayed
+    on the GPU box -- which has no smrt package -- as stand-ins that carry the class identities and public attributes
+    dumped from REAL smrt objects (tests/golden/reference_objects.json): bound `run_single_simulation` of an smrt-shaped
+    Model, ((sensor, snowpack), atmosphere, parallel_computation) triples.  One Result per item, in order, equal to
+    what smrt's own iba | dmrt + dort returned for those objects; the rtsolver protocol (DORT.solve per simulation with
+    stand-in emmodel instances) gives the same bits."""
+    from conftest import load_reference_objects, standins_from_dump
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    case = load_reference_objects()[name]
+    model, sims, packs, want = standins_from_dump(case)
+    results = HipBatchRunner()(model.run_single_simulation, [(sim, None, "outer") for sim in sims])
+    assert len(results) == len(sims)
+    for (sensor, sp), res, ref in zip(sims, results, want):
+        got = np.asarray(res.data.values)
+        assert got.shape == ref.shape
+        if sensor.mode == "P":
+            assert np.abs(got - ref).max() < 1e-6
+        else:
+            assert_backscatter_close(got, ref)
+        np.testing.assert_allclose(res.other_data["thickness"].values, [lay.thickness for lay in sp.layers])
+    # the rtsolver protocol: what Model.run_single_simulation does per item (model.py:596-617)
+    from smrt_amd.rtsolver.dort import DORT
+
+    sensor, sp = sims[-1]
+    emmodels = [model.emmodel(sensor, layer, **model.emmodel_options) for layer in sp.layers]
+    if name == "active_dense_auto":   # the reference's IBA instance keeps the volume fraction it worked with (iba.py:96-99)
+        for em, layer in zip(emmodels, sp.layers):
+            em.frac_volume = 1.0 - layer.frac_volume if layer.frac_volume > 0.5 else layer.frac_volume
+    one = DORT(**model.rtsolver_options).solve(sp, emmodels, sensor, sp.atmosphere)
+    assert np.array_equal(np.asarray(one.data.values), np.asarray(results[-1].data.values))

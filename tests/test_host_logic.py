@@ -649,3 +649,151 @@ def test_snowpack_caches_follow_layer_changes():
     sp.packed()
     sp.layers[0] = other                                     # same count, another object
     assert sp.packed()[0, 0] == 0.77 and not sp.has_layer_emmodels()
+
+
+def _own_objects_of(case):
+    """smrt_amd's own make_snowpack / sensor objects for the numbers of a reference_objects.json case."""
+    from conftest import _undump
+    from smrt_amd import make_snowpack
+    from smrt_amd.atmosphere.simple_isotropic_atmosphere import SimpleIsotropicAtmosphere
+    from smrt_amd.core.sensor import Sensor
+    from smrt_amd.substrate.flat import Flat
+    from smrt_amd.substrate.reflector import Reflector
+
+    packs = []
+    for d in case["snowpacks"]:
+        lay = d["layers"]
+        ms = lay[0]["microstructure"]["cls"][1]
+        kw = dict(density=[x["attrs"]["density"] for x in lay], temperature=[x["attrs"]["temperature"] for x in lay])
+        if ms == "Exponential":
+            name, kw["corr_length"] = "exponential", [x["microstructure"]["attrs"]["corr_length"] for x in lay]
+        else:
+            name = "sticky_hard_spheres"
+            kw["radius"] = [x["microstructure"]["attrs"]["radius"] for x in lay]
+            kw["stickiness"] = [x["microstructure"]["attrs"]["stickiness"] for x in lay]
+        sub = d["substrate"]
+        if sub is not None and sub["cls"][1] == "Flat":
+            table = {f: _undump(e) for f, e in sub["permittivity"]}
+            kw["substrate"] = Flat(temperature=sub["temperature"], permittivity_model=lambda f, _t=None, table=table: table[f])
+        elif sub is not None:
+            kw["substrate"] = Reflector(temperature=sub["temperature"], specular_reflection=_undump(sub["specular_reflection"]))
+        if d["atmosphere"] is not None:
+            a = {k: _undump(v) for k, v in d["atmosphere"]["attrs"].items()}
+            kw["atmosphere"] = SimpleIsotropicAtmosphere(tb_down=a["constant_tbdown"], tb_up=a["constant_tbup"],
+                                                         transmittance=a["constant_trans"])
+        packs.append(make_snowpack([x["attrs"]["thickness"] for x in lay], name, **kw))
+    sensors = []
+    for s in case["sensors"]:
+        a = s["attrs"]
+        sensors.append(Sensor(frequency=a["frequency"], theta_deg=a["theta_deg"], theta_inc_deg=a["theta_inc_deg"],
+                              polarization=a["polarization"], polarization_inc=a["polarization_inc"],
+                              phi_deg=None if not np.any(a["phi"]) else np.rad2deg(a["phi"]), channel_map=_undump(a["channel_map"])))
+    return [(sensors[i], packs[j]) for i, j in case["simulations"]]
+
+
+class _RecordingContext:
+    """Stands where rtsolver/dort.py:get_context returns the GPU context: records the batches, answers zeros."""
+
+    def __init__(self):
+        import threading
+
+        self.lock, self.batches = threading.RLock(), []
+
+    def set_block_threads(self, n):
+        pass
+
+    def run(self, batch, lo=0, n=None, pairs=None):
+        from smrt_amd._native import BatchOutput
+
+        self.batches.append((batch, None if pairs is None else np.array(pairs)))
+        out = BatchOutput(batch, (batch.n_pairs - lo if n is None else n) if pairs is None else len(pairs))
+        for a in (out.values, out.status, out.layers, out.streams):
+            a[...] = 0
+        out.streams[:, :3] = 2.0, 0.9, 0.5      # two air streams, so that the active result finds its incident ones
+        return out
+
+
+def _batch_bytes(batch):
+    import ctypes as C
+
+    out = {k: (v.dtype.str, v.shape, v.tobytes()) for k, v in vars(batch).items() if isinstance(v, np.ndarray)}
+    for k, v in vars(batch).items():
+        if isinstance(v, list) and v and all(isinstance(a, np.ndarray) for a in v):
+            out[k] = [(a.dtype.str, a.shape, a.tobytes()) for a in v]
+    for name, ctype in batch.struct._fields_:
+        if ctype in (C.c_int32, C.c_double):
+            out["struct." + name] = getattr(batch.struct, name)
+    return out
+
+
+@pytest.mark.parametrize("name", ["headline_shape_two_snowpacks", "flat_substrate_and_atmosphere", "dmrt_on_a_reflector",
+                                  "active_dense_auto"])
+def test_reference_shaped_objects_are_packed_like_own_objects(name, monkeypatch):
+    """The runner protocol fed with stand-ins that carry the class identities and public attributes of the REFERENCE's
+    Model / Sensor / Snowpack / Layer objects (tests/golden/reference_objects.json, dumped from real ones) -- what
+    smrt/core/model.py:395-398 hands over -- gives bitwise the device batch smrt_amd's own objects give, with the
+    reference's emmodel CLASS mapped to the device emmodel (incl. dense_snow_correction="auto" layer by layer).  The
+    executed counterpart with the real package: tests/test_reference_binding.py; on the GPU: tests/test_gpu_model.py."""
+    import smrt_amd.rtsolver.dort as dort
+    from conftest import load_reference_objects, standins_from_dump
+    from smrt_amd.rtsolver.dort import DORT
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    ctx = _RecordingContext()
+    monkeypatch.setattr(dort, "get_context", lambda device=None: ctx)
+    case = load_reference_objects()[name]
+    model, sims, packs, _ = standins_from_dump(case)
+    results = HipBatchRunner()(model.run_single_simulation, [(sim, None, "outer") for sim in sims])
+    assert len(results) == len(sims)
+    foreign = list(ctx.batches)
+    del ctx.batches[:]
+    own = _own_objects_of(case)
+    emmodel = {"IBA": "iba", "DMRT_QCA_ShortRange": "dmrt_qca_shortrange"}[case["model"]["emmodel"][1]]
+    options = model.rtsolver_options
+    if name == "active_dense_auto":   # what smrt_amd's own Model does with that option: per-layer device names
+        entries = [["iba_inverted" if lay.frac_volume > 0.5 else "iba" for lay in own[0][1].layers]]
+        DORT(**options).solve_batch(own, entries)
+    else:
+        DORT(**options).solve_batch(own, emmodel)
+    assert len(foreign) == len(ctx.batches) == 1
+    a, b = _batch_bytes(foreign[0][0]), _batch_bytes(ctx.batches[0][0])
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k] == b[k], f"the device batches differ in '{k}'"
+    assert (foreign[0][1] is None) == (ctx.batches[0][1] is None)
+
+
+def test_layers_of_the_reference_the_device_cannot_compute_are_not_computed_as_dry_snow():
+    """core/foreign.py: wet snow, a user permittivity, non-spherical inclusions, another microstructure model -> the layer
+    carries the reason; a device descriptor on it raises, a reference class on it is kept for the host route."""
+    from conftest import load_reference_objects, standin_class, standins_from_dump
+    from smrt_amd.core.error import SMRTError
+    from smrt_amd.core.foreign import adopt_snowpack, device_entry, entry_of_instance
+    from smrt_amd.emmodel.iba import IBA
+
+    case = load_reference_objects()["flat_substrate_and_atmosphere"]
+    model, sims, packs, _ = standins_from_dump(case)
+    sp = packs[0]
+    ok = adopt_snowpack(sp).layers
+    assert [lay.device_refusal for lay in ok] == [None] * 3
+    ref_iba = model.emmodel
+    assert device_entry(ref_iba, {}, ok[0]) == "iba" and device_entry(IBA, {}, ok[0]) == "iba"
+    assert device_entry(ref_iba, {"dense_snow_correction": "auto"}, ok[0]) == "iba"
+    specialised = type("Specialized IBA", (ref_iba,), {"__module__": ref_iba.__module__})
+    assert device_entry(specialised, {}, ok[0]) == (specialised, {})          # (a subclass may compute anything)
+    sp.layers[0].liquid_water = 0.02
+    sp.layers[1].inclusion_shape = "random_needles"
+    sp.layers[2].permittivity_model = (1.0, lambda f, **k: 3.2 + 0.001j)
+    bad = adopt_snowpack(sp).layers
+    assert "liquid water" in bad[0].device_refusal and "inclusion_shape" in bad[1].device_refusal
+    assert "permittivity" in bad[2].device_refusal
+    for lay in bad:
+        assert device_entry(ref_iba, {}, lay) == (ref_iba, {})
+        with pytest.raises(SMRTError, match="cannot compute this layer"):
+            device_entry(IBA, {}, lay)
+        inst = ref_iba(sims[0][0], lay.source)
+        assert entry_of_instance(inst, lay) is inst
+    sp.layers[0].liquid_water = 0
+    sp.layers[0].microstructure = standin_class("smrt.microstructure_model.gaussian_random_field", "GaussianRandomField")()
+    sp.layers[0].microstructure.frac_volume = 0.3
+    assert "no device implementation" in adopt_snowpack(sp).layers[0].device_refusal
