@@ -17,10 +17,16 @@ before timing); `value` is that rate.  The same JSON line also carries, measured
         bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU (only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the launcher -- no PyTorch in
-the path).  `--scaling weak` (default): every rank solves its own 1024 x 5 batch (different seeds); `--scaling strong`:
+the path).  Started WITHOUT a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) it spawns the N ranks
+itself; a world that does not match --gpus, or fewer visible GPUs than ranks, is an error (exit code 2), never a silent
+one-rank run.  `--scaling weak` (default): every rank solves its own 1024 x 5 batch (different seeds); `--scaling strong`:
 ONE 1024 x 5 batch cut into contiguous slices of equal estimated cost (sum N_l^3, smrt_dort_pair_cost).  Either way the
 only collective is the gather of the result rows to rank 0 over RCCL (smrt_dort_gather), inside every step.
 Prints ONE JSON line on rank 0.
+
+`--config 2 | 3` runs the same measurement on the shapes of BASELINE configs[2] (DMRT-QCA-SR, 50 layers, 64 streams,
+7 AMSR2 frequencies) and configs[3] (IBA active, Sentinel-1, 30 layers, 128 streams, m_max 2) with `--snowpacks S` per
+GPU; the CPU baseline and the secondary measurements belong to the default configuration only.
 """
 import os
 
@@ -50,20 +56,61 @@ N_STREAMS = 32
 THETA_DEG = 55.0
 
 
-def synthetic_snowpacks(seed, S=N_SNOWPACKS, L=N_LAYERS):
-    """SURVEY.md 8(d) cfg2 laws: per snowpack draw thickness (L-1), density (L), temperature (L), size (L)."""
+def synthetic_snowpacks(seed, S=N_SNOWPACKS, L=N_LAYERS, thick_range=(0.05, 0.30), last=100.0, size_range=(5e-5, 3e-4)):
+    """SURVEY.md 8(d) laws: per snowpack draw thickness (L-1), density (L), temperature (L), size (L)."""
     rng = np.random.default_rng(seed)
     thick = np.empty((S, L))
     dens = np.empty((S, L))
     temp = np.empty((S, L))
     lc = np.empty((S, L))
     for s in range(S):
-        thick[s, : L - 1] = rng.uniform(0.05, 0.30, L - 1)
-        thick[s, L - 1] = 100.0
+        thick[s, : L - 1] = rng.uniform(thick_range[0], thick_range[1], L - 1)
+        thick[s, L - 1] = last
         dens[s] = rng.uniform(150, 450, L)
         temp[s] = rng.uniform(230, 270, L)
-        lc[s] = rng.uniform(5e-5, 3e-4, L)
+        lc[s] = rng.uniform(size_range[0], size_range[1], L)
     return thick, dens, temp, lc
+
+
+def make_workload(config, rank, strong, n_snowpacks):
+    """(PackedBatch, arrays, description) of BASELINE configs[config] (cfg2 / cfg3 / cfg4 there)."""
+    from smrt_amd._native import PackedBatch
+
+    if config == 1:
+        S = n_snowpacks or N_SNOWPACKS
+        arrays = synthetic_snowpacks(seed=2 if strong else 2 + rank, S=S)
+        thick, dens, temp, lc = arrays
+        batch = PackedBatch([N_LAYERS] * S, thick, dens / 916.7, temp, lc, None, FREQS, np.deg2rad([THETA_DEG]),
+                            emmodel="iba", microstructure="exponential", mode="P", n_max_stream=N_STREAMS)
+        return batch, arrays, dict(
+            metric="snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
+            what="BASELINE configs[1]: IBA + DORT passive, 20 layers, 32 streams, 5 AMSR-E channels (10.65-89 GHz, 55 deg), "
+                 "%d synthetic snowpacks" % S,
+            kernel="dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_reg_kernel")
+    if config == 2:
+        S, L = n_snowpacks or 1024, 50
+        arrays = synthetic_snowpacks(seed=3 if strong else 3 + rank, S=S, L=L, size_range=(5e-5, 1.5e-4))
+        thick, dens, temp, radius = arrays
+        freqs = np.array([6.925e9, 7.3e9, 10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
+        batch = PackedBatch([L] * S, thick, dens / 916.7, temp, radius, np.full((S, L), 0.2), freqs, np.deg2rad([55.0]),
+                            emmodel="dmrt_qca_shortrange", microstructure="sticky_hard_spheres", n_max_stream=64)
+        return batch, arrays, dict(
+            metric="snowpack x frequency DORT solves/sec (50 layers, 64 streams)",
+            what="BASELINE configs[2] shape: DMRT-QCA short-range + DORT passive, 50 layers, 64 streams, 7 AMSR2 frequencies "
+                 "(stickiness 0.2), %d synthetic snowpacks" % S,
+            kernel="64 < N <= 128 pipeline = prep_gmem + jacobi<512> + finish_gmem<512>")
+    if config == 3:
+        S, L = n_snowpacks or 256, 30
+        arrays = synthetic_snowpacks(seed=4 if strong else 4 + rank, S=S, L=L, thick_range=(0.02, 0.10), last=1000.0)
+        thick, dens, temp, lc = arrays
+        batch = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, [5.405e9], np.deg2rad(np.arange(20.0, 46.0, 5.0)),
+                            emmodel="iba", microstructure="exponential", mode="A", n_max_stream=128, m_max=2)
+        return batch, arrays, dict(
+            metric="snowpack x frequency DORT solves/sec (active, 30 layers, 128 streams, m_max 2)",
+            what="BASELINE configs[3] shape: IBA + DORT active, Sentinel-1 C band (5.405 GHz, 20..45 deg), 30 layers, "
+                 "128 streams, m_max 2, %d synthetic snowpacks" % S,
+            kernel="128 < N <= 384 pipeline = active_big prep + jacobi_big + active_big finish")
+    raise SystemExit("bench.py: --config must be 1, 2 or 3")
 
 
 # ---- CPU baseline ------------------------------------------------------------------------------------------------
@@ -171,38 +218,95 @@ def model_run_rate(thick, dens, temp, lc, reference_values, reps=3):
                      "median of %d (objects built once, outside)" % reps)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one process per GPU with the
+    variables a launcher would export -- pass rank 0's line through and return the worst exit code."""
+    import socket
+    import subprocess
+
+    from smrt_amd._native import device_count
+
+    visible = device_count()
+    if visible < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible: refusing to measure fewer ranks than asked\n" % (n, visible))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    try:
+        for p in procs:
+            worst = max(worst, abs(p.wait()))
+            if worst:
+                break
+    finally:
+        for p in procs:      # (exactly the processes started above)
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 5 / 3 for --config 2 / 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 for --config 2 / 3)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--config", type=int, default=1, help="BASELINE configs[1] (default, the headline) | [2] | [3]")
+    ap.add_argument("--snowpacks", type=int, default=0, help="snowpacks per GPU (default 1024 / 1024 / 256 by --config)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size of the per-pair kernels (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the pcie_inclusive / model_run measurements")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {1: 20, 2: 5, 3: 3}.get(args.config, 20)
+    if args.warmup is None:
+        args.warmup = 3 if args.config == 1 else 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SMRT_BENCH_SPAWN") == "1"):
+        # no launcher: be the launcher (SMRT_BENCH_SPAWN=1 takes this route with one rank too -- tests/test_gpu_bench.py)
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n" % (args.gpus, world))
+        sys.exit(2)
     # SMRT_BENCH_DIST=1: take the RCCL path with a single rank too (tests/test_gpu_bench.py checks on a one-GPU box the
     # code the multi-GPU runs execute)
     use_comm = world > 1 or os.environ.get("SMRT_BENCH_DIST") == "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    from smrt_amd._native import DortContext, PackedBatch
+    from smrt_amd._native import DortContext, device_count
     from smrt_amd.rtsolver.dort import shard_by_cost
     from smrt_amd.runner.distributed import init_comm
 
+    if device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d needs GPU %d but %d GPU(s) are visible\n" % (rank, local_rank, device_count()))
+        sys.exit(2)
     strong = args.scaling == "strong"
-    thick, dens, temp, lc = synthetic_snowpacks(seed=2 if strong else 2 + rank)
-    batch = PackedBatch([N_LAYERS] * N_SNOWPACKS, thick, dens / 916.7, temp, lc, None, FREQS, np.deg2rad([THETA_DEG]),
-                        emmodel="iba", microstructure="exponential", mode="P", n_max_stream=N_STREAMS)
+    batch, (thick, dens, temp, lc), desc = make_workload(args.config, rank, strong, args.snowpacks)
+    headline = args.config == 1 and not args.snowpacks
     ctx = DortContext(local_rank)
     if args.threads:
         ctx.set_block_threads(args.threads)
+    rccl = None
     if use_comm:
         init_comm(ctx, rank, world)
+        rccl = DortContext.comm_library()     # (path the symbols were resolved from, version); SMRT_RCCL_LIB pins it
     lo, hi = 0, batch.n_pairs
     if strong and world > 1:  # equal estimated cost per rank, contiguous slices of the frequency-major list
         ctx.upload(batch)
@@ -266,12 +370,12 @@ def main():
     if os.path.exists(tpath):  # PMC counters cannot be collected from inside this process: measured with
         with open(tpath) as fh:  # tools/pmc_passes.sh on the same command, summary committed under profiles/
             tj = json.load(fh)
-        if tj.get("solves_per_launch") == n_pairs:
+        if headline and tj.get("solves_per_launch") == n_pairs:
             traffic = tj["traffic_bytes_per_launch"]
 
     if rank == 0:
         line = {
-            "metric": "snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
+            "metric": desc["metric"],
             "value": total_pairs * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
@@ -284,12 +388,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: IBA + DORT passive, 20 layers, 32 streams, 5 AMSR-E channels "
-                            "(10.65-89 GHz, 55 deg), 1024 synthetic snowpacks %s = %d solves per step"
-                            % ("in all, cut by estimated cost over the ranks" if strong else "per GPU", total_pairs),
+                "workload": "%s %s = %d solves per step"
+                            % (desc["what"], "in all, cut by estimated cost over the ranks" if strong else "per GPU", total_pairs),
                 "solves_per_step_per_gpu": n_pairs,
                 "parallelism": "%d independent rank(s), results gathered to rank 0%s" % (
-                    world, " by smrt_dort_gather (RCCL, no PyTorch)" if use_comm else ""),
+                    world, " by smrt_dort_gather (RCCL %s from %s, no PyTorch)" % (rccl[1], rccl[0]) if use_comm else ""),
                 "failed_solves": n_fail,
                 "timed_region": "smrt_dort_launch of the resident batch (+ smrt_dort_gather when N > 1), "
                                 "barrier + stream sync on both sides, max over ranks",
@@ -310,8 +413,8 @@ def main():
                 "hbm": (None if traffic is None or kernel_ms <= 0 else
                         {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}),
-                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_reg_kernel (one launch each "
-                          "per step; kernel_ms is their summed HIP-event time on the launch stream)",
+                "kernel": desc["kernel"] + " (one launch each per step; kernel_ms is their summed HIP-event time on the "
+                                            "launch stream)",
                 "per_rank": per_rank,
                 "kernel_ms": kernel_ms,
                 "flops_per_launch": flops_per_launch,
@@ -322,13 +425,14 @@ def main():
                         "through HBM/L2 between its kernels (DESIGN.md 4), still far from HBM-bound",
             },
         }
-        if world == 1 and not args.no_secondary:
+        if world == 1 and headline and not args.no_secondary:
             line["pcie_inclusive"] = pcie_inclusive(ctx, batch)
             line["model_run"] = model_run_rate(thick, dens, temp, lc, res.values)
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and headline:  # the CPU leg is reported at N = 1 only
             cb, err = cpu_baseline(thick, dens, temp, lc, res.values)
             line["cpu_baseline"] = cb
             line["config"]["max_abs_dTb_vs_oracle_K"] = err
+        assert line["n_gpus"] == args.gpus
         print(json.dumps(line), flush=True)
     if use_comm:
         ctx.barrier()

@@ -231,6 +231,25 @@ int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, dou
 /* HIP-event time (ms) of the most recent smrt_dort_launch on the context's stream (valid after sync),
  * and accumulated over all launches since the last reset (count returned through n_launches). */
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
+
+/* What the uploaded batch runs on, as numbers (tests assert the designed kernel choice with these instead of wall-clock
+ * ratios): info[SMRT_INFO_*], at most n entries written; returns SMRT_INFO_COUNT, -1 on error.
+ *   PIPELINE      SMRT_PIPELINE_*: the kernels a launch of this batch consists of
+ *   CHUNK_PAIRS   pairs per pipeline pass (the staging area holds one chunk), CHUNKS: passes per launch
+ *   PRUNE_ROUNDS  layer ranges the prep + Jacobi kernels run over under prune_deep_snowpack (1: all layers at once)
+ *   STAGED_ITEMS  (pair, azimuth mode, layer) items the LAST chunk of the last launch diagonalised -- known when the
+ *                 staging counts are reset per chunk (prune rounds, process_coherent_layers), else -1; synchronises
+ *   BLOCK_THREADS workgroup size of the per-pair kernels, N_MAX: padded matrix order (streams x polarisations) */
+enum { SMRT_INFO_PIPELINE = 0, SMRT_INFO_CHUNK_PAIRS, SMRT_INFO_CHUNKS, SMRT_INFO_PRUNE_ROUNDS, SMRT_INFO_STAGED_ITEMS,
+       SMRT_INFO_BLOCK_THREADS, SMRT_INFO_N_MAX, SMRT_INFO_COUNT };
+enum { SMRT_PIPELINE_FUSED = 0,          /* one kernel per pair, matrices in LDS (N <= 64) */
+       SMRT_PIPELINE_LDS_TWO_SLOT = 1,   /* prep + Jacobi + two-slot finish, matrices in LDS */
+       SMRT_PIPELINE_LDS_FOUR_SLOT = 2,  /* ... with the four-slot finish kernel (set_pipeline(2)) */
+       SMRT_PIPELINE_LDS_REG = 3,        /* ... with the register-resident finish kernel (passive default) */
+       SMRT_PIPELINE_FUSED_GMEM = 4,     /* one kernel per pair on a global workspace (N > 64) */
+       SMRT_PIPELINE_GMEM = 5,           /* prep + Jacobi + finish on the global workspace, 64 < N <= 128 */
+       SMRT_PIPELINE_BIG = 6 };          /* ... with the blocked Jacobi kernel, 128 < N <= 384 */
+int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n);
 double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset);
 
 /* Tuning knob: threads per workgroup of the per-pair kernels: 64 (one wavefront) or 256 (default, also 0). */
@@ -302,8 +321,13 @@ int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight);
  * It is enqueued on the context's stream behind the kernels and returns when the root has its rows.
  * smrt_dort_comm_allreduce_max: element-wise maximum over the ranks of n host doubles, in place (the max-over-ranks
  * of a timing; with n = 0 it is a barrier).
+ * smrt_dort_comm_library: which RCCL the gather runs on -- the file the symbols were resolved from (dladdr; on failure
+ * the reason) copied into path[capacity], and ncclGetVersion's code (e.g. 22703).  The environment variable
+ * SMRT_RCCL_LIB pins the library (path or soname; nothing else is tried then); by default a librccl.so.1 the process
+ * has already mapped is kept (it belongs to the HIP runtime in use), else /opt/rocm/lib/librccl.so.1, else the soname.
  */
 #define SMRT_COMM_ID_BYTES 128
+int32_t smrt_dort_comm_library(char* path, int32_t capacity, int32_t* version);
 int32_t smrt_dort_comm_unique_id(char* id);
 int32_t smrt_dort_comm_init(smrt_dort_ctx* ctx, int32_t world, int32_t rank, const char* id);
 int32_t smrt_dort_comm_init_all(smrt_dort_ctx** ctxs, int32_t n);

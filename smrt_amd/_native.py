@@ -240,6 +240,10 @@ def load_library():
     lib.smrt_dort_ft_even_phase.restype = C.c_int32
     lib.smrt_dort_pair_cost.argtypes = [C.c_void_p, P(C.c_double)]
     lib.smrt_dort_pair_cost.restype = C.c_int32
+    lib.smrt_dort_launch_info.argtypes = [C.c_void_p, P(C.c_int64), C.c_int32]
+    lib.smrt_dort_launch_info.restype = C.c_int32
+    lib.smrt_dort_comm_library.argtypes = [C.c_char_p, C.c_int32, P(C.c_int32)]
+    lib.smrt_dort_comm_library.restype = C.c_int32
     lib.smrt_dort_comm_unique_id.argtypes = [C.c_char_p]
     lib.smrt_dort_comm_unique_id.restype = C.c_int32
     lib.smrt_dort_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]
@@ -307,7 +311,7 @@ def check_struct_layout(lib):
 EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
     "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost", "smrt_dort_ft_even_phase",
-    "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
+    "smrt_dort_launch_info", "smrt_dort_comm_library", "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_gather_plan",
@@ -430,6 +434,32 @@ class DortContext:
         return cost
 
     # ---- multi-GPU: the RCCL gather of the C ABI (smrt_dort_comm_*, smrt_dort_gather) ----------------------------
+    PIPELINES = ("fused", "lds_two_slot", "lds_four_slot", "lds_reg", "fused_gmem", "gmem", "big")   # SMRT_PIPELINE_*
+
+    def launch_info(self):
+        """smrt_dort_launch_info as a dict: pipeline (name), chunk_pairs, chunks, prune_rounds, staged_items (None when
+        unknown), block_threads, n_max."""
+        v = (C.c_int64 * 16)()
+        n = self._lib.smrt_dort_launch_info(self._h, v, 16)
+        self._check(0 if n > 0 else -1, "smrt_dort_launch_info")
+        keys = ("pipeline", "chunk_pairs", "chunks", "prune_rounds", "staged_items", "block_threads", "n_max")
+        d = {k: int(v[i]) for i, k in enumerate(keys[:n])}
+        d["pipeline"] = self.PIPELINES[d["pipeline"]]
+        if d.get("staged_items", -1) < 0:
+            d["staged_items"] = None
+        return d
+
+    @staticmethod
+    def comm_library():
+        """(path of the RCCL library the gather runs on, its version string) -- smrt_dort_comm_library; SMRT_RCCL_LIB
+        pins it."""
+        lib = load_library()
+        buf, version = C.create_string_buffer(1024), C.c_int32(0)
+        if lib.smrt_dort_comm_library(buf, len(buf), C.byref(version)) != 0:
+            raise SMRTError("RCCL is not available: " + buf.value.decode(errors="replace"))
+        v = int(version.value)
+        return buf.value.decode(), "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100) if v >= 10000 else str(v)
+
     @staticmethod
     def comm_unique_id():
         lib = load_library()

@@ -34,7 +34,7 @@ class Microstructure:
             return float(self.corr_length), 0.0
         if self.name == "homogeneous":
             return 0.0, 0.0
-        return float(self.radius), float(getattr(self, "stickiness", np.inf))
+        return float(self.radius), float(getattr(self, "stickiness", 1000.0))
 
 
 MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
@@ -87,8 +87,8 @@ class Layer:
         frac_volume = min(frac_volume, 1.0)
         self.microstructure_model = name
         mparams = {k: float(params[k]) for k in MICROSTRUCTURE_ARGS[name] if k in params}
-        if name == "sticky_hard_spheres":
-            mparams.setdefault("stickiness", np.inf)
+        if name == "sticky_hard_spheres":   # the reference's default (smrt/microstructure_model/sticky_hard_spheres.py:30)
+            mparams.setdefault("stickiness", 1000.0)
         self.microstructure = Microstructure(name, frac_volume, **mparams)
         for k, v in mparams.items():
             setattr(self, k, v)

@@ -207,15 +207,32 @@ def _strongsqueeze(x):
     return float(x) if x.size == 1 else x
 
 
-def concat_arrays(arrays, dim_name, dim_values):
-    """Stack along a new leading dimension (what xr.concat(..., pd.Index) does at result.py:811)."""
+def stack_arrays(arrays, dim_name, dim_values):
+    """Stack along a new leading dimension.  Arrays of different extents are laid into the union of their coordinates
+    and the holes filled with NaN -- results of snowpacks with different layer counts carry per-layer diagnostics of
+    different lengths -- which is what the reference gets from xr.concat(..., join="outer") (smrt/core/result.py:811-815)."""
     first = arrays[0]
-    for a in arrays[1:]:
-        if a.dims != first.dims or any(not np.array_equal(a.coords[d], first.coords[d]) for d in first.dims):
-            raise SMRTError("cannot concatenate results with different coordinates")
-    vals = np.stack([a.values for a in arrays], axis=0)
-    return LabeledArray(vals, [(dim_name, np.asarray(list(dim_values)))] + list(first.coords.items()),
-                        name=first.name, attrs=first.attrs)
+    if any(a.dims != first.dims for a in arrays[1:]):
+        raise SMRTError("cannot concatenate results with different dimensions")
+    axes = []
+    for d in first.dims:            # the union of the labels of every axis, in order of first appearance
+        labels = list(first.coords[d])
+        for a in arrays[1:]:
+            if len(a.coords[d]) != len(labels) or not np.array_equal(a.coords[d], first.coords[d]):
+                known = set(labels)
+                labels += [v for v in a.coords[d] if v not in known]
+        axes.append(np.asarray(labels))
+    same_grid = all(a.shape == tuple(len(ax) for ax in axes) for a in arrays)
+    lead = (dim_name, np.asarray(list(dim_values)))
+    if same_grid:
+        out = np.stack([a.values for a in arrays], axis=0)
+    else:
+        dtype = np.result_type(np.float64, *[a.values.dtype for a in arrays])
+        out = np.full((len(arrays),) + tuple(len(ax) for ax in axes), np.nan, dtype=dtype)
+        for k, a in enumerate(arrays):
+            where = tuple(np.array([list(ax).index(v) for v in a.coords[d]], dtype=int) for d, ax in zip(first.dims, axes))
+            out[(k,) + np.ix_(*where)] = a.values
+    return LabeledArray(out, [lead] + list(zip(first.dims, axes)), name=first.name, attrs=first.attrs)
 
 
 class Result(object):
@@ -251,23 +268,48 @@ class Result(object):
     def sel_data(self, channel=None, **kwargs):
         raise NotImplementedError
 
+    def _selection(self, channel, selection):
+        """The keyword selection with the configuration of `channel` (frequency, polarization, ... of the sensor's channel
+        map) merged in, restricted to the dimensions this result has."""
+        if channel is None:
+            return dict(selection)
+        if channel not in self.channel_map:
+            raise SMRTError(f"unknown channel '{channel}' (the result knows {sorted(self.channel_map)})")
+        return {**selection, **{k: v for k, v in self.channel_map[channel].items() if k in self.data.dims}}
+
     def return_as_dataframe(self, name, channel_axis=None, **kwargs):
+        """A pandas view of the result: one column `name` indexed by the remaining dimensions (channel_axis=None), one
+        column per channel of the sensor ("column"), or the channels as the innermost index level ("index") --
+        smrt/core/result.py:152-216.  Built from the arrays, not by joining per-channel frames."""
         import pandas as pd
 
-        if channel_axis in ("column", "index"):
-            if not self.channel_map:
-                raise SMRTError("No channel information is given in the result. Unable to index the result by channel.")
-            df = pd.concat([self.sel_data(channel=ch, **kwargs).to_dataframe(name=ch) for ch in self.channel_map],
-                           axis=1, join="inner")
-            if channel_axis == "index":
-                df = df.stack()
-                if isinstance(df, pd.Series):
-                    df = pd.DataFrame(df, columns=[name])
-        elif channel_axis is None:
-            df = self.sel_data(**kwargs).to_dataframe(name=name)
-        else:
+        def index_of(arr):
+            if not arr.dims:
+                return pd.RangeIndex(1)
+            if len(arr.dims) == 1:
+                return pd.Index(arr.coords[arr.dims[0]], name=arr.dims[0])
+            return pd.MultiIndex.from_product([arr.coords[d] for d in arr.dims], names=list(arr.dims))
+
+        if channel_axis is None:
+            arr = self.sel_data(**kwargs)
+            return pd.DataFrame({name: np.reshape(arr.values, -1)}, index=index_of(arr))
+        if channel_axis not in ("column", "index"):
             raise SMRTError('channel_axis argument must be None, "column" or "index"')
-        if self.mother_df is not None and channel_axis == "column":
+        if not self.channel_map:
+            raise SMRTError("No channel information is given in the result. Unable to index the result by channel.")
+        channels = list(self.channel_map)
+        arrays = [self.sel_data(channel=ch, **kwargs) for ch in channels]
+        if any(a.dims != arrays[0].dims or a.shape != arrays[0].shape for a in arrays[1:]):
+            raise SMRTError("the channels of this result do not share their remaining dimensions")
+        table = np.column_stack([np.reshape(a.values, -1) for a in arrays])          # rows: remaining dims, columns: channels
+        df = pd.DataFrame(table, index=index_of(arrays[0]), columns=channels)
+        if channel_axis == "index":
+            long = df.stack()
+            long.index = long.index.set_names("channel", level=-1)
+            if not arrays[0].dims:      # (the one row of a result without remaining dimensions is not an index level)
+                long = long.droplevel(0)
+            return long.to_frame(name)
+        if self.mother_df is not None:  # one row per snowpack, in the order of the run: the user's columns ride along
             df = df.reset_index(drop=True).join(self.mother_df.reset_index(drop=True))
             df.index = self.mother_df.index
         return df
@@ -292,9 +334,7 @@ class PassiveResult(Result):
     mode = "P"
 
     def sel_data(self, channel=None, **kwargs):
-        if channel is not None:
-            kwargs.update({k: v for k, v in self.channel_map[channel].items() if k in self.data.dims})
-        return self.data.sel(drop=True, **kwargs)
+        return self.data.sel(**self._selection(channel, kwargs))
 
     def Tb(self, channel=None, **kwargs):
         """Brightness temperature; slice with e.g. frequency=37e9, polarization='V' or channel='37V'."""
@@ -326,31 +366,27 @@ class ActiveResult(Result):
     mode = "A"
 
     def sel_data(self, channel=None, return_backscatter=False, **kwargs):
-        if channel is not None:
-            kwargs.update({k: v for k, v in self.channel_map[channel].items() if k in self.data.dims})
-        if return_backscatter:
-            theta = kwargs.pop("theta", None)
-            theta_inc = kwargs.pop("theta_inc", None)
-            if theta is not None and theta_inc is not None and not np.all(theta_inc == theta):
-                raise SMRTError("theta and theta_inc must be the same when returning backscatter")
-            if theta is None:
-                theta = theta_inc
-            if theta is None:
-                theta = self.data.coords["theta_inc"]
-            if np.ndim(theta) > 0:
-                x = self.data.sel(drop=True, theta_inc=list(np.atleast_1d(theta)), **kwargs)
-                axis = x.dims.index("theta_inc")
-                shape = [1] * len(x.dims)
-                shape[axis] = -1
-                factor = (4 * np.pi * np.cos(np.deg2rad(np.atleast_1d(theta)))).reshape(shape)
-            else:
-                x = self.data.sel(drop=True, theta_inc=theta, **kwargs)
-                factor = 4 * np.pi * np.cos(np.deg2rad(theta))
-            x = x * factor  # sigma = 4 pi cos(theta) I (result.py:484-486)
-            if return_backscatter == "dB":
-                return LabeledArray(dB(x.values), list(x.coords.items()), name=x.name, attrs=x.attrs)
-            return x
-        return self.data.sel(drop=True, **kwargs)
+        """The selected intensities, or -- return_backscatter="natural" | "dB" -- the backscattering coefficient
+        sigma0 = 4 pi cos(theta) I of the selected incidence angles (smrt/core/result.py:430-486)."""
+        selection = self._selection(channel, kwargs)
+        if not return_backscatter:
+            return self.data.sel(**selection)
+        angles = [selection.pop(k) for k in ("theta", "theta_inc") if k in selection]
+        angles = [a for a in angles if a is not None]
+        if len(angles) == 2 and not np.array_equal(np.atleast_1d(angles[0]), np.atleast_1d(angles[1])):
+            raise SMRTError("theta and theta_inc must be the same when returning backscatter")
+        theta = angles[0] if angles else self.data.coords["theta_inc"]
+        several = np.ndim(theta) > 0
+        picked = self.data.sel(theta_inc=list(np.atleast_1d(theta)) if several else theta, **selection)
+        cos_theta = np.cos(np.deg2rad(np.asarray(theta, float)))
+        if several:                 # broadcast along the theta_inc axis that stayed
+            shape = [1] * len(picked.dims)
+            shape[picked.dims.index("theta_inc")] = -1
+            cos_theta = cos_theta.reshape(shape)
+        sigma0 = picked * (4 * np.pi * cos_theta)
+        if return_backscatter == "dB":
+            return LabeledArray(dB(sigma0.values), list(sigma0.coords.items()), name=sigma0.name, attrs=sigma0.attrs)
+        return sigma0
 
     def sigma(self, channel=None, name="sigma", **kwargs):
         return _strongsqueeze(self.sel_data(channel=channel, return_backscatter="natural", **kwargs).rename(name))
@@ -400,37 +436,28 @@ def make_result(sensor, *args, **kwargs):
 
 
 def concat_results(result_list, coord):
-    """Concatenate results along a new leading dimension (smrt/core/result.py:768-817)."""
-    if not isinstance(coord, tuple):
+    """One result out of several along a new leading dimension `coord` = (name, labels) -- the nesting step of Model.run
+    (smrt/core/result.py:768-817).  Results of sensors with different channel maps get the union of their channels, each
+    tagged with the label of the result it came from."""
+    if not (isinstance(coord, tuple) and len(coord) == 2):
         raise SMRTError("unknown type for the coord argument")
-    dim_name, dim_value = coord
-    ResultClass = type(result_list[0])
-    if not all(type(r) is ResultClass for r in result_list):
+    dim_name, labels = coord[0], list(coord[1])
+    results = list(result_list)
+    if len(labels) != len(results) or not results:
+        raise SMRTError(f"{len(results)} results cannot be labelled with {len(labels)} values of '{dim_name}'")
+    kind = type(results[0])
+    if any(type(r) is not kind for r in results):
         raise SMRTError("The results are not all of the same type")
-    if any(r.channel_map != result_list[0].channel_map for r in result_list):
-        channel_map = {ch: dict(**r.channel_map[ch], dim_name=dv) for r, dv in zip(result_list, dim_value)
-                       for ch in r.channel_map}
+    maps = [r.channel_map for r in results]
+    if all(m == maps[0] for m in maps):
+        channel_map = maps[0]
     else:
-        channel_map = result_list[0].channel_map
-    data = concat_arrays([r.data for r in result_list], dim_name, dim_value)
-    other = {}
-    for k in result_list[0].other_data:
-        arrs = [r.other_data[k] for r in result_list]
-        try:
-            other[k] = concat_arrays(arrs, dim_name, dim_value)
-        except SMRTError:  # ragged (e.g. different layer counts): pad with NaN like xr.concat(join="outer")
-            n = max(a.values.shape[0] for a in arrays_1d(arrs))
-            padded = []
-            for a in arrs:
-                v = np.full(n, np.nan, dtype=a.values.dtype)
-                v[: a.values.shape[0]] = a.values
-                padded.append(LabeledArray(v, [(a.dims[0], np.arange(n))], name=a.name))
-            other[k] = concat_arrays(padded, dim_name, dim_value)
-    return ResultClass(data, channel_map=channel_map, other_data=other)
-
-
-def arrays_1d(arrs):
-    for a in arrs:
-        if len(a.dims) != 1:
-            raise SMRTError("only one-dimensional diagnostic arrays can be padded")
-    return arrs
+        channel_map = {}
+        for m, label in zip(maps, labels):
+            for ch, config in m.items():
+                # (the reference files the label under the literal key "dim_name", smrt/core/result.py:798-802: no
+                # selection ever uses it, channel maps compare equal to the reference's)
+                channel_map[ch] = {**config, "dim_name": label}
+    data = stack_arrays([r.data for r in results], dim_name, labels)
+    other = {key: stack_arrays([r.other_data[key] for r in results], dim_name, labels) for key in results[0].other_data}
+    return kind(data, channel_map=channel_map, other_data=other)

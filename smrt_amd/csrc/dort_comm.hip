@@ -2,6 +2,7 @@
 // lazily with dlopen, so a single-GPU user never pays for it (and the library loads where RCCL is absent).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -26,6 +27,8 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string path;      // the file the symbols were resolved from (dladdr), reported by smrt_dort_comm_library
 };
 
 template <class F>
@@ -39,17 +42,32 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+        // SMRT_RCCL_LIB pins the library (a path or a soname); when it is set nothing else is tried.  Otherwise: a librccl
+        // the process has ALREADY mapped is taken as it is (RTLD_NOLOAD -- e.g. the copy bundled with PyTorch when the
+        // caller imported torch first: it belongs to the HIP runtime this process runs on, and a second RCCL next to it
+        // would be worse than an older one); else ROCm's own /opt/rocm/lib/librccl.so.1 by path; else the soname through
+        // the loader's search path.  smrt_dort_comm_library reports what was taken.
+        const char* pinned = getenv("SMRT_RCCL_LIB");
+        if (pinned && *pinned) {
+            api.handle = dlopen(pinned, RTLD_NOW | RTLD_LOCAL);
+            if (!api.handle) { api.err = std::string("SMRT_RCCL_LIB=") + pinned + ": " + dlerror(); return; }
+        } else {
+            api.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            for (const char* name : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+                if (api.handle) break;
+                api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            }
         }
         if (!api.handle) { api.err = std::string("cannot load librccl: ") + dlerror(); return; }
         bool ok = sym(api, api.GetUniqueId, "ncclGetUniqueId") && sym(api, api.CommInitRank, "ncclCommInitRank") &&
                   sym(api, api.CommInitAll, "ncclCommInitAll") && sym(api, api.CommDestroy, "ncclCommDestroy") &&
                   sym(api, api.GroupStart, "ncclGroupStart") && sym(api, api.GroupEnd, "ncclGroupEnd") &&
                   sym(api, api.Send, "ncclSend") && sym(api, api.Recv, "ncclRecv") &&
-                  sym(api, api.AllReduce, "ncclAllReduce") && sym(api, api.GetErrorString, "ncclGetErrorString");
-        if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+                  sym(api, api.AllReduce, "ncclAllReduce") && sym(api, api.GetErrorString, "ncclGetErrorString") &&
+                  sym(api, api.GetVersion, "ncclGetVersion");
+        if (!ok) { dlclose(api.handle); api.handle = nullptr; return; }
+        Dl_info info;
+        if (dladdr((void*)api.GetUniqueId, &info) && info.dli_fname) api.path = info.dli_fname;
     });
     return api;
 }
@@ -77,6 +95,18 @@ RcclApi& rccl() {
     } while (0)
 
 extern "C" {
+
+int32_t smrt_dort_comm_library(char* path, int32_t capacity, int32_t* version) {
+    RcclApi& R = rccl();
+    if (!R.handle) {
+        if (path && capacity > 0) { strncpy(path, R.err.c_str(), capacity - 1); path[capacity - 1] = 0; }
+        return -1;
+    }
+    if (path && capacity > 0) { strncpy(path, R.path.c_str(), capacity - 1); path[capacity - 1] = 0; }
+    int v = 0;
+    if (version) { if (R.GetVersion(&v) != ncclSuccess) v = 0; *version = v; }
+    return 0;
+}
 
 int32_t smrt_dort_comm_unique_id(char* id) {
     if (!id) return -1;

@@ -506,6 +506,40 @@ int32_t smrt_dort_sync(smrt_dort_ctx* ctx) {
 
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx) { return ctx ? (double)ctx->last_ms : -1.0; }
 
+int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
+    if (!ctx || !info || n < 0) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    const DevBatch& d = ctx->dev;
+    const bool lds_pipeline = !ctx->gmem_path && ctx->split && ctx->chunk_pairs > 0 && (!ctx->active || ctx->finish2);
+    int64_t v[SMRT_INFO_COUNT] = {0};
+    v[SMRT_INFO_PIPELINE] = ctx->gmem_split ? (ctx->big ? SMRT_PIPELINE_BIG : SMRT_PIPELINE_GMEM)
+                          : lds_pipeline ? (ctx->finish_reg ? SMRT_PIPELINE_LDS_REG : ctx->finish2 ? SMRT_PIPELINE_LDS_TWO_SLOT : SMRT_PIPELINE_LDS_FOUR_SLOT)
+                          : ctx->gmem_path ? SMRT_PIPELINE_FUSED_GMEM : SMRT_PIPELINE_FUSED;
+    const bool three = ctx->gmem_split || lds_pipeline;
+    v[SMRT_INFO_CHUNK_PAIRS] = three ? ctx->chunk_pairs : d.pair_count;
+    v[SMRT_INFO_CHUNKS] = three ? (d.pair_count + ctx->chunk_pairs - 1) / ctx->chunk_pairs : 1;
+    const int rounds = (three && d.prune_tau > 0.0 && !d.coherent && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
+    v[SMRT_INFO_PRUNE_ROUNDS] = rounds;
+    v[SMRT_INFO_STAGED_ITEMS] = -1;
+    if (three && (rounds > 1 || d.coherent) && ctx->n_launch + (ctx->timing_pending ? 1 : 0) > 0) {
+        // the staging counts of the LAST chunk of the last launch (reset before every chunk in these modes): how many
+        // (pair, mode, layer) items were diagonalised -- under prune_deep_snowpack the layers below a cut are not
+        HIPCHK(hipSetDevice(ctx->device));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
+        const long long last = d.pair_count - (v[SMRT_INFO_CHUNKS] - 1) * ctx->chunk_pairs;
+        std::vector<int> h((size_t)(last * items_per_pair));
+        HIPCHK(hipMemcpy(h.data(), ctx->stage.n, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+        long long staged = 0;
+        for (int x : h) staged += (x > 0);
+        v[SMRT_INFO_STAGED_ITEMS] = staged;
+    }
+    v[SMRT_INFO_BLOCK_THREADS] = ctx->nt;
+    v[SMRT_INFO_N_MAX] = ctx->nmax_rows;
+    for (int k = 0; k < n && k < SMRT_INFO_COUNT; ++k) info[k] = v[k];
+    return SMRT_INFO_COUNT;
+}
+
 double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset) {
     if (!ctx) return -1.0;
     const double tot = ctx->total_ms;

@@ -48,6 +48,9 @@ def make_snowpack(thickness, microstructure_model, density, interface=None, surf
 
     if isinstance(interface, (list, tuple)):
         _check_size(interface, n, "interface")
+        if surface is not None:   # smrt/inputs/make_medium.py:207-210
+            raise SMRTError("Setting both 'surface' and 'interface' arguments is ambiguous when interface is a list or any "
+                            "sequence: its first element already is the surface.")
     sp = Snowpack(substrate=substrate, atmosphere=atmosphere)
     for i, dz in enumerate(thickness):
         if dz <= 0:

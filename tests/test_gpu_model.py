@@ -472,6 +472,19 @@ def test_emmodels_without_a_device_implementation_through_the_model():
     # a layer list that mixes a device emmodel with a host one takes the host route as a whole
     mixed = make_model([WrappedIBA, "iba", WrappedIBA], "dort", rtsolver_options=opts).run(sensor, sp)
     np.testing.assert_allclose(mixed.TbV(), native.TbV(), atol=1e-7)
+    # ... also when the device emmodel of that list carries an option that changes its device name: IBA under
+    # dense_snow_correction="auto" on a layer above half ice ("iba_inverted" on the device) keeps the option on the host
+    # route (it was instantiated as a plugin named 'iba_inverted', without its options)
+    dense = make_snowpack([0.2, 0.5, 100], "exponential", density=[220, 700, 380], temperature=[255, 260, 268],
+                          corr_length=[8e-5, 2e-4, 1.5e-4])
+    auto = dict(dense_snow_correction="auto")
+    native = make_model("iba", "dort", rtsolver_options=opts, emmodel_options=auto).run(sensor, dense)
+    mixed = make_model([WrappedIBA, "iba", WrappedIBA], "dort", rtsolver_options=opts,
+                       emmodel_options=[{}, auto, {}]).run(sensor, dense)
+    np.testing.assert_allclose(mixed.TbV(), native.TbV(), atol=1e-7)
+    np.testing.assert_allclose(mixed.TbH(), native.TbH(), atol=1e-7)
+    plain = make_model("iba", "dort", rtsolver_options=opts).run(sensor, dense)
+    assert np.abs(np.asarray(plain.TbV()) - np.asarray(native.TbV())).max() > 1e-3    # (the option does matter here)
 
 
 def test_process_coherent_layers_through_the_model():

@@ -797,3 +797,18 @@ def test_layers_of_the_reference_the_device_cannot_compute_are_not_computed_as_d
     sp.layers[0].microstructure = standin_class("smrt.microstructure_model.gaussian_random_field", "GaussianRandomField")()
     sp.layers[0].microstructure.frac_volume = 0.3
     assert "no device implementation" in adopt_snowpack(sp).layers[0].device_refusal
+
+
+def test_make_snowpack_refusals_and_defaults_follow_the_reference():
+    """surface + a sequence of interfaces is ambiguous (smrt/inputs/make_medium.py:207-210); sticky hard spheres default to
+    stickiness 1000 (smrt/microstructure_model/sticky_hard_spheres.py:30)."""
+    from smrt_amd import make_snowpack
+    from smrt_amd.core.error import SMRTError
+    from smrt_amd.interface.flat import Flat
+
+    with pytest.raises(SMRTError, match="ambiguous"):
+        make_snowpack([0.1, 1.0], "exponential", density=300, corr_length=1e-4, interface=[Flat, Flat], surface=Flat)
+    sp = make_snowpack([0.1, 1.0], "exponential", density=300, corr_length=1e-4, interface=Flat, surface=Flat)
+    assert sp.nlayer == 2
+    shs = make_snowpack([1.0], "sticky_hard_spheres", density=300, radius=1e-4)
+    assert shs.layers[0].microstructure.device_params == (1e-4, 1000.0) and shs.packed()[4, 0] == 1000.0
