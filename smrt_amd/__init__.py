@@ -13,7 +13,7 @@ from .core.result import concat_results, open_result  # noqa: F401
 from .core.sensor import Sensor  # noqa: F401
 from .inputs import sensor_list  # noqa: F401
 from .atmosphere.simple_isotropic_atmosphere import make_atmosphere  # noqa: F401
-from .inputs.make_medium import make_snow_layer, make_snowpack  # noqa: F401
+from .inputs.make_medium import make_interface, make_snow_layer, make_snowpack, make_soil  # noqa: F401
 from .runner.hip_batch_runner import HipBatchRunner  # noqa: F401
 from .utils import dB, invdB  # noqa: F401
 

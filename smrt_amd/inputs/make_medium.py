@@ -22,6 +22,47 @@ def _check_size(x, n, name):
         raise SMRTError(f"The length of '{name}' must be the same as the number of layers ({n}).")
 
 
+def make_interface(inst_class_or_modulename=None, broadcast=True, **kwargs):
+    """An interface object from a name ("flat", "iem_fung92", "geometrical_optics", "geometrical_optics_backscatter" -- or
+    any module of a registered plugin package), a class or a ready instance; with sequences among the keyword arguments and
+    `broadcast`, one instance per element (smrt/core/interface.py:17-52).  Flat is evaluated on the device (Fresnel per
+    stream); every other model is evaluated on the host through the interface protocol."""
+    import inspect
+
+    from ..core.plugin import import_class
+
+    if inst_class_or_modulename is None or inst_class_or_modulename == "flat":
+        cls = Flat
+    elif isinstance(inst_class_or_modulename, str):
+        cls = import_class("interface", inst_class_or_modulename)
+    elif inspect.isclass(inst_class_or_modulename):
+        cls = inst_class_or_modulename
+    elif callable(getattr(inst_class_or_modulename, "specular_reflection_matrix", None)) or isinstance(inst_class_or_modulename, Flat):
+        return inst_class_or_modulename
+    else:
+        raise SMRTError("The interface must be either the name of a module in the interface directory of a plugin package, "
+                        "a class that implements the interface behavior, or an instance of such a class.")
+    if broadcast and kwargs:
+        lengths = [len(v) for v in kwargs.values() if isinstance(v, (collections.abc.Sequence, np.ndarray)) and not isinstance(v, str)]
+        if lengths:
+            return [cls(**{k: _get(v, i) for k, v in kwargs.items()}) for i in range(max(lengths))]
+    return cls(**kwargs)
+
+
+def make_soil(substrate_model, permittivity_model, temperature, **kwargs):
+    """A substrate by name ("flat", "reflector", "iem_fung92", "geometrical_optics", "geometrical_optics_backscatter") or
+    class, with a numeric permittivity or a callable of (frequency[, temperature]) -- the part of
+    smrt/inputs/make_soil.py:41-139 that needs no soil dielectric model (those are outside the DORT path: give the
+    permittivity as a number or your own function)."""
+    from ..core.plugin import import_class
+
+    if isinstance(permittivity_model, str):
+        raise SMRTError(f"the soil permittivity model '{permittivity_model}' is outside the scope of smrt_amd: give the "
+                        "permittivity as a number or as a function of (frequency, temperature)")
+    cls = import_class("substrate", substrate_model) if isinstance(substrate_model, str) else substrate_model
+    return cls(temperature=temperature, permittivity_model=permittivity_model, **kwargs)
+
+
 def make_snow_layer(layer_thickness, microstructure_model, density, temperature=FREEZING_POINT, **kwargs):
     return Layer(layer_thickness, microstructure_model, density, temperature=temperature, **kwargs)
 
@@ -37,14 +78,8 @@ def make_snowpack(thickness, microstructure_model, density, interface=None, surf
     _check_size(density, n, "density")
     for k, v in kwargs.items():
         _check_size(v, n, k)
-    def as_interface(itf):   # None / "flat" / the Flat class or an instance / an object with the reference's interface protocol
-        if itf is None or itf == "flat" or itf is Flat:
-            return Flat()
-        if isinstance(itf, str):
-            raise SMRTError(f"interface '{itf}' has no implementation in smrt_amd: pass Flat or an interface OBJECT with the "
-                            "reference's protocol (e.g. smrt's iem_fung92 / geometrical_optics instance); it is evaluated on "
-                            "the host")
-        return itf() if isinstance(itf, type) else itf
+    def as_interface(itf):   # None / a name / a class / an instance (smrt/core/interface.py:17-52)
+        return make_interface(itf)
 
     if isinstance(interface, (list, tuple)):
         _check_size(interface, n, "interface")

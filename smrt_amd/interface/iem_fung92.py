@@ -22,7 +22,8 @@ class KirchhoffCoherentPart:
 
     def specular_reflection_matrix(self, frequency, eps_1, eps_2, mu1, npol):
         mu1 = np.atleast_1d(np.asarray(mu1, float))
-        k2 = (2 * np.pi * frequency / C_SPEED) ** 2 * abs(complex(eps_1))
+        # (the reference scales the free-space wavenumber by |eps_1|^2 here, smrt/interface/interface_utils.py:37 -- kept)
+        k2 = (2 * np.pi * frequency / C_SPEED) ** 2 * abs(complex(eps_1)) ** 2
         return reflection_diagonal(eps_1, eps_2, mu1, npol) * np.exp(-4 * k2 * self.roughness_rms ** 2 * mu1 ** 2)
 
     def coherent_transmission_matrix(self, frequency, eps_1, eps_2, mu1, npol):

@@ -496,3 +496,18 @@ def load_reference_objects():
 
     with open(os.path.join(GOLDEN, "reference_objects.json")) as f:
         return {c["name"]: c for c in json.load(f)["cases"]}
+
+
+# what the rough-interface / rough-substrate fixtures were made with (tests/golden/make_golden.py): model name + parameters
+ROUGH_INTERFACE_MODELS = {
+    "rough_iem_surface_L3_n10_passive": ("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05)),
+    "rough_iem_inner_L3_n10_passive": ("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05)),
+    "rough_go_surface_L3_n10_active": ("geometrical_optics", dict(mean_square_slope=0.03)),
+    "rough_iem_inner_L3_n10_active": ("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05)),
+}
+ROUGH_SUBSTRATE_MODELS = {
+    "rough_go_substrate_L2_n12_active": ("geometrical_optics", dict(mean_square_slope=0.05)),
+    "rough_iem_substrate_L3_n10_active": ("iem_fung92", dict(roughness_rms=0.004, corr_length=0.05)),
+    "rough_iem_substrate_L3_n10_passive": ("iem_fung92", dict(roughness_rms=0.004, corr_length=0.05)),
+    "rough_gob_substrate_L2_n12_passive": ("geometrical_optics_backscatter", dict(mean_square_slope=0.05)),
+}

@@ -196,7 +196,8 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
     try:
         ctx.upload(batch)
         info = ctx.launch_info()
-        assert info["pipeline"] == "gmem" and info["n_max"] == 128 and info["chunks"] == 1, info
+        assert info["pipeline"] == "gmem" and info["n_max"] == 128, info
+        assert info["chunks"] * info["chunk_pairs"] >= batch.n_pairs > (info["chunks"] - 1) * info["chunk_pairs"], info
         ctx.launch(); ctx.sync()
         assert (ctx.download().status == 0).all()
         # the other shapes take the kernels DESIGN.md section 4 names

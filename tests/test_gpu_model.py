@@ -645,3 +645,44 @@ def test_reference_shaped_objects_through_the_runner(name):
             em.frac_volume = 1.0 - layer.frac_volume if layer.frac_volume > 0.5 else layer.frac_volume
     one = DORT(**model.rtsolver_options).solve(sp, emmodels, sensor, sp.atmosphere)
     assert np.array_equal(np.asarray(one.data.values), np.asarray(results[-1].data.values))
+
+
+def test_own_rough_models_end_to_end():
+    """Rough interfaces and rough substrates by NAME, standalone: make_interface("iem_fung92" | "geometrical_optics", ...)
+    in make_snowpack(interface=[...]) and make_soil("iem_fung92" | "geometrical_optics" | "geometrical_optics_backscatter",
+    eps, T, ...) under the snowpack -- smrt_amd's own evaluators (interface/iem_fung92.py, geometrical_optics*.py) feeding
+    the dense interface / bottom-boundary composition of the device -- against the reference's results for the same
+    models and parameters (the fixtures of the replayed-object tests above), passive and active."""
+    import warnings
+
+    from conftest import ROUGH_INTERFACE_MODELS, ROUGH_SUBSTRATE_MODELS, snowpack_dict
+    from smrt_amd import make_interface, make_model, make_snowpack, make_soil, sensor_list
+
+    def check(d, pack):
+        f = float(d["frequency"][0])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if str(d["mode"]) == "A":
+                opts = dict(n_max_stream=int(d["opt_n_max_stream"]), m_max=int(d["opt_m_max"]))
+                res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.active(f, list(d["theta_inc_deg"])), pack)
+                fac = 4 * np.pi * np.cos(np.deg2rad(d["theta_inc_deg"]))
+                np.testing.assert_allclose(np.ravel(res.sigmaVV()), fac * d["result"][0, 0, 0], rtol=1e-8)
+                np.testing.assert_allclose(np.ravel(res.sigmaHH()), fac * d["result"][0, 1, 1], rtol=1e-8)
+            else:
+                opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+                res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.passive(f, list(d["theta_deg"])), pack)
+                np.testing.assert_allclose(np.ravel(res.TbV()), d["result"][0, 0], atol=1e-6)
+                np.testing.assert_allclose(np.ravel(res.TbH()), d["result"][0, 1], atol=1e-6)
+
+    for name, (model, kw) in ROUGH_INTERFACE_MODELS.items():
+        d = load_golden(name)
+        sp = snowpack_dict(d)
+        itf = ["flat"] * len(sp["thickness"])
+        itf[int(d["rough_interface"][0])] = make_interface(model, **kw)
+        check(d, make_snowpack(sp["thickness"], "exponential", density=sp["density"], temperature=sp["temperature"],
+                               corr_length=sp["corr_length"], interface=itf))
+    for name, (model, kw) in ROUGH_SUBSTRATE_MODELS.items():
+        d = load_golden(name)
+        sp = snowpack_dict(d)
+        check(d, make_snowpack(sp["thickness"], "exponential", density=sp["density"], temperature=sp["temperature"],
+                               corr_length=sp["corr_length"], substrate=make_soil(model, complex(8.0, 1.0), 268.0, **kw)))

@@ -812,3 +812,68 @@ def test_make_snowpack_refusals_and_defaults_follow_the_reference():
     assert sp.nlayer == 2
     shs = make_snowpack([1.0], "sticky_hard_spheres", density=300, radius=1e-4)
     assert shs.layers[0].microstructure.device_params == (1e-4, 1000.0) and shs.packed()[4, 0] == 1000.0
+
+
+def _close(got, want, rtol=1e-12):
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    if want.ndim == 0 or not np.any(want):
+        assert not np.any(got)
+        return
+    np.testing.assert_allclose(got.reshape(want.shape), want, rtol=rtol, atol=rtol * np.abs(want).max())
+
+
+def test_own_rough_interface_evaluators_against_the_reference_outputs():
+    """smrt_amd/interface/iem_fung92.py and geometrical_optics.py (own NumPy evaluators of Fung et al. 1992 and of Tsang
+    vol. III section 2.1) against what the reference's objects returned on the stream grids of the fixtures
+    (itf_raw_*: specular reflection, coherent transmission, azimuth modes of the diffuse reflection / transmission, both
+    sides of the interface): 1e-12."""
+    import warnings
+
+    from conftest import ROUGH_INTERFACE_MODELS, load_golden
+    from smrt_amd import make_interface
+
+    for name, (model, kw) in ROUGH_INTERFACE_MODELS.items():
+        d = load_golden(name)
+        itf = make_interface(model, **kw)
+        f, act = float(d["frequency"][0]), str(d["mode"]) == "A"
+        npol, m_max = (3, 2) if act else (2, 0)
+        lo, up = complex(d["itf_eps_low"][0]), complex(d["itf_eps_up"][0])
+        mu_l, mu_u, mu_t = d["itf_mu_low"], d["itf_mu_up"], d["itf_mu_t_up"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # (the IEM validity warning, like the reference's)
+            _close(itf.specular_reflection_matrix(f, lo, up, mu_l, npol), d["itf_raw_spec_up"])
+            _close(itf.specular_reflection_matrix(f, up, lo, mu_u, npol), d["itf_raw_spec_dn"])
+            _close(itf.coherent_transmission_matrix(f, lo, up, mu_l, npol), d["itf_raw_ctr_up"])
+            _close(itf.coherent_transmission_matrix(f, up, lo, mu_u, npol), d["itf_raw_ctr_dn"])
+            _close(itf.ft_even_diffuse_reflection_matrix(f, lo, up, mu_l, mu_l, m_max, npol), d["itf_raw_drf_up"])
+            _close(itf.ft_even_diffuse_reflection_matrix(f, up, lo, mu_u, mu_u, m_max, npol), d["itf_raw_drf_dn"])
+            if "itf_raw_dtr_up" in d:
+                _close(itf.ft_even_diffuse_transmission_matrix(f, lo, up, mu_t, mu_l, m_max, npol), d["itf_raw_dtr_up"])
+                _close(itf.ft_even_diffuse_transmission_matrix(f, up, lo, mu_l, mu_u, m_max, npol), d["itf_raw_dtr_dn"])
+
+
+def test_own_rough_substrates_against_the_reference_outputs():
+    """make_soil("iem_fung92" | "geometrical_optics" | "geometrical_optics_backscatter", eps, T, ...): the substrate protocol
+    on the streams of the last layer against what the reference's substrates returned (sub_*_raw), incl. the hemispherical
+    integration behind the emissivity of the backscatter-only geometrical optics: 1e-12."""
+    import warnings
+
+    from conftest import ROUGH_SUBSTRATE_MODELS, load_golden
+    from smrt_amd import make_soil
+    from smrt_amd.core.snowpack import substrate_kind
+
+    for name, (model, kw) in ROUGH_SUBSTRATE_MODELS.items():
+        d = load_golden(name)
+        soil = make_soil(model, complex(8.0, 1.0), 268.0, **kw)
+        assert substrate_kind(soil) == "host" and soil.temperature == 268.0
+        f, act = float(d["frequency"][0]), str(d["mode"]) == "A"
+        npol, m_max = (3, 2) if act else (2, 0)
+        mu, eps = d["sub_mu"], complex(d["f0_effective_permittivity"][len(d["thickness"]) - 1])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _close(soil.specular_reflection_matrix(f, eps, mu, npol), d["sub_spec_raw"])
+            _close(soil.ft_even_diffuse_reflection_matrix(f, eps, mu, mu, m_max, npol), d["sub_diff_raw"])
+            if "sub_emis_raw" in d:
+                _close(soil.emissivity_matrix(f, eps, mu, npol), d["sub_emis_raw"])
+    with pytest.raises(Exception, match="outside the scope"):
+        make_soil("flat", "dobson85", 268.0)
