@@ -154,8 +154,8 @@ typedef struct smrt_batch {
      *                      0 is used); passive mode: the emissivity diagonal (substrate.emissivity_matrix,
      *                      rtsolver_utils.py:533-536), multiplied by B(substrate_temperature[s]) on the device
      * (The reference runs its purely diffuse substrates -- geometrical_optics -- in active mode only: in passive mode it
-     * raises, dort.py:437; iem_fung92*, geometrical_optics_backscatter run in both.)  Not combined with
-     * process_coherent_layers. */
+     * raises, dort.py:437; iem_fung92*, geometrical_optics_backscatter run in both.)  Under process_coherent_layers the
+     * caller samples them on the streams of the REDUCED snowpack (the layers with k0 Re(n) d >= 3 pi / 4). */
     const double* host_substrate;
     const double* host_substrate_coh;
     /* SMRT_INTERFACE_HOST: rough interfaces at the surface or between layers (smrt/interface/iem_fung92.py,
@@ -177,8 +177,11 @@ typedef struct smrt_batch {
      *                       reference does, dort.py:372-376,409-414);
      *   host_interface_coh  [F * S][host_interface_slots][4][NE]: the diagonals of the specular-only versions of the same
      *                       four for mode 0 (index 2 * stream + polarisation): the coherent pass of active mode.
-     * NULL host_interface_slot: every interface is Flat.  Not combined with process_coherent_layers; the interface under
-     * the last layer kept by prune_deep_snowpack is taken as Flat. */
+     * NULL host_interface_slot: every interface is Flat.  Under prune_deep_snowpack a rough interface right below the last
+     * kept layer closes the recursion with its Rbot (what the reference's truncated system keeps, dort.py:443-452).  Under
+     * process_coherent_layers the caller samples the matrices on the streams of the REDUCED snowpack and gives no slot to
+     * an interface on top of or right below a collapsed layer (the reference's CoherentFlat takes its place,
+     * interface/coherent_flat.py:37-45): the slot index stays the layer's index in the INPUT arrays. */
     const int32_t* host_interface_slot;
     const double* host_interface;
     const double* host_interface_coh;

@@ -181,6 +181,8 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 fresnel_RT3(cmk(s.eps_re[Lc - 1], s.eps_im[Lc - 1]), cmk(s.eps_re[Lc], s.eps_im[Lc]), sqrt(1.0 - rs * rs), R3, T3,
                             frequency, cmk(s.slab_re[Lc], s.slab_im[Lc]), s.slab_th[Lc]);
                 Rt = R3[pol];
+                const int hsb = host_interface_slot(b, gp, (int)s.lo[Lc]);   // a rough interface there: its specular part
+                if (hsb >= 0) Rt = host_interface_specular(b, gp, hsb)[2 * 3 * nmax + 2 * j + pol];
             }
         } else
         if (b.sub_kind == SUB_HOST && j < (int)s.nl[L - 1]) {   // specular part of a rough substrate, from the caller (mode 0)
@@ -292,6 +294,15 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     if (Lk < L) fresnel_RT3(el, ebelow, s.mu[j], R3, T3, frequency, cmk(s.slab_re[l + 1], s.slab_im[l + 1]), s.slab_th[l + 1]);
                     else fresnel_RT3(el, ebelow, s.mu[j], R3, T3);
                     for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
+                }
+                // ... or, when that interface is a rough one evaluated by the caller, its dense reflection of this azimuth
+                // mode seen from this layer (Rbot of the slot), as in the reference's truncated system (dort.py:443-452)
+                const int hsb = (Lk < L) ? host_interface_slot(b, gp, (int)s.lo[l + 1]) : -1;
+                if (hsb >= 0) {
+                    block_sync();
+                    const int NE = 3 * nmax;
+                    const double* Rb = host_interface_matrices(b, gp, hsb, m, m_max + 1) + 2LL * NE * NE;
+                    for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = Rb[r * NE + c]; });
                 }
             }
             if (MODE != 1 && l == Lk - 1 && Lk == L && b.sub_kind == SUB_HOST) {

@@ -134,8 +134,6 @@ inline const char* validate(const smrt_batch* b) {
     if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {
         if (!b->host_substrate || !b->host_substrate_coh) return "SMRT_SUBSTRATE_HOST needs host_substrate and host_substrate_coh";
         if (b->mode == SMRT_MODE_PASSIVE && !b->substrate_temperature) return "SMRT_SUBSTRATE_HOST in passive mode needs substrate_temperature";
-        if (b->process_coherent_layers)
-            return "process_coherent_layers cannot be combined with SMRT_SUBSTRATE_HOST (its matrices are the caller's, sampled on the streams of the full snowpack)";
     } else
     if (b->substrate_kind != SMRT_SUBSTRATE_NONE && (!b->substrate_p1 || !b->substrate_p2 || !b->substrate_temperature))
         return "substrate arrays missing";
@@ -144,7 +142,6 @@ inline const char* validate(const smrt_batch* b) {
     if (b->host_interface_slot) {
         if (!b->host_interface || !b->host_interface_coh || b->host_interface_slots < 1)
             return "host_interface_slot needs host_interface, host_interface_coh and host_interface_slots >= 1";
-        if (b->process_coherent_layers) return "process_coherent_layers cannot be combined with interfaces evaluated by the caller";
         const long long n = (long long)b->n_frequencies * b->n_snowpacks * b->n_layers_max;
         for (long long i = 0; i < n; ++i)
             if (b->host_interface_slot[i] < -1 || b->host_interface_slot[i] >= b->host_interface_slots) return "host_interface_slot entry out of range";

@@ -390,6 +390,18 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 const double* H = b.host_substrate + gp * (long long)NE * NE;
                 for_2d<NT>(N, N, [&](int r, int c) { if (r != c) s.M3[c * LD + r] = H[r * NE + c]; });
             }
+            if (Lk < L) {
+                // the interface to the first dropped layer is a rough one evaluated by the caller: its dense reflection
+                // seen from this layer (Rbot of the slot: specular + diffuse, rtsolver_utils.py:567-597) is what the
+                // reference's truncated system keeps (dort.py:443-452)
+                const int hsb = host_interface_slot(b, gp, (int)s.lo[l + 1]);
+                if (hsb >= 0) {
+                    block_sync();
+                    const int NE = 3 * nmax;
+                    const double* Rb = host_interface_matrices(b, gp, hsb, 0, 1) + 2LL * NE * NE;
+                    for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = Rb[r * NE + c]; });
+                }
+            }
         }
         block_sync();
         // -- weights (streams.py:324-330), per-row copies, interface diagonals

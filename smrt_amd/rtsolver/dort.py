@@ -338,6 +338,16 @@ class DORT(object):
         lay = res.layers.reshape(F, S, Lmax, 5)
         return lay[..., 0] + 1j * lay[..., 1]
 
+    def _staying_layers(self, frequency, eps_layers, thickness):
+        """Indices of the layers process_coherent_layers leaves in the snowpack at this frequency (all of them without the
+        option): a layer with k0 Re(n) d < 3 pi / 4 is collapsed into the interface below it
+        (smrt/interface/coherent_flat.py:16-30) -- the device applies the same criterion to the same permittivities."""
+        if not self.process_coherent_layers:
+            return list(range(len(eps_layers)))
+        k0 = 2.0 * np.pi * float(frequency) / C_SPEED
+        return [l for l in range(len(eps_layers))
+                if not k0 * np.sqrt(complex(eps_layers[l])).real * thickness[l] < 0.75 * np.pi]
+
     # ---- rough interfaces evaluated on the host (include/smrt_dort.h: SMRT_INTERFACE_HOST) --------------------------
     @staticmethod
     def _streams_of(eps_layers, n_max_stream):
@@ -427,8 +437,6 @@ class DORT(object):
         """(slot, matrices, specular diagonals) of PackedBatch(host_interfaces=...) for a group with rough interfaces: every
         interface object that is not Flat is evaluated through the reference's interface protocol on the streams of the
         two media it separates."""
-        if self.process_coherent_layers:
-            raise SMRTError("process_coherent_layers is not available with interfaces evaluated on the host")
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
@@ -443,21 +451,31 @@ class DORT(object):
                 if not rough[s]:
                     continue
                 e = eps[fi, s, :nl[s]]
-                mus, ws, outmu, outw = self._streams_of(e, self.n_max_stream)
+                # under process_coherent_layers the matrices are sampled on the streams of the REDUCED snowpack; a rough
+                # interface on top of or right below a collapsed layer goes into the reference's CoherentFlat, which takes
+                # it for a flat one (smrt/interface/coherent_flat.py:37-45): no slot, the device's Fabry-Perot slab stands
+                stay = self._staying_layers(f, e, cols[0][s])
+                if not stay:
+                    continue
+                at = {l: r for r, l in enumerate(stay)}
+                mus, ws, outmu, outw = self._streams_of(e[stay], self.n_max_stream)
                 for k, i in enumerate(rough[s]):
-                    mu_up, w_up, e_up = (mus[i - 1], ws[i - 1], complex(e[i - 1])) if i > 0 else (outmu, outw, 1.0)
-                    mu_t = mus[i - 1] if i > 1 else outmu      # (the reference's choice, rtsolver_utils.py:510)
-                    modes, coh = self.interface_matrices(sp.interfaces[i], float(f), complex(e[i]), e_up, mus[i], mu_up, mu_t,
-                                                         ws[i], w_up, self.m_max if act else 0, npol)
+                    if i not in at or (i > 0 and (i - 1) not in at):
+                        continue
+                    r = at[i]
+                    mu_up, w_up, e_up = (mus[r - 1], ws[r - 1], complex(e[i - 1])) if r > 0 else (outmu, outw, 1.0)
+                    mu_t = mus[r - 1] if r > 1 else outmu      # (the reference's choice, rtsolver_utils.py:510)
+                    modes, coh = self.interface_matrices(sp.interfaces[i], float(f), complex(e[i]), e_up, mus[r], mu_up, mu_t,
+                                                         ws[r], w_up, self.m_max if act else 0, npol)
                     slot[fi, s, i] = k
                     for m in range(nm):
                         P = 2 if m == 0 else 3
-                        n_low, n_up = len(mus[i]) * P, len(mu_up) * P
+                        n_low, n_up = len(mus[r]) * P, len(mu_up) * P
                         for q, (kind, rows) in enumerate((("Rtop", n_low), ("Ttop", n_up), ("Rbot", n_up), ("Tbot", n_low))):
                             A = modes[m][kind]
-                            r = min(A.shape[0], rows)     # cut to the common streams like dort.py:372-376,409-414
-                            M[fi, s, k, m, q, :r, :A.shape[1]] = A[:r]
-                    for q, (kind, rows) in enumerate((("Rtop", None), ("Ttop", len(mu_up) * 2), ("Rbot", None), ("Tbot", len(mus[i]) * 2))):
+                            rr = min(A.shape[0], rows)     # cut to the common streams like dort.py:372-376,409-414
+                            M[fi, s, k, m, q, :rr, :A.shape[1]] = A[:rr]
+                    for q, (kind, rows) in enumerate((("Rtop", None), ("Ttop", len(mu_up) * 2), ("Rbot", None), ("Tbot", len(mus[r]) * 2))):
                         c = coh[kind] if rows is None else coh[kind][:rows]
                         C[fi, s, k, q, :len(c)] = c
         return slot, M, C
@@ -503,9 +521,6 @@ class DORT(object):
         pre-pass of the device emmodels (four streams, layer diagnostics only)."""
         from .._native import PackedBatch, gauss_legendre_positive
 
-        if self.process_coherent_layers:
-            raise SMRTError("process_coherent_layers is not available with a substrate evaluated on the host (its matrices are "
-                            "sampled on the streams of the full snowpack, which may change when layers are removed)")
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
@@ -517,7 +532,10 @@ class DORT(object):
         for fi, f in enumerate(freqs):
             for s, sp in enumerate(sps):
                 e = eps[fi, s, :nl[s]]
-                star = max(range(len(e)), key=lambda l: (e[l].real, e[l].imag, -l))
+                # (under process_coherent_layers: the streams of the last layer in the REDUCED snowpack -- the most
+                # refringent layer is looked for among the layers that stay)
+                stay = self._staying_layers(f, e, cols[0][s]) or list(range(len(e)))
+                star = max(stay, key=lambda l: (e[l].real, e[l].imag, -l))
                 rs = np.sqrt(e[star] / e[-1]).real * gsin
                 mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
                 w = np.empty_like(mu)                       # streams.py:324-330

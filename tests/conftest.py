@@ -511,3 +511,100 @@ ROUGH_SUBSTRATE_MODELS = {
     "rough_iem_substrate_L3_n10_passive": ("iem_fung92", dict(roughness_rms=0.004, corr_length=0.05)),
     "rough_gob_substrate_L2_n12_passive": ("geometrical_optics_backscatter", dict(mean_square_slope=0.05)),
 }
+
+
+# DORT options x rough interfaces / substrates: the inputs of tests/golden/make_rough_option_fixtures.py (the fixtures of
+# these names hold the reference's results for them)
+_OPT_LAYERS = dict(density=[250.0, 320.0, 380.0, 400.0], temperature=[258.0, 261.0, 264.0, 266.0],
+                   corr_length=[1e-4, 3e-4, 2e-4, 1.5e-4])
+ROUGH_OPTION_CASES = {
+    "rough_prune_iem_L4_n10_passive": dict(
+        thickness=[0.3, 2.0, 0.5, 100.0], **_OPT_LAYERS, mode="P", frequency=36.5e9, theta=[40.0, 55.0],
+        options=dict(n_max_stream=10, prune_deep_snowpack=0.5),
+        interface=("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 2)),
+    "rough_prune_go_L4_n10_active": dict(
+        thickness=[0.3, 2.0, 0.5, 1000.0], **_OPT_LAYERS, mode="A", frequency=36.5e9, theta=[30.0, 40.0],
+        options=dict(n_max_stream=10, m_max=2, prune_deep_snowpack=0.5),
+        interface=("geometrical_optics", dict(mean_square_slope=0.03), 2)),
+    "rough_coherent_iem_L5_n10_passive": dict(
+        thickness=[0.3, 0.25, 0.002, 0.4, 100.0], density=[250.0, 300.0, 900.0, 350.0, 400.0],
+        temperature=[258.0, 260.0, 261.0, 263.0, 265.0], corr_length=[1e-4, 1.5e-4, 5e-5, 2e-4, 1.5e-4], mode="P",
+        frequency=18.7e9, theta=[40.0, 55.0], options=dict(n_max_stream=10, process_coherent_layers=True),
+        interface=("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 0)),
+    "rough_coherent_adjacent_L5_n10_passive": dict(
+        thickness=[0.3, 0.25, 0.002, 0.4, 100.0], density=[250.0, 300.0, 900.0, 350.0, 400.0],
+        temperature=[258.0, 260.0, 261.0, 263.0, 265.0], corr_length=[1e-4, 1.5e-4, 5e-5, 2e-4, 1.5e-4], mode="P",
+        frequency=18.7e9, theta=[40.0, 55.0], options=dict(n_max_stream=10, process_coherent_layers=True),
+        interface=("iem_fung92", dict(roughness_rms=0.002, corr_length=0.05), 2)),
+    "rough_coherent_gosub_L4_n10_active": dict(
+        thickness=[0.3, 0.002, 0.4, 0.8], density=[250.0, 900.0, 350.0, 400.0], temperature=[258.0, 261.0, 263.0, 265.0],
+        corr_length=[1e-4, 5e-5, 2e-4, 1.5e-4], mode="A", frequency=13.4e9, theta=[30.0, 40.0],
+        options=dict(n_max_stream=10, m_max=2, process_coherent_layers=True),
+        substrate=("geometrical_optics", dict(mean_square_slope=0.05)), substrate_eps=(8.0, 1.0), substrate_temperature=268.0),
+}
+
+
+# ---- the device source on the CPU, behind the product's own host code --------------------------------------------------
+EMU_LIB = os.path.join(ROOT, "tests", "hostemu", "libsmrt_emu.so")
+
+
+class EmulatedContext:
+    """Stands where rtsolver/dort.py:get_context returns the GPU context: same `run` signature, the device source run by
+    the CPU emulator; records every batch it is handed."""
+
+    def __init__(self):
+        if not os.path.exists(EMU_LIB):
+            pytest.skip("emulator library not built (python __graft_entry__.py)")
+        import ctypes as C
+        import threading
+
+        from smrt_amd._native import SmrtBatch
+
+        self.lib = C.CDLL(EMU_LIB)
+        P = C.POINTER
+        self.lib.smrt_emu_run.argtypes = [P(SmrtBatch), C.c_longlong, C.c_longlong, C.c_int, C.c_int, P(C.c_double),
+                                          P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_long)]
+        self.lock = threading.RLock()
+        self.batches = []
+        self.compute = True    # False: record the batch, hand back zeros (20 layers x 32 streams cost ~9 s per pair here)
+
+    def set_block_threads(self, n):
+        pass
+
+    def run(self, batch, lo=0, n=None, pairs=None):
+        import ctypes as C
+
+        from smrt_amd._native import BatchOutput
+
+        self.batches.append((batch, None if pairs is None else np.array(pairs)))
+        todo = [(int(lo), batch.n_pairs - int(lo) if n is None else int(n))] if pairs is None else [(int(p), 1) for p in pairs]
+        out = BatchOutput(batch, sum(c for _, c in todo))
+        if not self.compute:
+            for a in (out.values, out.status, out.layers, out.streams):
+                a[...] = 0
+            return out
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        row = 0
+        for begin, count in todo:
+            sl = slice(row, row + count)
+            v, st = np.empty_like(out.values[sl]), np.empty(count, np.int32)
+            lay, stream = np.empty_like(out.layers[sl]), np.empty_like(out.streams[sl])
+            rc = self.lib.smrt_emu_run(C.byref(batch.struct), begin, count, 64, 0, dp(v), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       dp(lay), dp(stream), None, None)
+            assert rc == 0
+            out.values[sl], out.status[sl], out.layers[sl], out.streams[sl] = v, st, lay, stream
+            row += count
+        return out
+
+
+
+
+@pytest.fixture()
+def emulated(monkeypatch):
+    """rtsolver/dort.py:get_context routed to the CPU emulator of the device source (EmulatedContext): Model.run, the
+    runners and the host-side packing run as they are, the kernels run under tests/hostemu."""
+    import smrt_amd.rtsolver.dort as dort
+
+    ctx = EmulatedContext()
+    monkeypatch.setattr(dort, "get_context", lambda device=None: ctx)
+    return ctx

@@ -686,3 +686,19 @@ def test_own_rough_models_end_to_end():
         sp = snowpack_dict(d)
         check(d, make_snowpack(sp["thickness"], "exponential", density=sp["density"], temperature=sp["temperature"],
                                corr_length=sp["corr_length"], substrate=make_soil(model, complex(8.0, 1.0), 268.0, **kw)))
+
+
+@pytest.mark.parametrize("name", ["rough_prune_iem_L4_n10_passive", "rough_prune_go_L4_n10_active",
+                                  "rough_coherent_iem_L5_n10_passive", "rough_coherent_adjacent_L5_n10_passive",
+                                  "rough_coherent_gosub_L4_n10_active"])
+def test_rough_interfaces_under_prune_and_coherent_options(name):
+    """The two parity holes of round 3's rough-interface work, closed: prune_deep_snowpack cutting above a rough interface
+    (the reference's truncated system keeps that interface's dense reflection, smrt/rtsolver/dort.py:443-452 with
+    rtsolver_utils.py:567-597) and process_coherent_layers together with rough interfaces / a rough substrate (sampled on
+    the streams of the reduced snowpack; an interface on the collapsed layer goes into the reference's CoherentFlat,
+    interface/coherent_flat.py:16-57).  make_snowpack / make_interface / make_soil by name -> Model.run -> the GPU,
+    against the reference's own results (tests/golden/make_rough_option_fixtures.py)."""
+    from conftest import ROUGH_OPTION_CASES
+    from test_hostemu_kernel import check_rough_option_case
+
+    check_rough_option_case(name, ROUGH_OPTION_CASES[name])

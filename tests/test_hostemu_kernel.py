@@ -349,3 +349,61 @@ def test_emulated_kernel_rough_substrate_passive(emu, name, nt, pipeline):
         C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
     assert (st == 0).all()
     assert np.abs(out - ref).max() < 1e-6
+
+
+def _own_rough_option_pack(case):
+    """smrt_amd's own objects for one of conftest.ROUGH_OPTION_CASES: the rough interface / substrate by name."""
+    from smrt_amd import make_interface, make_snowpack, make_soil, sensor_list
+
+    itf = ["flat"] * len(case["thickness"])
+    if case.get("interface"):
+        model, kw, where = case["interface"]
+        itf[where] = make_interface(model, **kw)
+    substrate = None
+    if case.get("substrate"):
+        model, kw = case["substrate"]
+        substrate = make_soil(model, complex(*case["substrate_eps"]), case["substrate_temperature"], **kw)
+    pack = make_snowpack(case["thickness"], "exponential", density=case["density"], temperature=case["temperature"],
+                         corr_length=case["corr_length"], interface=itf, substrate=substrate)
+    sensor = (sensor_list.active if case["mode"] == "A" else sensor_list.passive)(case["frequency"], case["theta"])
+    return sensor, pack
+
+
+def check_rough_option_case(name, case):
+    """Model.run on smrt_amd's own objects against the reference's result for the same models and options; where the
+    reference's answer depends on the rough model at all, the answer with Flat interfaces must NOT pass."""
+    import warnings
+
+    from smrt_amd import make_model
+
+    d = load_golden(name)
+    sensor, pack = _own_rough_option_pack(case)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = make_model("iba", "dort", rtsolver_options=case["options"]).run(sensor, pack)
+    got, ref, flat = np.asarray(res.data.values), d["result"][0], d["result_flat"][0]
+    assert got.shape == ref.shape
+    if case["mode"] == "P":
+        assert np.abs(got - ref).max() < 1e-6
+        if np.abs(ref - flat).max() > 1e-5:
+            assert np.abs(got - flat).max() > 1e-5
+    else:
+        assert_backscatter_close(got, ref)
+        rel = (np.abs(ref - flat) / np.abs(ref))[:2, :2].max()
+        if rel > 1e-7:
+            assert (np.abs(got - flat) / np.abs(ref))[:2, :2].max() > 1e-7
+    assert len(np.ravel(res.other_data["ks"].values)) == int(d["kept_layers"])
+
+
+@pytest.mark.parametrize("name", ["rough_prune_iem_L4_n10_passive", "rough_prune_go_L4_n10_active",
+                                  "rough_coherent_iem_L5_n10_passive", "rough_coherent_adjacent_L5_n10_passive",
+                                  "rough_coherent_gosub_L4_n10_active"])
+def test_emulated_rough_interfaces_under_prune_and_coherent_options(name, emulated):
+    """prune_deep_snowpack cutting above a rough interface (its dense reflection closes the recursion, dort.py:443-452) and
+    process_coherent_layers with a rough interface elsewhere / on the collapsed layer / with a rough substrate (matrices
+    sampled on the streams of the reduced snowpack; coherent_flat.py:16-57): the whole product path -- own interface
+    evaluators, host packing, device source under the emulator -- against the reference (fixtures of
+    tests/golden/make_rough_option_fixtures.py)."""
+    from conftest import ROUGH_OPTION_CASES
+
+    check_rough_option_case(name, ROUGH_OPTION_CASES[name])
