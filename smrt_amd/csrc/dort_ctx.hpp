@@ -48,6 +48,13 @@ struct smrt_dort_ctx {
     int max_lds = 0;
     bool split = true;          // three-kernel pipeline on the LDS path (fused single kernel if false)
     long long chunk_pairs = 0;  // pairs per pipeline pass (bounds the staging area)
+    // Concurrent pipeline passes (LDS pipelines): chunk c runs prep -> Jacobi -> finish on lane stream c % lanes with its own
+    // staging region, so that the kernels of different chunks overlap on the chip (the prep, Jacobi and finish kernels
+    // stall on different resources and each launch has a tail); joined into `stream` before the launch returns.
+    int lanes = 1;
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
     size_t jacobi_lds = 0;
     smrt::DevStage stage{};
     bool gmem_path = false;

@@ -51,6 +51,9 @@ static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long 
 // Jacobi kernels run in up to four ROUNDS over successive layer ranges, top-down, with a small kernel in between that
 // marks the pairs whose cut has been reached: the layers below a cut are never diagonalised (like in the reference),
 // exactly -- the decision uses the same singular values as the finish kernel.
+#ifndef SMRT_DORT_LANES_DEFAULT
+#define SMRT_DORT_LANES_DEFAULT 1   // concurrent pipeline passes on the LDS pipelines (SMRT_DORT_LANES overrides; measured in profiles/)
+#endif
 #ifndef SMRT_FINISH_REG_DEFAULT
 #define SMRT_FINISH_REG_DEFAULT 1   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
 #endif
@@ -72,17 +75,41 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         if (ctx->finish_reg) return smrt_launch::finish_reg(ctx, c);
         return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
     };
-    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
+    // lanes > 1: chunk k runs on lane stream k % lanes with the k % lanes-th region of the staging area (the launchers read
+    // ctx->stream / ctx->stage, swapped for the duration of the chunk's launches; restored below)
+    const hipStream_t main_stream = ctx->stream;
+    const DevStage stage0 = ctx->stage;
+    const int lanes = (ctx->lanes > 1 && d.pair_count > ctx->chunk_pairs) ? ctx->lanes : 1;
+    struct Restore { smrt_dort_ctx* c; hipStream_t s; DevStage st; ~Restore() { c->stream = s; c->stage = st; } } restore{ctx, main_stream, stage0};
+    if (lanes > 1) {
+        hipError_t e;
+        if ((e = hipEventRecord(ctx->fork_ev, main_stream)) != hipSuccess) return e;
+        for (int k = 0; k < lanes; ++k)
+            if ((e = hipStreamWaitEvent(ctx->lane_stream[k], ctx->fork_ev, 0)) != hipSuccess) return e;
+    }
+    long long chunk_index = 0;
+    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs, ++chunk_index) {
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
         DevBatch c = chunk_of(ctx, d, c0, cn);
         const unsigned grid = (unsigned)(ctx->gmem_path ? std::min<long long>(cn, ctx->gmem_grid) : cn);
         hipError_t e;
+        const int lane = (int)(chunk_index % lanes);
+        int* done_lane = (int*)ctx->d_done.p + (size_t)lane * ctx->chunk_pairs;
+        if (lanes > 1) {
+            const long long it0 = (long long)lane * ctx->chunk_pairs * items_per_pair;
+            ctx->stream = ctx->lane_stream[lane];
+            ctx->stage = stage0;
+            ctx->stage.L = stage0.L + it0 * stage0.mat_stride; ctx->stage.B = stage0.B + it0 * stage0.mat_stride;
+            ctx->stage.d = stage0.d + it0 * stage0.vec_stride; ctx->stage.sigma = stage0.sigma + it0 * stage0.vec_stride;
+            ctx->stage.n = stage0.n + it0; ctx->stage.Linv = stage0.Linv + it0 * 1024;
+            if (stage0.ws) ctx->stage.ws = stage0.ws + (long long)lane * ctx->chunk_pairs * rg::kSlotDoubles;
+        }
         if (rounds > 1 || d.coherent) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
             if ((e = hipMemsetAsync(ctx->stage.n, 0, sizeof(int) * (size_t)(cn * items_per_pair), ctx->stream)) != hipSuccess) return e;
         }
         if (rounds > 1) {
-            if ((e = hipMemsetAsync(ctx->d_done.p, 0, sizeof(int) * (size_t)cn, ctx->stream)) != hipSuccess) return e;
-            c.pair_done = (const int*)ctx->d_done.p;
+            if ((e = hipMemsetAsync(done_lane, 0, sizeof(int) * (size_t)cn, ctx->stream)) != hipSuccess) return e;
+            c.pair_done = (const int*)done_lane;
         }
         for (int r = 0; r < rounds; ++r) {
             c.layer_lo = (int)((long long)d.Lmax * r / rounds);
@@ -90,10 +117,17 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
             if ((e = prep(c, grid)) != hipSuccess) return e;
             const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
             if ((e = ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems)) != hipSuccess) return e;
-            if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, (int*)ctx->d_done.p)) != hipSuccess) return e;
+            if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, done_lane)) != hipSuccess) return e;
         }
         c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
         if ((e = finish(c, grid)) != hipSuccess) return e;
+    }
+    if (lanes > 1) {   // join: whatever follows on the context's stream (timing event, download, gather) waits for every lane
+        for (int k = 0; k < lanes; ++k) {
+            hipError_t e;
+            if ((e = hipEventRecord(ctx->lane_ev[k], ctx->lane_stream[k])) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(main_stream, ctx->lane_ev[k], 0)) != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -148,6 +182,11 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < 4; ++k) {
+        if (ctx->lane_ev[k]) (void)hipEventDestroy(ctx->lane_ev[k]);
+        if (ctx->lane_stream[k]) (void)hipStreamDestroy(ctx->lane_stream[k]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -258,12 +297,25 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         long long chunk = (long long)(budget / (double)per_pair);
         if (chunk < 1) chunk = 1;
         if (chunk > pair_count) chunk = pair_count;
+        ctx->lanes = 1;
+        if (!ctx->gmem_path) {   // (the global-workspace pipelines share one per-workgroup workspace: one pass at a time)
+            int want = SMRT_DORT_LANES_DEFAULT;
+            if (const char* e = getenv("SMRT_DORT_LANES")) want = atoi(e);
+            ctx->lanes = std::max(1, std::min(4, want));
+            if (pair_count < 1024LL * ctx->lanes) ctx->lanes = 1;   // small batches: one pass fills the chip at most once
+        }
         {   // equal chunks: a short last chunk would leave most of the chip idle for a whole pipeline pass
-            const long long nchunks = (pair_count + chunk - 1) / chunk;
+            long long nchunks = (pair_count + chunk - 1) / chunk;
+            if (ctx->lanes > 1) nchunks = ((nchunks + ctx->lanes - 1) / ctx->lanes) * ctx->lanes;
             chunk = (pair_count + nchunks - 1) / nchunks;
         }
         ctx->chunk_pairs = chunk;
-        const size_t items = (size_t)chunk * b->n_layers_max * nmodes;
+        for (int k = 0; k < ctx->lanes && ctx->lanes > 1; ++k) {
+            if (!ctx->lane_stream[k]) HIPCHK(hipStreamCreateWithFlags(&ctx->lane_stream[k], hipStreamNonBlocking));
+            if (!ctx->lane_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->lane_ev[k], hipEventDisableTiming));
+        }
+        if (ctx->lanes > 1 && !ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        const size_t items = (size_t)chunk * ctx->lanes * b->n_layers_max * nmodes;
         HIPCHK(ctx->d_stL.reserve(items * mat * sizeof(double)));
         HIPCHK(ctx->d_stB.reserve(items * mat * sizeof(double)));
         HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
@@ -296,7 +348,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
                           (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
         ctx->stage.ws = nullptr;
         if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
-            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * rg::kSlotDoubles));
+            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * ctx->lanes * rg::kSlotDoubles));
             ctx->stage.ws = (double*)ctx->d_regws.p;
         }
     }
@@ -397,7 +449,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
     d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
-    if (d.prune_tau > 0.0) HIPCHK(ctx->d_done.reserve(sizeof(int) * (size_t)std::max<long long>(ctx->chunk_pairs, 1)));
+    if (d.prune_tau > 0.0) HIPCHK(ctx->d_done.reserve(sizeof(int) * (size_t)std::max<long long>(ctx->chunk_pairs, 1) * ctx->lanes));
     // Jacobi thresholds on the squared cosine between two columns: below skip2 a pair is not rotated, a sweep without
     // a rotation above exit2 is the last one (dort_jacobi_kernel.hpp).  SMRT_DORT_JACOBI_SKIP2 / _EXIT2 override them
     // for experiments.  Passive mode, measured on the headline batch against the oracle (profiles/r3_jacobi_thresholds.txt):
@@ -529,7 +581,9 @@ int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
         const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
         const long long last = d.pair_count - (v[SMRT_INFO_CHUNKS] - 1) * ctx->chunk_pairs;
         std::vector<int> h((size_t)(last * items_per_pair));
-        HIPCHK(hipMemcpy(h.data(), ctx->stage.n, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+        const int lanes = (ctx->lanes > 1 && d.pair_count > ctx->chunk_pairs) ? ctx->lanes : 1;
+        const long long lane = (v[SMRT_INFO_CHUNKS] - 1) % lanes;    // the staging region the last chunk ran in
+        HIPCHK(hipMemcpy(h.data(), ctx->stage.n + lane * ctx->chunk_pairs * items_per_pair, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
         long long staged = 0;
         for (int x : h) staged += (x > 0);
         v[SMRT_INFO_STAGED_ITEMS] = staged;

@@ -77,6 +77,61 @@ SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, doub
     }
 }
 
+// One pass with the X columns resident in registers: lane group `slot` takes pass slot ps (ps < nslots; several rounds when
+// there are more pass slots than lane groups), loads its column xcol(ps) once, rotates it against ycol(ps, j) for
+// j = 0 .. steps - 1 -- only the Y column moves through LDS -- and stores it once.  The Y columns of one step must be
+// distinct among the pass slots; an idle lane group works on the all-zero padding column CP (g = 0: never rotates).
+template <int GS, int RPL, class FX, class FY>
+SMRT_DEV void rotate_resident(double* Bm, int LD, int CP, int nslots, int steps, int slot, int sub, double* nrm, int* flag,
+                              double skip2, double exit2, FX xcol, FY ycol) {
+    constexpr int SLOTS = SMRT_LANES / GS;
+    for (int ps0 = 0; ps0 < nslots; ps0 += SLOTS) {
+        const int ps = ps0 + slot;
+        const bool valid = ps < nslots;
+        const int pc = valid ? xcol(ps) : CP;
+        double* cp = Bm + pc * LD;
+        double x[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) x[i] = cp[sub + i * GS];
+        double a = nrm[pc];
+        for (int j = 0; j < steps; ++j) {
+            const int qc = valid ? ycol(ps, j) : CP;
+            double* cq = Bm + qc * LD;
+            double y[RPL];
+            double gg = 0.0, gg2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                y[i] = cq[sub + i * GS];
+                if (i & 1) gg2 += x[i] * y[i]; else gg += x[i] * y[i];
+            }
+            const double bb = nrm[qc];
+            gg = group_sum<GS>(gg + gg2);
+            const double g2 = gg * gg, ab = a * bb;
+            if (g2 > skip2 * ab) {
+                const double dd = bb - a;
+                double tt, c, sn;
+                jacobi_rotation(gg, g2, dd, tt, c, sn);
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const double xn = c * x[i] - sn * y[i];
+                    cq[sub + i * GS] = sn * x[i] + c * y[i];
+                    x[i] = xn;
+                }
+                if (sub == 0) {
+                    nrm[qc] = bb + tt * gg;
+                    if (g2 > exit2 * ab) lds_or(flag, 1);
+                }
+                a -= tt * gg;
+            }
+            wave_sync_lds();  // the Y columns just written are read by other lane groups in the next step
+        }
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) cp[sub + i * GS] = x[i];
+        if (sub == 0) nrm[pc] = a;
+        wave_sync_lds();
+    }
+}
+
 // Wavefronts that rotate block pairs for an N-column item: 64 / GS = 8 column pairs per wavefront and step, so one
 // wavefront per 16 columns keeps every lane group busy (NB = 2 JW column blocks of m = ceil(N / NB) <= 8 columns).  With
 // the fixed four wavefronts of the first versions a 42 ... 48-column item (60 % of the headline batch) left a quarter
@@ -105,6 +160,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
     const int m = (N + NB - 1) / NB;
     const int CP = NB * m;
     const int me = m + (m & 1);
+    (void)me;
     constexpr int NG = NT / GS;
     const int grp = t / GS;
     bool converged = false;
@@ -131,6 +187,7 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
             }
             const int i0 = I * m, j0 = J * m;
             if (s == 0 && m > 1) {
+#ifdef SMRT_JACOBI_INTRA_ROUND_ROBIN   // ablation build: the round-robin of the first versions (both columns through LDS)
                 const int half = me / 2;
                 for (int u = 0; u < me - 1; ++u) {
                     for (int ps0 = 0; ps0 < 2 * half; ps0 += SLOTS) {
@@ -149,54 +206,28 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
                     }
                     wave_sync_lds();
                 }
+#else
+                // pairs INSIDE the two blocks of this wavefront, by recursive halving: the columns of a block split into
+                // sub-blocks of 2h, whose halves are rotated against each other like two blocks (h inner steps, the column
+                // of the first half resident in registers), for h = mp / 2, mp / 4, ... 1 -- every pair of the block once,
+                // mp - 1 steps like the round-robin it replaces, but one column through LDS per rotation instead of two
+                int mp = 1;
+                while (mp < m) mp <<= 1;
+                for (int h = mp >> 1; h >= 1; h >>= 1) {
+                    rotate_resident<GS, RPL>(Bm, LD, CP, mp, h, slot, sub, nrm, flag, skip2, exit2,
+                        [&](int ps) { const int q = ps & ((mp >> 1) - 1); const int x = (q / h) * 2 * h + (q % h);
+                                      return x < m ? ((ps < (mp >> 1)) ? i0 : j0) + x : CP; },
+                        [&](int ps, int j) { const int q = ps & ((mp >> 1) - 1); int a = (q % h) + j; if (a >= h) a -= h;
+                                             const int y = (q / h) * 2 * h + h + a;
+                                             return y < m ? ((ps < (mp >> 1)) ? i0 : j0) + y : CP; });
+                }
+#endif
             }
             // cross pairs (I_a, J_(a+j)): the lane group of slot a keeps column I_a (and its tracked norm) in
             // registers for all m inner steps -- loaded once, stored once -- only the J column moves through LDS
-            for (int ps0 = 0; ps0 < m; ps0 += SLOTS) {
-                const int ps = ps0 + slot;
-                const bool valid = ps < m;
-                const int pc = valid ? i0 + ps : CP;
-                double* cp = Bm + pc * LD;
-                double x[RPL];
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) x[i] = cp[sub + i * GS];
-                double a = nrm[pc];
-                for (int j = 0; j < m; ++j) {
-                    int bq = ps + j; if (bq >= m) bq -= m;
-                    const int qc = valid ? j0 + bq : CP;
-                    double* cq = Bm + qc * LD;
-                    double y[RPL];
-                    double gg = 0.0, gg2 = 0.0;
-#pragma unroll
-                    for (int i = 0; i < RPL; ++i) {
-                        y[i] = cq[sub + i * GS];
-                        if (i & 1) gg2 += x[i] * y[i]; else gg += x[i] * y[i];
-                    }
-                    const double bb = nrm[qc];
-                    gg = group_sum<GS>(gg + gg2);
-                    const double g2 = gg * gg, ab = a * bb;
-                    if (g2 > skip2 * ab) {
-                        const double dd = bb - a;
-                        double tt, c, sn;
-                        jacobi_rotation(gg, g2, dd, tt, c, sn);
-#pragma unroll
-                        for (int i = 0; i < RPL; ++i) {
-                            const double xn = c * x[i] - sn * y[i];
-                            cq[sub + i * GS] = sn * x[i] + c * y[i];
-                            x[i] = xn;
-                        }
-                        if (sub == 0) {
-                            nrm[qc] = bb + tt * gg;
-                            if (g2 > exit2 * ab) lds_or(flag, 1);
-                        }
-                        a -= tt * gg;
-                    }
-                    wave_sync_lds();  // the J columns just written are read by other lane groups in the next step
-                }
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) cp[sub + i * GS] = x[i];
-                if (sub == 0) nrm[pc] = a;
-            }
+            rotate_resident<GS, RPL>(Bm, LD, CP, m, m, slot, sub, nrm, flag, skip2, exit2,
+                [&](int ps) { return i0 + ps; },
+                [&](int ps, int j) { int bq = ps + j; if (bq >= m) bq -= m; return j0 + bq; });
             block_sync();
         }
         converged = (*flag == 0);

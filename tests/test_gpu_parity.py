@@ -869,3 +869,69 @@ def test_register_resident_finish_on_hard_media(ctx):
     worst, checked, refused, mism = mod.run(3, 12, ctx, verbose=False)
     assert mism == 0 and checked > 150
     assert worst < 5e-7, worst
+
+
+def test_cfg3_full_batch_size(ctx):
+    """BASELINE configs[2] at its FULL batch size: 8192 snowpacks x 7 AMSR2 frequencies = 57 344 solves of DMRT-QCA-SR, 50
+    layers, 64 streams in one smrt_dort_run call (many staging chunks), with the reference fixture's snowpack embedded at
+    row 4321: its seven frequencies against the reference, every solve ok, a sub-range that straddles chunk boundaries
+    and a scattered pair list bitwise equal to the full run, sampled pairs against the CPU oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    d = load_golden("cfg3_dmrt_L50_n64_amsr2_sp1")
+    sp = snowpack_dict(d)
+    rng = np.random.default_rng(3)
+    S, L, k = 8192, 50, 4321
+    thick, fv, temp, p1 = _embed_fixture_snowpack(d, S, L, rng, k, 0.05, 0.3, 100.0, (5e-5, 1.5e-4))
+    p2 = np.full((S, L), 0.2)
+    p2[k] = np.broadcast_to(sp["stickiness"], (L,))
+    freqs = np.asarray(d["frequency"], float)
+    b = PackedBatch([L] * S, thick, fv, temp, p1, p2, freqs, np.deg2rad(d["theta_deg"]), emmodel="dmrt_qca_shortrange",
+                    microstructure="sticky_hard_spheres", n_max_stream=64)
+    full = ctx.run(b)
+    assert b.n_pairs == 57344 and (full.status == 0).all()
+    info = ctx.launch_info()
+    assert info["pipeline"] == "gmem" and info["chunks"] > 1
+    mine = full.values.reshape(len(freqs), S, *full.values.shape[1:])[:, k]
+    assert np.abs(mine - d["result"]).max() < TB_TOL
+    lo, hi = info["chunk_pairs"] - 700, 2 * info["chunk_pairs"] + 300
+    part = ctx.run(b, pair_begin=lo, pair_count=hi - lo)
+    assert np.array_equal(part.values, full.values[lo:hi])
+    pick = rng.permutation(b.n_pairs)[:1500]
+    assert np.array_equal(ctx.run(b, pairs=pick).values, full.values[pick])
+    for p in rng.choice(b.n_pairs, 3, replace=False):      # (about a second of oracle each at this shape)
+        f, s = divmod(int(p), S)
+        spo = dict(thickness=thick[s], density=fv[s] * O.DENSITY_OF_ICE, temperature=temp[s],
+                   microstructure="sticky_hard_spheres", radius=p1[s], stickiness=p2[s])
+        ref = O.solve(spo, freqs[f], list(d["theta_deg"]), emmodel="dmrt_qca_shortrange", n_max_stream=64)
+        assert np.abs(full.values[p] - ref).max() < TB_TOL
+
+
+def test_cfg5_per_gpu_share(ctx):
+    """BASELINE configs[4] (the Monte-Carlo ensemble: 1e6 (snowpack, frequency) pairs over 8 GPUs) at the share of ONE GPU:
+    25 000 snowpacks x 5 frequencies = 125 000 pairs, 20 layers, 32 streams, on this round's kernels -- every solve ok,
+    ranges that cut across the staging chunks and a scattered list bitwise equal to the full run, 32 sampled pairs
+    against the CPU oracle."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(5)
+    S, L = 25000, 20
+    thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 100.0)], axis=1)
+    dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
+    freqs = np.array([10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
+    b = PackedBatch([L] * S, thick, dens / O.DENSITY_OF_ICE, temp, lc, None, freqs, np.deg2rad([55.0]))
+    full = ctx.run(b)
+    assert b.n_pairs == 125000 and (full.status == 0).all()
+    info = ctx.launch_info()
+    assert info["pipeline"] == "lds_reg" and info["chunks"] >= 10
+    for lo, hi in ((0, 33333), (33333, 90001), (90001, 125000)):
+        part = ctx.run(b, pair_begin=lo, pair_count=hi - lo)
+        assert np.array_equal(part.values, full.values[lo:hi]) and np.array_equal(part.status, full.status[lo:hi])
+    pick = rng.permutation(b.n_pairs)[:20000]
+    assert np.array_equal(ctx.run(b, pairs=pick).values, full.values[pick])
+    for p in rng.choice(b.n_pairs, 32, replace=False):
+        f, s = divmod(int(p), S)
+        sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
+        assert np.abs(full.values[p] - O.solve(sp, freqs[f], [55.0])).max() < TB_TOL
