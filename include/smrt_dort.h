@@ -186,6 +186,13 @@ typedef struct smrt_batch {
     const double* host_interface;
     const double* host_interface_coh;
     int32_t host_interface_slots;
+    /* Wet snow (smrt/inputs/make_medium.py:316-434, smrt/permittivity/wetice.py:12-45): liquid_water [S][n_layers_max] =
+     * water volume / (ice + water volume) of every layer, or NULL: dry snow.  A wet layer (> 0) must be at the melting
+     * point (273.15 K: the water permittivity, Maetzler & Wegmuller 1987, is not defined below it -- status 5 otherwise);
+     * its scatterers are ice spheres coated in water: permittivity by Maxwell Garnett with water as the host
+     * (wetice_permittivity_bohren83, the reference's default for snow layers); frac_volume is then the volume fraction of
+     * ice + water (SnowLayer.compute_frac_volumes).  Applies to the device emmodels; ignored by SMRT_EM_HOST layers. */
+    const double* liquid_water;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

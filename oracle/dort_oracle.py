@@ -52,6 +52,33 @@ def ice_permittivity_maetzler06(frequency, temperature):
     return e_real + 1j * (alpha / f_ghz + (beta_m + delta_beta) * f_ghz)
 
 
+def water_permittivity_maetzler87(frequency, temperature):
+    """Liquid water, double Debye model of Maetzler & Wegmuller 1987: smrt/permittivity/water.py:14-43."""
+    if temperature < FREEZING_POINT:
+        raise OracleError("The water temperature must be higher or equal to the freezing point", 5)
+    f_ghz = frequency * 1e-9
+    theta = 1.0 - 300.0 / temperature
+    e0 = 77.66 - 103.3 * theta
+    e1 = 0.0671 * e0
+    f1 = 20.2 + 146.4 * theta + 316.0 * theta**2
+    e2 = 3.52 + 7.52 * theta
+    f2 = 39.8 * f1
+    return e2 + (e1 - e2) / complex(1, -f_ghz / f2) + (e0 - e1) / complex(1, -f_ghz / f1)
+
+
+def scatterer_permittivity(frequency, temperature, liquid_water=0.0):
+    """Permittivity of the ice grains of a snow layer, the reference's default model wetice_permittivity_bohren83
+    (smrt/permittivity/wetice.py:12-45): pure ice when dry; when wet, ice inclusions (1 - liquid_water) in a water host
+    mixed by Maxwell Garnett (smrt/permittivity/generic_mixing_formula.py:352-380)."""
+    eps_ice = ice_permittivity_maetzler06(frequency, temperature)
+    if not liquid_water > 0.0:
+        return eps_ice
+    e0 = water_permittivity_maetzler87(frequency, temperature)
+    c_plus = eps_ice + 2 * e0
+    c_minus = (eps_ice - e0) * (1.0 - liquid_water)
+    return (c_plus + 2 * c_minus) / (c_plus - c_minus) * e0
+
+
 def polder_van_santen_spheres(frac_volume, e0, eps):
     """Positive root of 2x^2 + bx - eps*e0 = 0, smrt/permittivity/generic_mixing_formula.py:117-145."""
     b = eps - 2.0 * e0 - 3.0 * frac_volume * (eps - e0)
@@ -133,7 +160,7 @@ class IBALayer(LayerEM):
         self.frequency = frequency
         self.k0 = 2.0 * np.pi * frequency / C_SPEED
         e0 = 1.0
-        eps = ice_permittivity_maetzler06(frequency, temperature)
+        eps = scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
         self.eps_ice = eps
         if frac_volume > 0.5 and self.dense_snow_correction == "auto":
             # iba.py:95-96 -> core/layer.py:186-201, microstructure_model/autocorrelation.py:146-153: the inverted
@@ -189,7 +216,7 @@ class DMRTQCAShortRangeLayer(LayerEM):
         f = frac_volume
         radius = mp["radius"]
         e0 = 1.0
-        es = ice_permittivity_maetzler06(frequency, temperature)
+        es = scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
         if f > 0.5:  # dense_snow_correction="auto": inverted medium (core/layer.py inverted_medium)
             f, e0, es = 1.0 - f, es, e0
         self.f = f
@@ -222,7 +249,7 @@ class DMRTQCACPShortRangeLayer(LayerEM):
         f = frac_volume
         radius = mp["radius"]
         e0 = 1.0
-        es = ice_permittivity_maetzler06(frequency, temperature)
+        es = scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
         if f > 0.5:  # dense_snow_correction="auto": inverted medium
             f, e0, es = 1.0 - f, es, e0
         t = shs_t_parameter(f, mp["stickiness"])
@@ -255,7 +282,7 @@ class NonScatteringLayer(LayerEM):
     kind = "nonscattering"
 
     def __init__(self, frequency, frac_volume, temperature, microstructure, **mp):
-        eps = ice_permittivity_maetzler06(frequency, temperature)
+        eps = scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
         self.f = frac_volume
         self.eps_eff = polder_van_santen_spheres(frac_volume, 1.0, eps)
         self.ka = float(2.0 * (2.0 * np.pi * frequency / C_SPEED) * np.sqrt(self.eps_eff).imag)
@@ -272,7 +299,7 @@ class RayleighLayer(LayerEM):
     kind = "rayleigh"
 
     def __init__(self, frequency, frac_volume, temperature, microstructure, radius, **mp):
-        e0, eps = 1.0, ice_permittivity_maetzler06(frequency, temperature)
+        e0, eps = 1.0, scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
         k0 = 2.0 * np.pi * frequency / C_SPEED
         self.eps_eff = complex(e0)
         self.ks = float(frac_volume * 2 * abs((eps - e0) / (eps + 2 * e0)) ** 2 * radius**3 * abs(e0) ** 2 * k0**4)
@@ -413,9 +440,10 @@ def make_layers(emmodel, frequency, sp):
     args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
             "independent_sphere": ("radius",), "homogeneous": ()}
     extra = {"prescribed_kskaeps": ("ks", "ka", "eps_re", "eps_im")}   # layer attributes that emmodel reads
+    wet = ("liquid_water",) if "liquid_water" in sp else ()              # water / (ice + water) volume per layer
     return [
         classes[ems[l]](frequency, float(fv[l]), float(sp["temperature"][l]), micros[l],
-                        **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in args[micros[l]] + extra.get(ems[l], ())})
+                        **{n: float(np.broadcast_to(sp[n], (L,))[l]) for n in args[micros[l]] + extra.get(ems[l], ()) + wet})
         for l in range(L)
     ]
 

@@ -78,6 +78,7 @@ class SmrtBatch(C.Structure):
         ("host_interface", C.POINTER(C.c_double)),
         ("host_interface_coh", C.POINTER(C.c_double)),
         ("host_interface_slots", C.c_int32),
+        ("liquid_water", C.POINTER(C.c_double)),
     ]
 
 
@@ -93,7 +94,7 @@ class PackedBatch:
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
                  prune_deep_snowpack=None, layer_kind=None, host_emmodel=None, process_coherent_layers=False,
-                 host_interfaces=None):
+                 host_interfaces=None, liquid_water=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
@@ -102,6 +103,8 @@ class PackedBatch:
         that mix emmodels / microstructure models (smrt/core/model.py:529-582).
         host_interfaces: None, or (slot[F*S][Lmax] int (-1: Flat), matrices[F*S][slots][modes][4][NE][NE],
         coh[F*S][slots][4][NE]) for rough interfaces evaluated by the caller (include/smrt_dort.h: SMRT_INTERFACE_HOST).
+        liquid_water: None (dry snow) or [S][Lmax] water / (ice + water) volume of every layer; frac_volume is then the
+        volume fraction of ice + water (include/smrt_dort.h).
         host_emmodel: None, or (host_layer[F*S][Lmax][4], host_streams[F*S][Lmax], host_phase[F*S][Lmax][modes][2][NE][NE])
         for the layers of kind "host" (emmodels evaluated by the caller, include/smrt_dort.h)."""
         self.n_layers = np.ascontiguousarray(n_layers, dtype=np.int32)
@@ -177,6 +180,11 @@ class PackedBatch:
             s.host_layer, s.host_phase = _dptr(self.host_layer), _dptr(self.host_phase)
             s.host_streams = self.host_streams.ctypes.data_as(C.POINTER(C.c_int32))
         s.process_coherent_layers = 1 if process_coherent_layers else 0
+        if liquid_water is not None:
+            self.liquid_water = two_d(liquid_water)
+            if self.liquid_water.shape != (S, Lmax):
+                raise SMRTError("per-layer arrays of a batch must share the shape (n_snowpacks, n_layers_max)")
+            s.liquid_water = _dptr(self.liquid_water)
         if host_interfaces is not None:
             FS, nm, ne = S * len(self.frequency), (int(m_max) + 1 if mode == "A" else 1), 3 * int(n_max_stream)
             slot = np.asarray(host_interfaces[0], dtype=np.int32).reshape(FS, Lmax)

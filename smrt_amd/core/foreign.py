@@ -18,7 +18,7 @@ place that reads them, through their public attributes only:
 
 `adopt_snowpack` turns a foreign snowpack into smrt_amd's `Snowpack` of `AdoptedLayer`s: from there on the packing code
 of rtsolver/dort.py sees one kind of object, and the device batch is bitwise the one smrt_amd's own objects give.
-A layer the device emmodels cannot reproduce (wet or saline snow, a user permittivity model, non-spherical inclusions,
+A layer the device emmodels cannot reproduce (saline snow, a user permittivity model, non-spherical inclusions,
 a microstructure model without device code) is never computed as if it were dry snow: with one of the reference's own
 emmodel classes it is evaluated on the host through the emmodel protocol, with a device emmodel it raises."""
 import importlib
@@ -62,8 +62,9 @@ def _device_microstructure(ms):
 
 
 def _why_not_on_device(layer, device_ms):
-    """None when the device emmodels reproduce the electromagnetics of this reference layer (dry snow: air background,
-    Maetzler 2006 ice, spherical inclusions -- smrt/inputs/make_medium.py:234-312), else the reason as a string."""
+    """None when the device emmodels reproduce the electromagnetics of this reference layer (dry or wet snow: air
+    background, Maetzler 2006 ice -- coated in water by wetice_permittivity_bohren83 when wet --, spherical inclusions:
+    smrt/inputs/make_medium.py:234-312), else the reason as a string."""
     if device_ms is None:
         return f"the microstructure model {type(layer.microstructure).__name__} has no device implementation"
     pm = getattr(layer, "permittivity_model", None)
@@ -73,9 +74,11 @@ def _why_not_on_device(layer, device_ms):
         return "the background is not air (permittivity 1)"
     if not callable(pm[1]) or getattr(pm[1], "__name__", None) not in DRY_ICE_PERMITTIVITIES \
             or (getattr(pm[1], "__module__", "") or "").split(".")[-2:-1] != ["permittivity"]:
-        return "the scatterer permittivity is not the default ice permittivity (Maetzler 2006)"
-    if (getattr(layer, "liquid_water", None) or 0) > 0 or (getattr(layer, "volumetric_liquid_water", None) or 0) > 0:
-        return "the layer holds liquid water"
+        return "the scatterer permittivity is not the default ice permittivity (Maetzler 2006 / wet: Bohren 1983)"
+    if (getattr(layer, "liquid_water", None) or 0) > 0 and pm[1].__name__ != "wetice_permittivity_bohren83":
+        return "the layer holds liquid water but its scatterer permittivity ignores it"
+    if (getattr(layer, "salinity", None) or 0) > 0 and "salinity" in getattr(pm[1], "required_arguments", ()):
+        return "the scatterer permittivity depends on the salinity"
     if getattr(layer, "inclusion_shape", None) not in (None, "spheres"):
         return f"inclusion_shape={layer.inclusion_shape!r}"
     if getattr(layer, "depolarization_factors", None) is not None or getattr(layer, "length_ratio", None) is not None:
@@ -102,6 +105,7 @@ class AdoptedLayer:
         self.source = source
         self.thickness = float(source.thickness)
         self.temperature = float(source.temperature)
+        self.liquid_water = float(getattr(source, "liquid_water", None) or 0)
         self.medium = getattr(source, "medium", None)
         self.emmodel = getattr(source, "emmodel", None)
         self.emmodel_options = getattr(source, "emmodel_options", None)

@@ -69,8 +69,8 @@ class Layer:
         if name not in MICROSTRUCTURE_ARGS:
             raise SMRTError(f"microstructure model '{name}' is outside the scope of smrt_amd "
                             f"(available: {', '.join(MICROSTRUCTURE_ARGS)})")
-        if (liquid_water or 0) > 0 or (volumetric_liquid_water or 0) > 0 or (salinity or 0) > 0:
-            raise SMRTError("wet or saline snow is outside the scope of smrt_amd (dry snow only)")
+        if (salinity or 0) > 0:
+            raise SMRTError("saline snow is outside the scope of smrt_amd")
         missing = [a for a in MICROSTRUCTURE_ARGS[name] if a not in params and a != "stickiness"]
         if missing:
             raise SMRTError(f"missing microstructure parameter(s) {missing} for '{name}'")
@@ -80,11 +80,9 @@ class Layer:
         self.medium = medium
         self.emmodel = emmodel
         self.emmodel_options = emmodel_options
-        # SnowLayer.compute_frac_volumes with no liquid water (make_medium.py:390-434)
-        frac_volume = self.density / DENSITY_OF_ICE
-        if not (0 <= frac_volume <= 1.01):
-            raise SMRTError(f"the frac_volume of ice in snow is {frac_volume} but must be between 0 and 1.")
-        frac_volume = min(frac_volume, 1.0)
+        frac_volume, lw = self.frac_volumes(self.density, volumetric_liquid_water, liquid_water)
+        self.liquid_water = lw
+        self.volumetric_liquid_water = volumetric_liquid_water
         self.microstructure_model = name
         mparams = {k: float(params[k]) for k in MICROSTRUCTURE_ARGS[name] if k in params}
         if name == "sticky_hard_spheres":   # the reference's default (smrt/microstructure_model/sticky_hard_spheres.py:30)
@@ -101,31 +99,47 @@ class Layer:
     def frac_volume(self):
         return self.microstructure.frac_volume
 
-    def update(self, **kwargs):
-        """Change attributes consistently (SnowLayer.update, smrt/inputs/make_medium.py:361-388): density recomputes the
-        ice volume fraction; liquid water stays outside the scope (dry snow only)."""
-        if (kwargs.get("liquid_water") or 0) > 0 or (kwargs.get("volumetric_liquid_water") or 0) > 0:
-            raise SMRTError("wet or saline snow is outside the scope of smrt_amd (dry snow only)")
-        if "density" in kwargs:
-            density = float(kwargs.pop("density"))
-            frac_volume = density / DENSITY_OF_ICE
-            if not (0 <= frac_volume <= 1.01):
-                raise SMRTError(f"the frac_volume of ice in snow is {frac_volume} but must be between 0 and 1.")
-            object.__setattr__(self, "density", density)
+    @staticmethod
+    def frac_volumes(density, volumetric_liquid_water=None, liquid_water=None):
+        """(frac_volume, liquid_water) of a snow layer as SnowLayer.compute_frac_volumes (smrt/inputs/make_medium.py:
+        390-434): frac_volume = (ice + water) / (ice + water + air) volume, liquid_water = water / (ice + water) volume,
+        from the density (ice and water phases) and ONE of the two measures of wetness."""
+        if volumetric_liquid_water is not None:
+            if liquid_water is not None:
+                raise SMRTError("Setting both liquid_water and volumetric_liquid_water is ambiguous")
+            frac_volume = (density - (DENSITY_OF_WATER - DENSITY_OF_ICE) * volumetric_liquid_water) / DENSITY_OF_ICE
+            liquid_water = volumetric_liquid_water / frac_volume
+        else:
+            liquid_water = liquid_water or 0
+            frac_volume = density / (DENSITY_OF_ICE * (1 - liquid_water) + DENSITY_OF_WATER * liquid_water)
+        if not (0 <= frac_volume <= 1.01):
+            raise SMRTError(f"the frac_volume of ice+water in snow is {frac_volume} but must be between 0 and 1.")
+        if not (0 <= liquid_water <= 1):
+            raise SMRTError(f"liquid_water is {liquid_water} but must be between 0 and 1.")
+        return min(frac_volume, 1.0), liquid_water
+
+    def update(self, density=None, volumetric_liquid_water=None, liquid_water=None, **kwargs):
+        """Change attributes consistently (SnowLayer.update, smrt/inputs/make_medium.py:361-388): density and the wetness
+        recompute the volume fraction of ice + water and the liquid water fraction."""
+        if density is not None:
+            object.__setattr__(self, "density", float(density))
+        if volumetric_liquid_water is not None:
+            object.__setattr__(self, "volumetric_liquid_water", volumetric_liquid_water)
+        if density is not None or volumetric_liquid_water is not None or liquid_water is not None:
+            fv, lw = self.frac_volumes(self.density, self.volumetric_liquid_water, liquid_water)
+            object.__setattr__(self, "liquid_water", lw)
             object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
-            self.microstructure.frac_volume = min(frac_volume, 1.0)
-        for k in ("liquid_water", "volumetric_liquid_water"):
-            kwargs.pop(k, None)
+            self.microstructure.frac_volume = fv
         for k, v in kwargs.items():
             setattr(self, k, v)
 
     def permittivity(self, i, frequency):
-        """Permittivity of the background (i = 0: air) or of the scatterers (i = 1: pure ice), smrt/core/layer.py:120-156
-        for dry snow.  The device emmodels compute the same on the GPU; this is for emmodels evaluated on the host."""
+        """Permittivity of the background (i = 0: air) or of the scatterers (i = 1: ice, coated in water when the layer is
+        wet), smrt/core/layer.py:120-156 with the default models of make_snow_layer.  The device emmodels compute the same on the GPU; this is for emmodels evaluated on the host."""
         if i == 0:
             return 1.0
         if i == 1:
-            from ..permittivity.ice import ice_permittivity_maetzler06
+            from ..permittivity.ice import wetice_permittivity_bohren83
 
-            return ice_permittivity_maetzler06(frequency, self.temperature)
+            return wetice_permittivity_bohren83(frequency, self.temperature, self.liquid_water)
         raise SMRTError("a snow layer has two constituents (0: air, 1: ice)")

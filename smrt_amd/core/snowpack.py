@@ -87,6 +87,12 @@ class Snowpack:
             self._packed = np.array(cols, dtype=np.float64).T.reshape(5, len(self.layers))
         return self._packed
 
+    def liquid_water(self):
+        """Per-layer liquid water (water / (ice + water) volume) as one array, or None for a dry snowpack -- the optional
+        sixth column of the device batch (include/smrt_dort.h: smrt_batch.liquid_water)."""
+        lw = [float(getattr(lay, "liquid_water", 0) or 0) for lay in self.layers]
+        return np.array(lw) if any(lw) else None
+
     def _fresh(self, slot):
         """Is the cache `slot` still valid?  Only if the layer list holds the same objects and none of them (nor its
         microstructure object) has been written to since the cache was filled: every Layer / Microstructure counts its

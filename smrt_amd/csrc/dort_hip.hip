@@ -177,7 +177,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
                       &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws, &ctx->d_itfslot, &ctx->d_itf, &ctx->d_itfcoh,
-                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_lw, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -373,6 +373,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
     if (pairs && upload_array(ctx, ctx->d_pairmap, pairs, sizeof(int64_t) * pair_count)) return -1;
     if (b->layer_kind && upload_array(ctx, ctx->d_kind, b->layer_kind, sizeof(int32_t) * SL)) return -1;
+    if (b->liquid_water && upload_array(ctx, ctx->d_lw, b->liquid_water, sizeof(double) * SL)) return -1;
     const size_t host_modes = ctx->active ? (size_t)b->m_max + 1 : 1, host_ne = (size_t)b->n_max_stream * P;
     if (b->host_layer && b->host_streams && b->host_phase) {   // emmodels evaluated by the caller
         const size_t PL = (size_t)npairs * b->n_layers_max;
@@ -430,6 +431,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
     d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
     d.layer_kind = b->layer_kind ? (const int*)ctx->d_kind.p : nullptr;
+    d.liquid_water = b->liquid_water ? (const double*)ctx->d_lw.p : nullptr;
     const bool has_host = b->host_layer && b->host_streams && b->host_phase;
     d.host_layer = has_host ? (const double*)ctx->d_hostlayer.p : nullptr;
     d.host_streams = has_host ? (const int*)ctx->d_hoststreams.p : nullptr;
@@ -510,7 +512,7 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
         SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers),
         SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh), SMRT_OFF(host_interface_slot), SMRT_OFF(host_interface),
-        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots)};
+        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots), SMRT_OFF(liquid_water)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

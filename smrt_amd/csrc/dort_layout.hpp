@@ -40,6 +40,7 @@ struct DevBatch {
     const double* host_itf;            // [F * S][slots][modes][4][NE * NE]
     const double* host_itf_coh;        // [F * S][slots][4][NE]
     int host_itf_slots;
+    const double* liquid_water;  // [S][Lmax] liquid water of wet layers (water / (ice + water) volume), or null: dry snow
     const double* gl_mu;  // [n_max_stream] positive Gauss-Legendre nodes of order 2 n_max, descending
     int sub_kind;                         // 0 none, 1 flat (p1 + i p2 = permittivity), 2 reflector (p1, p2 = R_V, R_H)
     const double *sub_p1, *sub_p2;        // [F][S]

@@ -125,7 +125,8 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
             } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
             pa = pb = 0.0;
         } else
-        layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
+        layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad,
+                 b.liquid_water ? b.liquid_water[(gp % b.S) * b.Lmax + l] : 0.0);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)((kind & 15) == EM_IBA_INV ? (kind & ~15) | EM_IBA : kind);   // the phase function is IBA's either way
         s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;

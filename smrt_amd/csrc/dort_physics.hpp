@@ -47,6 +47,20 @@ SMRT_DEV cplx ice_permittivity(double frequency, double T) {  // Maetzler 2006, 
     return cmk(er, alpha / fg + (betam + dbeta) * fg);
 }
 
+// Permittivity of liquid water, double Debye model of Maetzler & Wegmuller (1987) as smrt/permittivity/water.py:14-43
+SMRT_DEV cplx water_permittivity(double frequency, double T) {
+    const double fg = frequency * 1e-9;
+    const double th = 1.0 - 300.0 / T;
+    const double e0 = 77.66 - 103.3 * th;
+    const double e1 = 0.0671 * e0;
+    const double f1 = 20.2 + 146.4 * th + 316.0 * th * th;
+    const double e2 = 3.52 + 7.52 * th;
+    const double f2 = 39.8 * f1;
+    const cplx a = cdiv(cmk(e1 - e2, 0.0), cmk(1.0, -fg / f2));
+    const cplx b = cdiv(cmk(e0 - e1, 0.0), cmk(1.0, -fg / f1));
+    return cadd(cmk(e2, 0.0), cadd(a, b));
+}
+
 SMRT_DEV double sinc_(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
 
 // FT of the autocorrelation function at wavenumber k (k2 = k*k)
@@ -107,10 +121,21 @@ SMRT_DEV double planck_inverse(double frequency, double radiance) {  // core/lib
 // pa/pb/pc: IBA+exponential -> C(cosT) = pa / (1 + pb (1 - cosT))^2 ; IBA+SHS -> pa = iba_coeff, pb = kfac^2/2;
 // DMRT -> pa = 1.5 ks.
 // em / ms: the emmodel and the microstructure model of THIS layer (a snowpack may mix them, smrt/core/model.py:529-582).
+// lw: liquid water of a wet layer (water volume / (ice + water volume)), 0 for dry snow.
 SMRT_DEV void layer_em(int em, int ms, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
-                       double* ks, double* ka, double* pa, double* pb, int* bad) {
+                       double* ks, double* ka, double* pa, double* pb, int* bad, double lw = 0.0) {
     cplx es = ice_permittivity(frequency, T);
     if (T > kFreezing) *bad = 1;
+    if (lw > 0.0) {
+        // wet ice grains (wetice.py:12-45, Bohren & Huffman 1983 after Jin 1993 eq. 8-69): Maxwell Garnett mixing of ice
+        // inclusions, volume fraction 1 - lw, in a water host (generic_mixing_formula.py:352-380); water after Maetzler &
+        // Wegmuller 1987 (water.py:14-43), defined from the melting point up
+        if (T < kFreezing || lw > 1.0) *bad = 1;
+        const cplx ew = water_permittivity(frequency, T);
+        const cplx cplus = cadd(es, cscale(ew, 2.0));
+        const cplx cminus = cscale(csub(es, ew), 1.0 - lw);
+        es = cmul(cdiv(cadd(cplus, cscale(cminus, 2.0)), csub(cplus, cminus)), ew);
+    }
     double k0 = 2.0 * kPi * frequency / kCSpeed;
     if (em == EM_IBA || em == EM_IBA_INV) {
         // EM_IBA_INV: IBA's dense_snow_correction="auto" on a layer with more than half ice (iba.py:95-96,

@@ -47,15 +47,16 @@ class _DeviceEMModel:
             from ..rtsolver.dort import get_context
 
             p1, p2 = self.layer.microstructure.device_params
+            lw = float(getattr(self.layer, "liquid_water", 0) or 0)
             key = (self._device_name, self.layer.microstructure_model, self._frac_volume,
-                   float(self.layer.temperature), p1, p2, self.frequency)
+                   float(self.layer.temperature), p1, p2, self.frequency, lw)
             if key in _PROPS_CACHE:
                 self._props = _PROPS_CACHE[key]
                 return self._props
             batch = PackedBatch([1], [100.0], [self._frac_volume], [self.layer.temperature], [p1], [p2],
                                 [self.frequency], [0.0], emmodel=self._device_name,
                                 microstructure=self.layer.microstructure_model, n_max_stream=4,
-                                phase_normalization="forced")
+                                phase_normalization="forced", liquid_water=[lw] if lw > 0 else None)
             out = get_context().run(batch)   # the shared, cached context of this process's default GPU (serialised by its lock)
             lay = out.layers[0, 0]
             self._props = dict(eps=complex(lay[0], lay[1]), ks=float(lay[2]), ka=float(lay[3]))
@@ -90,6 +91,9 @@ class _DeviceEMModel:
         from ..rtsolver.dort import get_context
 
         npol = self.npol if npol is None else npol
+        if float(getattr(self.layer, "liquid_water", 0) or 0) > 0:
+            raise SMRTError("the stand-alone phase matrix of a device emmodel is implemented for dry snow (smrt_amd's own DORT "
+                            "assembles the wet one in its kernels)")
         if np.any(np.asarray(mu_i) == 1) and npol > 2:
             raise SMRTError("Phase matrix signs for sine elements of mode m = 2 incorrect")
         p1, p2 = self.layer.microstructure.device_params

@@ -289,6 +289,15 @@ class DORT(object):
             cols[1][inverted] = 1.0 - cols[1][inverted]
         elif device_name == "iba_inverted":   # every layer of the batch
             cols[1] = 1.0 - cols[1]
+        # wet snow: the optional liquid-water column (water / (ice + water) volume; the frac_volume column is ice + water)
+        wet = [sp.liquid_water() for sp in sps]
+        liquid_water = None
+        if any(w is not None for w in wet):
+            liquid_water = np.zeros((S, Lmax))
+            for s, w in enumerate(wet):
+                if w is not None:
+                    liquid_water[s, :nl[s]] = w
+        self._liquid_water = liquid_water     # (read by the probes of _layer_permittivities for this group)
         mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate
@@ -314,7 +323,8 @@ class DORT(object):
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
                            layer_kind=layer_kind, host_emmodel=host,
-                           process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces)
+                           process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces,
+                           liquid_water=liquid_water)
 
     def _layer_permittivities(self, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
         """Effective permittivity of every layer, (F, S, Lmax): from the host-evaluated emmodels if the group has them,
@@ -328,7 +338,8 @@ class DORT(object):
         name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
         probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
                             microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
-                            phase_normalization="forced", layer_kind=layer_kind)
+                            phase_normalization="forced", layer_kind=layer_kind,
+                            liquid_water=getattr(self, "_liquid_water", None))
         # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
         res = get_context((self.devices or [default_device()])[0]).run(probe)
         bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless

@@ -24,7 +24,7 @@ def snowpack_dict(d):
     """The plain-array snowpack description stored in a fixture."""
     sp = {k: d[k] for k in ("thickness", "density", "temperature", "frac_volume")}
     sp["microstructure"] = str(d["microstructure"]) if np.ndim(d["microstructure"]) == 0 else [str(m) for m in d["microstructure"]]
-    for k in ("corr_length", "radius", "stickiness", "ks", "ka", "eps_re", "eps_im"):
+    for k in ("corr_length", "radius", "stickiness", "ks", "ka", "eps_re", "eps_im", "liquid_water"):
         if k in d:
             sp[k] = d[k]
     return sp
@@ -124,7 +124,7 @@ def packed_batch_from_fixture(d, freqs=None):
                        emmodel=emmodel, microstructure=ms, mode="A" if active else "P",
                        n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
                        prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind,
-                       process_coherent_layers=fixture_coherent(d),
+                       process_coherent_layers=fixture_coherent(d), liquid_water=sp.get("liquid_water"),
                        host_interfaces=(pack_host_interfaces([fixture_interfaces(d)] * len(np.atleast_1d(d["frequency"][sel])),
                                                              len(sp["thickness"]), o["n_max_stream"],
                                                              (o["m_max"] + 1) if active else 1)
@@ -159,6 +159,9 @@ MIXED_FIXTURES = ["mixed_L4_n16_passive", "mixed_L4_n12_active"]
 # independent spheres, passive and active, and prescribed_kskaeps on a homogeneous microstructure
 # IBA with emmodel_options=dict(dense_snow_correction="auto"): layers above half ice on the inverted medium (air in ice)
 DENSE_AUTO_FIXTURES = ["iba_dense_auto_L5_n12", "iba_dense_auto_shs_active_L3_n8"]
+# wet snow: layers at the melting point holding liquid water (grains coated in water, Maxwell Garnett in a water host); the
+# active one with a very wet layer above half "ice + water" under dense_snow_correction="auto"
+WET_FIXTURES = ["iba_wet_L4_n12_passive", "iba_wet_L3_n10_active", "dmrt_wet_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)
@@ -424,6 +427,14 @@ def standin_class(module, name, **members):
     return _STANDIN_CLASSES[key]
 
 
+def standin_function(module, name):
+    """A function that carries the identity (module, name) of one of the reference's permittivity functions."""
+    def f(*a, **k):
+        raise AssertionError("a stand-in permittivity function is never evaluated")
+    f.__module__, f.__name__ = module, name
+    return f
+
+
 def _standin(cls_id, **attrs):
     obj = standin_class(*cls_id)()
     for k, v in attrs.items():
@@ -435,11 +446,7 @@ def standins_from_dump(case):
     """(model, simulations, snowpacks, expected results) of one case of reference_objects.json: objects with the classes'
     names, modules and public attributes of the reference's -- what its `Model.run` would hand to a runner -- and none of
     its behaviour beyond `substrate.permittivity(frequency)` (a table) and a constructor for the emmodel class."""
-    def function(module, name):
-        def f(*a, **k):
-            raise AssertionError("a stand-in permittivity function is never evaluated")
-        f.__module__, f.__name__ = module, name
-        return f
+    function = standin_function
 
     def layer(d):
         ms = _standin(d["microstructure"]["cls"], **{k: _undump(v) for k, v in d["microstructure"]["attrs"].items()})

@@ -52,6 +52,8 @@ def rebuild(d):
         assert str(d["substrate_kind"]) == "flat"
         T = float(d["substrate_temperature"])
         substrate = Flat(temperature=None if np.isnan(T) else T, permittivity_model=complex(d["substrate_eps"][0]))
+    if "liquid_water" in d:   # wet snow
+        kw["liquid_water"] = d["liquid_water"]
     return make_snowpack(d["thickness"], str(d["microstructure"]), density=d["density"], temperature=d["temperature"],
                          substrate=substrate, **kw)
 
@@ -60,7 +62,10 @@ def run(d, sp, **extra):
     opts = {k[4:]: d[k].item() for k in d if k.startswith("opt_")}
     opts.update(extra)
     em = str(d["emmodel"]) if np.ndim(d["emmodel"]) == 0 else [str(e) for e in d["emmodel"]]
-    m = make_model(em, "dort", rtsolver_options=opts)
+    em_opts = None
+    if em == "iba_dense_auto":   # the label make_golden.py gives IBA under dense_snow_correction="auto"
+        em, em_opts = "iba", dict(dense_snow_correction="auto")
+    m = make_model(em, "dort", rtsolver_options=opts, emmodel_options=em_opts)
     out = []
     for f in d["frequency"]:
         se = active(float(f), d["theta_inc_deg"])

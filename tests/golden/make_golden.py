@@ -38,6 +38,9 @@ def snowpack_arrays(sp):
         temperature=np.array([lay.temperature for lay in sp.layers], float),
         frac_volume=np.array([lay.frac_volume for lay in sp.layers], float),
     )
+    lw = [float(getattr(lay, "liquid_water", 0) or 0) for lay in sp.layers]
+    if any(lw):   # wet snow: water / (ice + water) volume per layer (frac_volume is then ice + water)
+        out["liquid_water"] = np.array(lw)
     kinds = {type(lay.microstructure).__name__ for lay in sp.layers}
     if len(kinds) > 1:   # mixed microstructure models: one name per layer, NaN for the parameters a layer does not have
         get = lambda lay, a: float(getattr(lay.microstructure, a, np.nan))  # noqa: E731
@@ -731,6 +734,31 @@ def main():
                                                          rtsolver_options=dict(n_max_stream=8, m_max=2),
                                                          emmodel_options=dict(dense_snow_correction="auto"),
                                                          emmodel_label="iba_dense_auto"))
+
+    # (iv-i) WET SNOW (smrt/inputs/make_medium.py:316-434, smrt/permittivity/wetice.py:12-45, water.py:14-43): layers at the
+    # melting point holding liquid water -- given as volumetric_liquid_water and as liquid_water --, the grains' permittivity
+    # by Maxwell Garnett in a water host; IBA passive / active (one very wet layer above half "ice + water": inverted by
+    # dense_snow_correction="auto") and DMRT
+    if wanted("iba_wet_L4_n12_passive"):
+        spx = make_snowpack([0.1, 0.25, 0.4, 100.0], "exponential", density=[250, 320, 380, 420],
+                            temperature=[273.15, 273.15, 268.0, 265.0], corr_length=[1.2e-4, 2e-4, 1.8e-4, 1.5e-4],
+                            volumetric_liquid_water=[0.03, 0.005, 0.0, 0.0])
+        save("iba_wet_L4_n12_passive", run_new("iba", passive([6.925e9, 18.7e9, 36.5e9], [40, 55]), spx,
+                                                rtsolver_options=dict(n_max_stream=12), stages=True, stage_layers=(0,)))
+    if wanted("iba_wet_L3_n10_active"):
+        spx = make_snowpack([0.05, 0.3, 1000.0], "sticky_hard_spheres", density=[300, 700, 400],
+                            temperature=[273.15, 273.15, 266.0], radius=[4e-4, 5e-4, 3e-4], stickiness=0.3,
+                            liquid_water=[0.003, 0.01, 0.0])
+        save("iba_wet_L3_n10_active", run_new("iba", active(13.4e9, [30, 40]), spx,
+                                               rtsolver_options=dict(n_max_stream=10, m_max=2),
+                                               emmodel_options=dict(dense_snow_correction="auto"),
+                                               emmodel_label="iba_dense_auto"))
+    if wanted("dmrt_wet_L3_n12_passive"):
+        spx = make_snowpack([0.2, 0.5, 100.0], "sticky_hard_spheres", density=[280, 350, 400],
+                            temperature=[273.15, 270.0, 266.0], radius=[1.5e-4, 2e-4, 1.2e-4], stickiness=0.2,
+                            volumetric_liquid_water=[0.02, 0.0, 0.0])
+        save("dmrt_wet_L3_n12_passive", run_new("dmrt_qca_shortrange", passive([10.65e9, 36.5e9], [55]), spx,
+                                                 rtsolver_options=dict(n_max_stream=12)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -182,6 +182,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.temperature = b->temperature; d.p1 = b->micro_p1; d.p2 = b->micro_p2 ? b->micro_p2 : b->micro_p1;
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
     d.layer_kind = b->layer_kind;
+    d.liquid_water = b->liquid_water;
     d.host_layer = b->host_layer; d.host_streams = b->host_streams; d.host_phase = b->host_phase;
     d.host_modes = active ? b->m_max + 1 : 1; d.host_ne = b->n_max_stream * (active ? 3 : 2);
     d.coherent = b->process_coherent_layers ? 1 : 0;

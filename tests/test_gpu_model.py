@@ -702,3 +702,39 @@ def test_rough_interfaces_under_prune_and_coherent_options(name):
     from test_hostemu_kernel import check_rough_option_case
 
     check_rough_option_case(name, ROUGH_OPTION_CASES[name])
+
+
+def test_wet_snow_through_the_model():
+    """Wet snow standalone: make_snowpack(volumetric_liquid_water=... | liquid_water=...) -> Model.run on the device emmodels
+    (ice grains coated in water: Maxwell Garnett in a water host, smrt/permittivity/wetice.py:12-45, water.py:14-43),
+    against the reference's results -- IBA passive, IBA active with a very wet layer inverted by dense_snow_correction=
+    "auto", DMRT-QCA passive -- and the layer diagnostics (effective permittivity, ks, ka) of the wet layers."""
+    from conftest import WET_FIXTURES, reference_method_spread
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    for name in WET_FIXTURES:
+        d = load_golden(name)
+        ms = str(d["microstructure"])
+        kw = dict(corr_length=d["corr_length"]) if ms == "exponential" else dict(radius=d["radius"], stickiness=d["stickiness"])
+        sp = make_snowpack(d["thickness"], ms, density=d["density"], temperature=d["temperature"],
+                           liquid_water=list(d["liquid_water"]), **kw)
+        np.testing.assert_allclose([lay.frac_volume for lay in sp.layers], d["frac_volume"], rtol=1e-13)
+        em = str(d["emmodel"])
+        em_opts = dict(dense_snow_correction="auto") if em == "iba_dense_auto" else None
+        opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+        if str(d["mode"]) == "A":
+            opts["m_max"] = int(d["opt_m_max"])
+            sensor = sensor_list.active(list(d["frequency"]), list(d["theta_inc_deg"]))
+        else:
+            sensor = sensor_list.passive(list(d["frequency"]), list(d["theta_deg"]))
+        res = make_model("iba" if em.startswith("iba") else em, "dort", rtsolver_options=opts, emmodel_options=em_opts).run(sensor, sp)
+        got = np.asarray(res.data.values).reshape(d["result"].shape)
+        if str(d["mode"]) == "A":
+            assert_backscatter_close(got, d["result"], spread=reference_method_spread(d))
+        else:
+            assert np.abs(got - d["result"]).max() < 1e-6
+        last = len(d["frequency"]) - 1
+        ks = np.asarray(res.other_data["ks"].values).reshape(len(d["frequency"]), -1)[last]
+        eps = np.asarray(res.other_data["effective_permittivity"].values).reshape(len(d["frequency"]), -1)[last]
+        np.testing.assert_allclose(ks, d["f%d_ks" % last], rtol=1e-10)
+        np.testing.assert_allclose(eps, d["f%d_effective_permittivity" % last], rtol=1e-11)

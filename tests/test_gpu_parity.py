@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -614,7 +614,7 @@ def test_cfg4_shape_batch_through_staging_chunks(ctx):
         assert np.array_equal(part.values, full.values[lo:hi])
 
 
-@pytest.mark.parametrize("name", MIXED_FIXTURES + DENSE_AUTO_FIXTURES)
+@pytest.mark.parametrize("name", MIXED_FIXTURES + DENSE_AUTO_FIXTURES + WET_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
     """smrt_batch.layer_kind: one emmodel per layer (IBA / DMRT QCA short range / non-scattering) over layers mixing the
@@ -869,6 +869,13 @@ def test_register_resident_finish_on_hard_media(ctx):
     worst, checked, refused, mism = mod.run(3, 12, ctx, verbose=False)
     assert mism == 0 and checked > 150
     assert worst < 5e-7, worst
+    # the same pairs through the two-slot finish kernel (set_pipeline(4)), whose Jacobi thresholds are the loose pair
+    # 1e-22 / 1e-12 (dort_host_common.hpp; ADVICE r3: measured 3e-7 K on this kind of input): explicit bound
+    assert mod.WORST_TWO[0] < 8e-7, mod.WORST_TWO[0]
+    # ... and the 64 < N <= 128 pipeline on the global workspace (40 / 64 streams), same thresholds
+    worst_big, checked_big, _, mism_big = mod.run(5, 4, ctx, verbose=False, streams=(40, 64))
+    assert mism_big == 0 and checked_big > 40
+    assert worst_big < 8e-7 and mod.WORST_TWO[0] < 8e-7, (worst_big, mod.WORST_TWO[0])
 
 
 def test_cfg3_full_batch_size(ctx):

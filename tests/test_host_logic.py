@@ -764,9 +764,9 @@ def test_reference_shaped_objects_are_packed_like_own_objects(name, monkeypatch)
 
 
 def test_layers_of_the_reference_the_device_cannot_compute_are_not_computed_as_dry_snow():
-    """core/foreign.py: wet snow, a user permittivity, non-spherical inclusions, another microstructure model -> the layer
-    carries the reason; a device descriptor on it raises, a reference class on it is kept for the host route."""
-    from conftest import load_reference_objects, standin_class, standins_from_dump
+    """core/foreign.py: a scatterer permittivity that is not the default one, non-spherical inclusions, another microstructure
+    model -> the layer carries the reason (wet snow with the default model is the device's business); a device descriptor on it raises, a reference class on it is kept for the host route."""
+    from conftest import load_reference_objects, standin_class, standin_function, standins_from_dump
     from smrt_amd.core.error import SMRTError
     from smrt_amd.core.foreign import adopt_snowpack, device_entry, entry_of_instance
     from smrt_amd.emmodel.iba import IBA
@@ -781,10 +781,14 @@ def test_layers_of_the_reference_the_device_cannot_compute_are_not_computed_as_d
     assert device_entry(ref_iba, {"dense_snow_correction": "auto"}, ok[0]) == "iba"
     specialised = type("Specialized IBA", (ref_iba,), {"__module__": ref_iba.__module__})
     assert device_entry(specialised, {}, ok[0]) == (specialised, {})          # (a subclass may compute anything)
-    sp.layers[0].liquid_water = 0.02
+    sp.layers[0].liquid_water = 0.02           # wet snow with the default permittivity model runs on the device ...
+    wet = adopt_snowpack(sp)
+    assert wet.layers[0].device_refusal is None and wet.liquid_water()[0] == 0.02 and device_entry(ref_iba, {}, wet.layers[0]) == "iba"
+    dry_ice = sp.layers[0].permittivity_model[1]
+    sp.layers[0].permittivity_model = (1.0, standin_function("smrt.permittivity.ice", "ice_permittivity_maetzler06"))
     sp.layers[1].inclusion_shape = "random_needles"
     sp.layers[2].permittivity_model = (1.0, lambda f, **k: 3.2 + 0.001j)
-    bad = adopt_snowpack(sp).layers
+    bad = adopt_snowpack(sp).layers               # ... but not with a scatterer permittivity that ignores the water
     assert "liquid water" in bad[0].device_refusal and "inclusion_shape" in bad[1].device_refusal
     assert "permittivity" in bad[2].device_refusal
     for lay in bad:
@@ -794,6 +798,7 @@ def test_layers_of_the_reference_the_device_cannot_compute_are_not_computed_as_d
         inst = ref_iba(sims[0][0], lay.source)
         assert entry_of_instance(inst, lay) is inst
     sp.layers[0].liquid_water = 0
+    sp.layers[0].permittivity_model = (1.0, dry_ice)
     sp.layers[0].microstructure = standin_class("smrt.microstructure_model.gaussian_random_field", "GaussianRandomField")()
     sp.layers[0].microstructure.frac_volume = 0.3
     assert "no device implementation" in adopt_snowpack(sp).layers[0].device_refusal
@@ -877,3 +882,34 @@ def test_own_rough_substrates_against_the_reference_outputs():
                 _close(soil.emissivity_matrix(f, eps, mu, npol), d["sub_emis_raw"])
     with pytest.raises(Exception, match="outside the scope"):
         make_soil("flat", "dobson85", 268.0)
+
+
+def test_wet_snow_layers_follow_the_reference_definitions():
+    """make_snowpack(volumetric_liquid_water=... | liquid_water=...): frac_volume = (ice + water) / total volume and
+    liquid_water = water / (ice + water) as SnowLayer.compute_frac_volumes (smrt/inputs/make_medium.py:390-434; the
+    fixture holds what the reference computed), read-only afterwards except through update(); the liquid-water column of
+    the device batch; the scatterer permittivity of a wet layer on the host (wetice.py:12-45) against the oracle's."""
+    from conftest import load_golden
+    from oracle import dort_oracle as O
+    from smrt_amd import make_snowpack
+    from smrt_amd.core.error import SMRTError
+
+    d = load_golden("iba_wet_L4_n12_passive")
+    sp = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                       corr_length=d["corr_length"], volumetric_liquid_water=[0.03, 0.005, 0.0, 0.0])
+    np.testing.assert_allclose([lay.frac_volume for lay in sp.layers], d["frac_volume"], rtol=1e-14)
+    np.testing.assert_allclose(sp.liquid_water(), d["liquid_water"], rtol=1e-14)
+    again = make_snowpack(d["thickness"], "exponential", density=d["density"], temperature=d["temperature"],
+                          corr_length=d["corr_length"], liquid_water=list(d["liquid_water"]))
+    np.testing.assert_allclose([lay.frac_volume for lay in again.layers], d["frac_volume"], rtol=1e-13)
+    dry = make_snowpack([1.0], "exponential", density=300, corr_length=1e-4)
+    assert dry.liquid_water() is None and dry.layers[0].liquid_water == 0
+    with pytest.raises(SMRTError, match="read-only"):
+        sp.layers[0].liquid_water = 0.5
+    with pytest.raises(SMRTError, match="ambiguous"):
+        make_snowpack([1.0], "exponential", density=300, corr_length=1e-4, liquid_water=0.1, volumetric_liquid_water=0.02)
+    sp.layers[2].update(volumetric_liquid_water=0.01)
+    assert sp.liquid_water()[2] > 0
+    eps = sp.layers[0].permittivity(1, 18.7e9)
+    assert abs(eps - O.scatterer_permittivity(18.7e9, 273.15, float(d["liquid_water"][0]))) < 1e-12
+    assert eps.imag > 10 * sp.layers[3].permittivity(1, 18.7e9).imag      # (water makes the grains lossy)
