@@ -370,7 +370,9 @@ def main():
     if os.path.exists(tpath):  # PMC counters cannot be collected from inside this process: measured with
         with open(tpath) as fh:  # tools/pmc_passes.sh on the same command, summary committed under profiles/
             tj = json.load(fh)
-        if headline and tj.get("solves_per_launch") == n_pairs:
+        if args.config != 1:        # the other shapes: their own PMC passes (PMC_CONFIG=2|3 tools/pmc_passes.sh)
+            tj = tj.get("configs", {}).get(str(args.config), {})
+        if tj.get("solves_per_launch") == n_pairs and (headline or args.config != 1):
             traffic = tj["traffic_bytes_per_launch"]
 
     if rank == 0:

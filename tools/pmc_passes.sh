@@ -2,13 +2,17 @@
 # PMC passes for the bench kernel (run on the GPU box through gpurun). Counters are collected in their own runs with
 # --kernel-trace only, never together with sys/hip/hsa traces (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+# PMC_CONFIG=2|3: the same for bench.py --config 2|3 (HBM traffic passes only), into gpurun_out/pmc_cfg2|3
+CFG=${PMC_CONFIG:-1}
 OUT=$R/gpurun_out/pmc
+[ "$CFG" != "1" ] && OUT=$R/gpurun_out/pmc_cfg$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
+CMD="python $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+[ "$CFG" != "1" ] && { find $OUT -name "*counter_collection.csv" | head; exit 0; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_LDS_UNALIGNED_STALL
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT

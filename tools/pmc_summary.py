@@ -4,7 +4,9 @@ dispatch) and the derived figures the design discussion uses -- HBM traffic per 
 WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE reports half of the bytes of wide coalesced reads),
 matrix-core busy fraction, share of wave cycles spent waiting, VALU instructions per launch.
 
-    python tools/pmc_summary.py gpurun_out/pmc [round-tag]     # prints the summary; with a tag also writes profiles/hbm_traffic.json
+    python tools/pmc_summary.py gpurun_out/pmc [round-tag [config solves_per_launch]]
+        prints the summary; with a tag also writes the entry of that bench configuration (default 1: the headline, 5120
+        solves per launch) into profiles/hbm_traffic.json
 """
 import glob
 import json
@@ -15,6 +17,8 @@ import pandas as pd
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 tag = sys.argv[2] if len(sys.argv) > 2 else None
+config = sys.argv[3] if len(sys.argv) > 3 else "1"
+solves = int(sys.argv[4]) if len(sys.argv) > 4 else 5120
 frames = []
 for f in sorted(glob.glob(root + "/*/*counter_collection.csv")):
     df = pd.read_csv(f)
@@ -54,9 +58,17 @@ if out and tag:
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "hbm_traffic.json")
     fetch = float(sum(tab[k]["FETCH_SIZE"] for k in out) * 1024)
     write = float(sum(tab[k]["WRITE_SIZE"] for k in out) * 1024)
-    json.dump({"round": tag, "solves_per_launch": 5120, "traffic_bytes_per_launch": total, "fetch_size_bytes_raw": fetch,
-               "write_size_bytes": write, "per_kernel_bytes": {k: float(v) for k, v in out.items()},
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB) summed over the pipeline kernels of one launch; traffic = "
-                       "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); collected with "
-                       "tools/pmc_passes.sh, summary in profiles/%s_pmc_counters.txt" % tag}, open(path, "w"), indent=1)
+    entry = {"round": tag, "solves_per_launch": solves, "traffic_bytes_per_launch": total, "fetch_size_bytes_raw": fetch,
+             "write_size_bytes": write, "per_kernel_bytes": {k: float(v) for k, v in out.items()},
+             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB) summed over the pipeline kernels of one launch; traffic = "
+                     "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); collected with "
+                     "tools/pmc_passes.sh" + (", summary in profiles/%s_pmc_counters.txt" % tag if config == "1" else "")}
+    doc = {}
+    if os.path.exists(path):
+        doc = json.load(open(path))
+    if config == "1":      # the headline entry stays at the top level (what bench.py has read since round 2)
+        doc = {**entry, "configs": doc.get("configs", {})}
+    else:
+        doc.setdefault("configs", {})[config] = entry
+    json.dump(doc, open(path, "w"), indent=1)
     print("\n# wrote", os.path.relpath(path), "traffic per launch %.4e bytes" % total)
