@@ -100,7 +100,7 @@ def make_workload(config, rank, strong, n_snowpacks):
                  "(stickiness 0.2), %d synthetic snowpacks" % S,
             kernel="64 < N <= 128 pipeline = prep_gmem + jacobi<512> + finish_gmem<512>")
     if config == 3:
-        S, L = n_snowpacks or 256, 30
+        S, L = n_snowpacks or 512, 30
         arrays = synthetic_snowpacks(seed=4 if strong else 4 + rank, S=S, L=L, thick_range=(0.02, 0.10), last=1000.0)
         thick, dens, temp, lc = arrays
         batch = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, [5.405e9], np.deg2rad(np.arange(20.0, 46.0, 5.0)),
@@ -264,7 +264,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 for --config 2 / 3)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--config", type=int, default=1, help="BASELINE configs[1] (default, the headline) | [2] | [3]")
-    ap.add_argument("--snowpacks", type=int, default=0, help="snowpacks per GPU (default 1024 / 1024 / 256 by --config)")
+    ap.add_argument("--snowpacks", type=int, default=0, help="snowpacks per GPU (default 1024 / 1024 / 512 by --config)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size of the per-pair kernels (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the pcie_inclusive / model_run measurements")

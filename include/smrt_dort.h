@@ -42,6 +42,8 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1
+#define SMRT_MS_INDEPENDENT_SPHERE 2   /* micro_p1 = radius (smrt/microstructure_model/independent_sphere.py:54-72); IBA only */
+#define SMRT_MS_TEUBNER_STREY 3        /* micro_p1 = corr_length, micro_p2 = repeat_distance (teubner_strey.py:45-55); IBA only */
 /* sensor mode (smrt/core/sensor.py:330-339) */
 #define SMRT_MODE_PASSIVE 0
 #define SMRT_MODE_ACTIVE 1

@@ -91,6 +91,22 @@ def ft_autocorr_exponential(k, frac_volume, corr_length):
     return frac_volume * (1.0 - frac_volume) * 8.0 * np.pi * corr_length**3 / (1.0 + x) ** 2
 
 
+def ft_autocorr_independent_sphere(k, frac_volume, radius):
+    """smrt/microstructure_model/independent_sphere.py:54-72."""
+    x = radius * np.asarray(k, float)
+    bessel = np.ones_like(x)
+    nz = ~np.isclose(x, 0)
+    bessel[nz] = 9 * ((np.sin(x[nz]) - x[nz] * np.cos(x[nz])) / x[nz] ** 3) ** 2
+    return frac_volume * (1.0 - frac_volume) * 4.0 / 3 * np.pi * radius**3 * bessel
+
+
+def ft_autocorr_teubner_strey(k, frac_volume, corr_length, repeat_distance):
+    """smrt/microstructure_model/teubner_strey.py:45-55."""
+    x = (np.asarray(k, float) * corr_length) ** 2
+    y = (2 * np.pi * corr_length / repeat_distance) ** 2
+    return frac_volume * (1.0 - frac_volume) * 8 * np.pi * corr_length**3 / ((1 + y) ** 2 + 2 * (1 - y) * x + x**2)
+
+
 def shs_t_parameter(frac_volume, stickiness):
     """Tsang vol II eq 8.4.22 root selection, smrt/microstructure_model/sticky_hard_spheres.py:132-167."""
     f = frac_volume
@@ -174,6 +190,12 @@ class IBALayer(LayerEM):
         elif microstructure == "sticky_hard_spheres":
             r, tau = mp["radius"], mp["stickiness"]
             self.ft_corr = lambda k: ft_autocorr_shs(k, frac_volume, r, tau)
+        elif microstructure == "independent_sphere":
+            r = mp["radius"]
+            self.ft_corr = lambda k: ft_autocorr_independent_sphere(np.atleast_1d(k), frac_volume, r).reshape(np.shape(k))
+        elif microstructure == "teubner_strey":
+            lc, rd = mp["corr_length"], mp["repeat_distance"]
+            self.ft_corr = lambda k: ft_autocorr_teubner_strey(k, frac_volume, lc, rd)
         else:
             raise ValueError(microstructure)
         # mean squared field ratio with depolarisation 1/3 on each axis (iba.py:152-162)
@@ -438,7 +460,7 @@ def make_layers(emmodel, frequency, sp):
     ems = [str(e) for e in np.broadcast_to(np.atleast_1d(emmodel), (L,))]
     micros = [str(m) for m in np.broadcast_to(np.atleast_1d(sp["microstructure"]), (L,))]
     args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
-            "independent_sphere": ("radius",), "homogeneous": ()}
+            "independent_sphere": ("radius",), "homogeneous": (), "teubner_strey": ("corr_length", "repeat_distance")}
     extra = {"prescribed_kskaeps": ("ks", "ka", "eps_re", "eps_im")}   # layer attributes that emmodel reads
     wet = ("liquid_water",) if "liquid_water" in sp else ()              # water / (ice + water) volume per layer
     return [

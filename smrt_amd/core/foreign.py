@@ -48,6 +48,8 @@ def _is_exactly(cls, scope, module, name):
 DEVICE_MICROSTRUCTURE_CLASSES = {            # (module, class) -> (device name, parameters, defaults)
     ("exponential", "Exponential"): ("exponential", ("corr_length",)),
     ("sticky_hard_spheres", "StickyHardSpheres"): ("sticky_hard_spheres", ("radius", "stickiness")),
+    ("independent_sphere", "IndependentSphere"): ("independent_sphere", ("radius",)),
+    ("teubner_strey", "TeubnerStrey"): ("teubner_strey", ("corr_length", "repeat_distance")),
 }
 DRY_ICE_PERMITTIVITIES = ("wetice_permittivity_bohren83", "ice_permittivity_maetzler06")   # equal for dry, fresh ice
 

@@ -32,15 +32,20 @@ class Microstructure:
     def device_params(self):
         if self.name == "exponential":
             return float(self.corr_length), 0.0
+        if self.name == "teubner_strey":
+            return float(self.corr_length), float(self.repeat_distance)
+        if self.name == "independent_sphere":
+            return float(self.radius), 0.0
         if self.name == "homogeneous":
             return 0.0, 0.0
         return float(self.radius), float(getattr(self, "stickiness", 1000.0))
 
 
 MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
-                       # these two have no device emmodel: they serve the emmodels evaluated on the host
-                       "independent_sphere": ("radius",), "homogeneous": ()}
-DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres")
+                       "independent_sphere": ("radius",), "teubner_strey": ("corr_length", "repeat_distance"),
+                       # no device emmodel uses this one: it serves emmodels evaluated on the host (prescribed_kskaeps)
+                       "homogeneous": ()}
+DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey")   # IBA; DMRT: SHS only
 
 
 class Layer:

@@ -402,7 +402,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                                 ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
                                 double C;
                                 if (ms_l == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
-                                else C = pa * ft_corr(MS_SHS, pb * (1.0 - ct), fv, q1, q2);
+                                else C = pa * ft_corr(ms_l, pb * (1.0 - ct), fv, q1, q2);
                                 const double fvv = c * mi * x + sisj, fvh = sn * mi, fhv = -sn * x, fhh = c;
                                 const double Cc = C * cw, Cs = C * sw;
                                 q[0][0] += fvv * fvv * Cc; q[0][1] += fvh * fvh * Cc;

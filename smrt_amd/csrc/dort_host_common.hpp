@@ -108,7 +108,7 @@ inline const char* validate(const smrt_batch* b) {
     if (b->n_max_stream < 2) return "n_max_stream must be >= 2";
     if (b->emmodel < SMRT_EM_IBA || b->emmodel > SMRT_EM_IBA_INVERTED) return "unknown emmodel";
     bool host_layers = (!b->layer_kind && b->emmodel == SMRT_EM_HOST);
-    if (b->microstructure != SMRT_MS_EXPONENTIAL && b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
+    if (b->microstructure < SMRT_MS_EXPONENTIAL || b->microstructure > SMRT_MS_TEUBNER_STREY)
         return "unknown microstructure";
     if (!b->layer_kind && (b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE || b->emmodel == SMRT_EM_DMRT_QCACP_SHORTRANGE) &&
         b->microstructure != SMRT_MS_STICKY_HARD_SPHERES)
@@ -117,7 +117,7 @@ inline const char* validate(const smrt_batch* b) {
         for (int s = 0; s < b->n_snowpacks; ++s)
             for (int l = 0; l < b->n_layers[s]; ++l) {
                 const int k = b->layer_kind[(long long)s * b->n_layers_max + l], em = k & 15, ms = k >> 4;
-                if (em < SMRT_EM_IBA || em > SMRT_EM_IBA_INVERTED || (ms != SMRT_MS_EXPONENTIAL && ms != SMRT_MS_STICKY_HARD_SPHERES))
+                if (em < SMRT_EM_IBA || em > SMRT_EM_IBA_INVERTED || ms < SMRT_MS_EXPONENTIAL || ms > SMRT_MS_TEUBNER_STREY)
                     return "invalid layer_kind entry";
                 if (em == SMRT_EM_HOST) host_layers = true;
                 if ((em == SMRT_EM_DMRT_QCA_SHORTRANGE || em == SMRT_EM_DMRT_QCACP_SHORTRANGE) && ms != SMRT_MS_STICKY_HARD_SPHERES)

@@ -492,8 +492,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                             const double q = (pa * wk) * fast_rcp(dp2 * dm2);
                             Cp = dm2 * q; Cm = dp2 * q;
                         } else {
-                            Cp = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
-                            Cm = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
+                            Cp = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_p), fv, q1, q2);
+                            Cm = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_m), fv, q1, q2);
                         }
                         const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
                         pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;

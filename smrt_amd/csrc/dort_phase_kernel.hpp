@@ -63,7 +63,7 @@ SMRT_DEV void ft_even_phase_entry(const PhaseRequest& q, int is, int ii) {
                 ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
                 double C;
                 if (q.ms == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
-                else C = pa * ft_corr(MS_SHS, pb * (1.0 - ct), q.frac_volume, q.p1, q.p2);
+                else C = pa * ft_corr(q.ms, pb * (1.0 - ct), q.frac_volume, q.p1, q.p2);
                 const double fvv = c * mi * x + sis * sjs, fvh = sn * mi, fhv = -sn * x, fhh = c;
                 const double Cc = C * cw, Cs = C * sw;
                 e[0][0] += fvv * fvv * Cc; e[0][1] += fvh * fvh * Cc;

@@ -70,6 +70,21 @@ SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
         double den = 1.0 + x;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
     }
+    if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length, p2 = repeat distance
+        const double x = k2 * p1 * p1;
+        const double yy = 2.0 * kPi * p1 / p2, y = yy * yy;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / ((1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * x + x * x);
+    }
+    if (micro == MS_SPHERE) {   // independent spheres of radius p1, independent_sphere.py:54-72
+        const double x = sqrt(k2) * p1;
+        const double vol = 4.0 / 3.0 * kPi * p1 * p1 * p1;
+        double bessel = 1.0;
+        if (!(fabs(x) <= 1e-8)) {   // (np.isclose(X, 0): |X| <= 1e-8)
+            const double b = (sin(x) - x * cos(x)) / (x * x * x);
+            bessel = 9.0 * b * b;
+        }
+        return fv * (1.0 - fv) * vol * bessel;
+    }
     // sticky hard spheres, sticky_hard_spheres.py:63-130
     double f = fv, tau = p2, radius = p1;
     double x = sqrt(k2) * radius;

@@ -24,7 +24,7 @@ def snowpack_dict(d):
     """The plain-array snowpack description stored in a fixture."""
     sp = {k: d[k] for k in ("thickness", "density", "temperature", "frac_volume")}
     sp["microstructure"] = str(d["microstructure"]) if np.ndim(d["microstructure"]) == 0 else [str(m) for m in d["microstructure"]]
-    for k in ("corr_length", "radius", "stickiness", "ks", "ka", "eps_re", "eps_im", "liquid_water"):
+    for k in ("corr_length", "radius", "stickiness", "repeat_distance", "ks", "ka", "eps_re", "eps_im", "liquid_water"):
         if k in d:
             sp[k] = d[k]
     return sp
@@ -91,9 +91,11 @@ def packed_batch_from_fixture(d, freqs=None):
         msl = ms if isinstance(ms, list) else [ms] * L
         eml = emmodel if isinstance(emmodel, list) else [emmodel] * L
         layer_kind = [EM_CODES[e] + 16 * MS_CODES[m] for e, m in zip(eml, msl)]
-        expo = np.array([m == "exponential" for m in msl])
-        p1 = np.where(expo, np.nan_to_num(sp.get("corr_length", np.zeros(L))), np.nan_to_num(sp.get("radius", np.zeros(L))))
-        p2 = np.nan_to_num(np.broadcast_to(sp.get("stickiness", np.zeros(L)), (L,)), nan=0.0)
+        col = lambda k: np.nan_to_num(np.broadcast_to(sp.get(k, np.zeros(L)), (L,)).astype(float))  # noqa: E731
+        first = {"exponential": "corr_length", "teubner_strey": "corr_length"}            # p1: corr_length or radius
+        second = {"sticky_hard_spheres": "stickiness", "teubner_strey": "repeat_distance"}  # p2, when the model has one
+        p1 = np.array([col(first.get(m, "radius"))[l] for l, m in enumerate(msl)])
+        p2 = np.array([col(second[m])[l] if m in second else 0.0 for l, m in enumerate(msl)])
         ms, emmodel = msl[0], eml[0]
     else:
         p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
@@ -162,6 +164,8 @@ DENSE_AUTO_FIXTURES = ["iba_dense_auto_L5_n12", "iba_dense_auto_shs_active_L3_n8
 # wet snow: layers at the melting point holding liquid water (grains coated in water, Maxwell Garnett in a water host); the
 # active one with a very wet layer above half "ice + water" under dense_snow_correction="auto"
 WET_FIXTURES = ["iba_wet_L4_n12_passive", "iba_wet_L3_n10_active", "dmrt_wet_L3_n12_passive"]
+# IBA over four microstructure models, one per layer: teubner_strey, independent_sphere, exponential, sticky_hard_spheres
+MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

@@ -39,9 +39,10 @@ def rebuild(d):
     kw = {}
     if np.ndim(d["microstructure"]) > 0:   # heterogeneous snowpack: per-layer names, None where a parameter is unused
         none = lambda a: [None if np.isnan(x) else float(x) for x in a]  # noqa: E731
+        more = {"repeat_distance": none(d["repeat_distance"])} if "repeat_distance" in d else {}
         return make_snowpack(d["thickness"], [str(m) for m in d["microstructure"]], density=d["density"],
                              temperature=d["temperature"], corr_length=none(d["corr_length"]), radius=none(d["radius"]),
-                             stickiness=none(d["stickiness"]))
+                             stickiness=none(d["stickiness"]), **more)
     if str(d["microstructure"]) == "exponential":
         kw["corr_length"] = d["corr_length"]
     else:

@@ -44,9 +44,10 @@ def snowpack_arrays(sp):
     kinds = {type(lay.microstructure).__name__ for lay in sp.layers}
     if len(kinds) > 1:   # mixed microstructure models: one name per layer, NaN for the parameters a layer does not have
         get = lambda lay, a: float(getattr(lay.microstructure, a, np.nan))  # noqa: E731
-        out["microstructure"] = np.array(["exponential" if hasattr(lay.microstructure, "corr_length") else
-                                          "sticky_hard_spheres" for lay in sp.layers])
-        for a in ("corr_length", "radius", "stickiness"):
+        names = {"Exponential": "exponential", "StickyHardSpheres": "sticky_hard_spheres",
+                 "IndependentSphere": "independent_sphere", "TeubnerStrey": "teubner_strey"}
+        out["microstructure"] = np.array([names[type(lay.microstructure).__name__] for lay in sp.layers])
+        for a in ("corr_length", "radius", "stickiness", "repeat_distance"):
             out[a] = np.array([get(lay, a) for lay in sp.layers])
         return out
     ms = sp.layers[0].microstructure
@@ -759,6 +760,21 @@ def main():
                             volumetric_liquid_water=[0.02, 0.0, 0.0])
         save("dmrt_wet_L3_n12_passive", run_new("dmrt_qca_shortrange", passive([10.65e9, 36.5e9], [55]), spx,
                                                  rtsolver_options=dict(n_max_stream=12)))
+
+    # (iv-j) IBA over the other closed-form microstructure models (smrt/microstructure_model/teubner_strey.py:45-55,
+    # independent_sphere.py:54-72) mixed with the two usual ones, one model per layer, passive and active
+    micro4 = ["teubner_strey", "independent_sphere", "exponential", "sticky_hard_spheres"]
+    if wanted("iba_micro4_L4_n12_passive") or wanted("iba_micro4_L4_n10_active"):
+        def micro_pack(last):
+            return make_snowpack([0.2, 0.3, 0.4, last], micro4, density=[280, 320, 360, 400], temperature=[258, 261, 264, 266],
+                                 corr_length=[1.5e-4, None, 2e-4, None], repeat_distance=[1.2e-3, None, None, None],
+                                 radius=[None, 2.5e-4, None, 2e-4], stickiness=[None, None, None, 0.3])
+        if wanted("iba_micro4_L4_n12_passive"):
+            save("iba_micro4_L4_n12_passive", run_new("iba", passive([18.7e9, 36.5e9, 89e9], [40, 55]), micro_pack(100.0),
+                                                       rtsolver_options=dict(n_max_stream=12)))
+        if wanted("iba_micro4_L4_n10_active"):
+            save("iba_micro4_L4_n10_active", run_new("iba", active(13.4e9, [30, 40]), micro_pack(1000.0),
+                                                      rtsolver_options=dict(n_max_stream=10, m_max=2)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -738,3 +738,37 @@ def test_wet_snow_through_the_model():
         eps = np.asarray(res.other_data["effective_permittivity"].values).reshape(len(d["frequency"]), -1)[last]
         np.testing.assert_allclose(ks, d["f%d_ks" % last], rtol=1e-10)
         np.testing.assert_allclose(eps, d["f%d_effective_permittivity" % last], rtol=1e-11)
+
+
+def test_other_microstructure_models_through_the_model():
+    """IBA over teubner_strey and independent_sphere layers (device: ft_corr, dort_physics.hpp) mixed with exponential and
+    sticky-hard-spheres ones, one microstructure model per layer through make_snowpack's list form, against the reference,
+    passive and active; a uniform teubner_strey snowpack takes the uniform-microstructure batch (no per-layer codes)."""
+    from conftest import MICRO_FIXTURES, reference_method_spread
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    none = lambda a: [None if np.isnan(x) else float(x) for x in a]   # noqa: E731
+    for name in MICRO_FIXTURES:
+        d = load_golden(name)
+        sp = make_snowpack(d["thickness"], [str(m) for m in d["microstructure"]], density=d["density"], temperature=d["temperature"],
+                           corr_length=none(d["corr_length"]), radius=none(d["radius"]), stickiness=none(d["stickiness"]),
+                           repeat_distance=none(d["repeat_distance"]))
+        opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+        if str(d["mode"]) == "A":
+            opts["m_max"] = int(d["opt_m_max"])
+            res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.active(list(d["frequency"]), list(d["theta_inc_deg"])), sp)
+            assert_backscatter_close(np.asarray(res.data.values).reshape(d["result"].shape), d["result"], spread=reference_method_spread(d))
+        else:
+            res = make_model("iba", "dort", rtsolver_options=opts).run(sensor_list.passive(list(d["frequency"]), list(d["theta_deg"])), sp)
+            assert np.abs(np.asarray(res.data.values).reshape(d["result"].shape) - d["result"]).max() < 1e-6
+        last = len(d["frequency"]) - 1
+        np.testing.assert_allclose(np.asarray(res.other_data["ks"].values).reshape(len(d["frequency"]), -1)[last], d["f%d_ks" % last], rtol=1e-10)
+    from oracle import dort_oracle as O
+
+    ts = make_snowpack([0.3, 100.0], "teubner_strey", density=[300, 380], temperature=[260, 265], corr_length=[1.5e-4, 2e-4],
+                       repeat_distance=[1e-3, 1.5e-3])
+    res = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=16)).run(sensor_list.passive(36.5e9, 55), ts)
+    ref = O.solve(dict(thickness=np.array([0.3, 100.0]), density=np.array([300.0, 380.0]), temperature=np.array([260.0, 265.0]),
+                       microstructure="teubner_strey", corr_length=np.array([1.5e-4, 2e-4]), repeat_distance=np.array([1e-3, 1.5e-3])),
+                  36.5e9, [55.0], n_max_stream=16)
+    assert np.abs(np.ravel(res.data.values) - np.ravel(ref)).max() < 1e-6

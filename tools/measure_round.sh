@@ -17,7 +17,7 @@ python bench.py --config 3 > $O/bench_line_cfg3.json 2> $O/bench_line_cfg3.err
 PMC_CONFIG=2 bash tools/pmc_passes.sh > $O/pmc_passes_cfg2.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_cfg2 ${ROUND_TAG:-r4} 2 7168 > $O/pmc_counters_cfg2.txt 2>&1
 PMC_CONFIG=3 bash tools/pmc_passes.sh > $O/pmc_passes_cfg3.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_cfg3 ${ROUND_TAG:-r4} 3 256 > $O/pmc_counters_cfg3.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_cfg3 ${ROUND_TAG:-r4} 3 512 > $O/pmc_counters_cfg3.txt 2>&1
 python bench.py --config 2 --no-secondary > $O/bench_line_cfg2_with_traffic.json 2>> $O/bench_line_cfg2.err
 python bench.py --config 3 --no-secondary > $O/bench_line_cfg3_with_traffic.json 2>> $O/bench_line_cfg3.err
 cp profiles/hbm_traffic.json $O/hbm_traffic.json 2>/dev/null
