@@ -1,0 +1,339 @@
+#!/usr/bin/env python
+"""Headline benchmark: (snowpack x frequency) DORT solves per second on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): IBA + DORT, 20 layers, 32 streams, 5 AMSR-E channels
+(10.65/18.7/23.8/36.5/89 GHz, 55 deg, V+H), batch of 1024 synthetic snowpacks per GPU = 5120 solves per step.
+A step = one pass of the hot path over that batch with the inputs already resident in HBM (packed and uploaded once,
+before timing); `value` is that rate.  The same JSON line also carries, measured in the same run:
+
+* `pcie_inclusive`  -- the one-shot C entry point smrt_dort_run on host buffers: H2D of the packed inputs, the kernels,
+                       D2H of results and diagnostics (SURVEY.md 8d counts the metric this way);
+* `model_run`       -- Model.run -> HipBatchRunner -> Result on 1024 Snowpack objects: the plugin surface end to end;
+* `roofline`        -- 68 sum N_l^3 flops / summed HIP-event time of the pipeline kernels, against the FP64 peak;
+* `cpu_baseline`    -- the CPU oracle on this box's cores, one BLAS thread per worker (N = 1 only).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU (only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the launcher -- no PyTorch in
+the path).  `--scaling weak` (default): every rank solves its own 1024 x 5 batch (different seeds); `--scaling strong`:
+ONE 1024 x 5 batch cut into contiguous slices of equal estimated cost (sum N_l^3, smrt_dort_pair_cost).  Either way the
+only collective is the gather of the result rows to rank 0 over RCCL (smrt_dort_gather), inside every step.
+Prints ONE JSON line on rank 0.
+"""
+import os
+
+# one BLAS / OpenMP thread per process, set BEFORE NumPy is imported anywhere in this process or its workers: the CPU
+# baseline runs one worker per core like the reference's joblib runner (smrt/runner/joblib_runner.py:18-31,
+# smrt/core/lib.py:655-666)
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ[_k] = "1"
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector == matrix peak (AMD spec sheet); SURVEY.md 8(d)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+FLOPS_PER_N3 = 68.0  # algorithmic flops per layer = 68 N^3 (N = streams x polarisations)
+FREQS = np.array([10.65e9, 18.7e9, 23.8e9, 36.5e9, 89e9])
+N_SNOWPACKS = 1024
+N_LAYERS = 20
+N_STREAMS = 32
+THETA_DEG = 55.0
+
+
+def synthetic_snowpacks(seed, S=N_SNOWPACKS, L=N_LAYERS):
+    """SURVEY.md 8(d) cfg2 laws: per snowpack draw thickness (L-1), density (L), temperature (L), size (L)."""
+    rng = np.random.default_rng(seed)
+    thick = np.empty((S, L))
+    dens = np.empty((S, L))
+    temp = np.empty((S, L))
+    lc = np.empty((S, L))
+    for s in range(S):
+        thick[s, : L - 1] = rng.uniform(0.05, 0.30, L - 1)
+        thick[s, L - 1] = 100.0
+        dens[s] = rng.uniform(150, 450, L)
+        temp[s] = rng.uniform(230, 270, L)
+        lc[s] = rng.uniform(5e-5, 3e-4, L)
+    return thick, dens, temp, lc
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------
+def _worker_init():
+    try:  # belt and braces on top of the environment variables: cap whatever BLAS this worker loaded
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def _worker_threads(_):
+    try:
+        from threadpoolctl import threadpool_info
+
+        info = threadpool_info()
+        return max([p.get("num_threads", 1) for p in info] or [1])
+    except Exception:  # noqa: BLE001
+        return -1
+
+
+def _oracle_solve(args):
+    from oracle import dort_oracle as O  # CPU baseline only
+
+    thick, dens, temp, lc, f, method = args
+    sp = dict(thickness=thick, density=dens, temperature=temp, microstructure="exponential", corr_length=lc)
+    return O.solve(sp, f, [THETA_DEG], n_max_stream=N_STREAMS, method=method)
+
+
+def cpu_baseline(thick, dens, temp, lc, gpu_values):
+    """The CPU oracle (NumPy/SciPy restatement of the reference) on the host cores of this box: one worker process per
+    core, one BLAS thread each (measured in the workers and reported), on a bounded sample of the same workload; with
+    the oracle's fastest diagonalisation (`half_rank_eig`, the headline number) and with the reference's default
+    (`schur_forcedtriu`)."""
+    import multiprocessing as mp
+
+    cores = min(os.cpu_count() or 1, 64)
+    S = thick.shape[0]
+
+    def items(n, method):
+        out = []
+        for i in range(n):  # pairs spread over the frequency-major list of the GPU batch
+            f, s = divmod(i * 37 % (len(FREQS) * S), S)
+            out.append(((thick[s], dens[s], temp[s], lc[s], FREQS[f], method), f, s))
+        return out
+
+    n_fast = int(min(512, max(64, 4 * cores)))
+    n_ref = int(min(256, max(32, 2 * cores)))
+    rates = {}
+    err = 0.0
+    with mp.get_context("spawn").Pool(cores, initializer=_worker_init) as pool:
+        threads = max(pool.map(_worker_threads, range(cores)))
+        pool.map(_oracle_solve, [it[0] for it in items(cores, "half_rank_eig")])  # warm the workers (imports)
+        for method, n in (("half_rank_eig", n_fast), ("schur_forcedtriu", n_ref)):
+            its = items(n, method)
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_solve, [it[0] for it in its], chunksize=1)
+            rates[method] = n / (time.perf_counter() - t0)
+            for it, r in zip(its, res):
+                err = max(err, float(np.abs(gpu_values[it[1] * S + it[2]] - r).max()))
+    return dict(value=rates["half_rank_eig"], unit="solves/s", cores=cores, kind="port",
+                blas_threads_per_worker=threads,
+                reference_default_method=dict(value=rates["schur_forcedtriu"], unit="solves/s", method="schur_forcedtriu",
+                                              sample=n_ref),
+                sample="%d of the %d pairs of rank 0's batch, oracle/dort_oracle.py half_rank_eig, %d spawned worker "
+                       "processes, %d BLAS thread(s) per worker (threadpoolctl)" % (n_fast, len(FREQS) * S, cores, threads)), err
+
+
+# ---- secondary measurements on rank 0 ----------------------------------------------------------------------------
+def pcie_inclusive(ctx, batch, reps=5):
+    ctx.run(batch)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ctx.run(batch)  # smrt_dort_run: H2D + kernels + D2H (values, status, layer and stream diagnostics)
+        times.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.median(times))
+    return dict(value=batch.n_pairs / (ms * 1e-3), unit="solves/s", ms=ms,
+                what="smrt_dort_run on host buffers: H2D of the packed inputs, kernels, D2H of results + diagnostics; "
+                     "median of %d" % reps)
+
+
+def model_run_rate(thick, dens, temp, lc, reference_values, reps=3):
+    from smrt_amd import make_model, make_snowpack
+    from smrt_amd.core.sensor import passive
+
+    t0 = time.perf_counter()
+    sps = [make_snowpack(thick[s], "exponential", density=dens[s], temperature=temp[s], corr_length=lc[s])
+           for s in range(thick.shape[0])]
+    build_s = time.perf_counter() - t0
+    sensor = passive(list(FREQS), THETA_DEG)
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=N_STREAMS, devices=[int(os.environ.get("LOCAL_RANK", "0"))]))
+    res = m.run(sensor, sps)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = m.run(sensor, sps)
+        times.append(time.perf_counter() - t0)
+    ms = 1e3 * float(np.median(times))
+    same = bool(np.array_equal(res.data.values.reshape(reference_values.shape), reference_values))
+    return dict(value=len(sps) * len(FREQS) / (ms * 1e-3), unit="solves/s", ms=ms, bitwise_equal_to_c_abi_run=same,
+                snowpack_objects_built_in_s=build_s,
+                what="make_model('iba','dort').run(passive(5 freqs), 1024 Snowpack objects) -> stacked Result, "
+                     "median of %d (objects built once, outside)" % reps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--threads", type=int, default=0, help="workgroup size of the per-pair kernels (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the pcie_inclusive / model_run measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SMRT_BENCH_DIST=1: take the RCCL path with a single rank too (tests/test_gpu_bench.py checks on a one-GPU box the
+    # code the multi-GPU runs execute)
+    use_comm = world > 1 or os.environ.get("SMRT_BENCH_DIST") == "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from smrt_amd._native import DortContext, PackedBatch
+    from smrt_amd.rtsolver.dort import shard_by_cost
+    from smrt_amd.runner.distributed import init_comm
+
+    strong = args.scaling == "strong"
+    thick, dens, temp, lc = synthetic_snowpacks(seed=2 if strong else 2 + rank)
+    batch = PackedBatch([N_LAYERS] * N_SNOWPACKS, thick, dens / 916.7, temp, lc, None, FREQS, np.deg2rad([THETA_DEG]),
+                        emmodel="iba", microstructure="exponential", mode="P", n_max_stream=N_STREAMS)
+    ctx = DortContext(local_rank)
+    if args.threads:
+        ctx.set_block_threads(args.threads)
+    if use_comm:
+        init_comm(ctx, rank, world)
+    lo, hi = 0, batch.n_pairs
+    if strong and world > 1:  # equal estimated cost per rank, contiguous slices of the frequency-major list
+        ctx.upload(batch)
+        bounds = shard_by_cost(ctx.pair_cost(), world)
+        counts = np.diff(bounds)
+        if (counts <= 0).any():   # every rank decides the same way (same costs): nobody is left waiting in the gather
+            raise SystemExit("bench.py --scaling strong: %d ranks for %d pairs leaves a rank without work" % (world, batch.n_pairs))
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    else:
+        counts = np.full(world, batch.n_pairs, np.int64)
+    ctx.upload(batch, lo, hi - lo)  # inputs resident in HBM before the timed region
+    n_pairs = hi - lo
+    total_pairs = int(counts.sum())
+    gathered = [None, None]
+
+    def step():
+        ctx.launch()
+        if use_comm:
+            gathered[0], gathered[1] = ctx.gather(counts, root=0)  # the only collective; waits for the kernels
+
+    def fence():
+        ctx.sync()
+        if use_comm:
+            ctx.barrier()
+            ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.total_kernel_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms_total, n_launch = ctx.total_kernel_ms()
+    per_rank = None
+    if use_comm:
+        elapsed = float(ctx.allreduce_max([elapsed])[0])   # MAX over ranks
+        # every rank's kernel time and pair count in rank 0's line (a vector with one own entry each, MAX-reduced):
+        # load imbalance shows in the first scaling record
+        mine = np.zeros(2 * world)
+        mine[rank] = kernel_ms_total / max(n_launch, 1)
+        mine[world + rank] = n_pairs
+        allv = ctx.allreduce_max(mine)
+        per_rank = {"kernel_ms": [float(v) for v in allv[:world]], "pairs": [int(v) for v in allv[world:]]}
+
+    res = ctx.download()
+    n_fail = int((res.status != 0).sum())
+    if use_comm and rank == 0:
+        n_fail = int((gathered[1] != 0).sum())
+        own = gathered[0][: n_pairs]  # rank 0's rows come first
+        assert np.array_equal(own, res.values), "gathered rows differ from the local ones"
+    sum_n3 = ctx.sum_n3()
+    flops_per_launch = FLOPS_PER_N3 * sum_n3
+    kernel_ms = kernel_ms_total / max(n_launch, 1)
+    achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):  # PMC counters cannot be collected from inside this process: measured with
+        with open(tpath) as fh:  # tools/pmc_passes.sh on the same command, summary committed under profiles/
+            tj = json.load(fh)
+        if tj.get("solves_per_launch") == n_pairs:
+            traffic = tj["traffic_bytes_per_launch"]
+
+    if rank == 0:
+        line = {
+            "metric": "snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
+            "value": total_pairs * args.steps / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: IBA + DORT passive, 20 layers, 32 streams, 5 AMSR-E channels "
+                            "(10.65-89 GHz, 55 deg), 1024 synthetic snowpacks %s = %d solves per step"
+                            % ("in all, cut by estimated cost over the ranks" if strong else "per GPU", total_pairs),
+                "solves_per_step_per_gpu": n_pairs,
+                "parallelism": "%d independent rank(s), results gathered to rank 0%s" % (
+                    world, " by smrt_dort_gather (RCCL, no PyTorch)" if use_comm else ""),
+                "failed_solves": n_fail,
+                "timed_region": "smrt_dort_launch of the resident batch (+ smrt_dort_gather when N > 1), "
+                                "barrier + stream sync on both sides, max over ranks",
+                "value_is": "the resident-input rate (inputs in HBM when the timed region starts); SURVEY 8(d)'s rate "
+                            "including H2D of the packed inputs and D2H of the results is `pcie_inclusive` of this line",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS,
+                "traffic": traffic,
+                "traffic_unit": "bytes per pipeline launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)",
+                "traffic_source": ("profiles/hbm_traffic.json (round %s; separate rocprofv3 --pmc passes over this command, "
+                                   "tools/pmc_passes.sh -- not measured in this run)" % tj.get("round")) if traffic is not None else None,
+                # the north star also asks for the fraction of the HBM roofline: measured bytes / pipeline time / 8 TB/s
+                "hbm": (None if traffic is None or kernel_ms <= 0 else
+                        {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}),
+                "kernel": "dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_reg_kernel (one launch each "
+                          "per step; kernel_ms is their summed HIP-event time on the launch stream)",
+                "per_rank": per_rank,
+                "kernel_ms": kernel_ms,
+                "flops_per_launch": flops_per_launch,
+                "note": "FP64 compute roofline: vector FMA and FP64 MFMA share one 78.6 TFLOP/s pipe on gfx950 "
+                        "(tools/micro/fp64_pipes.hip: 60 / 71 / 72 TFLOP/s alone / alone / together); algorithmic flops = "
+                        "68 * sum over pairs and layers of N_l^3 with the actual stream counts (SURVEY 8d); algorithmic "
+                        "HBM bytes are ~1.6 KB per solve; the pipeline additionally stages ~75 KB per (pair, layer) "
+                        "through HBM/L2 between its kernels (DESIGN.md 4), still far from HBM-bound",
+            },
+        }
+        if world == 1 and not args.no_secondary:
+            line["pcie_inclusive"] = pcie_inclusive(ctx, batch)
+            line["model_run"] = model_run_rate(thick, dens, temp, lc, res.values)
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
+            cb, err = cpu_baseline(thick, dens, temp, lc, res.values)
+            line["cpu_baseline"] = cb
+            line["config"]["max_abs_dTb_vs_oracle_K"] = err
+        print(json.dumps(line), flush=True)
+    if use_comm:
+        ctx.barrier()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -181,10 +181,6 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 fresnel_RT3(cmk(s.eps_re[Lc - 1], s.eps_im[Lc - 1]), cmk(s.eps_re[Lc], s.eps_im[Lc]), sqrt(1.0 - rs * rs), R3, T3,
                             frequency, cmk(s.slab_re[Lc], s.slab_im[Lc]), s.slab_th[Lc]);
                 Rt = R3[pol];
-                if (__builtin_expect(b.host_itf_slot != nullptr, 0)) {   // a rough interface there: its specular part
-                    const int hsb = host_interface_slot(b, gp, (int)s.lo[Lc]);
-                    if (hsb >= 0) Rt = host_interface_specular(b, gp, hsb)[2 * 3 * nmax + 2 * j + pol];
-                }
             }
         } else
         if (b.sub_kind == SUB_HOST && j < (int)s.nl[L - 1]) {   // specular part of a rough substrate, from the caller (mode 0)
@@ -298,22 +294,11 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                     for (int q = 0; q < P; ++q) s.M3[(P * j + q) * LD + P * j + q] = R3[q];
                 }
             }
-            if (MODE != 1 && l == Lk - 1) {
-                // a DENSE start of the recursion, from the caller (smrt_dort.h): the reflection matrix of this mode of a rough
-                // substrate, or -- deeper layers pruned right above a rough interface -- that interface's reflection seen
-                // from this layer (Rbot of its slot), what the reference's truncated system keeps (dort.py:443-452,
-                // rtsolver_utils.py:567-597).  One copy loop for both (the pointer is uniform over the workgroup).
-                const long long NE = 3LL * nmax;
-                const double* H = nullptr;
-                if (Lk == L) { if (b.sub_kind == SUB_HOST) H = b.host_substrate + (gp * (long long)(m_max + 1) + m) * NE * NE; }
-                else if (__builtin_expect(b.host_itf_slot != nullptr, 0)) {
-                    const int hsb = b.host_itf_slot[gp * b.Lmax + (int)s.lo[l + 1]];
-                    if (hsb >= 0) H = b.host_itf + (((gp * b.host_itf_slots + hsb) * (long long)(m_max + 1) + m) * 4 + 2) * NE * NE;
-                }
-                if (__builtin_expect(H != nullptr, 0)) {
-                    block_sync();
-                    for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = H[r * NE + c]; });
-                }
+            if (MODE != 1 && l == Lk - 1 && Lk == L && b.sub_kind == SUB_HOST) {
+                // rough substrate: the recursion starts from the caller's dense reflection matrix of this mode (smrt_dort.h)
+                const int NE = 3 * nmax;
+                const double* H = b.host_substrate + (gp * (long long)(m_max + 1) + m) * NE * NE;
+                for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = H[r * NE + c]; });
             }
             for (int j = t; j < n; j += NT) {
                 double w;
@@ -406,7 +391,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                                 ct = ct > 1.0 ? 1.0 : (ct < -1.0 ? -1.0 : ct);
                                 double C;
                                 if (ms_l == MS_EXP) { const double dp = 1.0 + pb * (1.0 - ct); C = pa / (dp * dp); }
-                                else C = pa * ft_corr(ms_l, pb * (1.0 - ct), fv, q1, q2);
+                                else C = pa * ft_corr(MS_SHS, pb * (1.0 - ct), fv, q1, q2);
                                 const double fvv = c * mi * x + sisj, fvh = sn * mi, fhv = -sn * x, fhh = c;
                                 const double Cc = C * cw, Cs = C * sw;
                                 q[0][0] += fvv * fvv * Cc; q[0][1] += fvh * fvh * Cc;

@@ -1,0 +1,613 @@
+// libsmrt_dort.so -- HIP implementation of include/smrt_dort.h for gfx950 (MI355X).
+// This file: the C ABI, the context, device buffers, packing, the chunk loops and HIP-event timing.  The kernels are
+// instantiated in k_*.hip (one translation unit per kernel family, compiled in parallel) behind the launchers of
+// dort_ctx.hpp; the device code itself is dort_device.hpp and the headers it lists.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dort_ctx.hpp"
+#include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
+#include "dort_host_common.hpp"
+#include "dort_phase_kernel.hpp"
+#include "dort_finish_reg.hpp"      // finish_reg_lds_doubles (device code is inline templates / functions: nothing is instantiated here)
+
+using namespace smrt;
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return -1;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+static int upload_array(smrt_dort_ctx* ctx, DevBuf& buf, const void* src, size_t bytes) {
+    HIPCHK(buf.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+
+// One chunk of the batch as its own DevBatch (outputs offset to the chunk's rows)
+static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long c0, long long cn) {
+    DevBatch c = d;
+    c.pair_begin = d.pair_begin + c0; c.pair_count = cn;
+    c.out = d.out + c0 * ctx->out_stride; c.status = d.status + c0;
+    c.layer_out = d.layer_out + c0 * (long long)d.Lmax * 5;
+    c.stream_out = d.stream_out + c0 * (long long)(1 + d.n_max_stream);
+    c.n3_out = d.n3_out + c0; c.stage_out = d.stage_out + c0 * 16;
+    if (d.dispatch) c.dispatch = d.dispatch + c0;
+    return c;
+}
+
+// prep -> Jacobi -> finish, chunk by chunk (the staging area holds one chunk).  Under prune_deep_snowpack the prep and
+// Jacobi kernels run in up to four ROUNDS over successive layer ranges, top-down, with a small kernel in between that
+// marks the pairs whose cut has been reached: the layers below a cut are never diagonalised (like in the reference),
+// exactly -- the decision uses the same singular values as the finish kernel.
+#ifndef SMRT_FINISH_REG_DEFAULT
+#define SMRT_FINISH_REG_DEFAULT 1   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
+#endif
+static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
+    const long long items_per_pair = (long long)(ctx->active ? d.m_max + 1 : 1) * d.Lmax;
+    const long long modes = ctx->active ? d.m_max + 1 : 1;
+    if (getenv("SMRT_DORT_DEBUG_OCCUPANCY") && !ctx->gmem_path && !ctx->active) smrt_launch::occupancy_report(ctx, ctx->nt);
+    // (under process_coherent_layers the layer indices of a pair are its own: one round, and the staging counts of the
+    // removed layers must read "nothing staged")
+    const int rounds = (d.prune_tau > 0.0 && !d.coherent && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
+    auto prep = [&](const DevBatch& c, unsigned grid) {
+        if (ctx->big) return smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->gmem_split) return smrt_launch::prep_gmem(ctx, c, grid, ctx->active);
+        return ctx->active ? smrt_launch::active_prep(ctx, c, ctx->nt) : smrt_launch::prep(ctx, c, ctx->nt);
+    };
+    auto finish = [&](const DevBatch& c, unsigned grid) {
+        if (ctx->big) return smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->gmem_split) return smrt_launch::finish_gmem(ctx, c, grid, ctx->active);
+        if (ctx->finish_reg) return smrt_launch::finish_reg(ctx, c);
+        return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
+    };
+    for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs) {
+        const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
+        DevBatch c = chunk_of(ctx, d, c0, cn);
+        const unsigned grid = (unsigned)(ctx->gmem_path ? std::min<long long>(cn, ctx->gmem_grid) : cn);
+        hipError_t e;
+        if (rounds > 1 || d.coherent) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
+            if ((e = hipMemsetAsync(ctx->stage.n, 0, sizeof(int) * (size_t)(cn * items_per_pair), ctx->stream)) != hipSuccess) return e;
+        }
+        if (rounds > 1) {
+            if ((e = hipMemsetAsync(ctx->d_done.p, 0, sizeof(int) * (size_t)cn, ctx->stream)) != hipSuccess) return e;
+            c.pair_done = (const int*)ctx->d_done.p;
+        }
+        for (int r = 0; r < rounds; ++r) {
+            c.layer_lo = (int)((long long)d.Lmax * r / rounds);
+            c.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
+            if ((e = prep(c, grid)) != hipSuccess) return e;
+            const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
+            if ((e = ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems)) != hipSuccess) return e;
+            if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, (int*)ctx->d_done.p)) != hipSuccess) return e;
+        }
+        c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
+        if ((e = finish(c, grid)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+extern "C" {
+
+const char* smrt_dort_version(void) { return "smrt_dort 0.1 (gfx950)"; }
+
+int32_t smrt_dort_out_stride(const smrt_batch* b) { return smrt_host::out_stride(b); }
+
+int32_t smrt_gauss_legendre_positive(int32_t n, double* mu, double* weight) {
+    if (n < 1 || !mu) return -1;
+    smrt_host::gauss_legendre_positive(n, mu, weight);
+    return 0;
+}
+
+int32_t smrt_dort_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
+}
+
+int32_t smrt_dort_create(smrt_dort_ctx** out, int32_t device) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -2;  // no GPU: the product has no CPU fallback
+    if (device < 0 || device >= ndev) return -3;
+    smrt_dort_ctx* ctx = new smrt_dort_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return -4;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->max_lds = (int)prop.sharedMemPerBlock;
+    if (ctx->max_lds < 160 * 1024) ctx->max_lds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+    *out = ctx;
+    return 0;
+}
+
+void smrt_dort_destroy(smrt_dort_ctx* ctx) {
+    if (!ctx) return;
+    (void)smrt_dort_comm_destroy(ctx);
+    (void)hipSetDevice(ctx->device);
+    DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
+                      &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws, &ctx->d_itfslot, &ctx->d_itf, &ctx->d_itfcoh,
+                      &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_gather_out, &ctx->d_gather_status,
+                      &ctx->d_scalar};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* smrt_dort_last_error(const smrt_dort_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
+    if (!ctx) return -1;
+    ctx->split = (split != 0);
+    ctx->finish2 = (split != 2);
+    ctx->finish_mode = (split == 3) ? 1 : (split == 4 ? 0 : -1);   // 3: register-resident finish wherever supported, 4: never
+    ctx->uploaded = false;  // the staging area is sized at upload time
+    return 0;
+}
+
+int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max) {
+    return (int32_t)(sizeof(double) * (size_t)finish_reg_lds_doubles(n_max_stream, n_layers_max));
+}
+
+int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
+    if (!ctx) return -1;
+    if (threads == 0) threads = 256;
+    if (threads != 64 && threads != 256) {   // one wavefront (the serial corner of every stage) or the tuned four
+        ctx->err = "block threads must be 64 or 256";
+        return -1;
+    }
+    ctx->nt = threads;
+    return 0;
+}
+
+}  // extern "C"
+
+// pairs == nullptr: the contiguous range [pair_begin, pair_begin + pair_count) of the flattened list; otherwise the
+// n = pair_count listed pairs (pair_begin ignored)
+static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count,
+                           const int64_t* pairs) {
+    if (!ctx) return -1;
+    const char* why = smrt_host::validate(b);
+    if (why) { ctx->err = why; return -1; }
+    // HIP's current device is per host thread: bind it BEFORE the first allocation below, or a buffer that has to
+    // grow would land on whatever device the calling thread used last
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->active = (b->mode == SMRT_MODE_ACTIVE);
+    if (ctx->active && (b->m_max < 0 || b->m_max > 64)) { ctx->err = "m_max must be in 0..64"; return -1; }
+    const int64_t npairs = (int64_t)b->n_snowpacks * b->n_frequencies;
+    if (pairs) {
+        pair_begin = 0;
+        if (pair_count <= 0) { ctx->err = "empty pair list"; return -1; }
+        for (int64_t i = 0; i < pair_count; ++i)
+            if (pairs[i] < 0 || pairs[i] >= npairs) { ctx->err = "pair index out of bounds"; return -1; }
+    } else {
+        if (pair_count < 0) pair_count = npairs - pair_begin;
+        if (pair_begin < 0 || pair_count <= 0 || pair_begin + pair_count > npairs) { ctx->err = "pair range out of bounds"; return -1; }
+    }
+    const int P = ctx->active ? 3 : 2;
+    const int nphi = ctx->active ? azimuth_samples(b->m_max) / 2 + 1 : 9;
+    const int actd = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta) : 0;
+    const int actd_fin = ctx->active ? active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta, false) : 0;   // finish kernels
+    LdsPlan plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd);
+    size_t lds = (size_t)plan.total * sizeof(double);
+    ctx->gmem_path = (plan.NMAX > 64 || lds > (size_t)ctx->max_lds || getenv("SMRT_DORT_FORCE_GLOBAL_WORKSPACE") != nullptr);
+    if (ctx->gmem_path) {
+        if (plan.NMAX > 384) {
+            ctx->err = "streams x polarisations above 384 (n_max_stream > 192 passive, > 128 active) is not supported by this build";
+            return -1;
+        }
+        plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 0, 1);   // with an LDS Jacobi matrix
+        ctx->jac_in_lds = 1;
+        if ((size_t)plan.total * sizeof(double) > (size_t)ctx->max_lds) {
+            plan = make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd);
+            ctx->jac_in_lds = 0;
+        }
+        lds = (size_t)plan.total * sizeof(double);
+        if (lds > (size_t)ctx->max_lds) { ctx->err = "too many layers for the LDS-resident per-layer tables"; return -1; }
+        ctx->gmem_grid = (int)std::min<int64_t>(pair_count, 1024);
+        ctx->ws_stride = (long long)plan.mat_doubles + plan.scratch_doubles;
+        HIPCHK(ctx->d_work.reserve(sizeof(double) * (size_t)ctx->gmem_grid * (size_t)ctx->ws_stride));
+    }
+    ctx->nmax_rows = plan.NMAX;
+    ctx->chunk_pairs = 0;
+    // N > 128: the pipeline with the blocked Jacobi kernel (matrix in the staging area, column blocks through LDS)
+    int big_min = 128;   // SMRT_DORT_BIG_MIN_N: experiments with the big pipeline on smaller matrices
+    if (const char* e = getenv("SMRT_DORT_BIG_MIN_N")) big_min = std::max(64, atoi(e));
+    ctx->big = ctx->gmem_path && ctx->split && plan.NMAX > big_min && getenv("SMRT_DORT_NO_BIG_PIPELINE") == nullptr &&
+               (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds;
+    // 64 < N <= 128: the three-kernel pipeline needs the Jacobi kernel's own LDS matrix and the 16 N doubles of LDS scratch
+    // of the finish kernel's blocked solvers -- NOT the whole-matrix Jacobi buffer of the fused kernel tested above (with 50
+    // layers that plan misses the 160 KB by a few hundred bytes, and the batch must not fall back to the fused kernel,
+    // four times slower, because of it)
+    const bool split128 = ctx->gmem_path && ctx->split && !ctx->big && plan.NMAX <= 128 &&
+        (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double) <= (size_t)ctx->max_lds &&
+        (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, 2).total * sizeof(double) <= (size_t)ctx->max_lds &&
+        (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd, 1).total * sizeof(double) <= (size_t)ctx->max_lds;
+    if (split128) ctx->jac_in_lds = 1;   // what the kernels read as "the finish kernel has its LDS scratch"
+    ctx->gmem_split = ctx->big || split128;
+    if (ctx->big) ctx->jac_in_lds = 0;   // prep / finish of the big pipeline keep no Jacobi buffer in LDS
+    if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
+        const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer
+        const size_t mat = (size_t)plan.NMAX * plan.LD;
+        const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
+        // staging budget: 12 GB, or -- for the large matrices of the big pipeline, where 12 GB hold too few pairs to fill
+        // the chip -- up to 60 % of the free device memory
+        double budget = 12.0e9;
+        if (ctx->big) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, 0.6 * (double)(free_b + ctx->d_stL.cap + ctx->d_stB.cap));
+        }
+        long long chunk = (long long)(budget / (double)per_pair);
+        if (chunk < 1) chunk = 1;
+        if (chunk > pair_count) chunk = pair_count;
+        {   // equal chunks: a short last chunk would leave most of the chip idle for a whole pipeline pass
+            const long long nchunks = (pair_count + chunk - 1) / chunk;
+            chunk = (pair_count + nchunks - 1) / nchunks;
+        }
+        ctx->chunk_pairs = chunk;
+        const size_t items = (size_t)chunk * b->n_layers_max * nmodes;
+        HIPCHK(ctx->d_stL.reserve(items * mat * sizeof(double)));
+        HIPCHK(ctx->d_stB.reserve(items * mat * sizeof(double)));
+        HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
+        HIPCHK(ctx->d_sts.reserve(items * plan.NMAX * sizeof(double)));
+        HIPCHK(ctx->d_stn.reserve(items * sizeof(int)));
+        HIPCHK(ctx->d_sti.reserve(items * 1024 * sizeof(double)));
+        ctx->stage.L = (double*)ctx->d_stL.p; ctx->stage.B = (double*)ctx->d_stB.p;
+        ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
+        ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
+        ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
+        ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
+                                   : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
+        // (the LDS-resident passive prep kernel stores its two matrices as packed lower triangles: plan 3)
+        ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd,
+                                                (!ctx->gmem_split && !ctx->active) ? 3 : 1).total * sizeof(double);
+        ctx->finish2_lds_bytes = ctx->gmem_split
+            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 0 : 2).total * sizeof(double)
+            : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd_fin, 2).total * sizeof(double);
+    }
+    // the register-resident finish kernel (one wavefront per pair, dort_finish_reg.hpp): LDS pipeline, passive mode, Flat
+    // interfaces with T = 1 - R (no coherent slabs), no host-evaluated dense substrate
+    {
+        const bool supported = !ctx->gmem_path && ctx->split && ctx->finish2 && !ctx->active && ctx->chunk_pairs > 0 &&
+                               !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
+        int want = ctx->finish_mode;
+        if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
+        ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
+        // (its per-layer tables grow with n_layers_max: beyond the LDS of a workgroup the two-slot kernel takes over)
+        ctx->finish_reg = supported && ctx->finish_reg_lds_bytes <= (size_t)64 * 1024 &&
+                          (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
+        ctx->stage.ws = nullptr;
+        if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
+            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * rg::kSlotDoubles));
+            ctx->stage.ws = (double*)ctx->d_regws.p;
+        }
+    }
+    if (b->prune_optical_depth > 0.0) {
+        // the kept layers are decided from the eigenvalues of ALL the layers before the bottom-up recursion starts:
+        // only the three-kernel pipelines have them at that point
+        const bool pipeline = ctx->chunk_pairs > 0 && (ctx->gmem_path || !ctx->active || ctx->finish2);
+        if (!pipeline) {
+            ctx->err = "prune_deep_snowpack needs the three-kernel pipeline (streams x polarisations <= 128, pipeline "
+                       "1, or 2 in passive mode)";
+            return -1;
+        }
+    }
+    const size_t SL = (size_t)b->n_snowpacks * b->n_layers_max;
+    if (upload_array(ctx, ctx->d_nl, b->n_layers, sizeof(int32_t) * b->n_snowpacks)) return -1;
+    if (upload_array(ctx, ctx->d_thick, b->thickness, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_fv, b->frac_volume, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_temp, b->temperature, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_p1, b->micro_p1, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_p2, b->micro_p2 ? b->micro_p2 : b->micro_p1, sizeof(double) * SL)) return -1;
+    if (upload_array(ctx, ctx->d_freq, b->frequency, sizeof(double) * b->n_frequencies)) return -1;
+    if (upload_array(ctx, ctx->d_theta, b->theta, sizeof(double) * b->n_theta)) return -1;
+    if (pairs && upload_array(ctx, ctx->d_pairmap, pairs, sizeof(int64_t) * pair_count)) return -1;
+    if (b->layer_kind && upload_array(ctx, ctx->d_kind, b->layer_kind, sizeof(int32_t) * SL)) return -1;
+    const size_t host_modes = ctx->active ? (size_t)b->m_max + 1 : 1, host_ne = (size_t)b->n_max_stream * P;
+    if (b->host_layer && b->host_streams && b->host_phase) {   // emmodels evaluated by the caller
+        const size_t PL = (size_t)npairs * b->n_layers_max;
+        if (upload_array(ctx, ctx->d_hostlayer, b->host_layer, sizeof(double) * PL * 4)) return -1;
+        if (upload_array(ctx, ctx->d_hoststreams, b->host_streams, sizeof(int32_t) * PL)) return -1;
+        if (upload_array(ctx, ctx->d_hostphase, b->host_phase, sizeof(double) * PL * host_modes * 2 * host_ne * host_ne)) return -1;
+    }
+    const size_t FS = (size_t)b->n_snowpacks * b->n_frequencies;
+    if (b->host_interface_slot) {   // rough interfaces evaluated by the caller
+        const size_t ne = 3 * (size_t)b->n_max_stream, nm = ctx->active ? (size_t)b->m_max + 1 : 1, ns = (size_t)b->host_interface_slots;
+        if (upload_array(ctx, ctx->d_itfslot, b->host_interface_slot, sizeof(int32_t) * FS * b->n_layers_max)) return -1;
+        if (upload_array(ctx, ctx->d_itf, b->host_interface, sizeof(double) * FS * ns * nm * 4 * ne * ne)) return -1;
+        if (upload_array(ctx, ctx->d_itfcoh, b->host_interface_coh, sizeof(double) * FS * ns * 4 * ne)) return -1;
+    }
+    if (b->substrate_kind == SMRT_SUBSTRATE_HOST) {   // dense reflection matrices of a rough substrate, evaluated by the caller
+        const size_t ne = 3 * (size_t)b->n_max_stream, nm = ctx->active ? (size_t)b->m_max + 1 : 1;
+        if (upload_array(ctx, ctx->d_sub1, b->host_substrate, sizeof(double) * FS * nm * ne * ne)) return -1;
+        if (upload_array(ctx, ctx->d_sub2, b->host_substrate_coh, sizeof(double) * FS * nm * ne)) return -1;
+        if (b->substrate_temperature && upload_array(ctx, ctx->d_subT, b->substrate_temperature, sizeof(double) * b->n_snowpacks)) return -1;
+    } else
+    if (b->substrate_kind != SMRT_SUBSTRATE_NONE) {
+        if (upload_array(ctx, ctx->d_sub1, b->substrate_p1, sizeof(double) * FS)) return -1;
+        if (upload_array(ctx, ctx->d_sub2, b->substrate_p2, sizeof(double) * FS)) return -1;
+        if (upload_array(ctx, ctx->d_subT, b->substrate_temperature, sizeof(double) * b->n_snowpacks)) return -1;
+    }
+    std::vector<double> atm;
+    if (b->atm_tb_down) {
+        atm.insert(atm.end(), b->atm_tb_down, b->atm_tb_down + b->n_frequencies);
+        atm.insert(atm.end(), b->atm_tb_up, b->atm_tb_up + b->n_frequencies);
+        atm.insert(atm.end(), b->atm_transmittance, b->atm_transmittance + b->n_frequencies);
+        if (upload_array(ctx, ctx->d_atm, atm.data(), sizeof(double) * atm.size())) return -1;
+    }
+    std::vector<double> gl(b->n_max_stream);
+    smrt_host::gauss_legendre_positive(b->n_max_stream, gl.data(), nullptr);
+    if (upload_array(ctx, ctx->d_gl, gl.data(), sizeof(double) * gl.size())) return -1;
+    ctx->out_stride = smrt_host::out_stride(b);
+    HIPCHK(ctx->d_out.reserve(sizeof(double) * pair_count * ctx->out_stride));
+    HIPCHK(ctx->d_status.reserve(sizeof(int32_t) * pair_count));
+    HIPCHK(ctx->d_layer.reserve(sizeof(double) * pair_count * b->n_layers_max * 5));
+    HIPCHK(ctx->d_stream.reserve(sizeof(double) * pair_count * (1 + b->n_max_stream)));
+    HIPCHK(ctx->d_n3.reserve(sizeof(double) * pair_count));
+    HIPCHK(ctx->d_stage.reserve(sizeof(double) * pair_count * 16));
+    HIPCHK(hipMemsetAsync(ctx->d_stage.p, 0, sizeof(double) * pair_count * 16, ctx->stream));
+    DevBatch& d = ctx->dev;
+    d.S = b->n_snowpacks; d.Lmax = b->n_layers_max; d.F = b->n_frequencies; d.n_theta = b->n_theta;
+    d.emmodel = b->emmodel; d.micro = b->microstructure; d.mode = b->mode; d.n_max_stream = b->n_max_stream;
+    d.m_max = b->m_max; d.normalization = b->phase_normalization; d.rayleigh_jeans = b->rayleigh_jeans;
+    d.want_layer_out = 1; d.want_stream_out = 1;
+    d.jac_in_lds = ctx->gmem_path ? ctx->jac_in_lds : 0;
+    d.pair_begin = pair_begin; d.pair_count = pair_count;
+    d.pair_map = pairs ? (const long long*)ctx->d_pairmap.p : nullptr;
+    d.n_layers = (const int*)ctx->d_nl.p; d.thickness = (const double*)ctx->d_thick.p;
+    d.frac_volume = (const double*)ctx->d_fv.p; d.temperature = (const double*)ctx->d_temp.p;
+    d.p1 = (const double*)ctx->d_p1.p; d.p2 = (const double*)ctx->d_p2.p;
+    d.frequency = (const double*)ctx->d_freq.p; d.theta = (const double*)ctx->d_theta.p;
+    d.gl_mu = (const double*)ctx->d_gl.p; d.phi = b->phi;
+    d.layer_kind = b->layer_kind ? (const int*)ctx->d_kind.p : nullptr;
+    const bool has_host = b->host_layer && b->host_streams && b->host_phase;
+    d.host_layer = has_host ? (const double*)ctx->d_hostlayer.p : nullptr;
+    d.host_streams = has_host ? (const int*)ctx->d_hoststreams.p : nullptr;
+    d.host_phase = has_host ? (const double*)ctx->d_hostphase.p : nullptr;
+    d.host_modes = (int)host_modes; d.host_ne = (int)host_ne;
+    d.coherent = b->process_coherent_layers ? 1 : 0;
+    d.sub_kind = b->substrate_kind;
+    d.sub_p1 = (const double*)ctx->d_sub1.p; d.sub_p2 = (const double*)ctx->d_sub2.p; d.sub_T = (const double*)ctx->d_subT.p;
+    d.host_itf_slot = b->host_interface_slot ? (const int*)ctx->d_itfslot.p : nullptr;
+    d.host_itf = b->host_interface_slot ? (const double*)ctx->d_itf.p : nullptr;
+    d.host_itf_coh = b->host_interface_slot ? (const double*)ctx->d_itfcoh.p : nullptr;
+    d.host_itf_slots = b->host_interface_slot ? b->host_interface_slots : 0;
+    d.host_substrate = (const double*)ctx->d_sub1.p; d.host_substrate_coh = (const double*)ctx->d_sub2.p;   // (SUB_HOST: the same buffers)
+    const bool has_atm = (b->atm_tb_down != nullptr) && b->mode == SMRT_MODE_PASSIVE;
+    d.atm_down = has_atm ? (const double*)ctx->d_atm.p : nullptr;
+    d.atm_up = has_atm ? (const double*)ctx->d_atm.p + b->n_frequencies : nullptr;
+    d.atm_trans = has_atm ? (const double*)ctx->d_atm.p + 2 * b->n_frequencies : nullptr;
+    d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
+    d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
+    if (d.prune_tau > 0.0) HIPCHK(ctx->d_done.reserve(sizeof(int) * (size_t)std::max<long long>(ctx->chunk_pairs, 1)));
+    // Jacobi thresholds on the squared cosine between two columns: below skip2 a pair is not rotated, a sweep without
+    // a rotation above exit2 is the last one (dort_jacobi_kernel.hpp).  SMRT_DORT_JACOBI_SKIP2 / _EXIT2 override them
+    // for experiments.  Passive mode, measured on the headline batch against the oracle (profiles/r3_jacobi_thresholds.txt):
+    // 1e-26 / 1e-15 -> 1.4e-10 K, 1e-22 / 1e-12 -> 1.6e-8 K (2.6 % faster), 1e-20 / 1e-10 -> 2.4e-7 K; the requirement is 1e-6 K.
+    // The register-resident finish kernel needs the tighter pair on weakly scattering media (dort_host_common.hpp).
+    d.jacobi_skip2 = ctx->active ? 1e-30 : (ctx->finish_reg ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);
+    d.jacobi_exit2 = ctx->active ? 1e-22 : (ctx->finish_reg ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
+    if (const char* e = getenv("SMRT_DORT_JACOBI_SKIP2")) d.jacobi_skip2 = atof(e);
+    if (const char* e = getenv("SMRT_DORT_JACOBI_EXIT2")) d.jacobi_exit2 = atof(e);
+    d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
+    d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
+    ctx->lds_bytes = lds;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vector `gl` and the caller's arrays may go away
+    ctx->uploaded = true;
+    // Dispatch order: inside every chunk the workgroups take the pairs sorted by their estimated cost (sum of N_l^3 from the
+    // stream counts: a cheap kernel).  Neighbouring workgroups -- the ones that share a CU -- then work on matrices of the
+    // same size: 59.9 instead of 61.4 ms on the headline batch, whichever way the sort goes (tools/lpt_order_probe.py).
+    // The outputs stay in the caller's order (only the workgroup -> pair map changes).  SMRT_DORT_NO_COST_ORDER=1: off.
+    d.dispatch = nullptr;
+    if (pair_count > 1 && getenv("SMRT_DORT_NO_COST_ORDER") == nullptr) {
+        HIPCHK(smrt_launch::pair_cost(ctx, d, d.n3_out));
+        std::vector<double> cost((size_t)pair_count);
+        HIPCHK(hipMemcpyAsync(cost.data(), d.n3_out, sizeof(double) * cost.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> order((size_t)pair_count);
+        const long long chunk = ctx->chunk_pairs > 0 ? ctx->chunk_pairs : pair_count;
+        for (long long c0 = 0; c0 < pair_count; c0 += chunk) {
+            const long long cn = std::min<long long>(chunk, pair_count - c0);
+            for (long long i = 0; i < cn; ++i) order[(size_t)(c0 + i)] = (int32_t)i;    // chunk-local pair slots
+            std::stable_sort(order.begin() + c0, order.begin() + c0 + cn,
+                             [&](int32_t a, int32_t b2) { return cost[(size_t)(c0 + a)] > cost[(size_t)(c0 + b2)]; });
+        }
+        if (upload_array(ctx, ctx->d_dispatch, order.data(), sizeof(int32_t) * order.size())) return -1;
+        d.dispatch = (const int*)ctx->d_dispatch.p;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int32_t smrt_dort_upload(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair_begin, int64_t pair_count) {
+    return upload_impl(ctx, b, pair_begin, pair_count, nullptr);
+}
+
+int32_t smrt_dort_upload_pairs(smrt_dort_ctx* ctx, const smrt_batch* b, const int64_t* pairs, int64_t n_pairs) {
+    if (ctx && !pairs) { ctx->err = "null pair list"; return -1; }
+    return upload_impl(ctx, b, 0, n_pairs, pairs);
+}
+
+int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
+#define SMRT_OFF(f) (int32_t)offsetof(smrt_batch, f)
+    const int32_t desc[] = {(int32_t)sizeof(smrt_batch),
+        SMRT_OFF(n_snowpacks), SMRT_OFF(n_layers_max), SMRT_OFF(n_frequencies), SMRT_OFF(n_theta), SMRT_OFF(emmodel),
+        SMRT_OFF(microstructure), SMRT_OFF(mode), SMRT_OFF(n_max_stream), SMRT_OFF(m_max), SMRT_OFF(phase_normalization),
+        SMRT_OFF(rayleigh_jeans), SMRT_OFF(substrate_kind), SMRT_OFF(n_layers), SMRT_OFF(thickness), SMRT_OFF(frac_volume),
+        SMRT_OFF(temperature), SMRT_OFF(micro_p1), SMRT_OFF(micro_p2), SMRT_OFF(frequency), SMRT_OFF(theta), SMRT_OFF(phi),
+        SMRT_OFF(substrate_p1), SMRT_OFF(substrate_p2), SMRT_OFF(substrate_temperature), SMRT_OFF(atm_tb_down),
+        SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
+        SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers),
+        SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh), SMRT_OFF(host_interface_slot), SMRT_OFF(host_interface),
+        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots)};
+#undef SMRT_OFF
+    const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
+    for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];
+    return n;
+}
+
+int32_t smrt_dort_launch(smrt_dort_ctx* ctx, void* out_dev, void* status_dev) {
+    if (!ctx) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBatch d = ctx->dev;
+    if (out_dev) d.out = (double*)out_dev;
+    if (status_dev) d.status = (int*)status_dev;
+    if (ctx->timing_pending) {  // fold the previous launch into the totals before reusing the events
+        HIPCHK(hipEventSynchronize(ctx->ev1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms = ms; ctx->total_ms += ms; ctx->n_launch++;
+        ctx->timing_pending = false;
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipError_t e;
+    const bool lds_pipeline = !ctx->gmem_path && ctx->split && ctx->chunk_pairs > 0 && (!ctx->active || ctx->finish2);
+    if (ctx->gmem_split || lds_pipeline) e = launch_pipeline(ctx, d);
+    else if (ctx->gmem_path) e = smrt_launch::fused_gmem(ctx, d, ctx->nmax_rows <= 128 ? 2 : ctx->nmax_rows <= 256 ? 4 : 6, ctx->active);
+    else e = smrt_launch::fused(ctx, d, ctx->nt, ctx->active);
+    HIPCHK(e);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timing_pending = true;
+    return 0;
+}
+
+int32_t smrt_dort_sync(smrt_dort_ctx* ctx) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing_pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms = ms; ctx->total_ms += ms; ctx->n_launch++;
+        ctx->timing_pending = false;
+    }
+    return 0;
+}
+
+double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx) { return ctx ? (double)ctx->last_ms : -1.0; }
+
+double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset) {
+    if (!ctx) return -1.0;
+    const double tot = ctx->total_ms;
+    if (n_launches) *n_launches = ctx->n_launch;
+    if (reset) { ctx->total_ms = 0.0; ctx->n_launch = 0; }
+    return tot;
+}
+
+int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, double* layer_out, double* stream_out) {
+    if (!ctx) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const DevBatch& d = ctx->dev;
+    const size_t np = (size_t)d.pair_count;
+    if (out) HIPCHK(hipMemcpyAsync(out, d.out, sizeof(double) * np * ctx->out_stride, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) HIPCHK(hipMemcpyAsync(status, d.status, sizeof(int32_t) * np, hipMemcpyDeviceToHost, ctx->stream));
+    if (layer_out) HIPCHK(hipMemcpyAsync(layer_out, d.layer_out, sizeof(double) * np * d.Lmax * 5, hipMemcpyDeviceToHost, ctx->stream));
+    if (stream_out) HIPCHK(hipMemcpyAsync(stream_out, d.stream_out, sizeof(double) * np * (1 + d.n_max_stream), hipMemcpyDeviceToHost, ctx->stream));
+    return smrt_dort_sync(ctx);
+}
+
+double smrt_dort_sum_n3(smrt_dort_ctx* ctx) {
+    if (!ctx || !ctx->uploaded) return -1.0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1.0;
+    std::vector<double> h((size_t)ctx->dev.pair_count);
+    if (hipMemcpy(h.data(), ctx->dev.n3_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    double s = 0.0;
+    for (double v : h) s += v;
+    return s;
+}
+
+int32_t smrt_dort_ft_even_phase(smrt_dort_ctx* ctx, int32_t emmodel, int32_t microstructure, double frequency, double frac_volume,
+                                double temperature, double micro_p1, double micro_p2, const double* mu_s, int32_t n_s,
+                                const double* mu_i, int32_t n_i, int32_t m_max, int32_t npol, double* out) {
+    if (!ctx) return -1;
+    if (!mu_s || !mu_i || !out || n_s < 1 || n_i < 1 || m_max < 0 || m_max > 64 || (npol != 2 && npol != 3)) {
+        ctx->err = "invalid ft_even_phase request";
+        return -1;
+    }
+    if (emmodel < SMRT_EM_IBA || (emmodel > SMRT_EM_NONSCATTERING && emmodel != SMRT_EM_IBA_INVERTED) ||
+        (microstructure != SMRT_MS_EXPONENTIAL && microstructure != SMRT_MS_STICKY_HARD_SPHERES)) {
+        ctx->err = "unknown emmodel / microstructure";
+        return -1;
+    }
+    for (int i = 0; i < n_s; ++i) if (!(fabs(mu_s[i]) <= 1.0)) { ctx->err = "cosines must lie in [-1, 1]"; return -1; }
+    for (int i = 0; i < n_i; ++i) if (!(fabs(mu_i[i]) <= 1.0)) { ctx->err = "cosines must lie in [-1, 1]"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n_out = (size_t)npol * npol * (m_max + 1) * n_s * n_i;
+    const size_t bytes = sizeof(double) * (n_out + n_s + n_i) + 16;
+    HIPCHK(ctx->d_phase.reserve(bytes));
+    double* d_out = (double*)ctx->d_phase.p;
+    double* d_mus = d_out + n_out;
+    double* d_mui = d_mus + n_s;
+    int* d_status = (int*)(d_mui + n_i);
+    HIPCHK(hipMemcpyAsync(d_mus, mu_s, sizeof(double) * n_s, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_mui, mu_i, sizeof(double) * n_i, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
+    PhaseRequest q{emmodel, microstructure, frequency, frac_volume, temperature, micro_p1, micro_p2, d_mus, n_s, d_mui, n_i,
+                   m_max, npol, azimuth_samples(m_max), d_out, d_status};
+    HIPCHK(smrt_launch::ft_even_phase(ctx, q));
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&st, d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (st != 0) { ctx->err = "invalid layer properties (temperature above the freezing point?)"; return -1; }
+    return 0;
+}
+
+int32_t smrt_dort_pair_cost(smrt_dort_ctx* ctx, double* cost) {
+    if (!ctx || !cost) return -1;
+    if (!ctx->uploaded) { ctx->err = "no batch uploaded"; return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    // the work counter buffer of the solve doubles as the output (a launch overwrites it anyway)
+    HIPCHK(smrt_launch::pair_cost(ctx, ctx->dev, ctx->dev.n3_out));
+    HIPCHK(hipMemcpyAsync(cost, ctx->dev.n3_out, sizeof(double) * (size_t)ctx->dev.pair_count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int32_t smrt_dort_stage_cycles(smrt_dort_ctx* ctx, double* out16) {
+    if (!ctx || !ctx->uploaded || !out16) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<double> h((size_t)ctx->dev.pair_count * 16);
+    HIPCHK(hipMemcpy(h.data(), ctx->dev.stage_out, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) out16[k] = 0.0;
+    for (size_t p = 0; p < (size_t)ctx->dev.pair_count; ++p)
+        for (int k = 0; k < 16; ++k) out16[k] += h[p * 16 + k];
+    return 0;
+}
+
+int32_t smrt_dort_run(smrt_dort_ctx* ctx, const smrt_batch* batch, int64_t pair_begin, int64_t pair_count, double* out,
+                      int32_t* status, double* layer_out, double* stream_out) {
+    if (smrt_dort_upload(ctx, batch, pair_begin, pair_count)) return -1;
+    if (smrt_dort_launch(ctx, nullptr, nullptr)) return -1;
+    return smrt_dort_download(ctx, out, status, layer_out, stream_out);
+}
+
+int32_t smrt_dort_run_pairs(smrt_dort_ctx* ctx, const smrt_batch* batch, const int64_t* pairs, int64_t n_pairs, double* out,
+                            int32_t* status, double* layer_out, double* stream_out) {
+    if (smrt_dort_upload_pairs(ctx, batch, pairs, n_pairs)) return -1;
+    if (smrt_dort_launch(ctx, nullptr, nullptr)) return -1;
+    return smrt_dort_download(ctx, out, status, layer_out, stream_out);
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// The Jacobi kernel of the three-kernel pipelines: one (pair, layer[, azimuth mode]) item per workgroup.
+// Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
+#pragma once
+#include "spmd.hpp"
+#include <math.h>
+#include <string.h>
+#include "dort_passive.hpp"
+
+namespace smrt {
+
+#ifndef SMRT_JACOBI_GS
+#define SMRT_JACOBI_GS 8     // lanes per column pair in the Jacobi kernel
+#endif
+#ifndef SMRT_JACOBI_NT
+#define SMRT_JACOBI_NT 256   // threads per workgroup of the Jacobi kernel
+#endif
+
+// Rotation that annihilates the inner product g of two columns with squared norms a, b (dd = b - a):
+// t = sign(dd) 2g / (|dd| + sqrt(dd^2 + 4 g^2)), c = 1 / sqrt(1 + t^2), s = c t.  From the third sweep on almost every
+// rotation is a small one, and the parameters sit on the sequential chain of the kernel: for g^2 < 1e-8 dd^2 the series
+// t = (g / dd)(1 - (g / dd)^2), c = 1 - t^2 / 2, s = c t (relative errors 2e-16, 4e-17, 4e-17) replaces two of the
+// three reciprocal (square root)s and their Newton steps.
+#ifndef SMRT_JACOBI_SMALL_ANGLE
+#define SMRT_JACOBI_SMALL_ANGLE 1e-8
+#endif
+SMRT_DEV void jacobi_rotation(double gg, double g2, double dd, double& tt, double& c, double& sn) {
+    if (g2 < SMRT_JACOBI_SMALL_ANGLE * (dd * dd)) {
+        const double t0 = gg * fast_rcp1(dd);
+        tt = t0 - t0 * (t0 * t0);
+        c = 1.0 - 0.5 * (tt * tt);
+        sn = c * tt;
+    } else {
+        const double hh = dd * dd + 4.0 * g2;
+        const double h = hh * fast_rsqrt1(hh);
+        tt = (dd >= 0.0 ? 2.0 : -2.0) * gg * fast_rcp1(fabs(dd) + h);
+        c = fast_rsqrt(1.0 + tt * tt);
+        sn = c * tt;
+    }
+}
+
+// ---- zero-padded Jacobi step for the split pipeline ----------------------------------------------------------
+// The matrix is padded with zero rows/columns up to CP = NB*m columns and RPL*GS rows, so no lane ever needs a
+// validity test or a masked load (a zero column never rotates: g = 0).  Column norms are tracked in LDS (a rotation
+// changes them by -/+ t g exactly) and refreshed once per sweep, so a step needs ONE dot product and ONE group sum.
+template <int GS, int RPL>
+SMRT_DEV void rotate_pair_padded(double* Bm, int LD, int p, int q, int sub, double* nrm, int* flag, double skip2,
+                                 double exit2) {
+    double x[RPL], y[RPL];
+    double gg = 0.0, gg2 = 0.0;
+    double* cp = Bm + p * LD;
+    double* cq = Bm + q * LD;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int r = sub + i * GS;
+        x[i] = cp[r];
+        y[i] = cq[r];
+        if (i & 1) gg2 += x[i] * y[i]; else gg += x[i] * y[i];
+    }
+    const double a = nrm[p], bb = nrm[q];
+    gg = group_sum<GS>(gg + gg2);
+    const double g2 = gg * gg, ab = a * bb;
+    if (g2 > skip2 * ab) {
+        const double dd = bb - a;
+        double tt, c, sn;
+        jacobi_rotation(gg, g2, dd, tt, c, sn);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = sub + i * GS;
+            cp[r] = c * x[i] - sn * y[i];
+            cq[r] = sn * x[i] + c * y[i];
+        }
+        if (sub == 0) {
+            nrm[p] = a - tt * gg;
+            nrm[q] = bb + tt * gg;
+            if (g2 > exit2 * ab) lds_or(flag, 1);
+        }
+    }
+}
+
+// Wavefronts that rotate block pairs for an N-column item: 64 / GS = 8 column pairs per wavefront and step, so one
+// wavefront per 16 columns keeps every lane group busy (NB = 2 JW column blocks of m = ceil(N / NB) <= 8 columns).  With
+// the fixed four wavefronts of the first versions a 42 ... 48-column item (60 % of the headline batch) left a quarter
+// of every wavefront rotating the padding column.
+SMRT_HD int jacobi_waves(int N, int jw_max) {
+#ifdef SMRT_JACOBI_ALL_WAVES   // ablation build (tools/build_variant.py): the fixed wavefront count of the first versions
+    return jw_max;
+#endif
+    const int w = (N + 2 * (SMRT_LANES / SMRT_JACOBI_GS) - 1) / (2 * (SMRT_LANES / SMRT_JACOBI_GS));
+    return w < 1 ? 1 : (w > jw_max ? jw_max : w);
+}
+
+// Two-level ordering as jacobi_onesided, on a zero-padded LDS matrix (rows < RPL*GS <= LD, columns < NB*m).
+// skip2 / exit2: squared-cosine thresholds below which a rotation is skipped / does not count against convergence.
+// Passive brightness temperatures (1e-6 K of ~250 K) tolerate 1e-26 / 1e-15; the backscatter is a small difference
+// of intensities (coherent part subtracted, azimuth modes cancelling in cross-pol), so active mode uses 1e-30 / 1e-22
+// (5e-10 -> 2e-11 relative error on the fixtures, about a third of a sweep more).
+template <int NT, int GS, int RPL>
+SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nrm, int* flag, int JW,
+                            double skip2 = SMRT_JACOBI_SKIP_COS2, double exit2 = SMRT_JACOBI_EXIT_COS2) {
+    const int t = tid();
+    const int lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES;
+    const int NB = 2 * JW;
+    constexpr int SLOTS = SMRT_LANES / GS;
+    const int slot = lane / GS, sub = lane % GS;
+    const int m = (N + NB - 1) / NB;
+    const int CP = NB * m;
+    const int me = m + (m & 1);
+    constexpr int NG = NT / GS;
+    const int grp = t / GS;
+    bool converged = false;
+    for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+        // refresh the tracked squared column norms (also the first computation)
+        for (int c0 = 0; c0 < CP; c0 += NG) {  // uniform trip count (the group sum is a wavefront operation)
+            const int c = c0 + grp;
+            const int cc = c < CP ? c : CP;
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { const double xx = Bm[cc * LD + sub + i * GS]; a += xx * xx; }
+            a = group_sum<GS>(a);
+            if (sub == 0 && c < CP) nrm[c] = a;
+        }
+        if (t == 0) { *flag = 0; nrm[CP] = 0.0; }
+        block_sync();
+        for (int s = 0; s < NB - 1; ++s) {
+            if (wave >= JW) { block_sync(); continue; }
+            int I, J;
+            if (wave == 0) { I = NB - 1; J = s; }
+            else {
+                I = s + wave; if (I >= NB - 1) I -= NB - 1;
+                J = s - wave; if (J < 0) J += NB - 1;
+            }
+            const int i0 = I * m, j0 = J * m;
+            if (s == 0 && m > 1) {
+                const int half = me / 2;
+                for (int u = 0; u < me - 1; ++u) {
+                    for (int ps0 = 0; ps0 < 2 * half; ps0 += SLOTS) {
+                        const int ps = ps0 + slot;
+                        const int base = (ps < half) ? i0 : j0;
+                        const int k = (ps < half) ? ps : ps - half;
+                        int a, b;
+                        if (k == 0) { a = me - 1; b = u; }
+                        else {
+                            a = u + k; if (a >= me - 1) a -= me - 1;
+                            b = u - k; if (b < 0) b += me - 1;
+                        }
+                        const bool valid = (ps < 2 * half) && (a < m) && (b < m);
+                        // an idle slot rotates the (all-zero) last padding column with itself: a no-op
+                        rotate_pair_padded<GS, RPL>(Bm, LD, valid ? base + a : CP, valid ? base + b : CP, sub, nrm, flag, skip2, exit2);
+                    }
+                    wave_sync_lds();
+                }
+            }
+            // cross pairs (I_a, J_(a+j)): the lane group of slot a keeps column I_a (and its tracked norm) in
+            // registers for all m inner steps -- loaded once, stored once -- only the J column moves through LDS
+            for (int ps0 = 0; ps0 < m; ps0 += SLOTS) {
+                const int ps = ps0 + slot;
+                const bool valid = ps < m;
+                const int pc = valid ? i0 + ps : CP;
+                double* cp = Bm + pc * LD;
+                double x[RPL];
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) x[i] = cp[sub + i * GS];
+                double a = nrm[pc];
+                for (int j = 0; j < m; ++j) {
+                    int bq = ps + j; if (bq >= m) bq -= m;
+                    const int qc = valid ? j0 + bq : CP;
+                    double* cq = Bm + qc * LD;
+                    double y[RPL];
+                    double gg = 0.0, gg2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i) {
+                        y[i] = cq[sub + i * GS];
+                        if (i & 1) gg2 += x[i] * y[i]; else gg += x[i] * y[i];
+                    }
+                    const double bb = nrm[qc];
+                    gg = group_sum<GS>(gg + gg2);
+                    const double g2 = gg * gg, ab = a * bb;
+                    if (g2 > skip2 * ab) {
+                        const double dd = bb - a;
+                        double tt, c, sn;
+                        jacobi_rotation(gg, g2, dd, tt, c, sn);
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) {
+                            const double xn = c * x[i] - sn * y[i];
+                            cq[sub + i * GS] = sn * x[i] + c * y[i];
+                            x[i] = xn;
+                        }
+                        if (sub == 0) {
+                            nrm[qc] = bb + tt * gg;
+                            if (g2 > exit2 * ab) lds_or(flag, 1);
+                        }
+                        a -= tt * gg;
+                    }
+                    wave_sync_lds();  // the J columns just written are read by other lane groups in the next step
+                }
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) cp[sub + i * GS] = x[i];
+                if (sub == 0) nrm[pc] = a;
+            }
+            block_sync();
+        }
+        converged = (*flag == 0);
+        block_sync();  // everyone has read the flag before it is cleared again
+    }
+    for (int c0 = 0; c0 < N; c0 += NG) {
+        const int c = c0 + grp;
+        const int cc = c < N ? c : N - 1;
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { const double xx = Bm[cc * LD + sub + i * GS]; a += xx * xx; }
+        a = group_sum<GS>(a);
+        if (sub == 0 && c < N) sigma[c] = a * fast_rsqrt(a);
+    }
+    block_sync();
+    return converged;
+}
+
+// ---- Jacobi kernel of the split pipeline: one (pair, layer) item per workgroup, ONE matrix in LDS, so that four
+// workgroups share a CU and hide each other's dependency latency (the rotation sequence of one matrix is strictly
+// sequential: N-1 steps per sweep).
+// LDJ: leading dimension of the LDS matrix inside the Jacobi kernel, == 8 (mod 32) eight-byte slots: the column
+// pairs a 32-lane group rotates together are ADJACENT columns (8 lanes each), so consecutive columns must start 8
+// bank slots apart to be conflict-free (with the odd LD of the other kernels they overlapped: 41 % of the LDS cycles
+// of this kernel were bank conflicts, profiles/r1f_pmc_counters.txt).
+struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
+SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
+    JacobiPlan p;
+    p.NMAX = n_max_stream * P;
+    p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
+    // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
+    const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
+    p.LDJ = ((rows + 31) / 32) * 32 + SMRT_JACOBI_GS;
+    // NB * ceil(N / NB) <= this - 1 for every N <= NMAX and its NB = 2 * jacobi_waves(N) column blocks (the padded column
+    // count grows with N inside a wavefront count and reaches 16 JW at its upper end, so NMAX decides), for workgroups of
+    // four and of eight wavefronts (k_jacobi.hip launches either on 64 < N <= 128); plus the idle-slot column
+    int cpmax = 0;
+    for (int jw_max = 4; jw_max <= 8; jw_max += 4) {
+        const int nb = 2 * jacobi_waves(p.NMAX, jw_max);
+        const int cp = nb * ((p.NMAX + nb - 1) / nb);
+        if (cp > cpmax) cpmax = cp;
+    }
+    p.NCOL = cpmax + 1;
+    int o = p.NCOL * p.LDJ;
+    p.o_sigma = o; o += p.NMAX + 16;
+    p.o_rsig = o; o += p.NMAX + 16; // tracked column norms (padded columns included)
+    p.o_int = o; o += 4;
+    p.total = o;
+    return p;
+}
+
+template <int NT, int RPL>
+SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
+    constexpr int JWMAX = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: at most 4, or 8 (N > 64)
+    constexpr int GS = SMRT_JACOBI_GS;
+    const int t = tid();
+    const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
+    const long long p = item / ((long long)b.Lmax * nmodes);
+    const int l = (int)(item % b.Lmax);
+    const long long gp = global_pair(b, p);
+    const int si = (int)(gp % b.S);
+    if (l >= b.n_layers[si]) return;          // uniform
+    if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
+    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2);
+    const int LD = plan.LD, LDJ = plan.LDJ;
+    const int N = stg.n[item];
+    if (N <= 0) return;                       // the prep kernel flagged this layer (uniform)
+    double* M = lds;
+    double* sigma = lds + plan.o_sigma;
+    double* nrm = lds + plan.o_rsig;
+    int* ints = (int*)(lds + plan.o_int);
+    double* gB = stg.B + item * stg.mat_stride;
+    // load B and zero the padding: rows N..RPL*GS-1 of every used column, columns N..CP (CP = NB*m, plus the idle
+    // slot column CP itself)
+    const int JW = jacobi_waves(N, JWMAX);
+    const int NB = 2 * JW;
+    const int m = (N + NB - 1) / NB;
+    const int CP = NB * m;
+    for_2d<NT>(RPL * GS, CP + 1, [&](int r, int c) { M[c * LDJ + r] = (r < N && c < N) ? gB[c * LD + r] : 0.0; });
+    if (t == 0) ints[0] = 0;
+    block_sync();
+    const bool ok = jacobi_padded<NT, GS, RPL>(M, N, LDJ, sigma, nrm, &ints[0], JW, b.jacobi_skip2, b.jacobi_exit2);
+    if (!ok) { if (t == 0) stg.n[item] = -ST_EIGEN; return; }   // per layer, like the prep kernel's failures
+#ifdef SMRT_GJ_FAST_PANEL
+    // eigenpairs out in ascending order of the singular value -- the order of the streams in the no-scattering limit,
+    // where column c of the recursion matrices then belongs to row c: what lets the Gauss-Jordan solves of the finish
+    // kernel take their pivots from the diagonal blocks (gj_panel16_fast).  Rank by counting; the dead norm buffer holds
+    // the permutation.
+    int* src = (int*)nrm;
+    for (int r = t; r < N; r += NT) {
+        const double sg = sigma[r];
+        int rank = 0;
+        for (int j = 0; j < N; ++j) { const double sj = sigma[j]; rank += (sj < sg || (sj == sg && j < r)) ? 1 : 0; }
+        src[rank] = r;
+    }
+    block_sync();
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[src[c] * LDJ + r]; });
+    for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[src[r]];
+#else
+    for_2d<NT>(N, N, [&](int r, int c) { gB[c * LD + r] = M[c * LDJ + r]; });
+    for (int r = t; r < N; r += NT) stg.sigma[item * stg.vec_stride + r] = sigma[r];
+#endif
+}
+
+// Rows per lane follow the item's OWN size N = stg.n[item] (streams x polarisations of that layer: total reflection
+// removes streams, so N varies from layer to layer), not the batch maximum: the padded rows RPL * GS are the first
+// multiple of GS >= N (a few sizes are merged to bound the number of instantiations).  The LDS layout (LDJ) is the
+// one of the batch maximum, so every variant fits.
+template <int NT>
+SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
+    constexpr int G = SMRT_JACOBI_GS;   // lanes per column pair
+    const int rows = stg.n[item];       // <= 0: nothing to do (the impl returns at once)
+    if (rows > 112) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
+    else if (rows > 96) dort_jacobi_item_impl<NT, 112 / G>(b, stg, item, lds);
+    else if (rows > 80) dort_jacobi_item_impl<NT, 96 / G>(b, stg, item, lds);
+    else if (rows > 64) dort_jacobi_item_impl<NT, 80 / G>(b, stg, item, lds);
+    else if (rows > 56) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
+    else if (rows > 48) dort_jacobi_item_impl<NT, 56 / G>(b, stg, item, lds);
+    else if (rows > 40) dort_jacobi_item_impl<NT, 48 / G>(b, stg, item, lds);
+    else if (rows > 32) dort_jacobi_item_impl<NT, 40 / G>(b, stg, item, lds);
+    else if (rows > 16) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
+    else if (rows > 8) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
+    else dort_jacobi_item_impl<NT, 8 / G>(b, stg, item, lds);
+}
+
+}  // namespace smrt

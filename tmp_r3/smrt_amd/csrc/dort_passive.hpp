@@ -125,8 +125,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
             } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
             pa = pb = 0.0;
         } else
-        layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad,
-                 __builtin_expect(b.liquid_water != nullptr, 0) ? b.liquid_water[(gp % b.S) * b.Lmax + l] : 0.0);
+        layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)((kind & 15) == EM_IBA_INV ? (kind & ~15) | EM_IBA : kind);   // the phase function is IBA's either way
         s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;
@@ -386,22 +385,10 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                 s.M3[r * LD + r] = Rs;
                 s.svec[r] = src;
             }
-            {
-                // a DENSE start of the recursion, from the caller (smrt_dort.h): the other entries of a rough substrate's
-                // reflection matrix, or -- deeper layers pruned right above a rough interface -- that interface's dense
-                // reflection seen from this layer (Rbot of its slot: specular + diffuse), what the reference's truncated
-                // system keeps (dort.py:443-452, rtsolver_utils.py:567-597).  One copy loop for both.
-                const long long NE = 3LL * nmax;
-                const double* H = nullptr;
-                if (Lk == L) { if (b.sub_kind == SUB_HOST) H = b.host_substrate + gp * NE * NE; }
-                else if (__builtin_expect(b.host_itf_slot != nullptr, 0)) {
-                    const int hsb = b.host_itf_slot[gp * b.Lmax + (int)s.lo[l + 1]];
-                    if (hsb >= 0) H = b.host_itf + ((gp * b.host_itf_slots + hsb) * 4 + 2) * NE * NE;
-                }
-                if (__builtin_expect(H != nullptr, 0)) {
-                    block_sync();
-                    for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = H[r * NE + c]; });
-                }
+            if (Lk == L && b.sub_kind == SUB_HOST) {
+                const int NE = 3 * nmax;
+                const double* H = b.host_substrate + gp * (long long)NE * NE;
+                for_2d<NT>(N, N, [&](int r, int c) { if (r != c) s.M3[c * LD + r] = H[r * NE + c]; });
             }
         }
         block_sync();
@@ -492,8 +479,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                             const double q = (pa * wk) * fast_rcp(dp2 * dm2);
                             Cp = dm2 * q; Cm = dp2 * q;
                         } else {
-                            Cp = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_p), fv, q1, q2);
-                            Cm = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_m), fv, q1, q2);
+                            Cp = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_p), fv, q1, q2);
+                            Cm = pa * wk * ft_corr(MS_SHS, pb * (1.0 - ct_m), fv, q1, q2);
                         }
                         const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
                         pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;

@@ -47,20 +47,6 @@ SMRT_DEV cplx ice_permittivity(double frequency, double T) {  // Maetzler 2006, 
     return cmk(er, alpha / fg + (betam + dbeta) * fg);
 }
 
-// Permittivity of liquid water, double Debye model of Maetzler & Wegmuller (1987) as smrt/permittivity/water.py:14-43
-SMRT_DEV cplx water_permittivity(double frequency, double T) {
-    const double fg = frequency * 1e-9;
-    const double th = 1.0 - 300.0 / T;
-    const double e0 = 77.66 - 103.3 * th;
-    const double e1 = 0.0671 * e0;
-    const double f1 = 20.2 + 146.4 * th + 316.0 * th * th;
-    const double e2 = 3.52 + 7.52 * th;
-    const double f2 = 39.8 * f1;
-    const cplx a = cdiv(cmk(e1 - e2, 0.0), cmk(1.0, -fg / f2));
-    const cplx b = cdiv(cmk(e0 - e1, 0.0), cmk(1.0, -fg / f1));
-    return cadd(cmk(e2, 0.0), cadd(a, b));
-}
-
 SMRT_DEV double sinc_(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
 
 // FT of the autocorrelation function at wavenumber k (k2 = k*k)
@@ -70,43 +56,27 @@ SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
         double den = 1.0 + x;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
     }
-    if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length, p2 = repeat distance
-        const double x = k2 * p1 * p1;
-        const double yy = 2.0 * kPi * p1 / p2, y = yy * yy;
-        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / ((1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * x + x * x);
-    }
-    // spheres of radius p1: sticky hard spheres (sticky_hard_spheres.py:63-130) and independent spheres
-    // (independent_sphere.py:54-72) share the form factor of the sphere, vint = 3 (sin x - x cos x) / x^3 -- ONE pair of
-    // sin / cos in the code of every kernel
+    // sticky hard spheres, sticky_hard_spheres.py:63-130
     double f = fv, tau = p2, radius = p1;
     double x = sqrt(k2) * radius;
-    double vd = 4.0 / 3.0 * kPi * radius * radius * radius;
-    double tt = 0.0, fr = 0.0, c1 = 0.0, c2 = 0.0;
-    if (micro == MS_SPHERE) {
-        if (fabs(x) <= 1e-2) {   // series of vint (the closed form cancels like x^-2 there): 1 - x^2 / 10 + x^4 / 280
-            const double x2 = x * x, v = 1.0 - x2 * (0.1 - x2 * (1.0 / 280.0));
-            return f * (1.0 - f) * vd * v * v;
-        }
-    } else {
-        if (isfinite(tau) && f > 0.0) {
-            double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
-                          36 * tau * tau - 12 * f;
-            tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
-        }
-        fr = f / (1.0 - f);
-        c1 = 1.0 - tt * f + 3.0 * fr;
-        c2 = 3.0 - tt * (1.0 - f);
-        if (fabs(x) <= 1e-3) {
-            double den = fr * (c1 + c2) + 1.0;
-            return f * vd / (den * den);
-        }
+    double tt = 0.0;
+    if (isfinite(tau) && f > 0.0) {
+        double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
+                      36 * tau * tau - 12 * f;
+        tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
     }
-    const double sx = sin(x), cx = cos(x), sc = sx / x;
-    double vint = 3.0 * (sc - cx) / (x * x);
-    if (micro == MS_SPHERE) return f * (1.0 - f) * vd * vint * vint;
-    double psi = sc / vint;
-    double a = fr * (c1 + c2 * psi) + cx / vint;
-    double b = fr * x + sx / vint;
+    double vd = 4.0 / 3.0 * kPi * radius * radius * radius;
+    double fr = f / (1.0 - f);
+    double c1 = 1.0 - tt * f + 3.0 * fr;
+    double c2 = 3.0 - tt * (1.0 - f);
+    if (fabs(x) <= 1e-3) {
+        double den = fr * (c1 + c2) + 1.0;
+        return f * vd / (den * den);
+    }
+    double vint = 3.0 * (sinc_(x) - cos(x)) / (x * x);
+    double psi = sinc_(x) / vint;
+    double a = fr * (c1 + c2 * psi) + cos(x) / vint;
+    double b = fr * x + sin(x) / vint;
     return f * vd / (a * a + b * b);
 }
 
@@ -137,21 +107,10 @@ SMRT_DEV double planck_inverse(double frequency, double radiance) {  // core/lib
 // pa/pb/pc: IBA+exponential -> C(cosT) = pa / (1 + pb (1 - cosT))^2 ; IBA+SHS -> pa = iba_coeff, pb = kfac^2/2;
 // DMRT -> pa = 1.5 ks.
 // em / ms: the emmodel and the microstructure model of THIS layer (a snowpack may mix them, smrt/core/model.py:529-582).
-// lw: liquid water of a wet layer (water volume / (ice + water volume)), 0 for dry snow.
 SMRT_DEV void layer_em(int em, int ms, double frequency, double fv, double T, double p1, double p2, cplx* eps_eff,
-                       double* ks, double* ka, double* pa, double* pb, int* bad, double lw = 0.0) {
+                       double* ks, double* ka, double* pa, double* pb, int* bad) {
     cplx es = ice_permittivity(frequency, T);
     if (T > kFreezing) *bad = 1;
-    if (__builtin_expect(lw > 0.0, 0)) {
-        // wet ice grains (wetice.py:12-45, Bohren & Huffman 1983 after Jin 1993 eq. 8-69): Maxwell Garnett mixing of ice
-        // inclusions, volume fraction 1 - lw, in a water host (generic_mixing_formula.py:352-380); water after Maetzler &
-        // Wegmuller 1987 (water.py:14-43), defined from the melting point up
-        if (T < kFreezing || lw > 1.0) *bad = 1;
-        const cplx ew = water_permittivity(frequency, T);
-        const cplx cplus = cadd(es, cscale(ew, 2.0));
-        const cplx cminus = cscale(csub(es, ew), 1.0 - lw);
-        es = cmul(cdiv(cadd(cplus, cscale(cminus, 2.0)), csub(cplus, cminus)), ew);
-    }
     double k0 = 2.0 * kPi * frequency / kCSpeed;
     if (em == EM_IBA || em == EM_IBA_INV) {
         // EM_IBA_INV: IBA's dense_snow_correction="auto" on a layer with more than half ice (iba.py:95-96,

@@ -1,0 +1,841 @@
+"""DORT radiative-transfer solver, MI355X-native (drop-in for smrt/rtsolver/dort.py:84-261).
+
+Same constructor options and `solve()` protocol as the reference class; the numerical work (layer electromagnetics,
+streams, interfaces, eigen-decomposition, boundary conditions) runs in the HIP kernels through the C ABI
+(include/smrt_dort.h).  Three entry points, from the reference's to the batched one:
+
+* `solve(snowpack, emmodels, sensor, atmosphere)` -- the rtsolver protocol, one simulation (what
+  `Model.run_single_simulation` calls, smrt/core/model.py:596-617);
+* `solve_batch(simulations, emmodel)` -- a list of (single-frequency sensor, snowpack) pairs in one launch per group,
+  one Result each;
+* `solve_plan(model, plan)` -- a whole `SimulationPlan` (smrt_amd/core/model.py): index vectors instead of pair
+  objects, distinct snowpacks packed once, the stacked Result built from the output array without per-pair objects.
+"""
+import threading
+
+import numpy as np
+
+from .._native import STATUS_MESSAGES, BatchOutput, DortContext, PackedBatch, device_count
+from ..core.error import SMRTError, smrt_warn
+from ..core.globalconstants import C_SPEED
+from ..core.result import LabeledArray, make_result
+from ..core.snowpack import Snowpack, substrate_kind
+from ..interface.flat import Flat
+
+_DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
+
+
+class DORT(object):
+    """Discrete-ordinate and eigenvalue solver (Picard et al. 2018), device implementation.
+
+    Arguments as smrt/rtsolver/dort.py:148-161.  `diagonalization_method` and `diagonalization_cache` are accepted for
+    compatibility: the device always uses its own symmetric reduction (every reference method agrees with it to
+    ~1e-11 K) and has nothing to cache.  `devices` (list of GPU indices, default: all visible ones for large batches)
+    and `block_threads` are smrt_amd's own knobs."""
+
+    _broadcast_capability = {"theta_inc", "polarization_inc", "theta", "phi", "polarization"}
+
+    def __init__(self, n_max_stream=32, m_max=2, stream_mode="most_refringent", phase_normalization="auto",
+                 phase_symmetrization=False, error_handling="exception", process_coherent_layers=False,
+                 prune_deep_snowpack=None, diagonalization_method="schur_forcedtriu", diagonalization_cache=False,
+                 rayleigh_jeans_approximation=False, devices=None, block_threads=0):
+        if stream_mode != "most_refringent":
+            # the reference's two other modes do not run in the reference either: "uniform_air" always fails the
+            # assertion at smrt/rtsolver/streams.py:288 (np.size of a scalar stream count is 1, never > 2), "air" is
+            # announced as untested there (streams.py:164-175)
+            raise SMRTError("smrt_amd's DORT implements stream_mode='most_refringent' only (the reference's "
+                            "'uniform_air' raises an AssertionError for every snowpack, its 'air' is untested code)")
+        if prune_deep_snowpack is True:  # True means an optical depth of 6 (smrt/rtsolver/dort.py:176-178)
+            prune_deep_snowpack = 6
+        if prune_deep_snowpack not in (None, False) and not float(prune_deep_snowpack) > 0:
+            raise SMRTError("prune_deep_snowpack must be None, True or a positive optical depth")
+        if diagonalization_method not in _DIAG_METHODS:
+            raise SMRTError(f"Unknown method '{diagonalization_method}' to diagonalize the matrix")
+        if diagonalization_method != "schur_forcedtriu":
+            # not silently: 'stamnes88' in the reference differs from its other methods by up to ~1 K
+            # (smrt/test/test_integration_iba.py atol table); the device has ONE route, equal to the default to 1e-8 K
+            smrt_warn(f"diagonalization_method='{diagonalization_method}' is ignored: smrt_amd's DORT always diagonalises with "
+                      "its own symmetric reduction (Cholesky x 2 + one-sided Jacobi), which reproduces the reference's "
+                      "default 'schur_forcedtriu'" + (" -- NOT the 'stamnes88' variant" if diagonalization_method == "stamnes88" else ""))
+        if error_handling not in ("exception", "nan"):
+            raise SMRTError("error_handling must be 'exception' or 'nan'")
+        if phase_normalization not in (True, False, "auto", "forced"):
+            raise SMRTError("phase_normalization must be True, False, 'auto' or 'forced'")
+        self.n_max_stream = int(n_max_stream)
+        self.m_max = int(m_max)
+        self.stream_mode = stream_mode
+        self.phase_normalization = phase_normalization
+        self.error_handling = error_handling
+        self.process_coherent_layers = bool(process_coherent_layers)
+        # phase_symmetrization (dort.py:104,173; rtsolver_utils.py:743-765) averages the (up, up) / (down, down) and the
+        # (up, down) / (down, up) blocks of the phase matrix.  The device formulation is built on exactly that mirror
+        # symmetry (it only ever forms P(mu, +mu') and P(mu, -mu')), which the device emmodels have to the last bit -- the
+        # reference's own result does not change by one ulp with the option on IBA -- so there it is a no-op; for emmodels
+        # evaluated on the host the averaging is applied when their matrices are packed.
+        self.phase_symmetrization = bool(phase_symmetrization)
+        self.prune_deep_snowpack = float(prune_deep_snowpack) if prune_deep_snowpack else None
+        self.diagonalization_method = diagonalization_method
+        self.rayleigh_jeans_approximation = bool(rayleigh_jeans_approximation)
+        self.devices = devices
+        self.block_threads = int(block_threads)
+
+    # ---- the reference's protocol --------------------------------------------------------------------------------
+    def solve(self, snowpack, emmodels, sensor, atmosphere=None, parallel_computation=None):
+        """One (snowpack, sensor configuration).  `emmodels`: the per-layer instances made by Model.prepare_emmodels;
+        they must be smrt_amd's device-backed classes, all of one kind (the device recomputes their numbers from the
+        layer properties)."""
+        if atmosphere is not None and snowpack.atmosphere is None:  # the deprecated route of Model.run (model.py:612)
+            snowpack = Snowpack(layers=snowpack.layers, interfaces=snowpack.interfaces, substrate=snowpack.substrate,
+                                atmosphere=atmosphere)
+        # device-backed instances by the device emmodel of their layer; any other instance is evaluated on the host
+        entries = [getattr(e, "_device_name", None) or getattr(type(e), "device_name", None) or e for e in emmodels]
+        return self.solve_batch([(sensor, snowpack)], [entries])[0]
+
+    # ---- batched entry points ------------------------------------------------------------------------------------
+    @staticmethod
+    def _device_name(emmodel_cls):
+        name = getattr(emmodel_cls, "device_name", None)
+        if name is None:
+            raise SMRTError(f"emmodel {emmodel_cls} has no device implementation in smrt_amd (iba, dmrt_qca_shortrange, "
+                            "dmrt_qcacp_shortrange, nonscattering)")
+        return name
+
+    def solve_batch(self, simulations, emmodel):
+        """simulations: sequence of (single-frequency sensor, snowpack).  One Result per simulation, in order.
+        emmodel: one emmodel class for every layer, or -- aligned with the distinct snowpacks in order of first
+        appearance -- a list of per-layer lists of device names for snowpacks that mix emmodels."""
+        sensors, packs, si, pi = [], [], [], []
+        seen_s, seen_p = {}, {}
+        for sensor, sp in simulations:
+            si.append(seen_s.setdefault(id(sensor), len(sensors)))
+            if si[-1] == len(sensors):
+                sensors.append(sensor)
+            pi.append(seen_p.setdefault(id(sp), len(packs)))
+            if pi[-1] == len(packs):
+                packs.append(sp)
+        if not si:
+            return []
+        names = emmodel if isinstance(emmodel, list) else self._device_name(emmodel)
+        sol = self._solve_indexed(sensors, packs, np.asarray(si), np.asarray(pi), names)
+        return [sol.result(i) for i in range(len(si))]
+
+    def solve_plan(self, model, plan):
+        """The whole plan of a Model.run: returns the nested Result directly."""
+        from ..core.model import nest_results
+
+        names = self.emmodel_names(model, plan)
+        sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, names)
+        stacked = sol.stacked_result(plan)
+        if stacked is not None:
+            return stacked
+        return nest_results([sol.result(i) for i in range(len(plan))], plan.dimensions)
+
+    @classmethod
+    def emmodel_names(cls, model, plan):
+        """The emmodel of every layer as the device knows it, after the same checks the per-simulation route applies
+        through Model.prepare_emmodels (per-layer overrides, lists / dicts of emmodels and emmodel options are honoured
+        or refused, never dropped): one device name when all the layers of all the snowpacks share it, otherwise a list
+        (per snowpack) of lists (per layer).  One instance is made per distinct (class, options) pair, which validates
+        the options against the class."""
+        simple = isinstance(model.emmodel, type)
+        checked = set()
+        per_pack, distinct = [], set()
+        simple_name = getattr(model.emmodel, "device_name", None) if simple else None
+        simple_options = None
+        for sp in plan.snowpacks:
+            n = sp.nlayer
+            plain = (simple and not sp.has_layer_emmodels() and not isinstance(model.emmodel_options, list)
+                     and model.emmodel_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
+            if plain and simple_name is not None and simple_options is not None:
+                # the common case -- one device emmodel, no per-layer settings, options already validated: no per-layer work
+                distinct.add(simple_name)
+                per_pack.append([simple_name] * n)
+                continue
+            if plain:
+                kinds = [model.emmodel] * n
+                todo = [(model.emmodel, sp.layers[0], 0)]
+                simple_options = True
+            else:
+                kinds = [model.emmodel_of_layer(k, layer, n) for k, layer in enumerate(sp.layers)]
+                todo = [(kind, layer, k) for k, (kind, layer) in enumerate(zip(kinds, sp.layers))]
+            for kind, layer, k in todo:
+                options = model.emmodel_options_of_layer(layer, k, n)
+                key = (kind, tuple(sorted(options.items())), options.get("dense_snow_correction") == "auto" and layer.frac_volume > 0.5)
+                if key not in checked:
+                    checked.add(key)
+                    kind(plan.sensors[0], layer, **options)     # validates the options against the class
+            # a class without a device implementation is evaluated on the host, layer by layer (_evaluate_on_host)
+            names = [kd.device_name_for(layer, model.emmodel_options_of_layer(layer, k, n))
+                     if getattr(kd, "device_name", None) else (kd, model.emmodel_options_of_layer(layer, k, n))
+                     for k, (kd, layer) in enumerate(zip(kinds, sp.layers))]
+            distinct.update(n if isinstance(n, str) else "host" for n in names)
+            per_pack.append(names)
+        return distinct.pop() if len(distinct) == 1 and "host" not in distinct else per_pack
+
+    # ---- grouping, packing, launching ----------------------------------------------------------------------------
+    def _check_sensor(self, sensor):
+        if np.ndim(sensor.frequency) != 0:
+            raise SMRTError("DORT does not broadcast the frequency: split the sensor first (Model.run does)")
+        if np.size(sensor.phi) > 1:
+            raise SMRTError("phi as an array must be implemented")
+        if sensor.mode == "A" and not np.array_equal(sensor.theta_deg, sensor.theta_inc_deg):
+            raise SMRTError("smrt_amd's DORT computes the backscatter (theta == theta_inc) in active mode")
+
+    def _solve_indexed(self, sensors, packs, sens_idx, pack_idx, emmodel_names):
+        # everything that must be uniform inside one device batch, as small integer codes per sensor / per snowpack
+        sensor_keys, pack_keys = {}, {}
+        s_code = np.empty(len(sensors), np.int64)
+        for k, sensor in enumerate(sensors):
+            self._check_sensor(sensor)
+            angles = sensor.theta_inc_deg if sensor.mode == "A" else sensor.theta_deg
+            key = (sensor.mode, tuple(np.round(angles, 12)), float(np.ravel(sensor.phi)[0]))
+            s_code[k] = sensor_keys.setdefault(key, len(sensor_keys))
+        p_code = np.empty(len(packs), np.int64)
+        for k, sp in enumerate(packs):
+            key = (substrate_kind(sp.substrate), id(sp.atmosphere) if sp.atmosphere is not None else None)
+            p_code[k] = pack_keys.setdefault(key, len(pack_keys))
+        freq = np.array([float(s.frequency) for s in sensors])
+        code = s_code[sens_idx] * len(pack_keys) + p_code[pack_idx]
+        sol = _Solution(self, sensors, packs, sens_idx, pack_idx)
+        for g in np.unique(code):
+            sel = np.nonzero(code == g)[0]
+            u_packs, inv_p = np.unique(pack_idx[sel], return_inverse=True)
+            u_freq, inv_f = np.unique(freq[sens_idx[sel]], return_inverse=True)
+            sensor0, sp0 = sensors[sens_idx[sel[0]]], packs[u_packs[0]]
+            names = emmodel_names if isinstance(emmodel_names, str) else [emmodel_names[k] for k in u_packs]
+            sensor_of = {float(sensors[k].frequency): sensors[k] for k in sens_idx[sel]}
+            batch = self._pack(sensor0, [packs[k] for k in u_packs], u_freq, names, sensor_of)
+            pairs = inv_f * len(u_packs) + inv_p
+            full = len(pairs) == batch.n_pairs and np.array_equal(pairs, np.arange(batch.n_pairs))
+            out = run_on_devices(batch, self.devices, self.block_threads, pairs=None if full else pairs)
+            bad = np.nonzero(out.status != 0)[0]
+            if len(bad) and self.error_handling == "exception":
+                st = int(out.status[bad[0]])
+                raise SMRTError(STATUS_MESSAGES.get(st, f"DORT failed with status {st}"))
+            sol.add_group(sel, out, sp0)
+        return sol
+
+    def _pack(self, sensor0, sps, freqs, emmodel_names, sensor_of=None):
+        """The device batch of one group: S distinct snowpacks x F distinct frequencies."""
+        from .._native import EM_CODES, MS_CODES
+
+        S = len(sps)
+        nl = np.fromiter((sp.nlayer for sp in sps), np.int32, S)
+        Lmax = int(nl.max())
+        # emmodel + 16 * microstructure per layer; handed to the device only when the batch really mixes them
+        micro = [sp.microstructure_models for sp in sps]
+        uniform_micro = len(set().union(*micro)) == 1
+        layer_kind = host = None
+        if not isinstance(emmodel_names, str):
+            for s, sp in enumerate(sps):
+                if len(emmodel_names[s]) != nl[s]:
+                    raise SMRTError("one emmodel per layer is needed")
+        if not isinstance(emmodel_names, str) and any(not isinstance(e, str) for row in emmodel_names for e in row):
+            # at least one emmodel without a device implementation: the whole group is evaluated through the emmodel
+            # protocol on the host (the device classes speak it too) and handed to the device as numbers
+            host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
+            layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
+        elif not (isinstance(emmodel_names, str) and uniform_micro):
+            layer_kind = np.zeros((S, Lmax), np.int32)
+            for s, sp in enumerate(sps):
+                em = [emmodel_names] * nl[s] if isinstance(emmodel_names, str) else emmodel_names[s]
+                layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * self._ms_code(lay) for e, lay in zip(em, sp.layers)]
+        if host is None:
+            from ..core.layer import DEVICE_MICROSTRUCTURES
+
+            foreign = set().union(*micro) - set(DEVICE_MICROSTRUCTURES)
+            if foreign:
+                raise SMRTError(f"the microstructure model(s) {sorted(foreign)} have no device implementation: they can only "
+                                "be used with an emmodel evaluated on the host (e.g. rayleigh, prescribed_kskaeps)")
+        device_name = "host" if host is not None else (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
+        if int(nl.min()) == Lmax:
+            cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
+        else:
+            cols = np.empty((5, S, Lmax))
+            cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
+            for s, sp in enumerate(sps):
+                cols[:, s, :nl[s]] = sp.packed()
+        if layer_kind is not None and host is None:
+            # IBA on the inverted medium (dense_snow_correction="auto" above half ice): the device takes the volume
+            # fraction of the inclusions, the air (include/smrt_dort.h: SMRT_EM_IBA_INVERTED)
+            inverted = (layer_kind & 15) == EM_CODES["iba_inverted"]
+            cols[1][inverted] = 1.0 - cols[1][inverted]
+        elif device_name == "iba_inverted":   # every layer of the batch
+            cols[1] = 1.0 - cols[1]
+        mode = sensor0.mode
+        substrate = atmosphere = None
+        sub0 = sps[0].substrate
+        if sub0 is not None and substrate_kind(sub0) == "host":
+            substrate = self._substrates_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        elif sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
+            q = np.array([[sp.substrate.device_params(f) for sp in sps] for f in freqs])  # (F, S, 2)
+            ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
+            substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
+        host_interfaces = None
+        if any(not isinstance(itf, Flat) for sp in sps for itf in sp.interfaces):
+            host_interfaces = self._interfaces_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        atm0 = sps[0].atmosphere
+        if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)
+            a = np.array([atm0.device_params(f) for f in freqs])  # (F, 3)
+            atmosphere = (a[:, 0], a[:, 1], a[:, 2])
+        return PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs,
+                           sensor0.theta_inc if mode == "A" else sensor0.theta, emmodel=device_name,
+                           microstructure=sps[0].layers[0].microstructure_model if host is None else "exponential",
+                           mode=mode,
+                           n_max_stream=self.n_max_stream, m_max=self.m_max,
+                           phase_normalization=self.phase_normalization,
+                           rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
+                           substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
+                           layer_kind=layer_kind, host_emmodel=host,
+                           process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces)
+
+    def _layer_permittivities(self, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """Effective permittivity of every layer, (F, S, Lmax): from the host-evaluated emmodels if the group has them,
+        otherwise from a cheap pre-pass of the device emmodels (four streams, layer diagnostics only) -- what the streams
+        of matrices evaluated on the host (rough substrates / interfaces) are placed with."""
+        from .._native import PackedBatch
+
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        if host is not None:
+            return host[0][..., 2] + 1j * host[0][..., 3]
+        name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
+        probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
+                            microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
+                            phase_normalization="forced", layer_kind=layer_kind)
+        # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
+        res = get_context((self.devices or [default_device()])[0]).run(probe)
+        bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless
+        if len(bad):
+            raise SMRTError("the layer electromagnetics of pair %d are not computable (status 5): cannot place the "
+                            "streams of the matrices evaluated on the host" % int(bad[0]))
+        lay = res.layers.reshape(F, S, Lmax, 5)
+        return lay[..., 0] + 1j * lay[..., 1]
+
+    # ---- rough interfaces evaluated on the host (include/smrt_dort.h: SMRT_INTERFACE_HOST) --------------------------
+    @staticmethod
+    def _streams_of(eps_layers, n_max_stream):
+        """mu and weights of every layer and of the air for one (snowpack, frequency): streams.py:136-223,300-330."""
+        from .._native import gauss_legendre_positive
+
+        gmu, _ = gauss_legendre_positive(n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+        e = np.asarray(eps_layers, complex)
+        star = max(range(len(e)), key=lambda l: (e[l].real, e[l].imag, -l))
+
+        def weights(mu, absolute):
+            w = np.empty_like(mu)
+            w[0], w[-1] = 1.0 - 0.5 * (mu[0] + mu[1]), 0.5 * (mu[-2] + mu[-1])
+            w[1:-1] = 0.5 * (mu[:-2] - mu[2:])
+            return np.abs(w) if absolute else w
+        mus, ws = [], []
+        for el in list(e) + [1.0 + 0j]:
+            rs = np.sqrt(e[star] / el).real * gsin
+            mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+            mus.append(mu)
+            ws.append(weights(mu, absolute=len(mus) <= len(e)))
+        return mus[:-1], ws[:-1], mus[-1], ws[-1]
+
+    @staticmethod
+    def interface_matrices(interface, frequency, eps_low, eps_up, mu_low, mu_up, mu_t_up, w_low, w_up, m_max, npol):
+        """The four matrices of a rough interface between a layer (eps_low, streams mu_low / weights w_low) and the medium
+        above it (eps_up, mu_up / w_up) as compute_interface_properties combines them (smrt/rtsolver/rtsolver_utils.py:
+        473-642,690-707,728-740): per azimuth mode m, in the compressed order (stream * P + polarisation, P = 2 for mode 0,
+        3 above),  specular / coherent part on the diagonal + (2 pi | pi) x the diffuse mode with the column scaled by
+        mu_i w_i and the row by 1 / mu_s (a diffuse part given as [P, m, n] is diagonal in the streams).  The diffuse
+        transmissions carry the ratio of the real permittivities (incident / transmitted side).  mu_t_up: the cosines the
+        reference evaluates the upward diffuse transmission on (streams.mu[layer - 1] for layer > 1, the air streams
+        otherwise, rtsolver_utils.py:510).  Returns (list over modes of {"Rtop", "Ttop", "Rbot", "Tbot"},
+        {"Rtop", ...: specular diagonal of mode 0})."""
+        def raw(method, *args):
+            f = getattr(interface, method, None)
+            if not callable(f):
+                return None
+            v = f(frequency, *args)
+            v = np.asarray(getattr(v, "values", v), float)
+            return None if v.ndim == 0 else v
+
+        def diag_of(spec, n, P):
+            return np.zeros(n * P) if spec is None else spec.reshape(npol, n)[:P].T.reshape(n * P)
+
+        def combined(spec, diff, m, mu_st, mu_i, w_i, scale, same):
+            P = 2 if m == 0 else 3
+            coef = 2 * np.pi if m == 0 else np.pi
+            M = np.diag(diag_of(spec, len(mu_i), P))
+            if diff is None:
+                return M
+            if diff.ndim == 5:      # [ps, pi, m, mu_st, mu_i]
+                D = diff[:P, :P, m] * scale * (mu_i * w_i)[None, None, None, :] / mu_st[None, None, :, None]
+                D = np.transpose(D, (2, 0, 3, 1)).reshape(len(mu_st) * P, len(mu_i) * P)
+                if M.shape != D.shape:   # rectangular transmission: the specular part sits on the common streams
+                    Mr = np.zeros_like(D)
+                    k = min(D.shape[0], M.shape[0])
+                    Mr[:k, :k] = M[:k, :k]
+                    M = Mr
+                return M + coef * D
+            if diff.ndim == 3:      # [p, m, mu]: diagonal in the streams and in the polarisation
+                fac = w_i if same else mu_i * w_i / mu_st
+                return M + coef * np.diag((diff[:P, m] * scale * fac[None, :]).T.reshape(len(mu_i) * P))
+            raise SMRTError("unsupported layout of a diffuse interface matrix (expected [p, p, m, mu_s, mu_i] or [p, m, mu])")
+
+        spec_up = raw("specular_reflection_matrix", eps_low, eps_up, mu_low, npol)
+        spec_dn = raw("specular_reflection_matrix", eps_up, eps_low, mu_up, npol)
+        ctr_up = raw("coherent_transmission_matrix", eps_low, eps_up, mu_low, npol)
+        ctr_dn = raw("coherent_transmission_matrix", eps_up, eps_low, mu_up, npol)
+        drf_up = raw("ft_even_diffuse_reflection_matrix", eps_low, eps_up, mu_low, mu_low, m_max, npol)
+        drf_dn = raw("ft_even_diffuse_reflection_matrix", eps_up, eps_low, mu_up, mu_up, m_max, npol)
+        dtr_up = raw("ft_even_diffuse_transmission_matrix", eps_low, eps_up, mu_t_up, mu_low, m_max, npol)
+        dtr_dn = raw("ft_even_diffuse_transmission_matrix", eps_up, eps_low, mu_low, mu_up, m_max, npol)
+        r_up, r_dn = complex(eps_low).real / complex(eps_up).real, complex(eps_up).real / complex(eps_low).real
+        modes = []
+        for m in range(m_max + 1):
+            modes.append(dict(Rtop=combined(spec_up, drf_up, m, mu_low, mu_low, w_low, 1.0, True),
+                              Ttop=combined(ctr_up, dtr_up, m, mu_t_up, mu_low, w_low, r_up, False),
+                              Rbot=combined(spec_dn, drf_dn, m, mu_up, mu_up, w_up, 1.0, True),
+                              Tbot=combined(ctr_dn, dtr_dn, m, mu_low, mu_up, w_up, r_dn, False)))
+        coh = dict(Rtop=diag_of(spec_up, len(mu_low), 2), Ttop=diag_of(ctr_up, len(mu_low), 2),
+                   Rbot=diag_of(spec_dn, len(mu_up), 2), Tbot=diag_of(ctr_dn, len(mu_up), 2))
+        return modes, coh
+
+    def _interfaces_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """(slot, matrices, specular diagonals) of PackedBatch(host_interfaces=...) for a group with rough interfaces: every
+        interface object that is not Flat is evaluated through the reference's interface protocol on the streams of the
+        two media it separates."""
+        if self.process_coherent_layers:
+            raise SMRTError("process_coherent_layers is not available with interfaces evaluated on the host")
+        act = sensor0.mode == "A"
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        nm, ne, npol = (self.m_max + 1 if act else 1), 3 * self.n_max_stream, (3 if act else 2)
+        rough = [[i for i, itf in enumerate(sp.interfaces) if not isinstance(itf, Flat)] for sp in sps]
+        nslots = max(1, max(len(r) for r in rough))
+        slot = -np.ones((F, S, Lmax), np.int32)
+        M = np.zeros((F, S, nslots, nm, 4, ne, ne))
+        C = np.zeros((F, S, nslots, 4, ne))
+        for fi, f in enumerate(freqs):
+            for s, sp in enumerate(sps):
+                if not rough[s]:
+                    continue
+                e = eps[fi, s, :nl[s]]
+                mus, ws, outmu, outw = self._streams_of(e, self.n_max_stream)
+                for k, i in enumerate(rough[s]):
+                    mu_up, w_up, e_up = (mus[i - 1], ws[i - 1], complex(e[i - 1])) if i > 0 else (outmu, outw, 1.0)
+                    mu_t = mus[i - 1] if i > 1 else outmu      # (the reference's choice, rtsolver_utils.py:510)
+                    modes, coh = self.interface_matrices(sp.interfaces[i], float(f), complex(e[i]), e_up, mus[i], mu_up, mu_t,
+                                                         ws[i], w_up, self.m_max if act else 0, npol)
+                    slot[fi, s, i] = k
+                    for m in range(nm):
+                        P = 2 if m == 0 else 3
+                        n_low, n_up = len(mus[i]) * P, len(mu_up) * P
+                        for q, (kind, rows) in enumerate((("Rtop", n_low), ("Ttop", n_up), ("Rbot", n_up), ("Tbot", n_low))):
+                            A = modes[m][kind]
+                            r = min(A.shape[0], rows)     # cut to the common streams like dort.py:372-376,409-414
+                            M[fi, s, k, m, q, :r, :A.shape[1]] = A[:r]
+                    for q, (kind, rows) in enumerate((("Rtop", None), ("Ttop", len(mu_up) * 2), ("Rbot", None), ("Tbot", len(mus[i]) * 2))):
+                        c = coh[kind] if rows is None else coh[kind][:rows]
+                        C[fi, s, k, q, :len(c)] = c
+        return slot, M, C
+
+    # ---- substrates evaluated on the host (include/smrt_dort.h: SMRT_SUBSTRATE_HOST) -------------------------------
+    @staticmethod
+    def substrate_matrices(substrate, frequency, eps_last, mu, weight, m_max, npol=3):
+        """Reflection matrices of the bottom boundary as compute_interface_properties builds them for a substrate object
+        (smrt/rtsolver/rtsolver_utils.py:567-597,690-707,728-740): per azimuth mode m, in the compressed order (stream *
+        P + polarisation, P = 2 for mode 0 and 3 above), diag(specular) + (2 pi | pi) x the diffuse mode with the column
+        scaled by mu_i w_i and the row by 1 / mu_s (a diffuse part given as [P, m, n] is diagonal in the streams: scaled by
+        w only).  Returns (list of dense matrices, list of specular diagonals)."""
+        n = len(mu)
+        spec = substrate.specular_reflection_matrix(frequency, eps_last, mu, npol)
+        spec = np.asarray(getattr(spec, "values", spec), float)       # (an smrt_matrix keeps its array in .values)
+        spec = np.zeros((npol, n)) if spec.ndim == 0 else spec.reshape(npol, n)
+        diff = None
+        if callable(getattr(substrate, "ft_even_diffuse_reflection_matrix", None)):
+            diff = substrate.ft_even_diffuse_reflection_matrix(frequency, eps_last, mu, mu, m_max, npol)
+            diff = np.asarray(getattr(diff, "values", diff), float)
+            diff = None if diff.ndim == 0 else diff
+        dense, coh = [], []
+        for m in range(m_max + 1):
+            P = 2 if m == 0 else 3
+            c = spec[:P].T.reshape(n * P)
+            R = np.diag(c)
+            coef = 2 * np.pi if m == 0 else np.pi
+            if diff is not None and diff.ndim == 5:      # [ps, pi, m, mu_s, mu_i]
+                D = diff[:P, :P, m] * (mu * weight)[None, None, None, :] / mu[None, None, :, None]
+                R = R + coef * np.transpose(D, (2, 0, 3, 1)).reshape(n * P, n * P)
+            elif diff is not None and diff.ndim == 3:    # [p, m, mu]: diagonal in the streams and in the polarisation
+                R = R + coef * np.diag((diff[:P, m] * weight[None, :]).T.reshape(n * P))
+            elif diff is not None:
+                raise SMRTError(f"ft_even_diffuse_reflection_matrix returned an array of {diff.ndim} dimensions")
+            dense.append(R)
+            coh.append(c)
+        return dense, coh
+
+    def _substrates_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+        """("host", R, Rcoh) of PackedBatch for a group whose snowpacks lie on substrates without a device implementation
+        (rough ones: geometrical optics, IEM, ...).  Needs the streams of every last layer, hence the effective
+        permittivity of every layer: from the host-evaluated emmodels if the group has them, otherwise from a cheap
+        pre-pass of the device emmodels (four streams, layer diagnostics only)."""
+        from .._native import PackedBatch, gauss_legendre_positive
+
+        if self.process_coherent_layers:
+            raise SMRTError("process_coherent_layers is not available with a substrate evaluated on the host (its matrices are "
+                            "sampled on the streams of the full snowpack, which may change when layers are removed)")
+        act = sensor0.mode == "A"
+        F, S, Lmax = len(freqs), len(sps), cols.shape[2]
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        nm, ne = (self.m_max + 1 if act else 1), 3 * self.n_max_stream
+        R = np.zeros((F, S, nm, ne, ne))
+        Rc = np.zeros((F, S, nm, ne))
+        gmu, _ = gauss_legendre_positive(self.n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+        for fi, f in enumerate(freqs):
+            for s, sp in enumerate(sps):
+                e = eps[fi, s, :nl[s]]
+                star = max(range(len(e)), key=lambda l: (e[l].real, e[l].imag, -l))
+                rs = np.sqrt(e[star] / e[-1]).real * gsin
+                mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+                w = np.empty_like(mu)                       # streams.py:324-330
+                w[0], w[-1] = 1.0 - 0.5 * (mu[0] + mu[1]), 0.5 * (mu[-2] + mu[-1])
+                w[1:-1] = 0.5 * (mu[:-2] - mu[2:])
+                dense, coh = self.substrate_matrices(sp.substrate, float(f), complex(e[-1]), mu, np.abs(w),
+                                                     self.m_max if act else 0, 3 if act else 2)
+                for m in range(nm):
+                    k = dense[m].shape[0]
+                    R[fi, s, m, :k, :k] = dense[m]
+                    Rc[fi, s, m, :k] = coh[m]
+                if not act:   # the emissivity diagonal takes the place of the specular one (rtsolver_utils.py:533-536)
+                    if not callable(getattr(sp.substrate, "emissivity_matrix", None)):
+                        raise SMRTError("a substrate evaluated on the host needs an emissivity_matrix method in passive mode")
+                    em = sp.substrate.emissivity_matrix(float(f), complex(e[-1]), mu, 2)
+                    em = np.asarray(getattr(em, "values", em), float)
+                    Rc[fi, s, 0, :2 * len(mu)] = 0.0 if em.ndim == 0 else em.reshape(2, len(mu)).T.reshape(-1)
+        if act:
+            return ("host", R, Rc)
+        return ("host", R, Rc, [sp.substrate.temperature if getattr(sp.substrate, "temperature", None) is not None else 0.0
+                                for sp in sps])
+
+    @staticmethod
+    def _ms_code(layer):
+        from .._native import MS_CODES
+
+        code = MS_CODES.get(layer.microstructure_model)
+        if code is None:
+            raise SMRTError(f"the microstructure model '{layer.microstructure_model}' has no device implementation: it "
+                            "can only be used with an emmodel evaluated on the host (e.g. rayleigh, prescribed_kskaeps)")
+        return code
+
+    # ---- emmodels evaluated on the host (include/smrt_dort.h: SMRT_EM_HOST) ----------------------------------------
+    HOST_PHASE_BYTES_MAX = 8e9
+
+    def _evaluate_on_host(self, sensor0, sps, freqs, entries, nl, Lmax, sensor_of):
+        """What smrt/rtsolver/dort.py:189,231-247,714-762 asks of the emmodels -- effective permittivity, ks, ka and the
+        azimuth modes of the phase matrix on the layer's own streams -- for every (frequency, snowpack, layer) of the
+        group, as the three arrays of PackedBatch(host_emmodel=...).  An entry is a device emmodel name, an (emmodel
+        class, options) pair or a ready instance (rtsolver protocol).  The streams are the ones the device will find
+        (Gauss-Legendre nodes in the most refringent layer + Snell, streams.py:136-223); it checks the counts."""
+        import copy
+
+        from .._native import gauss_legendre_positive
+        from ..core.plugin import import_class
+
+        mode = sensor0.mode
+        P = 2 if mode == "P" else 3
+        modes = 1 if mode == "P" else self.m_max + 1
+        m_arg = modes - 1
+        F, S, NE = len(freqs), len(sps), self.n_max_stream * P
+        nbytes = 8.0 * F * S * Lmax * modes * 2 * NE * NE
+        if nbytes > self.HOST_PHASE_BYTES_MAX:
+            raise SMRTError(f"the phase matrices of this batch would take {nbytes / 1e9:.1f} GB on the host: run emmodels "
+                            "without a device implementation in smaller groups of snowpacks")
+        hl = np.zeros((F, S, Lmax, 4))
+        hl[..., 2] = 1.0
+        hs = np.zeros((F, S, Lmax), np.int32)
+        hp = np.zeros((F, S, Lmax, modes, 2, NE, NE))
+        gmu, _ = gauss_legendre_positive(self.n_max_stream)
+        gsin = np.sqrt(1.0 - gmu * gmu)
+
+        def instance(entry, sensor, layer):
+            if isinstance(entry, str):
+                return import_class("emmodel", entry)(sensor, layer)
+            if isinstance(entry, tuple):
+                return entry[0](sensor, layer, **entry[1])
+            return entry
+
+        def scalar(value, what):
+            a = np.asarray(value, float).ravel()
+            if a.size == 0 or not np.allclose(a, a[0], rtol=1e-12, atol=0.0):
+                raise SMRTError(f"smrt_amd's DORT needs an isotropic {what} (one number per layer)")
+            return float(a[0])
+
+        for fi, f in enumerate(freqs):
+            sensor = sensor_of.get(float(f))
+            if sensor is None:
+                sensor = copy.copy(sensor0)
+                sensor.frequency = float(f)
+            for s, sp in enumerate(sps):
+                ems = [instance(entries[s][l], sensor, layer) for l, layer in enumerate(sp.layers)]
+                eps = np.array([complex(em.effective_permittivity()) for em in ems])
+                stay = list(range(len(eps)))
+                if self.process_coherent_layers:
+                    # the layers the device will take out at this frequency (interface/coherent_flat.py:16-57, k0 Re(n) d
+                    # < 3 pi / 4): the streams of the others are those of the REDUCED snowpack.  (Where the reference
+                    # refuses -- the last layer or two in a row -- the device answers status 6 whatever is put here.)
+                    k0 = 2.0 * np.pi * float(f) / C_SPEED
+                    stay = [l for l, lay in enumerate(sp.layers) if not k0 * np.sqrt(eps[l]).real * lay.thickness < 0.75 * np.pi]
+                    for l in set(range(len(eps))) - set(stay):
+                        hl[fi, s, l, 2:] = eps[l].real, eps[l].imag
+                    if not stay:
+                        continue
+                star = max(stay, key=lambda l: (eps[l].real, eps[l].imag, -l))   # np.argmax on complex
+                for l in stay:
+                    em = ems[l]
+                    rs = np.sqrt(eps[star] / eps[l]).real * gsin
+                    mu = np.sqrt(1.0 - rs[rs < 1.0] ** 2)
+                    n = len(mu)
+                    ks = em.ks(mu, P) if callable(getattr(em, "ks", None)) else em.ks
+                    ka = em.ka(mu, P) if callable(getattr(em, "ka", None)) else em.ka
+                    hl[fi, s, l] = scalar(ks, "ks"), scalar(ka, "ka"), eps[l].real, eps[l].imag
+                    hs[fi, s, l] = n
+                    if hl[fi, s, l, 0] == 0.0 or n == 0:
+                        continue
+                    full = np.concatenate((mu, -mu))
+                    ft = np.asarray(em.ft_even_phase(full, full, m_arg, npol=P), float)
+                    if ft.shape != (P, P, modes, 2 * n, 2 * n):
+                        raise SMRTError(f"ft_even_phase returned the shape {ft.shape}, expected {(P, P, modes, 2 * n, 2 * n)}")
+                    # (ps, pi, m, mu_s, mu_i) -> m, (mu_s, ps), (mu_i, pi): the compressed order of core/lib.py:336-347
+                    C = np.transpose(ft, (2, 3, 0, 4, 1)).reshape(modes, 2 * n * P, 2 * n * P)
+                    nP = n * P
+                    if self.phase_symmetrization:   # rtsolver_utils.py:743-765 (sign -1 between U and V | H for m >= 1)
+                        sgn = np.where(np.arange(nP) % P < 2, 1.0, -1.0)
+                        d = np.ones((modes, 1, 1)) * (sgn[:, None] * sgn[None, :])
+                        d[0] = 1.0 if P == 2 else d[0]
+                        C = C.copy()
+                        C[:, :nP, :nP] = 0.5 * (C[:, :nP, :nP] + d * C[:, nP:, nP:])
+                        C[:, :nP, nP:] = 0.5 * (C[:, :nP, nP:] + d * C[:, nP:, :nP])
+                    vh = np.arange(nP)[np.arange(nP) % P < 2]
+                    for blk in (C[0][:nP, :nP], C[0][:nP, nP:]):   # the device reads the lower triangles only
+                        sub = blk[np.ix_(vh, vh)]
+                        if not np.allclose(sub, sub.T, rtol=1e-9, atol=1e-12 * np.abs(sub).max()):
+                            raise SMRTError("the phase matrix of this emmodel does not obey reciprocity: smrt_amd's DORT "
+                                            "(symmetric eigenproblem) cannot solve it")
+                    hp[fi, s, l, :, 0, :nP, :nP] = C[:, :nP, :nP]
+                    hp[fi, s, l, :, 1, :nP, :nP] = C[:, :nP, nP:]
+        return hl, hs, hp
+
+
+class _Solution:
+    """Outputs of the device batches of one call, addressable per simulation and stackable as one Result."""
+
+    def __init__(self, solver, sensors, packs, sens_idx, pack_idx):
+        self.solver, self.sensors, self.packs = solver, sensors, packs
+        self.sens_idx, self.pack_idx = np.asarray(sens_idx), np.asarray(pack_idx)
+        n = len(self.sens_idx)
+        self.group_of = np.full(n, -1, np.int64)
+        self.row_of = np.zeros(n, np.int64)
+        self.outputs = []
+
+    def add_group(self, sel, out, sp0):
+        self.group_of[sel] = len(self.outputs)
+        self.row_of[sel] = np.arange(len(sel))
+        self.outputs.append(out)
+
+    # -- labels ----------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _coords(sensor):
+        if sensor.mode == "P":
+            return [("polarization", ["V", "H"]), ("theta", sensor.theta_deg)]
+        pola = ["V", "H", "U"]
+        return [("polarization_inc", pola), ("polarization", pola), ("theta_inc", sensor.theta_inc_deg)]
+
+    @staticmethod
+    def _reported_streams(sensor, streams_row):
+        """Cosines of the air streams of Result.other_data['stream_angles']: all of them in passive mode, only the
+        incident ones in active mode (rtsolver_utils.py:307-316, dort.py:210-226)."""
+        n_air = int(streams_row[0])
+        outmu = streams_row[1:1 + n_air]
+        if sensor.mode == "A":
+            keep = set()
+            for mu_inc in np.cos(np.atleast_1d(sensor.theta_inc)):
+                i0 = int(np.searchsorted(-outmu, -mu_inc))
+                keep.update((0,) if i0 == 0 else ((n_air - 1,) if i0 == n_air else (i0, i0 - 1)))
+            outmu = outmu[sorted(keep)]
+        return outmu
+
+    def result(self, i):
+        """The Result of simulation i with the labels and diagnostics of DiscreteOrdinatesMixin.make_result
+        (rtsolver_utils.py:322-344,373-398)."""
+        sensor, sp = self.sensors[self.sens_idx[i]], self.packs[self.pack_idx[i]]
+        out, row = self.outputs[self.group_of[i]], self.row_of[i]
+        L = sp.nlayer
+        thickness = sp.layer_thicknesses
+        layers = out.layers[row]
+        if self.solver.process_coherent_layers:   # the layers that were solved: column 4 = streams + 1024 x input index
+            code = layers[:L, 4]
+            kept = int(np.count_nonzero(code > 0))
+            thickness = thickness[(code[:kept] // 1024).astype(int)]
+            layers = layers.copy()
+            layers[:, 4] = layers[:, 4] % 1024
+            L = kept
+        outmu = self._reported_streams(sensor, out.streams[row])
+        layer_idx = ("layer", np.arange(L))
+        lay = layers[:L]
+        other = {
+            "stream_angles": LabeledArray(np.rad2deg(np.arccos(outmu)), [("dim_0", np.arange(len(outmu)))]),
+            "effective_permittivity": LabeledArray(lay[:, 0] + 1j * lay[:, 1], [layer_idx]),
+            "ks": LabeledArray(lay[:, 2].copy(), [layer_idx], name="ks"),
+            "ke": LabeledArray(lay[:, 2] + lay[:, 3], [layer_idx], name="ke"),
+            "ka": LabeledArray(lay[:, 3].copy(), [layer_idx], name="ka"),
+            "thickness": LabeledArray(thickness, [layer_idx], name="thickness"),
+        }
+        return make_result(sensor, out.values[row], self._coords(sensor), other_data=other)
+
+    def stacked_result(self, plan):
+        """All simulations as ONE Result whose leading dimensions are the plan's -- built from the output arrays by
+        reshaping (no per-simulation objects).  None when the simulations are not one homogeneous grid (several device
+        groups, different channel maps): the caller then nests per-simulation results."""
+        if len(self.outputs) != 1 or not plan.dimensions:
+            return None
+        sensor0 = self.sensors[0]
+        if any(s.channel_map != sensor0.channel_map or s.mode != sensor0.mode for s in self.sensors[1:]):
+            return None
+        out = self.outputs[0]
+        order = self.row_of                       # simulation i -> row of the group output
+        lead = [(name, np.asarray(list(values))) for name, values in plan.dimensions]
+        shape = tuple(len(v) for _, v in lead)
+        if int(np.prod(shape)) != len(order):
+            return None
+        data = LabeledArray(out.values[order].reshape(shape + out.values.shape[1:]), lead + self._coords(sensor0))
+        nl = np.fromiter((sp.nlayer for sp in self.packs), np.int64, len(self.packs))[self.pack_idx]
+        Lmax = int(nl.max())
+        lay = out.layers[order][:, :Lmax].copy()
+        lay[np.arange(Lmax)[None, :] >= nl[:, None]] = np.nan      # ragged packs: NaN below the last layer
+        layer_dim = [("layer", np.arange(Lmax))]
+
+        def stack(values, name=None):
+            return LabeledArray(values.reshape(shape + (Lmax,)), lead + layer_dim, name=name)
+
+        thick = np.full((len(self.packs), Lmax), np.nan)
+        for k, sp in enumerate(self.packs):
+            thick[k, :sp.nlayer] = sp.packed()[0]
+        thick_rows = thick[self.pack_idx]
+        if self.solver.process_coherent_layers:   # per simulation: the layers that were solved, top first, NaN after them
+            code = np.nan_to_num(lay[:, :, 4])    # streams + 1024 x index in the input (include/smrt_dort.h)
+            kept = code > 0
+            thick_rows = np.where(kept, np.take_along_axis(thick_rows, (code // 1024).astype(np.int64), axis=1), np.nan)
+            lay[~kept] = np.nan
+        streams = [self._reported_streams(self.sensors[s], out.streams[r]) for s, r in zip(self.sens_idx, order)] \
+            if sensor0.mode == "A" else None
+        if streams is None:
+            n_air = out.streams[order, 0].astype(np.int64)
+            width = int(n_air.max())
+            mu = out.streams[order, 1:1 + width].copy()
+            mu[np.arange(width)[None, :] >= n_air[:, None]] = np.nan
+        else:
+            width = max(len(s) for s in streams)
+            mu = np.full((len(order), width), np.nan)
+            for k, s in enumerate(streams):
+                mu[k, :len(s)] = s
+        other = {
+            "stream_angles": LabeledArray(np.rad2deg(np.arccos(mu)).reshape(shape + (width,)),
+                                          lead + [("dim_0", np.arange(width))]),
+            "effective_permittivity": stack(lay[:, :, 0] + 1j * lay[:, :, 1]),
+            "ks": stack(lay[:, :, 2], "ks"),
+            "ke": stack(lay[:, :, 2] + lay[:, :, 3], "ke"),
+            "ka": stack(lay[:, :, 3], "ka"),
+            "thickness": stack(thick_rows, "thickness"),
+        }
+        return make_result(sensor0, data, other_data=other)
+
+
+# ---- contexts and the multi-GPU fan-out ----------------------------------------------------------------------------
+_ctx_cache = {}
+_ctx_lock = threading.Lock()
+
+
+def default_device():
+    """The GPU the helpers outside a solver run use (emmodel accessors, ft_even_phase): SMRT_DORT_DEVICE, else this
+    process's LOCAL_RANK in a one-process-per-GPU launch, else 0 -- never blindly GPU 0."""
+    import os
+
+    for key in ("SMRT_DORT_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v.strip().isdigit():
+            from .._native import device_count
+
+            n = device_count()
+            return int(v) % n if n > 0 else int(v)
+    return 0
+
+
+def get_context(device=None):
+    """The cached context of a GPU (created on first use; its calls are serialised by DortContext.lock); None: the
+    default device of this process (default_device)."""
+    if device is None:
+        device = default_device()
+    with _ctx_lock:
+        if device not in _ctx_cache:
+            _ctx_cache[device] = DortContext(device)
+        return _ctx_cache[device]
+
+
+def visible_devices():
+    return list(range(device_count()))
+
+
+def shard_by_cost(cost, n_shards):
+    """Contiguous slices [b[k], b[k+1]) of a cost vector with (nearly) equal cost each: the boundaries are where the
+    running cost crosses k / n_shards of the total (shard by sum_l N_l^3, not by count)."""
+    cost = np.asarray(cost, dtype=np.float64)
+    running = np.concatenate([[0.0], np.cumsum(cost)])
+    targets = running[-1] * np.arange(1, n_shards) / n_shards
+    inner = np.searchsorted(running, targets, side="left")
+    return np.concatenate([[0], np.clip(inner, 0, len(cost)), [len(cost)]]).astype(np.int64)
+
+
+def run_on_devices(batch, devices=None, block_threads=0, pairs=None, cost=None):
+    """Run a packed batch -- all of it, or the listed pair indices -- sharded over the given GPUs: contiguous slices of
+    the work list (equal cost when `cost` per work item is given, equal counts otherwise), one host thread and one
+    context per GPU, no collective: every GPU writes disjoint rows of the same host arrays."""
+    n = batch.n_pairs if pairs is None else len(pairs)
+    if devices is None:
+        devices = visible_devices() if n >= 4096 else [0]
+    devices = list(devices) or [0]
+
+    def one(dev, lo, hi):
+        ctx = get_context(dev)
+        with ctx.lock:
+            ctx.set_block_threads(block_threads)
+            if pairs is None:
+                return ctx.run(batch, int(lo), int(hi - lo))
+            return ctx.run(batch, pairs=pairs[lo:hi])
+
+    if len(devices) == 1:
+        return one(devices[0], 0, n)
+    if cost is None:   # the work of a pair varies with its stream counts: estimate it on the first device (cheap kernel)
+        ctx = get_context(devices[0])
+        with ctx.lock:
+            if pairs is None:
+                ctx.upload(batch)
+            else:
+                ctx.upload(batch, pairs=pairs)
+            cost = ctx.pair_cost()
+    bounds = shard_by_cost(cost, len(devices))
+    out = BatchOutput(batch, n)
+    errors = []
+
+    def work(dev, lo, hi):
+        try:
+            part = one(dev, lo, hi)
+            out.values[lo:hi], out.status[lo:hi] = part.values, part.status
+            out.layers[lo:hi], out.streams[lo:hi] = part.layers, part.streams
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(d, bounds[k], bounds[k + 1]))
+               for k, d in enumerate(devices) if bounds[k + 1] > bounds[k]]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
