@@ -8,18 +8,21 @@
 // Jacobi thresholds of the pipelines in passive mode (squared cosines; the kernels take them as run-time parameters):
 // rotations below SKIP are not applied, a sweep without a rotation above EXIT is the last one.  Active mode keeps
 // 1e-30 / 1e-22 (dort_jacobi_kernel.hpp).  Two sets:
-//  * the pipelines that solve with the eigenvector matrices as they come (two-slot / global-workspace / big finish kernels)
-//    tolerate columns of B' that are orthogonal to 1e-6 only: 1e-22 / 1e-12, 2e-8 K against the oracle;
+//  * the pipelines that solve with the eigenvector matrices as they come (two-slot / global-workspace / big finish kernels):
+//    1e-24 / 1e-14 since round 4.  The 1e-22 / 1e-12 of round 3 (2e-8 K on ordinary snow) were 4.4e-5 K off on a wet,
+//    weakly scattering snowpack of the randomised sweep (tools/stress_vs_oracle.py 71 wetmicro, 40 streams: nearly
+//    degenerate singular values again -- ADVICE r3 had asked for exactly this check); 1e-24 / 1e-14: 1.4e-9 K on that
+//    sweep for 1.2 % of the configs[2]-shape step, 1e-26 / 1e-15: 1.4e-10 K for 2.1 %;
 //  * the register-resident finish kernel uses the orthogonality itself (the inverses of the eigenvector matrices are their
 //    transposes): with 1e-22 / 1e-12 it is at 1.6e-8 K on the headline batch but loses up to 2.4e-4 K on weakly
 //    scattering media (1.4 GHz: nearly degenerate singular values) -- tools/stress_reg_extremes.py, 860 hard pairs:
 //    1e-24 / 1e-14 -> 2.6e-6 K, 1e-26 / 1e-15 -> 1.3e-7 K (+1.1 ms per headline step), 1e-28 / 1e-16 -> 1.9e-8 K (+1.5 ms).
 //    The requirement is 1e-6 K.
 #ifndef SMRT_JACOBI_PASSIVE_SKIP_COS2
-#define SMRT_JACOBI_PASSIVE_SKIP_COS2 1e-22
+#define SMRT_JACOBI_PASSIVE_SKIP_COS2 1e-24
 #endif
 #ifndef SMRT_JACOBI_PASSIVE_EXIT_COS2
-#define SMRT_JACOBI_PASSIVE_EXIT_COS2 1e-12
+#define SMRT_JACOBI_PASSIVE_EXIT_COS2 1e-14
 #endif
 #ifndef SMRT_JACOBI_REG_SKIP_COS2
 #define SMRT_JACOBI_REG_SKIP_COS2 1e-26

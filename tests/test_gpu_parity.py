@@ -942,3 +942,40 @@ def test_cfg5_per_gpu_share(ctx):
         f, s = divmod(int(p), S)
         sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
         assert np.abs(full.values[p] - O.solve(sp, freqs[f], [55.0])).max() < TB_TOL
+
+
+def test_wet_weakly_scattering_media_on_the_other_pipelines(ctx):
+    """Wet, weakly scattering snowpacks (a wet top layer absorbs, small independent spheres barely scatter: nearly degenerate
+    singular values) on the pipelines whose finish kernels invert the eigenvector matrices numerically -- two-slot
+    (set_pipeline(4)), and 40 streams on the global workspace.  With the Jacobi thresholds these pipelines had until round
+    3 (1e-22 / 1e-12) a snowpack of this kind was 4.4e-5 K off (tools/stress_vs_oracle.py 71 wetmicro); the requirement is
+    1e-6 K.  Microstructure model drawn per layer among the four of the device."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    names = ["exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey"]
+    rng = np.random.default_rng(77)
+    S, L = 12, 5
+    worst = {}
+    for n_stream, pipeline in ((40, 1), (24, 4)):
+        thick = rng.uniform(0.03, 0.4, (S, L)); thick[:, -1] = 100.0
+        fv = rng.uniform(0.17, 0.5, (S, L)); temp = rng.uniform(230, 270, (S, L))
+        msl = rng.integers(0, 4, (S, L)); msl[:, 0] = 2                   # independent spheres on top
+        p1 = np.where((msl == 0) | (msl == 3), rng.uniform(5e-5, 3e-4, (S, L)), rng.uniform(5e-5, 1.5e-4, (S, L)))
+        p2 = np.where(msl == 1, 0.2, np.where(msl == 3, rng.uniform(5e-4, 3e-3, (S, L)), 0.0))
+        lw = np.zeros((S, L)); lw[:, 0] = 10.0 ** rng.uniform(-2.5, -1.5, S); temp[:, 0] = 273.15
+        freqs = np.array([6.925e9, 10.65e9, 18.7e9])
+        b = PackedBatch([L] * S, thick, fv, temp, p1, p2, freqs, np.deg2rad([25.0, 55.0]), n_max_stream=n_stream,
+                        layer_kind=16 * msl, liquid_water=lw)
+        ctx.set_pipeline(pipeline)
+        out = ctx.run(b)
+        ctx.set_pipeline(1)
+        assert (out.status == 0).all()
+        err = 0.0
+        for fi, f in enumerate(freqs):
+            for s in range(S):
+                sp = dict(thickness=thick[s], frac_volume=fv[s], temperature=temp[s], microstructure=[names[c] for c in msl[s]],
+                          corr_length=p1[s], radius=p1[s], stickiness=p2[s], repeat_distance=p2[s], liquid_water=lw[s])
+                err = max(err, float(np.abs(out.values[fi * S + s] - O.solve(sp, float(f), [25.0, 55.0], n_max_stream=n_stream)).max()))
+        worst[(n_stream, pipeline)] = err
+    assert max(worst.values()) < TB_TOL, worst

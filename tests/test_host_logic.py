@@ -206,8 +206,10 @@ def test_snowpack_builder_scope():
         make_snowpack([1], "exponential", density=300, corr_length=1e-4, substrate="soil")  # not a substrate object
     with pytest.raises(SMRTError):
         make_snowpack([1], "gaussian_random_field", density=300, corr_length=1e-4)
+    wet = make_snowpack([1], "exponential", density=300, corr_length=1e-4, temperature=273.15, liquid_water=0.1)   # wet snow: round 4
+    assert wet.layers[0].liquid_water == 0.1 and np.isclose(wet.layers[0].frac_volume, 300 / (916.7 * 0.9 + 1000 * 0.1))
     with pytest.raises(SMRTError):
-        make_snowpack([1], "exponential", density=300, corr_length=1e-4, liquid_water=0.1)
+        make_snowpack([1], "exponential", density=300, corr_length=1e-4, salinity=0.01)
 
 
 def test_substrate_atmosphere_and_emmodel_descriptors():
@@ -494,8 +496,11 @@ def test_host_evaluated_emmodels_are_packed_for_the_device():
         with pytest.raises(SMRTError, match=msg):
             solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(cls, {})] * 2])
     # a device emmodel on a microstructure it does not know is refused before anything is launched
+    homog = make_snowpack([0.3, 10], "homogeneous", density=[150, 200], temperature=[260, 265])
     with pytest.raises(SMRTError, match="no device implementation"):
-        solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), "iba")
+        solver._pack(passive(37e9, 55), [homog], np.array([37e9]), "iba")
+    # (independent spheres are a device microstructure model since round 4: IBA on them packs like any other)
+    assert int(solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), "iba").struct.microstructure) == 2
 
 
 def test_host_evaluated_substrates_matrices_and_refusals():
@@ -561,8 +566,10 @@ def test_layer_density_is_read_only_and_update_keeps_the_layer_consistent():
     sp.layers[0].update(density=400.0)
     assert sp.layers[0].density == 400.0 and abs(sp.layers[0].frac_volume - 400.0 / 916.7) < 1e-12
     assert abs(sp.packed()[1, 0] - 400.0 / 916.7) < 1e-12 and sp.packed()[1, 0] != before[1, 0]
-    with pytest.raises(SMRTError, match="wet"):
-        sp.layers[0].update(liquid_water=0.1)
+    sp.layers[0].update(liquid_water=0.1)          # wet snow (round 4): frac_volume becomes ice + water
+    assert sp.layers[0].liquid_water == 0.1 and abs(sp.layers[0].frac_volume - 400.0 / (916.7 * 0.9 + 100.0)) < 1e-12
+    sp.layers[0].update(liquid_water=0)
+    assert abs(sp.layers[0].frac_volume - 400.0 / 916.7) < 1e-12 and sp.liquid_water() is None
     # the caches of one snowpack do not care about layers built or changed elsewhere
     filled = sp.packed()
     other = two_layer()
