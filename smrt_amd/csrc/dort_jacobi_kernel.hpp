@@ -254,33 +254,61 @@ SMRT_DEV bool jacobi_padded(double* Bm, int N, int LD, double* sigma, double* nr
 // bank slots apart to be conflict-free (with the odd LD of the other kernels they overlapped: 41 % of the LDS cycles
 // of this kernel were bank conflicts, profiles/r1f_pmc_counters.txt).
 struct JacobiPlan { int NMAX, LD, LDJ, NCOL, o_sigma, o_rsig, o_int, total; };
-SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P) {
+// Padded row count of an N-column item = RPL * GS of the instantiation dort_jacobi_item dispatches it to.
+SMRT_HD int jacobi_padded_rows(int N) {
+    return N > 112 ? 128 : N > 96 ? 112 : N > 80 ? 96 : N > 64 ? 80 : N > 56 ? 64 : N > 48 ? 56 : N > 40 ? 48
+         : N > 32 ? 40 : N > 16 ? 32 : N > 8 ? 16 : 8;
+}
+// cap > 0: the LDS layout of a SIZE CLASS -- items of at most `cap` columns (the staged matrices in global memory keep
+// the layout of the batch maximum) -- so that the small items of a batch do not pay the LDS of its largest one.
+SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P, int cap = 0) {
     JacobiPlan p;
     p.NMAX = n_max_stream * P;
     p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
-    // padded rows = RPL * GS with the rows-per-lane count dort_jacobi_item dispatches on
-    const int rows = p.NMAX > 64 ? 128 : p.NMAX > 32 ? 64 : p.NMAX > 16 ? 32 : p.NMAX > 8 ? 16 : 8;
-    p.LDJ = ((rows + 31) / 32) * 32 + SMRT_JACOBI_GS;
-    // NB * ceil(N / NB) <= this - 1 for every N <= NMAX and its NB = 2 * jacobi_waves(N) column blocks (the padded column
-    // count grows with N inside a wavefront count and reaches 16 JW at its upper end, so NMAX decides), for workgroups of
+    const int nmax = (cap > 0 && cap < p.NMAX) ? cap : p.NMAX;   // columns of the largest item held in this layout
+    // leading dimension: the first value >= the padded rows that is == 8 or == 24 (mod 32) -- four adjacent columns
+    // then start at bank slots {0, 8, 16, 24} in one order or the other
+    int ldj = jacobi_padded_rows(nmax);
+    while ((ldj & 31) != SMRT_JACOBI_GS && (ldj & 31) != 32 - SMRT_JACOBI_GS) ++ldj;
+    p.LDJ = ldj;
+    // NB * ceil(N / NB) <= this - 1 for every N <= nmax and its NB = 2 * jacobi_waves(N) column blocks (the padded column
+    // count grows with N inside a wavefront count and reaches 16 JW at its upper end, so nmax decides), for workgroups of
     // four and of eight wavefronts (k_jacobi.hip launches either on 64 < N <= 128); plus the idle-slot column
     int cpmax = 0;
     for (int jw_max = 4; jw_max <= 8; jw_max += 4) {
-        const int nb = 2 * jacobi_waves(p.NMAX, jw_max);
-        const int cp = nb * ((p.NMAX + nb - 1) / nb);
+        const int nb = 2 * jacobi_waves(nmax, jw_max);
+        const int cp = nb * ((nmax + nb - 1) / nb);
         if (cp > cpmax) cpmax = cp;
     }
     p.NCOL = cpmax + 1;
     int o = p.NCOL * p.LDJ;
-    p.o_sigma = o; o += p.NMAX + 16;
-    p.o_rsig = o; o += p.NMAX + 16; // tracked column norms (padded columns included)
+    p.o_sigma = o; o += nmax + 16;
+    p.o_rsig = o; o += nmax + 16; // tracked column norms (padded columns included)
     p.o_int = o; o += 4;
     p.total = o;
     return p;
 }
 
+// Size classes of the N <= 64 pipelines (k_jacobi.hip launches one kernel per class over all items; an item outside the
+// class leaves at once): a kernel that only holds the instantiations of ITS row counts needs 68-80 registers instead of
+// the 114 of the one that holds them all, and the LDS of its own largest item -- 7 / 6 / 4 workgroups per CU for the
+// items of <= 48 / <= 56 / <= 64 columns instead of 4 for all (62 % / 26 % / 12 % of the headline batch).
+struct JacobiClass { int nt, lo, hi; };   // threads per workgroup, items with lo < N <= hi
+// one wavefront per 2 * (64 / GS) columns of the largest item of the class (jacobi_waves)
+constexpr int jacobi_class_nt(int hi) {
+    return SMRT_LANES * ((hi + 2 * (SMRT_LANES / SMRT_JACOBI_GS) - 1) / (2 * (SMRT_LANES / SMRT_JACOBI_GS)));
+}
+SMRT_HD int jacobi_classes(int NMAX, JacobiClass* out) {
+    const JacobiClass all[4] = {{jacobi_class_nt(32), 0, 32}, {jacobi_class_nt(48), 32, 48}, {jacobi_class_nt(56), 48, 56},
+                                {jacobi_class_nt(64), 56, 64}};
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        if (NMAX > all[i].lo) out[n++] = all[i];
+    return n;
+}
+
 template <int NT, int RPL>
-SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
+SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds, int cap = 0) {
     constexpr int JWMAX = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: at most 4, or 8 (N > 64)
     constexpr int GS = SMRT_JACOBI_GS;
     const int t = tid();
@@ -291,7 +319,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     const int si = (int)(gp % b.S);
     if (l >= b.n_layers[si]) return;          // uniform
     if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
-    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2);
+    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2, cap);
     const int LD = plan.LD, LDJ = plan.LDJ;
     const int N = stg.n[item];
     if (N <= 0) return;                       // the prep kernel flagged this layer (uniform)
@@ -336,21 +364,19 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
 // removes streams, so N varies from layer to layer), not the batch maximum: the padded rows RPL * GS are the first
 // multiple of GS >= N (a few sizes are merged to bound the number of instantiations).  The LDS layout (LDJ) is the
 // one of the batch maximum, so every variant fits.
-template <int NT>
+template <int NT, int LO = 0, int HI = 128>
 SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     constexpr int G = SMRT_JACOBI_GS;   // lanes per column pair
-    const int rows = stg.n[item];       // <= 0: nothing to do (the impl returns at once)
-    if (rows > 112) dort_jacobi_item_impl<NT, 128 / G>(b, stg, item, lds);
-    else if (rows > 96) dort_jacobi_item_impl<NT, 112 / G>(b, stg, item, lds);
-    else if (rows > 80) dort_jacobi_item_impl<NT, 96 / G>(b, stg, item, lds);
-    else if (rows > 64) dort_jacobi_item_impl<NT, 80 / G>(b, stg, item, lds);
-    else if (rows > 56) dort_jacobi_item_impl<NT, 64 / G>(b, stg, item, lds);
-    else if (rows > 48) dort_jacobi_item_impl<NT, 56 / G>(b, stg, item, lds);
-    else if (rows > 40) dort_jacobi_item_impl<NT, 48 / G>(b, stg, item, lds);
-    else if (rows > 32) dort_jacobi_item_impl<NT, 40 / G>(b, stg, item, lds);
-    else if (rows > 16) dort_jacobi_item_impl<NT, 32 / G>(b, stg, item, lds);
-    else if (rows > 8) dort_jacobi_item_impl<NT, 16 / G>(b, stg, item, lds);
-    else dort_jacobi_item_impl<NT, 8 / G>(b, stg, item, lds);
+    const int rows = stg.n[item];       // <= 0: nothing to do
+    if (rows <= LO || rows > HI) return;   // another size class's item (uniform); HI = 128, LO = 0: every item
+    constexpr int cap = HI < 128 ? HI : 0;
+    // (PREV, R]: the row counts of one instantiation; only those that meet (LO, HI] exist in this kernel
+#define SMRT_JACOBI_ROWS(PREV, R) \
+    if constexpr (LO < (R) && (PREV) < HI) if (rows <= (R)) { dort_jacobi_item_impl<NT, (R) / G>(b, stg, item, lds, cap); return; }
+    SMRT_JACOBI_ROWS(0, 8) SMRT_JACOBI_ROWS(8, 16) SMRT_JACOBI_ROWS(16, 32) SMRT_JACOBI_ROWS(32, 40)
+    SMRT_JACOBI_ROWS(40, 48) SMRT_JACOBI_ROWS(48, 56) SMRT_JACOBI_ROWS(56, 64) SMRT_JACOBI_ROWS(64, 80)
+    SMRT_JACOBI_ROWS(80, 96) SMRT_JACOBI_ROWS(96, 112) SMRT_JACOBI_ROWS(112, 128)
+#undef SMRT_JACOBI_ROWS
 }
 
 }  // namespace smrt

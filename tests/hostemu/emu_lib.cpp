@@ -119,6 +119,22 @@ static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
                                                   : emu::run_block(512, order, [&]() { dort_pair_passive<512, CH, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
+// The Jacobi stage of the N <= 64 pipelines as the library launches it (k_jacobi.hip): one pass per size class of
+// jacobi_classes over the item, each with the LDS layout of its class; an item outside the class leaves at once.
+static long run_jacobi_classes(DevBatch& d, const DevStage& st, long long it, int P, int order, std::vector<double>& jl) {
+    JacobiClass cls[4];
+    const int n = jacobi_classes(d.n_max_stream * P, cls);
+    long nb = 0;
+    for (int i = 0; i < n; ++i) {
+        jl.assign((size_t)make_jacobi_plan(d.n_max_stream, P, cls[i].hi).total, NAN);
+        if (cls[i].hi == 32) nb += emu::run_block(jacobi_class_nt(32), order, [&]() { dort_jacobi_item<jacobi_class_nt(32), 0, 32>(d, st, it, jl.data()); });
+        else if (cls[i].hi == 48) nb += emu::run_block(jacobi_class_nt(48), order, [&]() { dort_jacobi_item<jacobi_class_nt(48), 32, 48>(d, st, it, jl.data()); });
+        else if (cls[i].hi == 56) nb += emu::run_block(jacobi_class_nt(56), order, [&]() { dort_jacobi_item<jacobi_class_nt(56), 48, 56>(d, st, it, jl.data()); });
+        else nb += emu::run_block(jacobi_class_nt(64), order, [&]() { dort_jacobi_item<jacobi_class_nt(64), 56, 64>(d, st, it, jl.data()); });
+    }
+    return nb;
+}
+
 // active mode through the three-kernel pipeline: staging items are (pair, azimuth mode, layer)
 template <int NT>
 static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
@@ -129,7 +145,7 @@ static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const L
     std::vector<double> jl(jp.total);
     return run_rounds(d, order, nmodes, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
-        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long it) { return run_jacobi_classes(d, sg.st, it, 3, order, jl); },
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_active<NT, 1, 3>(d, p, lds.data(), nullptr, &sg.st); }); });
 }
 
@@ -142,7 +158,7 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
     std::vector<double> jl(jp.total);
     return run_rounds(d, order, 1, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
-        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(NT, order, [&]() { dort_jacobi_item<NT>(d, sg.st, it, jl.data()); }); },
+        [&](long long it) { return run_jacobi_classes(d, sg.st, it, 2, order, jl); },
         [&](long long p) { for (auto& x : lds) x = NAN;
                            if (smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the register-resident finish kernel: one wavefront per pair (where the library uses it)
                                return emu::run_block(64, order, [&]() { dort_pair_passive_reg(d, p, lds.data(), sg.st); });
