@@ -284,6 +284,12 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
  * n_max_stream and n_layers_max: four of them share the 160 KB of a CU while this is <= 40 KB. */
 int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max);
 
+/* LDS bytes one workgroup of the Jacobi kernel takes in the three-kernel pipelines of up to 128 columns (n_pol = 2
+ * passive, 3 active).  The N <= 64 pipelines launch one kernel per SIZE CLASS of items (at most 32 / 33-48 / 49-56 /
+ * 57-64 columns), each with the layout of its own largest item: size_class_columns = that bound, or 0 for the layout of
+ * the batch maximum (the one launch of the 64 < N <= 128 pipeline).  Returns -1 for shapes outside these pipelines. */
+int32_t smrt_dort_jacobi_lds_bytes(int32_t n_max_stream, int32_t n_pol, int32_t size_class_columns);
+
 /* Algorithmic work of the uploaded batch after a launch: sum over pairs, modes and layers of N_l^3
  * (N_l = streams x polarisations in layer l), the quantity SURVEY.md 8(d) prices at 68 flops. */
 double smrt_dort_sum_n3(smrt_dort_ctx* ctx);

@@ -285,6 +285,8 @@ def load_library():
     lib.smrt_dort_gather_plan.restype = C.c_int32
     lib.smrt_dort_finish_reg_lds_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.smrt_dort_finish_reg_lds_bytes.restype = C.c_int32
+    lib.smrt_dort_jacobi_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.smrt_dort_jacobi_lds_bytes.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
     lib.smrt_dort_sum_n3.restype = C.c_double
     lib.smrt_dort_stage_cycles.argtypes = [C.c_void_p, P(C.c_double)]
@@ -322,7 +324,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_launch_info", "smrt_dort_comm_library", "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
-    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_gather_plan",
+    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_jacobi_lds_bytes", "smrt_dort_gather_plan",
 ]
 
 

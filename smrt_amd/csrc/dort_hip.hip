@@ -206,6 +206,11 @@ int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_ma
     return (int32_t)(sizeof(double) * (size_t)finish_reg_lds_doubles(n_max_stream, n_layers_max));
 }
 
+int32_t smrt_dort_jacobi_lds_bytes(int32_t n_max_stream, int32_t n_pol, int32_t size_class_columns) {
+    if (n_max_stream < 1 || (n_pol != 2 && n_pol != 3) || n_max_stream * n_pol > 128 || size_class_columns < 0) return -1;
+    return (int32_t)(make_jacobi_plan(n_max_stream, n_pol, size_class_columns).total * sizeof(double));
+}
+
 int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads) {
     if (!ctx) return -1;
     if (threads == 0) threads = 256;

@@ -406,7 +406,7 @@ def test_sensor_catalogue_matches_reference():
 
 def test_kernel_occupancy_as_designed():
     """The pipeline kernels are designed for a number of resident workgroups per CU: two for the prep and
-    finish kernels, four for the Jacobi kernel.  What decides it besides LDS is the register count the COMPILER ends up
+    finish kernels, four or more for the Jacobi kernel (its size classes: as many as their LDS lets in).  What decides it besides LDS is the register count the COMPILER ends up
     with -- a helper function that spills into accumulation registers silently halves it (it happened: 288 registers,
     one workgroup per CU, 50 ms instead of 29 ms).  The build keeps the compiler's resource remarks per translation unit
     (smrt_amd/csrc/build/*.resources.txt, -Rpass-analysis=kernel-resource-usage); this test reads them."""
@@ -420,7 +420,10 @@ def test_kernel_occupancy_as_designed():
         for blk in open(f).read().split(" Function Name: ")[1:]:
             name = blk.split()[0]
             waves[name] = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk).group(1))
-    want = {"dort_finish2_kernelILi256E": 2, "dort_prep_kernelILi256E": 3, "dort_jacobi_kernelILi256E": 4,
+    want = {"dort_finish2_kernelILi256E": 2, "dort_prep_kernelILi256E": 3, "dort_jacobi_kernelILi256ELi0ELi128E": 4,
+            # the size classes of the Jacobi kernel (k_jacobi.hip): 7 / 6 / 4 workgroups of 3 / 4 / 4 wavefronts per CU by LDS
+            "dort_jacobi_kernelILi128ELi0ELi32E": 7, "dort_jacobi_kernelILi192ELi32ELi48E": 6,
+            "dort_jacobi_kernelILi256ELi48ELi56E": 6, "dort_jacobi_kernelILi256ELi56ELi64E": 4,
             "dort_active_finish_kernelILi256E": 2, "dort_active_prep_kernelILi256E": 2, "dort_finish_kernel_gmemILi256E": 2,
             "dort_active_finish_kernel_gmemILi256E": 2, "dort_passive_big_kernelILi256ELi6ELi2E": 2,
             "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3,
@@ -432,7 +435,15 @@ def test_kernel_occupancy_as_designed():
     # the register-resident finish kernel must fit four wavefronts in the LDS of a CU at the headline shape (32 streams,
     # 20 layers): matrix slot + exchange vectors + tables <= 40 KB
     from smrt_amd import _native
-    assert _native.load_library().smrt_dort_finish_reg_lds_bytes(32, 20) <= 40 * 1024
+    lib = _native.load_library()
+    assert lib.smrt_dort_finish_reg_lds_bytes(32, 20) <= 40 * 1024
+    # the size classes of the Jacobi kernel at the headline shape: 7 / 6 / 4 workgroups in the 160 KB of a CU, each with
+    # the layout of its own largest item (one layout for all would hold 4), bank-conflict-free leading dimensions
+    for columns, per_cu in ((32, 14), (48, 7), (56, 6), (64, 4), (0, 4)):
+        assert lib.smrt_dort_jacobi_lds_bytes(32, 2, columns) * per_cu <= 160 * 1024, columns
+    assert lib.smrt_dort_jacobi_lds_bytes(32, 2, 64) == lib.smrt_dort_jacobi_lds_bytes(32, 2, 0)
+    assert lib.smrt_dort_jacobi_lds_bytes(64, 2, 0) <= 160 * 1024 < 2 * lib.smrt_dort_jacobi_lds_bytes(64, 2, 0)
+    assert lib.smrt_dort_jacobi_lds_bytes(64, 3, 0) == -1
 
 
 def test_host_evaluated_emmodels_are_packed_for_the_device():
