@@ -86,7 +86,7 @@ def make_workload(config, rank, strong, n_snowpacks):
             metric="snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
             what="BASELINE configs[1]: IBA + DORT passive, 20 layers, 32 streams, 5 AMSR-E channels (10.65-89 GHz, 55 deg), "
                  "%d synthetic snowpacks" % S,
-            kernel="dort pipeline = dort_prep_kernel + dort_jacobi_kernel + dort_finish_reg_kernel")
+            kernel="dort pipeline = dort_prep_kernel + dort_jacobi_kernel (one launch per size class of items: <= 32 | 33-48 | 49-56 | 57-64 columns) + dort_finish_reg_kernel")
     if config == 2:
         S, L = n_snowpacks or 1024, 50
         arrays = synthetic_snowpacks(seed=3 if strong else 3 + rank, S=S, L=L, size_range=(5e-5, 1.5e-4))

@@ -41,9 +41,11 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_EM_IBA_INVERTED 5
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
-#define SMRT_MS_STICKY_HARD_SPHERES 1
+#define SMRT_MS_STICKY_HARD_SPHERES 1   /* micro_p1 = radius, micro_p2 = stickiness (> 0), or -t: the parameter t itself
+                                        * (unified_sticky_hard_spheres.py:24-27; IBA only -- the dmrt emmodels take a stickiness) */
 #define SMRT_MS_INDEPENDENT_SPHERE 2   /* micro_p1 = radius (smrt/microstructure_model/independent_sphere.py:54-72); IBA only */
-#define SMRT_MS_TEUBNER_STREY 3        /* micro_p1 = corr_length, micro_p2 = repeat_distance (teubner_strey.py:45-55); IBA only */
+#define SMRT_MS_TEUBNER_STREY 3        /* micro_p1 = corr_length xi, micro_p2 = Y = (2 pi xi / repeat_distance)^2 (teubner_strey.py:45-55); a
+                                        * negative Y gives the two-length form of unified_teubner_strey.py:69-72; IBA only */
 /* sensor mode (smrt/core/sensor.py:330-339) */
 #define SMRT_MODE_PASSIVE 0
 #define SMRT_MODE_ACTIVE 1
@@ -89,7 +91,8 @@ typedef struct smrt_batch {
     const double* frac_volume;/* [S][Lmax] ice volume fraction (SnowLayer.compute_frac_volumes, make_medium.py:390-434) */
     const double* temperature;/* [S][Lmax] K */
     const double* micro_p1;   /* [S][Lmax] corr_length (exponential) | radius (sticky_hard_spheres), m */
-    const double* micro_p2;   /* [S][Lmax] unused (exponential) | stickiness (sticky_hard_spheres) */
+    const double* micro_p2;   /* [S][Lmax] unused (exponential, independent_sphere) | stickiness or -t (sticky_hard_spheres) |
+                               * Y (teubner_strey): see SMRT_MS_* */
     const double* frequency;  /* [F] Hz */
     const double* theta;      /* [n_theta] rad: Sensor.theta (== theta_inc in active/backscatter mode) */
     double phi;               /* active: azimuth (rad), pi for backscatter (sensor.py:179-180) */

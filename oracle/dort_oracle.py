@@ -107,6 +107,40 @@ def ft_autocorr_teubner_strey(k, frac_volume, corr_length, repeat_distance):
     return frac_volume * (1.0 - frac_volume) * 8 * np.pi * corr_length**3 / ((1 + y) ** 2 + 2 * (1 - y) * x + x**2)
 
 
+# ---- the models on the unified parameters (porod_length, polydispersity): smrt/microstructure_model/unified_*.py ---------
+def ft_autocorr_unified_scaled_exponential(k, frac_volume, porod_length, polydispersity):
+    """smrt/microstructure_model/unified_scaled_exponential.py:26-35 (corr_length = polydispersity * porod_length)."""
+    corr_length = polydispersity * porod_length
+    x = (np.asarray(k, float) * corr_length) ** 2
+    return frac_volume * (1.0 - frac_volume) * 8 * np.pi * corr_length**3 / (1.0 + x) ** 2
+
+
+def ft_autocorr_unified_teubner_strey(k, frac_volume, porod_length, polydispersity):
+    """smrt/microstructure_model/unified_teubner_strey.py:24-36 (the two lengths) and :63-78 (the transform), as written
+    there: two Lorentzians from polydispersity 1 on, the factored Teubner-Strey denominator below."""
+    k = np.asarray(k, float)
+    k32 = polydispersity ** (3 / 2)
+    if polydispersity >= 1:
+        b = porod_length * k32
+        delta = np.sqrt(1 - 1 / k32)
+        z1, z2 = b * (1 - delta), b * (1 + delta)
+        ft = (4 * np.pi * z1 * z2 * (z1 + z2)) / ((1 + (z1 * k) ** 2) * (1 + (z2 * k) ** 2))
+    else:
+        z1 = porod_length
+        z2 = porod_length * np.sqrt(1 / (1 / k32 - 1))
+        x1, r12 = k * z1, z1 / z2
+        ft = 8 * np.pi * z1**3 / ((1 + (x1 - r12) ** 2) * (1 + (x1 + r12) ** 2))
+    return frac_volume * (1.0 - frac_volume) * ft
+
+
+def ft_autocorr_unified_shs(k, frac_volume, porod_length, polydispersity):
+    """smrt/microstructure_model/unified_sticky_hard_spheres.py:22-27 (radius and t from the unified parameters), :43-76."""
+    f = frac_volume
+    radius = 3 / 4 * porod_length / (1 - f)
+    t = (1 + 2 * f - 3 / (8 * np.sqrt(2)) * polydispersity ** (-3 / 2)) / (f * (1.0 - f))
+    return ft_autocorr_shs(k, f, radius, None, t=t)
+
+
 def shs_t_parameter(frac_volume, stickiness):
     """Tsang vol II eq 8.4.22 root selection, smrt/microstructure_model/sticky_hard_spheres.py:132-167."""
     f = frac_volume
@@ -126,11 +160,15 @@ def shs_t_parameter(frac_volume, stickiness):
     return t
 
 
-def ft_autocorr_shs(k, frac_volume, radius, stickiness):
-    """Percus-Yevick sticky-hard-sphere structure factor form, sticky_hard_spheres.py:63-130."""
+def ft_autocorr_shs(k, frac_volume, radius, stickiness, t=None):
+    """Percus-Yevick sticky-hard-sphere structure factor form, sticky_hard_spheres.py:63-130; with `t` given the same
+    expression as smrt/microstructure_model/unified_sticky_hard_spheres.py:43-76 evaluates it (its t comes from the
+    polydispersity, :24-27, not from a stickiness)."""
     f, tau = frac_volume, stickiness
     x = np.atleast_1d(np.asarray(k, float)) * radius
-    if np.isfinite(tau) and f > 0:
+    if t is not None:
+        pass
+    elif np.isfinite(tau) and f > 0:
         t = (
             6 * tau * f - 6 * f - 6 * tau
             + (36 * tau**2 * f**2 - 72 * tau * f**2 - 72 * tau**2 * f + 30 * f**2 + 72 * tau * f + 36 * tau**2
@@ -148,6 +186,11 @@ def ft_autocorr_shs(k, frac_volume, radius, stickiness):
     c_tilde = f * vd / (a_**2 + b_**2)
     c0 = f * vd / (f / (1 - f) * ((1 - t * f + 3 * f / (1 - f)) + (3 - t * (1 - f))) + 1) ** 2
     return np.where(small, c0, c_tilde).reshape(np.shape(k))
+
+
+UNIFIED_FT = {"unified_scaled_exponential": ft_autocorr_unified_scaled_exponential,
+              "unified_teubner_strey": ft_autocorr_unified_teubner_strey,
+              "unified_sticky_hard_spheres": ft_autocorr_unified_shs}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -196,6 +239,9 @@ class IBALayer(LayerEM):
         elif microstructure == "teubner_strey":
             lc, rd = mp["corr_length"], mp["repeat_distance"]
             self.ft_corr = lambda k: ft_autocorr_teubner_strey(k, frac_volume, lc, rd)
+        elif microstructure in UNIFIED_FT:
+            lp, pk, ft = mp["porod_length"], mp["polydispersity"], UNIFIED_FT[microstructure]
+            self.ft_corr = lambda k: ft(k, frac_volume, lp, pk)
         else:
             raise ValueError(microstructure)
         # mean squared field ratio with depolarisation 1/3 on each axis (iba.py:152-162)
@@ -460,7 +506,8 @@ def make_layers(emmodel, frequency, sp):
     ems = [str(e) for e in np.broadcast_to(np.atleast_1d(emmodel), (L,))]
     micros = [str(m) for m in np.broadcast_to(np.atleast_1d(sp["microstructure"]), (L,))]
     args = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
-            "independent_sphere": ("radius",), "homogeneous": (), "teubner_strey": ("corr_length", "repeat_distance")}
+            "independent_sphere": ("radius",), "homogeneous": (), "teubner_strey": ("corr_length", "repeat_distance"),
+            **{n: ("porod_length", "polydispersity") for n in UNIFIED_FT}}
     extra = {"prescribed_kskaeps": ("ks", "ka", "eps_re", "eps_im")}   # layer attributes that emmodel reads
     wet = ("liquid_water",) if "liquid_water" in sp else ()              # water / (ice + water) volume per layer
     return [

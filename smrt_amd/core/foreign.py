@@ -50,6 +50,9 @@ DEVICE_MICROSTRUCTURE_CLASSES = {            # (module, class) -> (device name, 
     ("sticky_hard_spheres", "StickyHardSpheres"): ("sticky_hard_spheres", ("radius", "stickiness")),
     ("independent_sphere", "IndependentSphere"): ("independent_sphere", ("radius",)),
     ("teubner_strey", "TeubnerStrey"): ("teubner_strey", ("corr_length", "repeat_distance")),
+    ("unified_scaled_exponential", "UnifiedScaledExponential"): ("unified_scaled_exponential", ("porod_length", "polydispersity")),
+    ("unified_teubner_strey", "UnifiedTeubnerStrey"): ("unified_teubner_strey", ("porod_length", "polydispersity")),
+    ("unified_sticky_hard_spheres", "UnifiedStickyHardSpheres"): ("unified_sticky_hard_spheres", ("porod_length", "polydispersity")),
 }
 DRY_ICE_PERMITTIVITIES = ("wetice_permittivity_bohren83", "ice_permittivity_maetzler06")   # equal for dry, fresh ice
 
@@ -58,8 +61,8 @@ def _device_microstructure(ms):
     """(device name, p1, p2) of a reference microstructure object, or (None, 0, 0) when the device has no code for it."""
     for (module, name), (dev, params) in DEVICE_MICROSTRUCTURE_CLASSES.items():
         if _is_exactly(type(ms), "microstructure_model", module, name):
-            values = [float(getattr(ms, p)) for p in params]
-            return dev, values[0], (values[1] if len(values) > 1 else 0.0)
+            from .layer import device_microstructure_params
+            return (dev,) + device_microstructure_params(dev, float(ms.frac_volume), **{p: float(getattr(ms, p)) for p in params})
     return None, 0.0, 0.0
 
 

@@ -13,8 +13,7 @@ WRITES = [0]
 
 
 class Microstructure:
-    """Parameters of one of the two supported microstructure models (exponential: corr_length;
-    sticky_hard_spheres: radius, stickiness)."""
+    """Parameters of one of the microstructure models of MICROSTRUCTURE_ARGS."""
 
     def __setattr__(self, key, value):
         # every write bumps the object's own version: Snowpack's per-run caches (packed columns, microstructure set,
@@ -30,22 +29,67 @@ class Microstructure:
 
     @property
     def device_params(self):
-        if self.name == "exponential":
-            return float(self.corr_length), 0.0
-        if self.name == "teubner_strey":
-            return float(self.corr_length), float(self.repeat_distance)
-        if self.name == "independent_sphere":
-            return float(self.radius), 0.0
-        if self.name == "homogeneous":
-            return 0.0, 0.0
-        return float(self.radius), float(getattr(self, "stickiness", 1000.0))
+        return device_microstructure_params(self.name, self.frac_volume, **{k: getattr(self, k) for k in
+                                                                            MICROSTRUCTURE_ARGS[self.name] if hasattr(self, k)})
+
+
+def device_microstructure_params(name, frac_volume, **p):
+    """(micro_p1, micro_p2) of include/smrt_dort.h for a microstructure model and its parameters.  Four closed forms of the
+    Fourier transform of the autocorrelation function exist on the device (dort_physics.hpp: ft_corr); the models with
+    the UNIFIED parameters (porod_length, polydispersity: Picard et al. 2022; smrt/microstructure_model/unified_*.py)
+    are reparametrisations of three of them:
+      unified_scaled_exponential  the exponential with corr_length = polydispersity * porod_length
+                                  (unified_scaled_exponential.py:26-35);
+      unified_teubner_strey       8 pi xi^3 / ((1 + Y)^2 + 2 (1 - Y) X + X^2), X = (k xi)^2 -- Teubner-Strey's expression
+                                  (teubner_strey.py:45-55) with Y = (2 pi xi / d)^2: below polydispersity 1 with xi = zeta1,
+                                  Y = (zeta1 / zeta2)^2 (the factored denominator of unified_teubner_strey.py:73-76
+                                  multiplied out); from 1 on its product of two Lorentzians, 4 pi zeta1 zeta2 (zeta1 +
+                                  zeta2) / ((1 + zeta1^2 k^2)(1 + zeta2^2 k^2)) (:69-72), IS that expression with a
+                                  NEGATIVE Y = (1 - r) / (1 + r), r = (zeta1^2 + zeta2^2) / (2 zeta1 zeta2), and
+                                  xi^2 = zeta1 zeta2 (1 + Y) (the amplitudes agree identically);
+      unified_sticky_hard_spheres sticky hard spheres of radius 3/4 porod_length / (1 - frac_volume) whose parameter t is
+                                  GIVEN (unified_sticky_hard_spheres.py:24-27) instead of solved for from a stickiness:
+                                  handed to the device as micro_p2 = -t (a stickiness is positive)."""
+    if name == "exponential":
+        return float(p["corr_length"]), 0.0
+    if name == "teubner_strey":
+        xi = float(p["corr_length"])
+        return xi, (2.0 * np.pi * xi / float(p["repeat_distance"])) ** 2
+    if name == "independent_sphere":
+        return float(p["radius"]), 0.0
+    if name == "homogeneous":
+        return 0.0, 0.0
+    if name == "sticky_hard_spheres":
+        return float(p["radius"]), float(p.get("stickiness", 1000.0))
+    lp, K = float(p["porod_length"]), float(p["polydispersity"])
+    if name == "unified_scaled_exponential":
+        return K * lp, 0.0
+    if name == "unified_teubner_strey":
+        K32 = K ** 1.5
+        if K >= 1:
+            b, delta = lp * K32, np.sqrt(1 - 1 / K32)
+            z1, z2 = b * (1 - delta), b * (1 + delta)
+            g = z1 * z2
+            r = (z1 * z1 + z2 * z2) / (2 * g)
+            return float(np.sqrt(2 * g / (1 + r))), float((1 - r) / (1 + r))
+        z2 = lp * np.sqrt(1 / (1 / K32 - 1))
+        return lp, float((lp / z2) ** 2)
+    if name == "unified_sticky_hard_spheres":
+        f = float(frac_volume)
+        t = (1 + 2 * f - 3 / (8 * np.sqrt(2)) * K ** -1.5) / (f * (1 - f))
+        return 0.75 * lp / (1 - f), float(-t)
+    raise SMRTError(f"no device parameters for the microstructure model '{name}'")
 
 
 MICROSTRUCTURE_ARGS = {"exponential": ("corr_length",), "sticky_hard_spheres": ("radius", "stickiness"),
                        "independent_sphere": ("radius",), "teubner_strey": ("corr_length", "repeat_distance"),
+                       "unified_scaled_exponential": ("porod_length", "polydispersity"),
+                       "unified_teubner_strey": ("porod_length", "polydispersity"),
+                       "unified_sticky_hard_spheres": ("porod_length", "polydispersity"),
                        # no device emmodel uses this one: it serves emmodels evaluated on the host (prescribed_kskaeps)
                        "homogeneous": ()}
-DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey")   # IBA; DMRT: SHS only
+DEVICE_MICROSTRUCTURES = ("exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey",
+                          "unified_scaled_exponential", "unified_teubner_strey", "unified_sticky_hard_spheres")   # IBA; DMRT: SHS only
 
 
 class Layer:

@@ -70,9 +70,10 @@ SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
         double den = 1.0 + x;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
     }
-    if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length, p2 = repeat distance
-        const double x = k2 * p1 * p1;
-        const double yy = 2.0 * kPi * p1 / p2, y = yy * yy;
+    if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length xi, p2 = Y = (2 pi xi / repeat distance)^2;
+        // with a negative Y the same expression is the product of two Lorentzians of unified_teubner_strey.py:69-72
+        // (smrt_amd/core/layer.py: device_microstructure_params)
+        const double x = k2 * p1 * p1, y = p2;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / ((1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * x + x * x);
     }
     // spheres of radius p1: sticky hard spheres (sticky_hard_spheres.py:63-130) and independent spheres
@@ -88,7 +89,8 @@ SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
             return f * (1.0 - f) * vd * v * v;
         }
     } else {
-        if (isfinite(tau) && f > 0.0) {
+        if (__builtin_expect(tau < 0.0, 0)) tt = -tau;   // t given, not a stickiness (unified_sticky_hard_spheres.py:24-27)
+        else if (isfinite(tau) && f > 0.0) {
             double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
                           36 * tau * tau - 12 * f;
             tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));

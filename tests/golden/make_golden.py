@@ -45,9 +45,13 @@ def snowpack_arrays(sp):
     if len(kinds) > 1:   # mixed microstructure models: one name per layer, NaN for the parameters a layer does not have
         get = lambda lay, a: float(getattr(lay.microstructure, a, np.nan))  # noqa: E731
         names = {"Exponential": "exponential", "StickyHardSpheres": "sticky_hard_spheres",
-                 "IndependentSphere": "independent_sphere", "TeubnerStrey": "teubner_strey"}
+                 "IndependentSphere": "independent_sphere", "TeubnerStrey": "teubner_strey",
+                 "UnifiedScaledExponential": "unified_scaled_exponential", "UnifiedTeubnerStrey": "unified_teubner_strey",
+                 "UnifiedStickyHardSpheres": "unified_sticky_hard_spheres"}
         out["microstructure"] = np.array([names[type(lay.microstructure).__name__] for lay in sp.layers])
-        for a in ("corr_length", "radius", "stickiness", "repeat_distance"):
+        unified = any(n.startswith("Unified") for n in kinds)
+        # (the unified models derive corr_length / radius internally: only their own parameters are inputs)
+        for a in ("porod_length", "polydispersity") if unified else ("corr_length", "radius", "stickiness", "repeat_distance"):
             out[a] = np.array([get(lay, a) for lay in sp.layers])
         return out
     ms = sp.layers[0].microstructure
@@ -775,6 +779,20 @@ def main():
         if wanted("iba_micro4_L4_n10_active"):
             save("iba_micro4_L4_n10_active", run_new("iba", active(13.4e9, [30, 40]), micro_pack(1000.0),
                                                       rtsolver_options=dict(n_max_stream=10, m_max=2)))
+
+    # (iv-k) IBA over the models on the unified parameters (smrt/microstructure_model/unified_scaled_exponential.py,
+    # unified_teubner_strey.py on both sides of polydispersity 1, unified_sticky_hard_spheres.py), one per layer
+    unified4 = ["unified_scaled_exponential", "unified_teubner_strey", "unified_teubner_strey", "unified_sticky_hard_spheres"]
+    if wanted("iba_unified4_L4_n12_passive") or wanted("iba_unified4_L4_n10_active"):
+        def unified_pack(last):
+            return make_snowpack([0.2, 0.3, 0.4, last], unified4, density=[280, 320, 360, 400], temperature=[258, 261, 264, 266],
+                                 porod_length=[1.2e-4, 1.5e-4, 1.1e-4, 1.6e-4], polydispersity=[0.8, 0.7, 1.6, 1.2])
+        if wanted("iba_unified4_L4_n12_passive"):
+            save("iba_unified4_L4_n12_passive", run_new("iba", passive([18.7e9, 36.5e9, 89e9], [40, 55]), unified_pack(100.0),
+                                                         rtsolver_options=dict(n_max_stream=12)))
+        if wanted("iba_unified4_L4_n10_active"):
+            save("iba_unified4_L4_n10_active", run_new("iba", active(13.4e9, [30, 40]), unified_pack(1000.0),
+                                                        rtsolver_options=dict(n_max_stream=10, m_max=2)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

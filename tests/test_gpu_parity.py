@@ -962,10 +962,11 @@ def test_wet_weakly_scattering_media_on_the_other_pipelines(ctx):
         fv = rng.uniform(0.17, 0.5, (S, L)); temp = rng.uniform(230, 270, (S, L))
         msl = rng.integers(0, 4, (S, L)); msl[:, 0] = 2                   # independent spheres on top
         p1 = np.where((msl == 0) | (msl == 3), rng.uniform(5e-5, 3e-4, (S, L)), rng.uniform(5e-5, 1.5e-4, (S, L)))
-        p2 = np.where(msl == 1, 0.2, np.where(msl == 3, rng.uniform(5e-4, 3e-3, (S, L)), 0.0))
+        p2 = np.where(msl == 1, 0.2, np.where(msl == 3, rng.uniform(5e-4, 3e-3, (S, L)), 0.0))   # stickiness | repeat distance
         lw = np.zeros((S, L)); lw[:, 0] = 10.0 ** rng.uniform(-2.5, -1.5, S); temp[:, 0] = 273.15
         freqs = np.array([6.925e9, 10.65e9, 18.7e9])
-        b = PackedBatch([L] * S, thick, fv, temp, p1, p2, freqs, np.deg2rad([25.0, 55.0]), n_max_stream=n_stream,
+        dev_p2 = np.where(msl == 3, (2 * np.pi * p1 / np.where(msl == 3, p2, 1.0)) ** 2, p2)      # Teubner-Strey: micro_p2 = Y
+        b = PackedBatch([L] * S, thick, fv, temp, p1, dev_p2, freqs, np.deg2rad([25.0, 55.0]), n_max_stream=n_stream,
                         layer_kind=16 * msl, liquid_water=lw)
         ctx.set_pipeline(pipeline)
         out = ctx.run(b)

@@ -931,3 +931,29 @@ def test_wet_snow_layers_follow_the_reference_definitions():
     eps = sp.layers[0].permittivity(1, 18.7e9)
     assert abs(eps - O.scatterer_permittivity(18.7e9, 273.15, float(d["liquid_water"][0]))) < 1e-12
     assert eps.imag > 10 * sp.layers[3].permittivity(1, 18.7e9).imag      # (water makes the grains lossy)
+
+
+def test_unified_microstructure_parameters_are_reparametrisations_of_the_device_forms():
+    """core/layer.py: device_microstructure_params -- the models on the unified parameters (porod length, polydispersity)
+    expressed through the closed forms the device has (dort_physics.hpp: ft_corr): against the reference's own expressions
+    (restated in the oracle) over the wavenumbers IBA samples, on both sides of polydispersity 1."""
+    from oracle import dort_oracle as O
+    from smrt_amd.core.layer import device_microstructure_params as dp
+
+    k = np.linspace(0.0, 6e4, 601)
+    for f, lp in ((0.15, 0.8e-4), (0.3, 1.2e-4), (0.45, 2.5e-4)):
+        for K in (0.5, 0.8, 0.999, 1.0, 1.001, 1.3, 2.0, 3.5):
+            xi, Y = dp("unified_teubner_strey", f, porod_length=lp, polydispersity=K)
+            assert (Y >= 0) == (K <= 1.0) or abs(Y) < 1e-3
+            x = (k * xi) ** 2
+            device_form = f * (1 - f) * 8 * np.pi * xi**3 / ((1 + Y) ** 2 + 2 * (1 - Y) * x + x**2)
+            np.testing.assert_allclose(device_form, O.ft_autocorr_unified_teubner_strey(k, f, lp, K), rtol=1e-11)
+            lc, zero = dp("unified_scaled_exponential", f, porod_length=lp, polydispersity=K)
+            assert zero == 0.0
+            np.testing.assert_allclose(O.ft_autocorr_exponential(k, f, lc), O.ft_autocorr_unified_scaled_exponential(k, f, lp, K), rtol=1e-13)
+            radius, minus_t = dp("unified_sticky_hard_spheres", f, porod_length=lp, polydispersity=K)
+            assert minus_t < 0
+            np.testing.assert_allclose(O.ft_autocorr_shs(k, f, radius, None, t=-minus_t), O.ft_autocorr_unified_shs(k, f, lp, K), rtol=1e-13)
+    # Teubner-Strey itself: micro_p2 is Y = (2 pi xi / d)^2
+    xi, Y = dp("teubner_strey", 0.3, corr_length=1.5e-4, repeat_distance=1.2e-3)
+    assert xi == 1.5e-4 and Y == (2 * np.pi * 1.5e-4 / 1.2e-3) ** 2

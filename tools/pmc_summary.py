@@ -27,10 +27,13 @@ for f in sorted(glob.glob(root + "/*/*counter_collection.csv")):
 df = pd.concat(frames)
 df = df[df.Kernel_Name.str.contains("dort")]
 df["kernel"] = df.Kernel_Name.str.extract(r"(dort_[a-z0-9_]+)")[0]
-tab = df.groupby(["kernel", "Counter_Name"])["Counter_Value"].mean().unstack(0)
+# mean per dispatch of every instantiation, then the SUM over the instantiations of a kernel that run in one pipeline launch
+# (the Jacobi kernel is launched once per size class of items: k_jacobi.hip)
+tab = (df.groupby(["kernel", "Kernel_Name", "Counter_Name"])["Counter_Value"].mean()
+         .groupby(level=["kernel", "Counter_Name"]).sum().unstack(0))
 pd.set_option("display.width", 250)
 pd.set_option("display.float_format", lambda v: "%.4g" % v)
-print("# rocprofv3 --pmc, mean per dispatch of each pipeline kernel (bench.py headline batch, 5120 solves per launch); source:", root)
+print("# rocprofv3 --pmc, per pipeline launch: mean per dispatch of each kernel, summed over the size-class launches of the Jacobi kernel (bench.py --config %s, %d solves per launch); source:" % (config, solves), root)
 print(tab.to_string())
 print()
 print("# derived, per kernel")

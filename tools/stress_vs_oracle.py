@@ -75,7 +75,7 @@ for mode, n, em, ms in cases:
         msl = rng_prune.integers(0, 4, (S, Lmax))                       # microstructure model of every layer
         size = np.where((msl == 0) | (msl == 3), rng_prune.uniform(5e-5, 3e-4, (S, Lmax)), rng_prune.uniform(5e-5, 1.5e-4, (S, Lmax)))
         second = np.where(msl == 1, 0.2, np.where(msl == 3, rng_prune.uniform(5e-4, 3e-3, (S, Lmax)), 0.0))
-        p1, p2 = size, second
+        p1, p2 = size, np.where(msl == 3, (2 * np.pi * size / np.where(msl == 3, second, 1.0)) ** 2, second)   # Teubner-Strey: micro_p2 = Y
         kinds = 16 * msl                                                  # emmodel code 0 = iba
         lw = np.zeros((S, Lmax))
         for s in range(S):
@@ -94,7 +94,7 @@ for mode, n, em, ms in cases:
             if msl is not None:   # per-layer microstructure models and wetness
                 sp = dict(thickness=thick[s, :k], frac_volume=dens[s, :k] / 916.7, temperature=temp[s, :k],
                           microstructure=[MS_NAMES[c] for c in msl[s, :k]], corr_length=p1[s, :k], radius=p1[s, :k],
-                          stickiness=p2[s, :k], repeat_distance=p2[s, :k], liquid_water=lw[s, :k])
+                          stickiness=second[s, :k], repeat_distance=second[s, :k], liquid_water=lw[s, :k])
             elif ms == "exponential": sp["corr_length"] = p1[s, :k]
             else: sp["radius"] = p1[s, :k]; sp["stickiness"] = p2[s, :k]
             osub = None if sub is None else dict(kind="flat", eps=complex(sub[1][f, s], sub[2][f, s]), temperature=float(sub[3][s]))
