@@ -742,7 +742,8 @@ def test_wet_snow_through_the_model():
 
 def test_other_microstructure_models_through_the_model():
     """IBA over teubner_strey and independent_sphere layers (device: ft_corr, dort_physics.hpp) mixed with exponential and
-    sticky-hard-spheres ones, one microstructure model per layer through make_snowpack's list form, against the reference,
+    sticky-hard-spheres ones, and over the three models on the unified parameters (reparametrisations of the same closed
+    forms, core/layer.py), one microstructure model per layer through make_snowpack's list form, against the reference,
     passive and active; a uniform teubner_strey snowpack takes the uniform-microstructure batch (no per-layer codes)."""
     from conftest import MICRO_FIXTURES, reference_method_spread
     from smrt_amd import make_model, make_snowpack, sensor_list
@@ -750,9 +751,10 @@ def test_other_microstructure_models_through_the_model():
     none = lambda a: [None if np.isnan(x) else float(x) for x in a]   # noqa: E731
     for name in MICRO_FIXTURES:
         d = load_golden(name)
+        micro_args = {k: none(d[k]) for k in ("corr_length", "radius", "stickiness", "repeat_distance", "porod_length",
+                                               "polydispersity") if k in d}   # (the unified fixtures: porod length, polydispersity)
         sp = make_snowpack(d["thickness"], [str(m) for m in d["microstructure"]], density=d["density"], temperature=d["temperature"],
-                           corr_length=none(d["corr_length"]), radius=none(d["radius"]), stickiness=none(d["stickiness"]),
-                           repeat_distance=none(d["repeat_distance"]))
+                           **micro_args)
         opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
         if str(d["mode"]) == "A":
             opts["m_max"] = int(d["opt_m_max"])
