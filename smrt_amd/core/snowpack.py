@@ -33,6 +33,7 @@ class Snowpack:
             self._check_interface(itf)
         self._packed = None
         self._micro = self._overrides = None
+        self._wet = self._flat = None
         self.substrate = substrate
         self.atmosphere = atmosphere
 
@@ -74,7 +75,7 @@ class Snowpack:
         self._check_interface(interface)
         self.layers.append(layer)
         self.interfaces.append(interface or Flat())
-        self._packed = self._micro = self._overrides = None
+        self._packed = self._micro = self._overrides = self._wet = self._flat = None
 
     def packed(self):
         """The per-layer columns of the device batch for this snowpack -- thickness, ice volume fraction, temperature,
@@ -90,8 +91,18 @@ class Snowpack:
     def liquid_water(self):
         """Per-layer liquid water (water / (ice + water) volume) as one array, or None for a dry snowpack -- the optional
         sixth column of the device batch (include/smrt_dort.h: smrt_batch.liquid_water)."""
-        lw = [float(getattr(lay, "liquid_water", 0) or 0) for lay in self.layers]
-        return np.array(lw) if any(lw) else None
+        fresh = self._fresh("_wet_key")
+        if self._wet is None or not fresh:   # (looked up once per snowpack, like packed(): the runner asks on every run)
+            lw = [float(getattr(lay, "liquid_water", 0) or 0) for lay in self.layers]
+            self._wet = (np.array(lw) if any(lw) else None,)
+        return self._wet[0]
+
+    def all_interfaces_flat(self):
+        """No interface of this snowpack needs the host (Flat everywhere): cached per interface list."""
+        key = self._flat
+        if key is None or key[0] != self.interfaces:   # (list equality: identity first, element by element, in C)
+            key = self._flat = (list(self.interfaces), all(isinstance(itf, Flat) for itf in self.interfaces))
+        return key[1]
 
     def _fresh(self, slot):
         """Is the cache `slot` still valid?  Only if the layer list holds the same objects and none of them (nor its

@@ -308,7 +308,7 @@ class DORT(object):
             ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
             substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
         host_interfaces = None
-        if any(not isinstance(itf, Flat) for sp in sps for itf in sp.interfaces):
+        if not all(sp.all_interfaces_flat() for sp in sps):
             host_interfaces = self._interfaces_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
         atm0 = sps[0].atmosphere
         if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)

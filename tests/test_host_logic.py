@@ -957,3 +957,25 @@ def test_unified_microstructure_parameters_are_reparametrisations_of_the_device_
     # Teubner-Strey itself: micro_p2 is Y = (2 pi xi / d)^2
     xi, Y = dp("teubner_strey", 0.3, corr_length=1.5e-4, repeat_distance=1.2e-3)
     assert xi == 1.5e-4 and Y == (2 * np.pi * 1.5e-4 / 1.2e-3) ** 2
+
+
+def test_snowpack_caches_follow_in_place_changes():
+    """Snowpack.liquid_water() / all_interfaces_flat() are looked up once per snowpack (the batching runner asks on every run
+    of every snowpack): a layer made wet or dry with update(), a layer appended, an interface replaced in place must all
+    show at the next call."""
+    from smrt_amd import make_snowpack
+    from smrt_amd.inputs.make_medium import make_interface, make_snow_layer
+
+    sp = make_snowpack([0.2, 0.3, 10.0], "exponential", density=[250, 300, 350], temperature=[273.15, 265, 260], corr_length=1e-4)
+    assert sp.liquid_water() is None and sp.all_interfaces_flat()
+    sp.layers[0].update(volumetric_liquid_water=0.02)
+    assert sp.liquid_water()[0] > 0 and sp.liquid_water()[1] == 0
+    sp.layers[0].update(volumetric_liquid_water=0.0)
+    assert sp.liquid_water() is None
+    rough = make_interface("iem_fung92", roughness_rms=1e-3, corr_length=5e-2)
+    sp.interfaces[1] = rough
+    assert not sp.all_interfaces_flat()
+    sp.interfaces[1] = type(sp.interfaces[0])()
+    assert sp.all_interfaces_flat()
+    sp.append(make_snow_layer(1.0, "exponential", density=400, temperature=273.15, corr_length=2e-4, volumetric_liquid_water=0.01), rough)
+    assert sp.liquid_water()[3] > 0 and not sp.all_interfaces_flat()
