@@ -39,6 +39,15 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
  * smrt/core/layer.py:186-201): air inclusions in an ice background.  The layer's frac_volume entry is then the volume
  * fraction of the INCLUSIONS, i.e. 1 - (ice fraction), exactly what the reference's inverted layer carries. */
 #define SMRT_EM_IBA_INVERTED 5
+/* IBA's PHASE FUNCTION on the layer's microstructure model with the layer's SCALARS from the caller: every emmodel whose
+ * phase matrix is (coefficient) x (Fourier transform of the autocorrelation function at 2 k0 Re sqrt(eps_eff) sin(Theta/2)) x
+ * (Rayleigh geometry) -- smrt/emmodel/iba.py:228-244 -- and that differs from IBA in the numbers only: iba_original.py
+ * (absorption), iba_maxwell_garnett.py (mixing formula, field ratio), derived_IBA(<mixing formula>), IBA on layers with
+ * another permittivity model, non-spherical inclusions, a background that is not air (saline ice).  host_layer holds
+ * (ks, ka, Re eps_eff, Im eps_eff) of the layer as for SMRT_EM_HOST, host_iba_coeff the coefficient (iba.py:139-150);
+ * frac_volume and micro_p1 / micro_p2 are the ones of the (possibly inverted) medium the emmodel works on.  The phase
+ * matrices are assembled on the device: no host_streams / host_phase. */
+#define SMRT_EM_IBA_HOST 6
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1   /* micro_p1 = radius, micro_p2 = stickiness (> 0), or -t: the parameter t itself
@@ -198,6 +207,9 @@ typedef struct smrt_batch {
      * (wetice_permittivity_bohren83, the reference's default for snow layers); frac_volume is then the volume fraction of
      * ice + water (SnowLayer.compute_frac_volumes).  Applies to the device emmodels; ignored by SMRT_EM_HOST layers. */
     const double* liquid_water;
+    /* layers of kind SMRT_EM_IBA_HOST: [F * S][Lmax] the coefficient of IBA's phase matrix (see SMRT_EM_IBA_HOST), indexed
+     * like host_layer by the global pair f * S + s; null when no layer has that kind */
+    const double* host_iba_coeff;
 } smrt_batch;
 
 /* Sizes of the output rows (doubles per pair). Passive: Tb[pol V,H][theta].  Active: I[pol][pol_inc][theta_inc]

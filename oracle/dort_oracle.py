@@ -226,7 +226,7 @@ class IBALayer(LayerEM):
             # medium -- same autocorrelation family with frac_volume -> 1 - frac_volume, permittivities swapped
             frac_volume, e0, eps = 1.0 - frac_volume, eps, e0
         self.f = frac_volume
-        self.eps_eff = polder_van_santen_spheres(frac_volume, e0, eps)  # emmodel/common.py:269-289
+        self.eps_eff = self.mixing(frac_volume, e0, eps)  # emmodel/common.py:269-289
         if microstructure == "exponential":
             lc = mp["corr_length"]
             self.ft_corr = lambda k: ft_autocorr_exponential(k, frac_volume, lc)
@@ -246,15 +246,24 @@ class IBALayer(LayerEM):
             raise ValueError(microstructure)
         # mean squared field ratio with depolarisation 1/3 on each axis (iba.py:152-162)
         depol = 1.0 / 3.0
-        app = self.eps_eff * (1.0 - depol) + e0 * depol
+        app = self.apparent_permittivity(e0, depol)
         y2 = abs(app / (app + (eps - e0) * depol)) ** 2
         self.iba_coeff = (1.0 / (4.0 * np.pi)) * abs(eps - e0) ** 2 * y2 * self.k0**4  # iba.py:148-150
-        self.ka = 2.0 * self.k0 * np.sqrt(self.eps_eff).imag  # iba.py:265
+        self.ka = self.absorption(frac_volume, eps, y2)
         # ks by Romberg on 65 samples of mu in [1,-1] (iba.py:176-226); note abs(sqrt(eps_eff)) here
         mu = np.linspace(1.0, -1.0, 65)
         kd = 2.0 * self.k0 * np.sqrt((1.0 - mu) / 2.0) * abs(np.sqrt(self.eps_eff))
         y = (self.iba_coeff * self.ft_corr(kd)).real * (mu**2 + 1.0)
         self.ks = romberg65(y, mu[0] - mu[1]) / 4.0
+
+    # the three places where the other members of IBA's family differ (iba_original.py, iba_maxwell_garnett.py)
+    mixing = staticmethod(polder_van_santen_spheres)
+
+    def apparent_permittivity(self, e0, depol):
+        return self.eps_eff * (1.0 - depol) + e0 * depol           # iba.py:152-162
+
+    def absorption(self, frac_volume, eps, y2):
+        return 2.0 * self.k0 * np.sqrt(self.eps_eff).imag          # iba.py:265
 
     def phase(self, mu_s, mu_i, dphi, npol):
         """iba.py:228-244: Rayleigh matrix times the microstructure term at the half scattering angle."""
@@ -271,6 +280,33 @@ class IBADenseAutoLayer(IBALayer):
     """IBA with emmodel_options=dict(dense_snow_correction="auto") (iba.py:85-105)."""
 
     dense_snow_correction = "auto"
+
+
+class IBAOriginalLayer(IBALayer):
+    """smrt/emmodel/iba_original.py:29-44 (Maetzler 1998): IBA with the absorption k0 f Im(eps) |y2| instead of the one of
+    the effective medium."""
+
+    kind = "iba_original"
+
+    def absorption(self, frac_volume, eps, y2):
+        return self.k0 * frac_volume * complex(eps).imag * abs(y2)
+
+
+def maxwell_garnett_spheres(frac_volume, e0, eps):
+    """smrt/permittivity/generic_mixing_formula.py:361-380."""
+    cplus = eps + 2 * e0
+    cminus = (eps - e0) * frac_volume
+    return (cplus + 2 * cminus) / (cplus - cminus) * e0
+
+
+class IBAMaxwellGarnettLayer(IBALayer):
+    """smrt/emmodel/iba_maxwell_garnett.py:36-52: Maxwell Garnett mixing and the apparent permittivity of the background."""
+
+    kind = "iba_maxwell_garnett"
+    mixing = staticmethod(maxwell_garnett_spheres)
+
+    def apparent_permittivity(self, e0, depol):
+        return e0
 
 
 class DMRTQCAShortRangeLayer(LayerEM):
@@ -496,7 +532,8 @@ def rayleigh_ft_even_phase(ks, mu_s, mu_i, m_max, npol):
 def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
-    classes = {"iba": IBALayer, "iba_dense_auto": IBADenseAutoLayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
+    classes = {"iba": IBALayer, "iba_dense_auto": IBADenseAutoLayer, "iba_original": IBAOriginalLayer,
+               "iba_maxwell_garnett": IBAMaxwellGarnettLayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
                "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer,
                "rayleigh": RayleighLayer, "prescribed_kskaeps": PrescribedLayer}
     L = len(sp["thickness"])

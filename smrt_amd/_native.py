@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
 EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4,
-            "iba_inverted": 5}   # include/smrt_dort.h: SMRT_EM_*
+            "iba_inverted": 5, "iba_host": 6}   # include/smrt_dort.h: SMRT_EM_*
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1, "independent_sphere": 2, "teubner_strey": 3,   # SMRT_MS_*
             # the models on the unified parameters are reparametrisations (core/layer.py: device_microstructure_params)
             "unified_scaled_exponential": 0, "unified_sticky_hard_spheres": 1, "unified_teubner_strey": 3}
@@ -81,6 +81,7 @@ class SmrtBatch(C.Structure):
         ("host_interface_coh", C.POINTER(C.c_double)),
         ("host_interface_slots", C.c_int32),
         ("liquid_water", C.POINTER(C.c_double)),
+        ("host_iba_coeff", C.POINTER(C.c_double)),
     ]
 
 
@@ -96,7 +97,7 @@ class PackedBatch:
                  emmodel="iba", microstructure="exponential", mode="P", n_max_stream=32, m_max=2,
                  phase_normalization="auto", rayleigh_jeans=False, phi=np.pi, substrate=None, atmosphere=None,
                  prune_deep_snowpack=None, layer_kind=None, host_emmodel=None, process_coherent_layers=False,
-                 host_interfaces=None, liquid_water=None):
+                 host_interfaces=None, liquid_water=None, host_scalars=None):
         """substrate: None or (kind, p1[F][S], p2[F][S], temperature[S]) with kind "flat" (p1 + i p2 = permittivity) or
         "reflector" (p1, p2 = specular reflection V, H); temperature <= 0 or NaN = no emission.
         atmosphere: None or (tb_down[F], tb_up[F], transmittance[F]).
@@ -105,6 +106,8 @@ class PackedBatch:
         that mix emmodels / microstructure models (smrt/core/model.py:529-582).
         host_interfaces: None, or (slot[F*S][Lmax] int (-1: Flat), matrices[F*S][slots][modes][4][NE][NE],
         coh[F*S][slots][4][NE]) for rough interfaces evaluated by the caller (include/smrt_dort.h: SMRT_INTERFACE_HOST).
+        host_scalars: None, or (host_layer [F*S][Lmax][4] = ks, ka, Re eps_eff, Im eps_eff; iba_coeff [F*S][Lmax]) for layers of
+            kind "iba_host" (SMRT_EM_IBA_HOST: IBA's phase function on the device, the layer's scalars from the caller)
         liquid_water: None (dry snow) or [S][Lmax] water / (ice + water) volume of every layer; frac_volume is then the
         volume fraction of ice + water (include/smrt_dort.h).
         host_emmodel: None, or (host_layer[F*S][Lmax][4], host_streams[F*S][Lmax], host_phase[F*S][Lmax][modes][2][NE][NE])
@@ -181,6 +184,13 @@ class PackedBatch:
             self.host_phase = np.ascontiguousarray(np.asarray(hp, np.float64).reshape(FS, Lmax, modes, 2, ne, ne))
             s.host_layer, s.host_phase = _dptr(self.host_layer), _dptr(self.host_phase)
             s.host_streams = self.host_streams.ctypes.data_as(C.POINTER(C.c_int32))
+        if host_scalars is not None:
+            if host_emmodel is not None:
+                raise SMRTError("host_emmodel and host_scalars are alternatives (one host_layer array)")
+            FS = S * len(self.frequency)
+            self.host_layer = np.ascontiguousarray(np.asarray(host_scalars[0], np.float64).reshape(FS, Lmax, 4))
+            self.host_iba_coeff = np.ascontiguousarray(np.asarray(host_scalars[1], np.float64).reshape(FS, Lmax))
+            s.host_layer, s.host_iba_coeff = _dptr(self.host_layer), _dptr(self.host_iba_coeff)
         s.process_coherent_layers = 1 if process_coherent_layers else 0
         if liquid_water is not None:
             self.liquid_water = two_d(liquid_water)

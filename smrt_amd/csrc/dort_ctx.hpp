@@ -29,7 +29,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase, d_done, d_hostlayer, d_hoststreams, d_hostphase, d_dispatch, d_regws, d_itfslot, d_itf, d_itfcoh, d_lw;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase, d_done, d_hostlayer, d_hostcoeff, d_hoststreams, d_hostphase, d_dispatch, d_regws, d_itfslot, d_itf, d_itfcoh, d_lw;
     smrt::DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;

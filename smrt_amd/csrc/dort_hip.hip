@@ -380,9 +380,13 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if (b->layer_kind && upload_array(ctx, ctx->d_kind, b->layer_kind, sizeof(int32_t) * SL)) return -1;
     if (b->liquid_water && upload_array(ctx, ctx->d_lw, b->liquid_water, sizeof(double) * SL)) return -1;
     const size_t host_modes = ctx->active ? (size_t)b->m_max + 1 : 1, host_ne = (size_t)b->n_max_stream * P;
-    if (b->host_layer && b->host_streams && b->host_phase) {   // emmodels evaluated by the caller
+    if (b->host_layer) {   // scalars of the layers evaluated by the caller (SMRT_EM_HOST, SMRT_EM_IBA_HOST)
         const size_t PL = (size_t)npairs * b->n_layers_max;
         if (upload_array(ctx, ctx->d_hostlayer, b->host_layer, sizeof(double) * PL * 4)) return -1;
+        if (b->host_iba_coeff && upload_array(ctx, ctx->d_hostcoeff, b->host_iba_coeff, sizeof(double) * PL)) return -1;
+    }
+    if (b->host_layer && b->host_streams && b->host_phase) {   // ... and their phase matrices (SMRT_EM_HOST)
+        const size_t PL = (size_t)npairs * b->n_layers_max;
         if (upload_array(ctx, ctx->d_hoststreams, b->host_streams, sizeof(int32_t) * PL)) return -1;
         if (upload_array(ctx, ctx->d_hostphase, b->host_phase, sizeof(double) * PL * host_modes * 2 * host_ne * host_ne)) return -1;
     }
@@ -438,7 +442,8 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     d.layer_kind = b->layer_kind ? (const int*)ctx->d_kind.p : nullptr;
     d.liquid_water = b->liquid_water ? (const double*)ctx->d_lw.p : nullptr;
     const bool has_host = b->host_layer && b->host_streams && b->host_phase;
-    d.host_layer = has_host ? (const double*)ctx->d_hostlayer.p : nullptr;
+    d.host_layer = b->host_layer ? (const double*)ctx->d_hostlayer.p : nullptr;
+    d.host_coeff = (b->host_layer && b->host_iba_coeff) ? (const double*)ctx->d_hostcoeff.p : nullptr;
     d.host_streams = has_host ? (const int*)ctx->d_hoststreams.p : nullptr;
     d.host_phase = has_host ? (const double*)ctx->d_hostphase.p : nullptr;
     d.host_modes = (int)host_modes; d.host_ne = (int)host_ne;
@@ -517,7 +522,7 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity) {
         SMRT_OFF(atm_tb_up), SMRT_OFF(atm_transmittance), SMRT_OFF(prune_optical_depth), SMRT_OFF(layer_kind),
         SMRT_OFF(host_layer), SMRT_OFF(host_streams), SMRT_OFF(host_phase), SMRT_OFF(process_coherent_layers),
         SMRT_OFF(host_substrate), SMRT_OFF(host_substrate_coh), SMRT_OFF(host_interface_slot), SMRT_OFF(host_interface),
-        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots), SMRT_OFF(liquid_water)};
+        SMRT_OFF(host_interface_coh), SMRT_OFF(host_interface_slots), SMRT_OFF(liquid_water), SMRT_OFF(host_iba_coeff)};
 #undef SMRT_OFF
     const int32_t n = (int32_t)(sizeof(desc) / sizeof(desc[0]));
     for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = desc[i];

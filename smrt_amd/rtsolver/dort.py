@@ -257,24 +257,32 @@ class DORT(object):
             for s, sp in enumerate(sps):
                 if len(emmodel_names[s]) != nl[s]:
                     raise SMRTError("one emmodel per layer is needed")
+        scalars = None
         if not isinstance(emmodel_names, str) and any(not isinstance(e, str) for row in emmodel_names for e in row):
-            # at least one emmodel without a device implementation: the whole group is evaluated through the emmodel
-            # protocol on the host (the device classes speak it too) and handed to the device as numbers
-            host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
-            layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
+            # at least one emmodel without a device implementation.  Emmodels of IBA's family on a microstructure model the
+            # device has hand over their scalars only -- the phase matrices are assembled on the device
+            # (SMRT_EM_IBA_HOST); otherwise the whole group is evaluated through the emmodel protocol on the host (the
+            # device classes speak it too) and handed to the device as numbers, phase matrices included (SMRT_EM_HOST)
+            scalars = self._iba_scalars_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
+            if scalars is not None:
+                layer_kind = scalars[2]
+            else:
+                host = self._evaluate_on_host(sensor0, sps, freqs, emmodel_names, nl, Lmax, sensor_of or {})
+                layer_kind = np.full((S, Lmax), EM_CODES["host"], np.int32)
         elif not (isinstance(emmodel_names, str) and uniform_micro):
             layer_kind = np.zeros((S, Lmax), np.int32)
             for s, sp in enumerate(sps):
                 em = [emmodel_names] * nl[s] if isinstance(emmodel_names, str) else emmodel_names[s]
                 layer_kind[s, :nl[s]] = [EM_CODES[e] + 16 * self._ms_code(lay) for e, lay in zip(em, sp.layers)]
-        if host is None:
+        if host is None and scalars is None:
             from ..core.layer import DEVICE_MICROSTRUCTURES
 
             foreign = set().union(*micro) - set(DEVICE_MICROSTRUCTURES)
             if foreign:
                 raise SMRTError(f"the microstructure model(s) {sorted(foreign)} have no device implementation: they can only "
                                 "be used with an emmodel evaluated on the host (e.g. rayleigh, prescribed_kskaeps)")
-        device_name = "host" if host is not None else (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
+        device_name = "host" if host is not None else "iba" if scalars is not None else \
+            (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
             cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
         else:
@@ -282,7 +290,11 @@ class DORT(object):
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
             for s, sp in enumerate(sps):
                 cols[:, s, :nl[s]] = sp.packed()
-        if layer_kind is not None and host is None:
+        if scalars is not None:
+            # the medium every emmodel object works on (its own frac_volume and microstructure: inverted above half ice
+            # under dense_snow_correction="auto"), read while the scalars were taken
+            cols[1], cols[3], cols[4] = scalars[3], scalars[4], scalars[5]
+        elif layer_kind is not None and host is None:
             # IBA on the inverted medium (dense_snow_correction="auto" above half ice): the device takes the volume
             # fraction of the inclusions, the air (include/smrt_dort.h: SMRT_EM_IBA_INVERTED)
             inverted = (layer_kind & 15) == EM_CODES["iba_inverted"]
@@ -298,6 +310,7 @@ class DORT(object):
                 if w is not None:
                     liquid_water[s, :nl[s]] = w
         self._liquid_water = liquid_water     # (read by the probes of _layer_permittivities for this group)
+        self._host_scalars = scalars
         mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate
@@ -316,13 +329,14 @@ class DORT(object):
             atmosphere = (a[:, 0], a[:, 1], a[:, 2])
         return PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs,
                            sensor0.theta_inc if mode == "A" else sensor0.theta, emmodel=device_name,
-                           microstructure=sps[0].layers[0].microstructure_model if host is None else "exponential",
+                           microstructure=sps[0].layers[0].microstructure_model if host is None and scalars is None else "exponential",
                            mode=mode,
                            n_max_stream=self.n_max_stream, m_max=self.m_max,
                            phase_normalization=self.phase_normalization,
                            rayleigh_jeans=self.rayleigh_jeans_approximation, phi=float(np.ravel(sensor0.phi)[0]),
                            substrate=substrate, atmosphere=atmosphere, prune_deep_snowpack=self.prune_deep_snowpack,
                            layer_kind=layer_kind, host_emmodel=host,
+                           host_scalars=None if scalars is None else scalars[:2],
                            process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces,
                            liquid_water=liquid_water)
 
@@ -335,10 +349,12 @@ class DORT(object):
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         if host is not None:
             return host[0][..., 2] + 1j * host[0][..., 3]
-        name = emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
+        scal = getattr(self, "_host_scalars", None)   # emmodels of IBA's family: their scalars travel with the probe
+        name = "iba" if scal is not None else emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
         probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
-                            microstructure=sps[0].layers[0].microstructure_model, n_max_stream=4,
-                            phase_normalization="forced", layer_kind=layer_kind,
+                            microstructure=sps[0].layers[0].microstructure_model if scal is None else "exponential",
+                            n_max_stream=4, phase_normalization="forced", layer_kind=layer_kind,
+                            host_scalars=None if scal is None else scal[:2],
                             liquid_water=getattr(self, "_liquid_water", None))
         # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
         res = get_context((self.devices or [default_device()])[0]).run(probe)
@@ -582,6 +598,109 @@ class DORT(object):
     # ---- emmodels evaluated on the host (include/smrt_dort.h: SMRT_EM_HOST) ----------------------------------------
     HOST_PHASE_BYTES_MAX = 8e9
 
+    @staticmethod
+    def _emmodel_instance(entry, sensor, layer):
+        """The emmodel object of a layer from its entry: a device emmodel name, an (emmodel class, options) pair or a ready
+        instance (rtsolver protocol)."""
+        from ..core.foreign import is_native
+        from ..core.plugin import import_class
+
+        if isinstance(entry, str):
+            # a device emmodel inside a group that is evaluated on the host: its descriptor class speaks the protocol
+            # too ("iba_inverted" is IBA under dense_snow_correction="auto", the only option the device names carry)
+            if entry == "iba_inverted":
+                return import_class("emmodel", "iba")(sensor, layer, dense_snow_correction="auto")
+            return import_class("emmodel", entry)(sensor, layer)
+        if isinstance(entry, tuple):
+            # a class of the reference package is given the reference's own layer object (core/foreign.py)
+            target = layer if is_native(entry[0]) else getattr(layer, "source", layer)
+            return entry[0](sensor, target, **entry[1])
+        return entry
+
+    @staticmethod
+    def _isotropic(value, what):
+        a = np.asarray(getattr(value, "values", value), float).ravel()   # (an smrt_matrix keeps its array in .values)
+        if a.size == 0 or not np.allclose(a, a[0], rtol=1e-12, atol=0.0):
+            raise SMRTError(f"smrt_amd's DORT needs an isotropic {what} (one number per layer)")
+        return float(a[0])
+
+    @staticmethod
+    def _iba_phase_coefficient(em):
+        """The coefficient of the phase matrix when `em` is an emmodel of IBA's family -- its phase matrix is IBA's own
+        `phase` / `ft_even_phase` (smrt/emmodel/iba.py:228-244: coefficient x Fourier transform of the autocorrelation
+        function x Rayleigh geometry), whatever it does to the scalars: IBA on any permittivity model / inclusion shape /
+        background, IBA_original, IBA_MaxwellGarnett, derived_IBA(...); or a class that declares `iba_phase_family = True`
+        and carries `iba_coeff`, `frac_volume`, `microstructure` next to the scalar accessors of the protocol -- else None."""
+        cls = type(em)
+        coeff = getattr(em, "iba_coeff", None)
+        if coeff is None or not hasattr(em, "microstructure") or not hasattr(em, "frac_volume"):
+            return None
+        if not getattr(cls, "iba_phase_family", False):   # (a class of the caller's own may declare the family itself)
+            base = next((c for c in cls.__mro__ if c.__name__ == "IBA" and (c.__module__ or "").endswith("emmodel.iba")), None)
+            if base is None:
+                return None
+            for method in ("phase", "ft_even_phase"):
+                if getattr(cls, method, None) is not getattr(base, method, None):
+                    return None
+        coeff = complex(coeff)
+        return coeff.real if coeff.imag == 0.0 and coeff.real >= 0.0 else None
+
+    def _iba_scalars_on_host(self, sensor0, sps, freqs, entries, nl, Lmax, sensor_of):
+        """The cheap half of the host route for emmodels of IBA's family (include/smrt_dort.h: SMRT_EM_IBA_HOST): effective
+        permittivity, ks, ka and the coefficient of the phase matrix of every (frequency, snowpack, layer) from the emmodel
+        objects; the phase matrices themselves are assembled on the device from the layer's microstructure model.  Returns
+        (host_layer [F, S, Lmax, 4], coefficient [F, S, Lmax], per-layer kinds, frac_volume, micro_p1, micro_p2 [S, Lmax])
+        -- the medium the emmodel works on (inverted above half ice under dense_snow_correction="auto") --, or None when
+        a layer's emmodel is of another family or its microstructure model has no device code: the full host route
+        (_evaluate_on_host) then applies."""
+        import copy
+
+        from .._native import EM_CODES, MS_CODES
+        from ..core.foreign import _device_microstructure, is_native
+
+        P = 2 if sensor0.mode == "P" else 3
+        F, S = len(freqs), len(sps)
+        hl = np.zeros((F, S, Lmax, 4)); hl[..., 2] = 1.0
+        coeff = np.zeros((F, S, Lmax))
+        kinds = np.zeros((S, Lmax), np.int32)
+        fv = np.full((S, Lmax), 0.3); p1 = np.full((S, Lmax), 1e-4); p2 = np.full((S, Lmax), 0.2)   # harmless padding
+        one = np.array([1.0])
+        for fi, f in enumerate(freqs):
+            sensor = sensor_of.get(float(f))
+            if sensor is None:
+                sensor = copy.copy(sensor0)
+                sensor.frequency = float(f)
+            for s, sp in enumerate(sps):
+                for l, layer in enumerate(sp.layers):
+                    if isinstance(entries[s][l], str):     # a device emmodel: nothing to evaluate here
+                        if fi == 0:
+                            name = entries[s][l]
+                            kinds[s, l] = EM_CODES[name] + 16 * self._ms_code(layer)
+                            q = layer.microstructure.device_params
+                            fv[s, l] = 1.0 - layer.frac_volume if name == "iba_inverted" else layer.frac_volume
+                            p1[s, l], p2[s, l] = q
+                        continue
+                    em = self._emmodel_instance(entries[s][l], sensor, layer)
+                    c = self._iba_phase_coefficient(em)
+                    if c is None:
+                        return None
+                    ms = em.microstructure
+                    if is_native(ms) or hasattr(ms, "device_params"):
+                        name, (q1, q2) = getattr(ms, "name", None), ms.device_params
+                    else:
+                        name, q1, q2 = _device_microstructure(ms)
+                    if name not in MS_CODES:
+                        return None
+                    ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
+                    ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
+                    eps = complex(em.effective_permittivity())
+                    hl[fi, s, l] = self._isotropic(ks, "ks"), self._isotropic(ka, "ka"), eps.real, eps.imag
+                    coeff[fi, s, l] = c
+                    if fi == 0:
+                        kinds[s, l] = EM_CODES["iba_host"] + 16 * MS_CODES[name]
+                        fv[s, l], p1[s, l], p2[s, l] = float(em.frac_volume), q1, q2
+        return hl, coeff, kinds, fv, p1, p2
+
     def _evaluate_on_host(self, sensor0, sps, freqs, entries, nl, Lmax, sensor_of):
         """What smrt/rtsolver/dort.py:189,231-247,714-762 asks of the emmodels -- effective permittivity, ks, ka and the
         azimuth modes of the phase matrix on the layer's own streams -- for every (frequency, snowpack, layer) of the
@@ -610,24 +729,7 @@ class DORT(object):
         gmu, _ = gauss_legendre_positive(self.n_max_stream)
         gsin = np.sqrt(1.0 - gmu * gmu)
 
-        def instance(entry, sensor, layer):
-            if isinstance(entry, str):
-                # a device emmodel inside a group that is evaluated on the host: its descriptor class speaks the protocol
-                # too ("iba_inverted" is IBA under dense_snow_correction="auto", the only option the device names carry)
-                if entry == "iba_inverted":
-                    return import_class("emmodel", "iba")(sensor, layer, dense_snow_correction="auto")
-                return import_class("emmodel", entry)(sensor, layer)
-            if isinstance(entry, tuple):
-                # a class of the reference package is given the reference's own layer object (core/foreign.py)
-                target = layer if is_native(entry[0]) else getattr(layer, "source", layer)
-                return entry[0](sensor, target, **entry[1])
-            return entry
-
-        def scalar(value, what):
-            a = np.asarray(getattr(value, "values", value), float).ravel()   # (an smrt_matrix keeps its array in .values)
-            if a.size == 0 or not np.allclose(a, a[0], rtol=1e-12, atol=0.0):
-                raise SMRTError(f"smrt_amd's DORT needs an isotropic {what} (one number per layer)")
-            return float(a[0])
+        instance, scalar = self._emmodel_instance, self._isotropic
 
         for fi, f in enumerate(freqs):
             sensor = sensor_of.get(float(f))

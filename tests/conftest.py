@@ -87,6 +87,23 @@ def packed_batch_from_fixture(d, freqs=None):
         dense = np.asarray(sp["frac_volume"]) > 0.5
         emmodel = ["iba_inverted" if x else "iba" for x in dense]
         sp["frac_volume"] = np.where(dense, 1.0 - np.asarray(sp["frac_volume"]), sp["frac_volume"])
+    host_scalars = None
+    family = ("iba_original", "iba_maxwell_garnett")     # IBA's phase function, other scalars: SMRT_EM_IBA_HOST
+    if emmodel in family or (isinstance(emmodel, list) and any(e in family for e in emmodel)):
+        # the scalars the emmodel OBJECT would hand over (rtsolver/dort.py:_iba_scalars_on_host), here from the oracle's
+        # layer objects: ks, ka, effective permittivity, the coefficient of the phase matrix -- per frequency and layer
+        from oracle import dort_oracle as O
+
+        L = len(sp["thickness"])
+        names = emmodel if isinstance(emmodel, list) else [emmodel] * L
+        fsel = np.atleast_1d(d["frequency"])[slice(None) if freqs is None else freqs]
+        hl, hc = np.zeros((len(fsel), 1, L, 4)), np.zeros((len(fsel), 1, L))
+        for fi, f in enumerate(fsel):
+            for l, em in enumerate(O.make_layers(names, float(f), sp)):
+                hl[fi, 0, l] = em.ks, em.ka, complex(em.eps_eff).real, complex(em.eps_eff).imag
+                hc[fi, 0, l] = em.iba_coeff
+        host_scalars = (hl, hc)
+        emmodel = ["iba_host" if e in family else e for e in names]
     if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
         L = len(sp["thickness"])
         msl = ms if isinstance(ms, list) else [ms] * L
@@ -131,6 +148,7 @@ def packed_batch_from_fixture(d, freqs=None):
                        n_max_stream=o["n_max_stream"], m_max=o["m_max"], substrate=substrate, atmosphere=atmosphere,
                        prune_deep_snowpack=o.get("prune_deep_snowpack"), layer_kind=layer_kind,
                        process_coherent_layers=fixture_coherent(d), liquid_water=sp.get("liquid_water"),
+                       host_scalars=host_scalars,
                        host_interfaces=(pack_host_interfaces([fixture_interfaces(d)] * len(np.atleast_1d(d["frequency"][sel])),
                                                              len(sp["thickness"]), o["n_max_stream"],
                                                              (o["m_max"] + 1) if active else 1)
@@ -173,6 +191,9 @@ WET_FIXTURES = ["iba_wet_L4_n12_passive", "iba_wet_L3_n10_active", "dmrt_wet_L3_
 # both sides of polydispersity 1, sticky hard spheres -- reparametrisations of the device's closed forms
 MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active", "iba_unified4_L4_n12_passive",
                   "iba_unified4_L4_n10_active"]
+# the other members of IBA's family (iba_original, iba_maxwell_garnett; one per layer mixed with plain IBA): IBA's phase
+# matrix assembled on the device, the scalars from the emmodel object (SMRT_EM_IBA_HOST)
+IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

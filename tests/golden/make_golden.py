@@ -794,6 +794,25 @@ def main():
             save("iba_unified4_L4_n10_active", run_new("iba", active(13.4e9, [30, 40]), unified_pack(1000.0),
                                                         rtsolver_options=dict(n_max_stream=10, m_max=2)))
 
+    # (iv-l) the other members of IBA's family (smrt/emmodel/iba_original.py, iba_maxwell_garnett.py): IBA's phase matrix with
+    # other scalars -- on the device through SMRT_EM_IBA_HOST (the scalars from the emmodel object, the phase matrices
+    # assembled by the kernels); one emmodel for the snowpack, and one per layer mixed with plain IBA
+    if wanted("iba_original_L3_n12_passive") or wanted("iba_mg_L3_n10_active") or wanted("iba_family_L3_n12_passive"):
+        def family_pack(last, micro="exponential"):
+            return make_snowpack([0.25, 0.35, last], micro, density=[220, 310, 390], temperature=[257, 262, 266],
+                                 corr_length=[1.2e-4, 2.0e-4, 2.6e-4]) if micro == "exponential" else \
+                make_snowpack([0.25, 0.35, last], micro, density=[220, 310, 390], temperature=[257, 262, 266],
+                              radius=[1.5e-4, 2.0e-4, 2.4e-4], stickiness=[0.2, 0.3, 0.5])
+        if wanted("iba_original_L3_n12_passive"):
+            save("iba_original_L3_n12_passive", run_new("iba_original", passive([10.65e9, 36.5e9, 89e9], [40, 55]), family_pack(100.0),
+                                                         rtsolver_options=dict(n_max_stream=12)))
+        if wanted("iba_mg_L3_n10_active"):
+            save("iba_mg_L3_n10_active", run_new("iba_maxwell_garnett", active(13.4e9, [30, 40]), family_pack(1000.0, "sticky_hard_spheres"),
+                                                  rtsolver_options=dict(n_max_stream=10, m_max=2)))
+        if wanted("iba_family_L3_n12_passive"):
+            save("iba_family_L3_n12_passive", run_new(["iba_maxwell_garnett", "iba", "iba_original"], passive([18.7e9, 36.5e9], [55]),
+                                                       family_pack(100.0), rtsolver_options=dict(n_max_stream=12)))
+
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
     from smrt.emmodel.iba import IBA

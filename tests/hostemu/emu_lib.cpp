@@ -199,7 +199,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.frequency = b->frequency; d.theta = b->theta; d.gl_mu = gl.data(); d.phi = b->phi;
     d.layer_kind = b->layer_kind;
     d.liquid_water = b->liquid_water;
-    d.host_layer = b->host_layer; d.host_streams = b->host_streams; d.host_phase = b->host_phase;
+    d.host_layer = b->host_layer; d.host_coeff = b->host_iba_coeff; d.host_streams = b->host_streams; d.host_phase = b->host_phase;
     d.host_modes = active ? b->m_max + 1 : 1; d.host_ne = b->n_max_stream * (active ? 3 : 2);
     d.coherent = b->process_coherent_layers ? 1 : 0;
     d.host_substrate = b->host_substrate; d.host_substrate_coh = b->host_substrate_coh;

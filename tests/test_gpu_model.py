@@ -774,3 +774,50 @@ def test_other_microstructure_models_through_the_model():
                        microstructure="teubner_strey", corr_length=np.array([1.5e-4, 2e-4]), repeat_distance=np.array([1e-3, 1.5e-3])),
                   36.5e9, [55.0], n_max_stream=16)
     assert np.abs(np.ravel(res.data.values) - np.ravel(ref)).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_an_emmodel_of_the_iba_family_hands_over_its_scalars():
+    """SMRT_EM_IBA_HOST through Model.run: an emmodel class whose phase matrix is IBA's and whose scalars are its own --
+    here IBA_original's and IBA_MaxwellGarnett's numbers, evaluated by a class of this test file from the oracle's layer
+    objects (the GPU box has no reference package; with the reference's own classes: tests/test_reference_binding.py) --
+    declares `iba_phase_family`, and the solver takes effective permittivity, ks, ka and the phase coefficient from the
+    object and assembles the phase matrices on the device: the reference's results for these emmodels (fixtures)."""
+    from conftest import IBA_FAMILY_FIXTURES, reference_method_spread
+    from oracle import dort_oracle as O
+    from smrt_amd import make_model, make_snowpack, sensor_list
+
+    def family_member(oracle_class):
+        class Member:
+            iba_phase_family = True          # phase matrix = iba_coeff x FT of the autocorrelation function x Rayleigh geometry
+
+            def __init__(self, sensor, layer):
+                ms = layer.microstructure
+                params = {k: getattr(ms, k) for k in ("corr_length", "radius", "stickiness") if hasattr(ms, k)}
+                em = oracle_class(float(sensor.frequency), layer.frac_volume, layer.temperature, layer.microstructure_model, **params)
+                self.frac_volume, self.microstructure = layer.frac_volume, ms
+                self.iba_coeff, self.ka, self._ks, self._eps = em.iba_coeff, em.ka, em.ks, em.eps_eff
+
+            def effective_permittivity(self):
+                return self._eps
+
+            def ks(self, mu, npol=2):
+                return np.full((npol, np.size(mu)), self._ks)
+        return Member
+
+    members = {"iba_original": family_member(O.IBAOriginalLayer), "iba_maxwell_garnett": family_member(O.IBAMaxwellGarnettLayer)}
+    for name in IBA_FAMILY_FIXTURES:
+        d = load_golden(name)
+        ms = str(d["microstructure"])
+        args = dict(corr_length=d["corr_length"]) if ms == "exponential" else dict(radius=d["radius"], stickiness=d["stickiness"])
+        sp = make_snowpack(d["thickness"], ms, density=d["density"], temperature=d["temperature"], **args)
+        em = [members.get(str(e), str(e)) for e in np.atleast_1d(d["emmodel"])]
+        em = em[0] if len(em) == 1 else em
+        opts = dict(n_max_stream=int(d["opt_n_max_stream"]))
+        if str(d["mode"]) == "A":
+            opts["m_max"] = int(d["opt_m_max"])
+            res = make_model(em, "dort", rtsolver_options=opts).run(sensor_list.active(list(d["frequency"]), list(d["theta_inc_deg"])), sp)
+            assert_backscatter_close(np.asarray(res.data.values).reshape(d["result"].shape), d["result"], spread=reference_method_spread(d))
+        else:
+            res = make_model(em, "dort", rtsolver_options=opts).run(sensor_list.passive(list(d["frequency"]), list(d["theta_deg"])), sp)
+            assert np.abs(np.asarray(res.data.values).reshape(d["result"].shape) - d["result"]).max() < 1e-6

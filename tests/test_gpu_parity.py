@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, BIG_ACTIVE_FIXTURES, COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, IBA_FAMILY_FIXTURES, host_batch_from_fixture, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES,
                       SUBSTRATE_FIXTURES, assert_backscatter_close, fixture_options, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread, snowpack_dict)
 
@@ -614,7 +614,7 @@ def test_cfg4_shape_batch_through_staging_chunks(ctx):
         assert np.array_equal(part.values, full.values[lo:hi])
 
 
-@pytest.mark.parametrize("name", MIXED_FIXTURES + DENSE_AUTO_FIXTURES + WET_FIXTURES + MICRO_FIXTURES)
+@pytest.mark.parametrize("name", MIXED_FIXTURES + DENSE_AUTO_FIXTURES + WET_FIXTURES + MICRO_FIXTURES + IBA_FAMILY_FIXTURES)
 @pytest.mark.parametrize("threads,pipeline", KERNEL_VARIANTS)
 def test_heterogeneous_snowpacks_golden(ctx, name, threads, pipeline):
     """smrt_batch.layer_kind: one emmodel per layer (IBA / DMRT QCA short range / non-scattering) over layers mixing the

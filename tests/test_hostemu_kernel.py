@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import (COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
+from conftest import (COHERENT_FIXTURES, COHERENT_HOST_FIXTURES, HOST_EMMODEL_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, IBA_FAMILY_FIXTURES, host_batch_from_fixture, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, ROOT, SUBSTRATE_FIXTURES, assert_backscatter_close, load_golden, oracle_method_spread,
                       packed_batch_from_fixture, reference_method_spread)
 from smrt_amd._native import PackedBatch, SmrtBatch
 
@@ -236,7 +236,8 @@ def test_blocked_jacobi_kernel_gives_the_singular_values(emu, n_max_stream, N, o
 
 
 @pytest.mark.parametrize("name,nt", [(MIXED_FIXTURES[0], 64), (MIXED_FIXTURES[1], 256), (DENSE_AUTO_FIXTURES[0], 256),
-                                     (DENSE_AUTO_FIXTURES[1], 128), (WET_FIXTURES[0], 256), (WET_FIXTURES[1], 64), (WET_FIXTURES[2], 128), (MICRO_FIXTURES[0], 256), (MICRO_FIXTURES[1], 64), (MICRO_FIXTURES[2], 256), (MICRO_FIXTURES[3], 64)])
+                                     (DENSE_AUTO_FIXTURES[1], 128), (WET_FIXTURES[0], 256), (WET_FIXTURES[1], 64), (WET_FIXTURES[2], 128), (MICRO_FIXTURES[0], 256), (MICRO_FIXTURES[1], 64), (MICRO_FIXTURES[2], 256), (MICRO_FIXTURES[3], 64),
+                                     (IBA_FAMILY_FIXTURES[0], 256), (IBA_FAMILY_FIXTURES[1], 64), (IBA_FAMILY_FIXTURES[2], 64)])
 def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
     """Per-layer emmodel and microstructure codes (smrt_batch.layer_kind) through the device code; IBA on the inverted
     medium for layers above half ice (SMRT_EM_IBA_INVERTED, the reference's dense_snow_correction="auto")."""
