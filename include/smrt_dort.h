@@ -48,6 +48,11 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
  * frac_volume and micro_p1 / micro_p2 are the ones of the (possibly inverted) medium the emmodel works on.  The phase
  * matrices are assembled on the device: no host_streams / host_phase. */
 #define SMRT_EM_IBA_HOST 6
+/* The RAYLEIGH phase matrix, 3 ks / 2 x the geometry of smrt/emmodel/rayleigh.py:52-127, with the layer's scalars from the
+ * caller (host_layer = ks, ka, Re eps_eff, Im eps_eff): every emmodel that inherits ft_even_phase from smrt's Rayleigh --
+ * rayleigh.py, sft_rayleigh.py, prescribed_kskaeps.py, the dmrt short-range emmodels on layers the device versions
+ * refuse.  The microstructure code and parameters of such a layer are not read. */
+#define SMRT_EM_RAYLEIGH_HOST 7
 /* microstructure (smrt/microstructure_model/exponential.py, sticky_hard_spheres.py) */
 #define SMRT_MS_EXPONENTIAL 0
 #define SMRT_MS_STICKY_HARD_SPHERES 1   /* micro_p1 = radius, micro_p2 = stickiness (> 0), or -t: the parameter t itself

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMRT_DORT_LIB") or os.path.join(_HERE, "csrc", "libsmrt_dort.so")
 
 EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "nonscattering": 3, "host": 4,
-            "iba_inverted": 5, "iba_host": 6}   # include/smrt_dort.h: SMRT_EM_*
+            "iba_inverted": 5, "iba_host": 6, "rayleigh_host": 7}   # include/smrt_dort.h: SMRT_EM_*
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1, "independent_sphere": 2, "teubner_strey": 3,   # SMRT_MS_*
             # the models on the unified parameters are reparametrisations (core/layer.py: device_microstructure_params)
             "unified_scaled_exponential": 0, "unified_sticky_hard_spheres": 1, "unified_teubner_strey": 3}

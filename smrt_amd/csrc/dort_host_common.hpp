@@ -109,9 +109,10 @@ inline const char* validate(const smrt_batch* b) {
     if (b->n_snowpacks <= 0 || b->n_frequencies <= 0 || b->n_layers_max <= 0) return "empty batch";
     if (b->n_theta <= 0) return "n_theta must be positive";
     if (b->n_max_stream < 2) return "n_max_stream must be >= 2";
-    if (b->emmodel < SMRT_EM_IBA || b->emmodel > SMRT_EM_IBA_HOST) return "unknown emmodel";
+    if (b->emmodel < SMRT_EM_IBA || b->emmodel > SMRT_EM_RAYLEIGH_HOST) return "unknown emmodel";
     bool host_layers = (!b->layer_kind && b->emmodel == SMRT_EM_HOST);
     bool scalar_layers = (!b->layer_kind && b->emmodel == SMRT_EM_IBA_HOST);
+    bool rayleigh_layers = (!b->layer_kind && b->emmodel == SMRT_EM_RAYLEIGH_HOST);
     if (b->microstructure < SMRT_MS_EXPONENTIAL || b->microstructure > SMRT_MS_TEUBNER_STREY)
         return "unknown microstructure";
     if (!b->layer_kind && (b->emmodel == SMRT_EM_DMRT_QCA_SHORTRANGE || b->emmodel == SMRT_EM_DMRT_QCACP_SHORTRANGE) &&
@@ -121,10 +122,11 @@ inline const char* validate(const smrt_batch* b) {
         for (int s = 0; s < b->n_snowpacks; ++s)
             for (int l = 0; l < b->n_layers[s]; ++l) {
                 const int k = b->layer_kind[(long long)s * b->n_layers_max + l], em = k & 15, ms = k >> 4;
-                if (em < SMRT_EM_IBA || em > SMRT_EM_IBA_HOST || ms < SMRT_MS_EXPONENTIAL || ms > SMRT_MS_TEUBNER_STREY)
+                if (em < SMRT_EM_IBA || em > SMRT_EM_RAYLEIGH_HOST || ms < SMRT_MS_EXPONENTIAL || ms > SMRT_MS_TEUBNER_STREY)
                     return "invalid layer_kind entry";
                 if (em == SMRT_EM_HOST) host_layers = true;
                 if (em == SMRT_EM_IBA_HOST) scalar_layers = true;
+                if (em == SMRT_EM_RAYLEIGH_HOST) rayleigh_layers = true;
                 if ((em == SMRT_EM_DMRT_QCA_SHORTRANGE || em == SMRT_EM_DMRT_QCACP_SHORTRANGE) && ms != SMRT_MS_STICKY_HARD_SPHERES)
                     return "the dmrt short-range emmodels are only compatible with sticky_hard_spheres";
             }
@@ -132,6 +134,7 @@ inline const char* validate(const smrt_batch* b) {
         return "layers of kind SMRT_EM_HOST need host_layer, host_streams and host_phase";
     if (scalar_layers && (!b->host_layer || !b->host_iba_coeff))
         return "layers of kind SMRT_EM_IBA_HOST need host_layer and host_iba_coeff";
+    if (rayleigh_layers && !b->host_layer) return "layers of kind SMRT_EM_RAYLEIGH_HOST need host_layer";
     if (b->mode != SMRT_MODE_PASSIVE && b->mode != SMRT_MODE_ACTIVE) return "unknown mode";
     if (!b->n_layers || !b->thickness || !b->frac_volume || !b->temperature || !b->micro_p1 || !b->frequency ||
         !b->theta)

@@ -117,13 +117,14 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
     for (int l = t; l < L; l += NT) {
         cplx ee; double ks, ka, pa, pb; int bad = 0;
         const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
-        if (__builtin_expect((kind & 15) == EM_HOST || (kind & 15) == EM_IBA_HOST, 0)) {   // scalars from the caller (smrt_batch.host_layer)
+        if (__builtin_expect((kind & 15) == EM_HOST || (kind & 15) == EM_IBA_HOST || (kind & 15) == EM_RAYLEIGH_HOST, 0)) {   // scalars from the caller (smrt_batch.host_layer)
             if (b.host_layer) {
                 const double* h = b.host_layer + (gp * b.Lmax + l) * 4;   // (l: still the index in the input arrays here)
                 ks = h[0]; ka = h[1]; ee = cmk(h[2], h[3]);
                 if (!(ka >= 0.0) || !(ee.re > 0.0)) bad = 1;
             } else { ks = ka = 0.0; ee = cmk(1.0, 0.0); bad = 1; }
             pa = pb = 0.0;
+            if ((kind & 15) == EM_RAYLEIGH_HOST) pa = 1.5 * ks;   // the Rayleigh phase matrix of the dmrt kinds (rayleigh.py:127)
             if ((kind & 15) == EM_IBA_HOST) {
                 // IBA's phase function with the caller's coefficient: pa / pb as layer_em leaves them for IBA (iba.py:228-244)
                 const double coeff = b.host_coeff ? b.host_coeff[gp * b.Lmax + l] : -1.0;
@@ -137,7 +138,8 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad,
                  __builtin_expect(b.liquid_water != nullptr, 0) ? b.liquid_water[(gp % b.S) * b.Lmax + l] : 0.0);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
-        s.pc[l] = (double)(((kind & 15) == EM_IBA_INV || (kind & 15) == EM_IBA_HOST) ? (kind & ~15) | EM_IBA : kind);   // the phase function is IBA's either way
+        s.pc[l] = (double)(((kind & 15) == EM_IBA_INV || (kind & 15) == EM_IBA_HOST) ? (kind & ~15) | EM_IBA   // the phase function is IBA's either way
+                           : (kind & 15) == EM_RAYLEIGH_HOST ? (kind & ~15) | EM_DMRT : kind);                // ... or Rayleigh's
         s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;
         s.thick[l] = thickness[l];
         s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);

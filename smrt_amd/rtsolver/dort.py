@@ -645,10 +645,28 @@ class DORT(object):
         coeff = complex(coeff)
         return coeff.real if coeff.imag == 0.0 and coeff.real >= 0.0 else None
 
+    @staticmethod
+    def _has_rayleigh_phase(em):
+        """Is the phase matrix of `em` the Rayleigh one, 3 ks / 2 x the geometry of smrt/emmodel/rayleigh.py:52-127?  True for a
+        class that inherits `ft_even_phase` from smrt's `Rayleigh` unchanged (rayleigh, sft_rayleigh, prescribed_kskaeps, the
+        dmrt short-range emmodels), for smrt_amd's own host emmodels of that shape (emmodel/rayleigh.py), and for a class
+        that declares `rayleigh_phase_family = True`."""
+        cls = type(em)
+        if getattr(cls, "rayleigh_phase_family", False):
+            return True
+        for c in cls.__mro__:
+            module = c.__module__ or ""
+            if c.__name__ == "Rayleigh" and module.endswith("emmodel.rayleigh") and not module.startswith("smrt_amd."):
+                return getattr(cls, "ft_even_phase", None) is getattr(c, "ft_even_phase", None)
+            if c.__name__ == "_RayleighPhase" and module == "smrt_amd.emmodel.rayleigh":
+                return getattr(cls, "ft_even_phase", None) is getattr(c, "ft_even_phase", None)
+        return False
+
     def _iba_scalars_on_host(self, sensor0, sps, freqs, entries, nl, Lmax, sensor_of):
-        """The cheap half of the host route for emmodels of IBA's family (include/smrt_dort.h: SMRT_EM_IBA_HOST): effective
-        permittivity, ks, ka and the coefficient of the phase matrix of every (frequency, snowpack, layer) from the emmodel
-        objects; the phase matrices themselves are assembled on the device from the layer's microstructure model.  Returns
+        """The cheap half of the host route for emmodels whose phase matrix the device can assemble itself -- IBA's family
+        (include/smrt_dort.h: SMRT_EM_IBA_HOST) and the Rayleigh family (SMRT_EM_RAYLEIGH_HOST): effective permittivity, ks,
+        ka (and, for IBA's family, the coefficient of the phase matrix) of every (frequency, snowpack, layer) from the
+        emmodel objects; the phase matrices themselves are assembled on the device.  Returns
         (host_layer [F, S, Lmax, 4], coefficient [F, S, Lmax], per-layer kinds, frac_volume, micro_p1, micro_p2 [S, Lmax])
         -- the medium the emmodel works on (inverted above half ice under dense_snow_correction="auto") --, or None when
         a layer's emmodel is of another family or its microstructure model has no device code: the full host route
@@ -664,7 +682,7 @@ class DORT(object):
         coeff = np.zeros((F, S, Lmax))
         kinds = np.zeros((S, Lmax), np.int32)
         fv = np.full((S, Lmax), 0.3); p1 = np.full((S, Lmax), 1e-4); p2 = np.full((S, Lmax), 0.2)   # harmless padding
-        one = np.array([1.0])
+        one = np.array([1.0, 0.55, 0.1])   # (three directions: an anisotropic ks / ka shows and is refused)
         for fi, f in enumerate(freqs):
             sensor = sensor_of.get(float(f))
             if sensor is None:
@@ -681,6 +699,16 @@ class DORT(object):
                             p1[s, l], p2[s, l] = q
                         continue
                     em = self._emmodel_instance(entries[s][l], sensor, layer)
+                    if self._has_rayleigh_phase(em):
+                        # the Rayleigh phase matrix needs ks only (SMRT_EM_RAYLEIGH_HOST); no microstructure is read
+                        ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
+                        ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
+                        eps = complex(em.effective_permittivity())
+                        hl[fi, s, l] = self._isotropic(ks, "ks"), self._isotropic(ka, "ka"), eps.real, eps.imag
+                        if fi == 0:
+                            kinds[s, l] = EM_CODES["rayleigh_host"]
+                            fv[s, l] = min(max(float(layer.frac_volume), 0.0), 1.0)
+                        continue
                     c = self._iba_phase_coefficient(em)
                     if c is None:
                         return None

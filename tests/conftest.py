@@ -313,8 +313,13 @@ def host_batch_from_fixture(d):
     act = str(d["mode"]) == "A"
     f0 = float(d["frequency"][0])
     sensor0 = active(f0, d["theta_inc_deg"]) if act else passive(f0, d["theta_deg"])
-    cls = import_class("emmodel", str(d["emmodel"]))
-    return solver._pack(sensor0, [sp], np.asarray(d["frequency"], float), [[(cls, {})] * sp.nlayer])
+    base = import_class("emmodel", str(d["emmodel"]))
+
+    class OwnPhase(base):   # a phase function "of its own" (same numbers): outside the Rayleigh family, whose members hand over
+        def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):   # their scalars only (SMRT_EM_RAYLEIGH_HOST) -- this helper
+            return super().ft_even_phase(mu_s, mu_i, m_max, npol)  # is about the dense route (SMRT_EM_HOST)
+
+    return solver._pack(sensor0, [sp], np.asarray(d["frequency"], float), [[(OwnPhase, {})] * sp.nlayer])
 
 
 def fixture_emmodel(d):

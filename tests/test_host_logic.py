@@ -498,7 +498,15 @@ def test_host_evaluated_emmodels_are_packed_for_the_device():
             P[..., h:, h:] *= 1.02
             return P
 
-    plain = solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Rayleigh, {})] * 2])
+    class Dense(Rayleigh):   # (a pass-through ft_even_phase of its own keeps the class on the dense route: the Rayleigh
+        def ft_even_phase(self, mu_s, mu_i, m_max, npol=None):   # family itself hands over its scalars only, below)
+            return super().ft_even_phase(mu_s, mu_i, m_max, npol)
+
+    plain = solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Dense, {})] * 2])
+    # the family itself: kind SMRT_EM_RAYLEIGH_HOST, ks / ka / permittivity only, the same numbers
+    fam = solver._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Rayleigh, {})] * 2])
+    assert (fam.layer_kind & 15 == 7).all() and not fam.struct.host_phase and not fam.struct.host_streams
+    np.testing.assert_array_equal(fam.host_layer, plain.host_layer)
     lop = DORT(n_max_stream=8, phase_symmetrization=True)._pack(passive(37e9, 55), [sp2], np.array([37e9]), [[(Lopsided, {})] * 2])
     np.testing.assert_allclose(lop.host_phase[..., 0, :, :], 1.01 * plain.host_phase[..., 0, :, :], rtol=1e-12)
     np.testing.assert_allclose(lop.host_phase[..., 1, :, :], plain.host_phase[..., 1, :, :], rtol=1e-12)
