@@ -301,7 +301,9 @@ int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
 
 /* LDS bytes one workgroup (= one wavefront) of the register-resident finish kernel takes for a batch with this
- * n_max_stream and n_layers_max: four of them share the 160 KB of a CU while this is <= 40 KB. */
+ * n_max_stream and n_layers_max: four of them share the 160 KB of a CU while this is <= 40 KB (40 layers at 32 streams),
+ * three up to 160 KB / 3 (~140 layers) -- the range in which the default pipeline takes this kernel --, two up to the
+ * 64 KB a workgroup may have, where only smrt_dort_set_pipeline(ctx, 3) selects it (it ties with the two-slot kernel). */
 int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max);
 
 /* LDS bytes one workgroup of the Jacobi kernel takes in the three-kernel pipelines of up to 128 columns (n_pol = 2

@@ -207,5 +207,29 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
                             rng.uniform(5e-5, 3e-4, (8, 4)), None, [18.7e9], np.deg2rad([40.0]), n_max_stream=n_stream, mode=mode)
             ctx.upload(b)
             assert ctx.launch_info()["pipeline"] == want, (n_stream, mode, ctx.launch_info())
+        # deep snowpacks: the register-resident finish kernel's LDS grows with the layer count -- four of its wavefronts per
+        # CU up to 40 layers at 32 streams, three beyond; it stays the default while three fit (160 KB / 3), and before that
+        # limit is reached the per-layer tables of the OTHER kernels have already sent the batch to the global-workspace
+        # pipeline: the kernel never runs at two per CU by default.  Same brightness temperatures as the
+        # two-slot kernel at a depth where it runs three per CU.
+        lib = ctx._lib
+        assert lib.smrt_dort_finish_reg_lds_bytes(32, 40) <= 40 * 1024 < lib.smrt_dort_finish_reg_lds_bytes(32, 41)
+        seen = {}
+        for deep in (60, 100, 150):
+            th = rng.uniform(0.01, 0.05, (2, deep)); th[:, -1] = 100.0
+            b = PackedBatch([deep] * 2, th, rng.uniform(0.2, 0.45, (2, deep)), rng.uniform(235, 268, (2, deep)),
+                            rng.uniform(5e-5, 3e-4, (2, deep)), None, [18.7e9], np.deg2rad([40.0]), n_max_stream=32)
+            ctx.upload(b)
+            seen[deep] = ctx.launch_info()["pipeline"]
+            if seen[deep] == "lds_reg":
+                assert lib.smrt_dort_finish_reg_lds_bytes(32, deep) <= 160 * 1024 // 3, deep
+            if deep == 60:
+                ctx.launch(); ctx.sync(); by_default = ctx.download()
+                ctx.set_pipeline(4); ctx.upload(b)
+                assert ctx.launch_info()["pipeline"] == "lds_two_slot"
+                ctx.launch(); ctx.sync(); two_slot = ctx.download()
+                ctx.set_pipeline(1)
+                assert (by_default.status == 0).all() and np.abs(by_default.values - two_slot.values).max() < 1e-6
+        assert seen[60] == "lds_reg" and seen[150] == "gmem", seen
     finally:
         ctx.close()
