@@ -10,6 +10,10 @@ passive / active, with and without substrate and atmosphere, ragged layer counts
         "wetmicro": in the IBA cases every layer draws its own microstructure model among the four the device has
         (exponential, sticky_hard_spheres, teubner_strey, independent_sphere) and the top layers may be wet (melting
         point, liquid water 0.1 ... 5 %)
+        "family": in the IBA cases every layer draws its emmodel among iba, iba_original and iba_maxwell_garnett; the
+        last two reach the device as SMRT_EM_IBA_HOST layers -- effective permittivity, ks, ka and the phase coefficient
+        from the oracle's layer objects (what the emmodel objects hand over in the product), the phase matrices
+        assembled by the kernels
 """
 import os, sys, time
 import numpy as np
@@ -22,6 +26,9 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 with_prune = len(sys.argv) > 2 and sys.argv[2] == "prune"
 with_coherent = len(sys.argv) > 2 and sys.argv[2] == "coherent"
 with_wetmicro = len(sys.argv) > 2 and sys.argv[2] == "wetmicro"
+with_family = len(sys.argv) > 2 and sys.argv[2] == "family"
+FAMILY = ["iba", "iba_original", "iba_maxwell_garnett"]
+n_family = 0
 MS_NAMES = ["exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey"]   # = MS codes 0 .. 3
 n_wet = n_conditioned = 0
 n_coherent = n_refused = 0
@@ -82,9 +89,26 @@ for mode, n, em, ms in cases:
             for l in range(min(int(rng_prune.integers(0, 3)), nl[s])):   # 0 .. 2 wet layers at the top
                 lw[s, l] = 10.0 ** rng_prune.uniform(-3, -1.3); temp[s, l] = 273.15
         n_wet += int((lw > 0).any(axis=1).sum()) * len(freqs)
+    host_scalars = eml = None
+    if with_family and em == "iba":
+        from smrt_amd._native import EM_CODES, MS_CODES
+        eml = rng_prune.integers(0, 3, (S, Lmax))                      # emmodel of every layer: index into FAMILY
+        hl = np.zeros((len(freqs), S, Lmax, 4)); hl[..., 2] = 1.0
+        hc = np.zeros((len(freqs), S, Lmax))
+        for fi, fr in enumerate(freqs):
+            for s in range(S):
+                k = nl[s]
+                spd = dict(thickness=thick[s, :k], density=dens[s, :k], temperature=temp[s, :k], microstructure=ms)
+                spd.update(dict(corr_length=p1[s, :k]) if ms == "exponential" else dict(radius=p1[s, :k], stickiness=p2[s, :k]))
+                for l, lay in enumerate(O.make_layers([FAMILY[c] for c in eml[s, :k]], float(fr), spd)):
+                    hl[fi, s, l] = lay.ks, lay.ka, complex(lay.eps_eff).real, complex(lay.eps_eff).imag
+                    hc[fi, s, l] = lay.iba_coeff
+        host_scalars = (hl, hc)
+        kinds = np.where(eml == 0, EM_CODES["iba"], EM_CODES["iba_host"]) + 16 * MS_CODES[ms]
+        n_family += int((eml[:, 0] > 0).sum()) * len(freqs)
     b = PackedBatch(nl, thick, dens / 916.7, temp, p1, p2, freqs, np.deg2rad(theta), emmodel=em, microstructure=ms, mode=mode,
                     n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm, prune_deep_snowpack=prune,
-                    process_coherent_layers=with_coherent, layer_kind=kinds, liquid_water=lw)
+                    process_coherent_layers=with_coherent, layer_kind=kinds, liquid_water=lw, host_scalars=host_scalars)
     out = ctx.run(b)
     case_co = case_cx = 0.0; case_ratio = 1.0
     for f in range(len(freqs)):
@@ -102,7 +126,7 @@ for mode, n, em, ms in cases:
             p = f * S + s
             try:
                 det = {}
-                ref = O.solve(sp, float(freqs[f]), theta, emmodel=em, mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2,
+                ref = O.solve(sp, float(freqs[f]), theta, emmodel=em if eml is None else [FAMILY[c] for c in eml[s, :k]], mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2,
                               method="schur_forcedtriu", substrate=osub, atmosphere=oatm, prune_deep_snowpack=prune, details=det,
                               process_coherent_layers_=with_coherent)
                 n_pruned += bool(det["pruned_at"]) and min(det["pruned_at"]) < k
@@ -159,6 +183,7 @@ for mode, n, em, ms in cases:
     print("%s n=%-3d %-22s %-20s sub=%d atm=%d  ok  (%.0f s)%s" % (mode, n, em, ms, sub is not None, atm is not None, time.time() - t0, extra), flush=True)
 if with_coherent: print("process_coherent_layers: %d of the checked pairs lost at least one layer, %d pairs refused (status 6) by both" % (n_coherent, n_refused))
 if with_wetmicro: print("wetmicro: microstructure model drawn per layer in the IBA cases, %d of the pairs with wet layers on top; %d active pairs beyond 1e-8 but within 3 x the spread of the oracle's own methods" % (n_wet, n_conditioned))
+if with_family: print("family: emmodel drawn per layer among iba / iba_original / iba_maxwell_garnett in the IBA cases (the last two as SMRT_EM_IBA_HOST layers); %d pairs with such a layer on top" % n_family)
 if with_prune: print("prune_deep_snowpack drawn per case: %d of the checked pairs were cut above their last layer" % n_pruned)
 print("checked %d pairs: max |dTb| = %.2e K, backscatter max rel (co-pol scale) = %.2e, cross-pol own scale (where cross/co > 1e-3) = %.2e" % (n_checked, worst_tb, worst_co, worst_cx))
 assert worst_tb < 1e-6 and worst_co < 1e-8 and worst_cx < 1e-6
