@@ -60,6 +60,11 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 #define SMRT_MS_INDEPENDENT_SPHERE 2   /* micro_p1 = radius (smrt/microstructure_model/independent_sphere.py:54-72); IBA only */
 #define SMRT_MS_TEUBNER_STREY 3        /* micro_p1 = corr_length xi, micro_p2 = Y = (2 pi xi / repeat_distance)^2 (teubner_strey.py:45-55); a
                                         * negative Y gives the two-length form of unified_teubner_strey.py:69-72; IBA only */
+/* The exponential model evaluated at the COMPLEX wavenumber of the strong-contrast-expansion emmodels (smrt/emmodel/
+ * sce_common.py:222-233: 2 k0 sqrt(eps_eff) sin(Theta / 2) with the complex eps_eff, real part of the transform kept,
+ * emmodel/common.py:107-117): micro_p1 = corr_length; eps_eff comes from host_layer.  Only as the microstructure code of
+ * SMRT_EM_IBA_HOST layers (layer_kind), passive mode. */
+#define SMRT_MS_EXPONENTIAL_COMPLEX_K 4
 /* sensor mode (smrt/core/sensor.py:330-339) */
 #define SMRT_MODE_PASSIVE 0
 #define SMRT_MODE_ACTIVE 1

@@ -111,7 +111,7 @@ def ft_autocorr_teubner_strey(k, frac_volume, corr_length, repeat_distance):
 def ft_autocorr_unified_scaled_exponential(k, frac_volume, porod_length, polydispersity):
     """smrt/microstructure_model/unified_scaled_exponential.py:26-35 (corr_length = polydispersity * porod_length)."""
     corr_length = polydispersity * porod_length
-    x = (np.asarray(k, float) * corr_length) ** 2
+    x = (np.asarray(k) * corr_length) ** 2          # (k may be complex: the strong-contrast-expansion emmodels)
     return frac_volume * (1.0 - frac_volume) * 8 * np.pi * corr_length**3 / (1.0 + x) ** 2
 
 
@@ -307,6 +307,95 @@ class IBAMaxwellGarnettLayer(IBALayer):
 
     def apparent_permittivity(self, e0, depol):
         return e0
+
+
+def romberg_pow2(y, dx):
+    """scipy.integrate.romb on 2**k + 1 samples (romberg65 for any k)."""
+    n = len(y) - 1
+    k = int(round(np.log2(n)))
+    assert 2**k == n
+    r = np.array([(n >> i) * dx * (0.5 * (y[:: n >> i][0] + y[:: n >> i][-1]) + y[:: n >> i][1:-1].sum()) for i in range(k + 1)])
+    for j in range(1, k + 1):
+        r = (4.0**j * r[1:] - r[:-1]) / (4.0**j - 1.0)
+    return r[0]
+
+
+def sce_a2_nonlocal(q_big, ft_corr):
+    """smrt/emmodel/sce_common.py:284-320 (compute_A2_nonlocal): the second-order coefficient of the strong-contrast
+    expansion in its non-local form, from the Fourier transform of the autocorrelation function -- a cumulative trapezoid
+    for Im F, a Romberg integral with the two singularities taken out and an asymptotic tail for Re F."""
+    margin, k = 4, 12
+    n = 2**k
+    nq = n // margin
+    maxq = margin * q_big
+    q = np.linspace(0, maxq, n + 1)
+    y = 2 * q * ft_corr(2 * q)
+    x = 2 * q.real
+    primitive = np.concatenate(([0.0], np.cumsum(0.5 * (y.real[1:] + y.real[:-1]) * np.diff(x))))   # cumulative_trapezoid, initial=0
+    im_f = -1 / (2 * (2 * np.pi) ** 1.5) * q * primitive
+    with np.errstate(invalid="ignore", divide="ignore"):
+        y1 = im_f / ((q_big + q) * q)
+        y1[0] = 0
+        y2 = (im_f - im_f[nq]) / (q_big**2 - q**2)
+        y2[nq] = (y2[nq - 1] + y2[nq + 1]) / 2
+    yy = y1 + y2
+    tail = (im_f[nq] - q_big / maxq * im_f[-1]) * np.log(np.abs((maxq + q_big) / (maxq - q_big)))
+    re_f = -2 / np.pi * q_big * romberg_pow2(yy.real, maxq.real / n) - 1 / np.pi * tail
+    return -(2 * np.pi) / (2**1.5 * 0.5 * np.sqrt(np.pi)) * (re_f + 1j * im_f[nq])
+
+
+class SymSCELayer(LayerEM):
+    """Symmetrised strong-contrast expansion, Torquato & Kim 2021 as smrt implements it (smrt/emmodel/symsce_torquato21.py:
+    37-45 -> sce_common.py:24-62 with local=False, symmetrical=True, scaled=True): the effective permittivity of Polder-van
+    Santen, ke / ks from the quadratic of compute_ke_ks_symmetrical (:95-114) with A2 of the medium and of its inverse at the
+    wavenumber of the effective medium (:64-77), ka = 2 k0 Im sqrt(eps_eff) (:236-247), and IBA's phase function normalised to
+    ks (:145-160) -- evaluated at the COMPLEX wavenumber 2 k0 sqrt(eps_eff) sin(Theta / 2) (:222), of which the Fourier
+    decomposition keeps the real part (emmodel/common.py:107-117)."""
+
+    kind = "symsce_torquato21"
+
+    def __init__(self, frequency, frac_volume, temperature, microstructure, **mp):
+        self.frequency = frequency
+        self.k0 = 2.0 * np.pi * frequency / C_SPEED
+        e0 = 1.0
+        eps = scatterer_permittivity(frequency, temperature, mp.get("liquid_water", 0.0))
+        f = self.f = frac_volume
+        self.eps_eff = polder_van_santen_spheres(f, e0, eps)
+
+        def ft_of(fv):
+            if microstructure == "exponential":
+                return lambda k: ft_autocorr_exponential(k, fv, mp["corr_length"])
+            if microstructure == "unified_scaled_exponential":
+                return lambda k: ft_autocorr_unified_scaled_exponential(k, fv, mp["porod_length"], mp["polydispersity"])
+            raise ValueError(microstructure)
+
+        self.ft_corr = ft_of(f)
+        k_sym = self.k0 * np.sqrt(self.eps_eff)
+        a2, a2inv = sce_a2_nonlocal(k_sym, ft_of(f)), sce_a2_nonlocal(k_sym, ft_of(1.0 - f))   # (inverted_medium: 1 - f)
+        big = 2 if f in (0, 1) else 2 + a2 / f + a2inv / (1 - f)
+        se, pe = e0 + eps, e0 * eps
+        wm = e0 * f + eps * (1 - f)
+        eeff = se / 2 + 1 / (2 * big) * (-3 * wm + np.sqrt(4 * big * (3 - big) * pe + (se * big - 3 * wm) ** 2))
+        eeff0 = se / 2 + 1 / 4 * (-3 * wm + np.sqrt(8 * pe + (se * 2 - 3 * wm) ** 2))
+        ke = 2 * self.k0 * np.sqrt(eeff).imag
+        self.ks = float(ke - 2 * self.k0 * np.sqrt(eeff0).imag)
+        self.ka = float(2 * self.k0 * np.sqrt(self.eps_eff).imag)
+        # phase norm: ks over the integral of the unnormalised phase function (|sqrt(eps_eff)| there, :189)
+        mu = np.linspace(1.0, -1.0, 65)
+        kd = 2.0 * self.k0 * np.sqrt((1.0 - mu) / 2.0) * abs(np.sqrt(self.eps_eff))
+        integral = romberg65(self.ft_corr(kd).real * (mu**2 + 1.0), mu[0] - mu[1])
+        self.iba_coeff = 0.0 if self.ks == 0 or integral == 0 else self.ks / (integral / 4.0)   # (_phase_norm)
+
+    def phase(self, mu_s, mu_i, dphi, npol):
+        p, sin_half = rayleigh_matrix_and_half_angle(mu_s, mu_i, dphi, npol)
+        kd = 2.0 * self.k0 * np.sqrt(self.eps_eff) * sin_half           # complex
+        return (self.iba_coeff * self.ft_corr(kd) * p).real               # what the real part of the FFT keeps for mode 0
+
+    def ft_even_phase(self, mu_s, mu_i, m_max, npol):
+        if npol != 2 or m_max != 0:
+            raise ValueError("the oracle restates the strong-contrast expansion for passive mode")
+        nsamples = int(2 ** np.ceil(4 + np.log(m_max + 1) / np.log(2)))
+        return ft_even_matrix(lambda dphi: self.phase(mu_s, mu_i, dphi, npol), m_max, nsamples, npol)
 
 
 class DMRTQCAShortRangeLayer(LayerEM):
@@ -533,7 +622,7 @@ def make_layers(emmodel, frequency, sp):
     """One LayerEM per layer (smrt/core/model.py:529-582).  `sp` is a dict of arrays: thickness, density (or
     frac_volume), temperature, microstructure name and its parameters."""
     classes = {"iba": IBALayer, "iba_dense_auto": IBADenseAutoLayer, "iba_original": IBAOriginalLayer,
-               "iba_maxwell_garnett": IBAMaxwellGarnettLayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
+               "iba_maxwell_garnett": IBAMaxwellGarnettLayer, "symsce_torquato21": SymSCELayer, "dmrt_qca_shortrange": DMRTQCAShortRangeLayer,
                "dmrt_qcacp_shortrange": DMRTQCACPShortRangeLayer, "nonscattering": NonScatteringLayer,
                "rayleigh": RayleighLayer, "prescribed_kskaeps": PrescribedLayer}
     L = len(sp["thickness"])

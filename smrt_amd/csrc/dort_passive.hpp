@@ -115,7 +115,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
     const int t = tid();
     const int nmax = b.n_max_stream;
     for (int l = t; l < L; l += NT) {
-        cplx ee; double ks, ka, pa, pb; int bad = 0;
+        cplx ee; double ks, ka, pa, pb, krho = 0.0; int bad = 0;
         const int kind = kinds ? kinds[l] : b.emmodel + 16 * b.micro;   // emmodel + 16 * microstructure of this layer
         if (__builtin_expect((kind & 15) == EM_HOST || (kind & 15) == EM_IBA_HOST || (kind & 15) == EM_RAYLEIGH_HOST, 0)) {   // scalars from the caller (smrt_batch.host_layer)
             if (b.host_layer) {
@@ -133,13 +133,20 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
                 const double p1 = mp1[l], fv = fracvol[l];
                 if ((kind >> 4) == MS_EXP) { pa = coeff * fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1; pb = 0.5 * kfac * kfac * p1 * p1; }
                 else { pa = coeff; pb = 0.5 * kfac * kfac; }
+                if ((kind >> 4) == MS_EXPC) {   // complex wavenumber: k^2 = 4 k0^2 eps_eff sin^2(Theta / 2); Im / Re travels in pc
+                    const double k0 = 2.0 * kPi * frequency / kCSpeed;
+                    pb = 2.0 * k0 * k0 * ee.re;
+                    krho = ee.im / ee.re;
+                    if (!(krho >= 0.0 && krho < 0.5)) bad = 1;
+                }
             }
         } else
         layer_em(kind & 15, kind >> 4, frequency, fracvol[l], temperature[l], mp1[l], mp2[l], &ee, &ks, &ka, &pa, &pb, &bad,
                  __builtin_expect(b.liquid_water != nullptr, 0) ? b.liquid_water[(gp % b.S) * b.Lmax + l] : 0.0);
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)(((kind & 15) == EM_IBA_INV || (kind & 15) == EM_IBA_HOST) ? (kind & ~15) | EM_IBA   // the phase function is IBA's either way
-                           : (kind & 15) == EM_RAYLEIGH_HOST ? (kind & ~15) | EM_DMRT : kind);                // ... or Rayleigh's
+                           : (kind & 15) == EM_RAYLEIGH_HOST ? (kind & ~15) | EM_DMRT : kind)                 // ... or Rayleigh's
+                  + krho;   // (MS_EXPC: Im / Re of the squared wavenumber, < 0.5, rides in the fraction; 0 otherwise)
         s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;
         s.thick[l] = thickness[l];
         s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
@@ -459,8 +466,9 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             const int T = n * (n + 1) / 2;
             const double pa = s.pa[l], pb = s.pb[l];
             const int lo = (int)s.lo[l];   // the layer's index in the input arrays
-            const double fv = fracvol[lo], q1 = mp1[lo], q2 = mp2[lo];
             const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
+            const double fv = fracvol[lo], q1 = mp1[lo],
+                         q2 = __builtin_expect(ms_l == MS_EXPC, 0) ? s.pc[l] - (double)(int)s.pc[l] : mp2[lo];
             for (int idx = t; idx < T; idx += NT) {
                 int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
                 while ((i + 1) * (i + 2) / 2 <= idx) ++i;

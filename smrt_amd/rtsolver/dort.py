@@ -646,6 +646,25 @@ class DORT(object):
         return coeff.real if coeff.imag == 0.0 and coeff.real >= 0.0 else None
 
     @staticmethod
+    def _sce_phase_coefficient(em):
+        """The norm of the phase function when `em` is one of smrt's strong-contrast-expansion emmodels (sce_common.py:
+        SCEBase -- symsce_torquato21, sce_torquato21, ... -- with `phase` / `ft_even_phase` unchanged): IBA's phase function
+        normalised to ks and evaluated at the COMPLEX wavenumber 2 k0 sqrt(eps_eff) sin(Theta / 2) (:222), which the device
+        does for the exponential model (SMRT_MS_EXPONENTIAL_COMPLEX_K); else None."""
+        cls = type(em)
+        base = next((c for c in cls.__mro__ if c.__name__ == "SCEBase" and (c.__module__ or "").endswith("emmodel.sce_common")), None)
+        if base is None or not hasattr(em, "microstructure") or not hasattr(em, "frac_volume"):
+            return None
+        for method in ("phase", "ft_even_phase"):
+            if getattr(cls, method, None) is not getattr(base, method, None):
+                return None
+        norm = getattr(em, "_phase_norm", None)
+        if norm is None:
+            norm = em.compute_phase_norm()
+        norm = complex(norm)
+        return norm.real if norm.imag == 0.0 and norm.real >= 0.0 else None
+
+    @staticmethod
     def _has_rayleigh_phase(em):
         """Is the phase matrix of `em` the Rayleigh one, 3 ks / 2 x the geometry of smrt/emmodel/rayleigh.py:52-127?  True for a
         class that inherits `ft_even_phase` from smrt's `Rayleigh` unchanged (rayleigh, sft_rayleigh, prescribed_kskaeps, the
@@ -710,6 +729,13 @@ class DORT(object):
                             fv[s, l] = min(max(float(layer.frac_volume), 0.0), 1.0)
                         continue
                     c = self._iba_phase_coefficient(em)
+                    # (a class of the caller's own may declare iba_phase_family = "complex_k": the strong-contrast form)
+                    complex_k = c is not None and getattr(type(em), "iba_phase_family", None) == "complex_k"
+                    if complex_k and sensor0.mode != "P":
+                        return None
+                    if c is None and sensor0.mode == "P":   # (the complex phase function in active mode: dense route)
+                        c = self._sce_phase_coefficient(em)
+                        complex_k = c is not None
                     if c is None:
                         return None
                     ms = em.microstructure
@@ -719,6 +745,10 @@ class DORT(object):
                         name, q1, q2 = _device_microstructure(ms)
                     if name not in MS_CODES:
                         return None
+                    if complex_k:
+                        if MS_CODES[name] != MS_CODES["exponential"]:   # the complex wavenumber: the exponential form only
+                            return None
+                        name = "exponential_complex_k"
                     ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
                     ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
                     eps = complex(em.effective_permittivity())

@@ -88,7 +88,7 @@ def packed_batch_from_fixture(d, freqs=None):
         emmodel = ["iba_inverted" if x else "iba" for x in dense]
         sp["frac_volume"] = np.where(dense, 1.0 - np.asarray(sp["frac_volume"]), sp["frac_volume"])
     host_scalars = None
-    family = ("iba_original", "iba_maxwell_garnett")     # IBA's phase function, other scalars: SMRT_EM_IBA_HOST
+    family = ("iba_original", "iba_maxwell_garnett", "symsce_torquato21")     # IBA's phase function, other scalars: SMRT_EM_IBA_HOST
     if emmodel in family or (isinstance(emmodel, list) and any(e in family for e in emmodel)):
         # the scalars the emmodel OBJECT would hand over (rtsolver/dort.py:_iba_scalars_on_host), here from the oracle's
         # layer objects: ks, ka, effective permittivity, the coefficient of the phase matrix -- per frequency and layer
@@ -104,6 +104,14 @@ def packed_batch_from_fixture(d, freqs=None):
                 hc[fi, 0, l] = em.iba_coeff
         host_scalars = (hl, hc)
         emmodel = ["iba_host" if e in family else e for e in names]
+        if "symsce_torquato21" in names:   # ... at the complex wavenumber of the strong-contrast expansion (exponential model)
+            assert ms in ("exponential", "unified_scaled_exponential") and all(e == "symsce_torquato21" for e in names)
+            from smrt_amd.core.layer import device_microstructure_params
+            lc = [device_microstructure_params(ms, 0.0, **{k: float(np.broadcast_to(sp[k], (L,))[l]) for k in
+                                                           (("corr_length",) if ms == "exponential" else ("porod_length", "polydispersity"))})[0]
+                  for l in range(L)]
+            sp = dict(sp, corr_length=np.array(lc))
+            ms = ["exponential_complex_k"] * L
     if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
         L = len(sp["thickness"])
         msl = ms if isinstance(ms, list) else [ms] * L
@@ -114,10 +122,12 @@ def packed_batch_from_fixture(d, freqs=None):
         # stickiness as they are, Teubner-Strey's repeat distance as Y, the unified parameters reparametrised
         from smrt_amd.core.layer import MICROSTRUCTURE_ARGS, device_microstructure_params
         fvl = np.broadcast_to(sp["frac_volume"], (L,))
-        pp = [device_microstructure_params(m, float(fvl[l]), **{a: float(col(a)[l]) for a in MICROSTRUCTURE_ARGS[m]})
+        pp = [(float(col("corr_length")[l]), 0.0) if m == "exponential_complex_k" else
+              device_microstructure_params(m, float(fvl[l]), **{a: float(col(a)[l]) for a in MICROSTRUCTURE_ARGS[m]})
               for l, m in enumerate(msl)]
         p1, p2 = np.array([q[0] for q in pp]), np.array([q[1] for q in pp])
         ms, emmodel = msl[0], eml[0]
+        ms = "exponential" if ms == "exponential_complex_k" else ms   # (a per-layer code only: the batch-level one is not read)
     else:
         p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
         p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
@@ -193,7 +203,9 @@ MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active", "iba_
                   "iba_unified4_L4_n10_active"]
 # the other members of IBA's family (iba_original, iba_maxwell_garnett; one per layer mixed with plain IBA): IBA's phase
 # matrix assembled on the device, the scalars from the emmodel object (SMRT_EM_IBA_HOST)
-IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive"]
+IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive",
+                       # the symmetrised strong-contrast expansion: IBA's phase function at a complex wavenumber (passive)
+                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

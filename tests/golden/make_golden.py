@@ -65,6 +65,10 @@ def snowpack_arrays(sp):
         out["radius"] = np.array([lay.microstructure.radius for lay in sp.layers], float)
     elif type(ms).__name__ == "Homogeneous":
         out["microstructure"] = "homogeneous"
+    elif type(ms).__name__ == "UnifiedScaledExponential":
+        out["microstructure"] = "unified_scaled_exponential"
+        out["porod_length"] = np.array([lay.microstructure.porod_length for lay in sp.layers], float)
+        out["polydispersity"] = np.array([lay.microstructure.polydispersity for lay in sp.layers], float)
     elif hasattr(ms, "corr_length"):
         out["microstructure"] = "exponential"
         out["corr_length"] = np.array([lay.microstructure.corr_length for lay in sp.layers], float)
@@ -812,6 +816,20 @@ def main():
         if wanted("iba_family_L3_n12_passive"):
             save("iba_family_L3_n12_passive", run_new(["iba_maxwell_garnett", "iba", "iba_original"], passive([18.7e9, 36.5e9], [55]),
                                                        family_pack(100.0), rtsolver_options=dict(n_max_stream=12)))
+
+    # (iv-m) the symmetrised strong-contrast expansion (smrt/emmodel/symsce_torquato21.py): IBA's phase function at a complex
+    # wavenumber; passive, on the exponential model and on its unified parametrisation
+    if wanted("symsce_L3_n12_passive") or wanted("symsce_unified_L3_n12_passive"):
+        if wanted("symsce_L3_n12_passive"):
+            spx = make_snowpack([0.25, 0.35, 100.0], "exponential", density=[220, 310, 390], temperature=[257, 262, 266],
+                                corr_length=[1.2e-4, 2.0e-4, 2.6e-4])
+            save("symsce_L3_n12_passive", run_new("symsce_torquato21", passive([10.65e9, 36.5e9, 89e9], [40, 55]), spx,
+                                                   rtsolver_options=dict(n_max_stream=12)))
+        if wanted("symsce_unified_L3_n12_passive"):
+            spx = make_snowpack([0.25, 0.35, 100.0], "unified_scaled_exponential", density=[220, 310, 390], temperature=[257, 262, 266],
+                                porod_length=[1.0e-4, 1.6e-4, 2.0e-4], polydispersity=[1.2, 1.1, 1.3])
+            save("symsce_unified_L3_n12_passive", run_new("symsce_torquato21", passive([18.7e9, 36.5e9], [55]), spx,
+                                                           rtsolver_options=dict(n_max_stream=12)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -787,13 +787,14 @@ def test_an_emmodel_of_the_iba_family_hands_over_its_scalars():
     from oracle import dort_oracle as O
     from smrt_amd import make_model, make_snowpack, sensor_list
 
-    def family_member(oracle_class):
+    def family_member(oracle_class, family=True):
         class Member:
-            iba_phase_family = True          # phase matrix = iba_coeff x FT of the autocorrelation function x Rayleigh geometry
+            iba_phase_family = family        # phase matrix = iba_coeff x FT of the autocorrelation function x Rayleigh geometry
+                                             # ("complex_k": at the complex wavenumber of the strong-contrast expansion)
 
             def __init__(self, sensor, layer):
                 ms = layer.microstructure
-                params = {k: getattr(ms, k) for k in ("corr_length", "radius", "stickiness") if hasattr(ms, k)}
+                params = {k: getattr(ms, k) for k in ("corr_length", "radius", "stickiness", "porod_length", "polydispersity") if hasattr(ms, k)}
                 em = oracle_class(float(sensor.frequency), layer.frac_volume, layer.temperature, layer.microstructure_model, **params)
                 self.frac_volume, self.microstructure = layer.frac_volume, ms
                 self.iba_coeff, self.ka, self._ks, self._eps = em.iba_coeff, em.ka, em.ks, em.eps_eff
@@ -805,11 +806,14 @@ def test_an_emmodel_of_the_iba_family_hands_over_its_scalars():
                 return np.full((npol, np.size(mu)), self._ks)
         return Member
 
-    members = {"iba_original": family_member(O.IBAOriginalLayer), "iba_maxwell_garnett": family_member(O.IBAMaxwellGarnettLayer)}
+    members = {"iba_original": family_member(O.IBAOriginalLayer), "iba_maxwell_garnett": family_member(O.IBAMaxwellGarnettLayer),
+               "symsce_torquato21": family_member(O.SymSCELayer, "complex_k")}
     for name in IBA_FAMILY_FIXTURES:
         d = load_golden(name)
         ms = str(d["microstructure"])
-        args = dict(corr_length=d["corr_length"]) if ms == "exponential" else dict(radius=d["radius"], stickiness=d["stickiness"])
+        args = dict(corr_length=d["corr_length"]) if ms == "exponential" else \
+            dict(porod_length=d["porod_length"], polydispersity=d["polydispersity"]) if ms.startswith("unified") else \
+            dict(radius=d["radius"], stickiness=d["stickiness"])
         sp = make_snowpack(d["thickness"], ms, density=d["density"], temperature=d["temperature"], **args)
         em = [members.get(str(e), str(e)) for e in np.atleast_1d(d["emmodel"])]
         em = em[0] if len(em) == 1 else em
