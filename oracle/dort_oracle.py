@@ -102,7 +102,7 @@ def ft_autocorr_independent_sphere(k, frac_volume, radius):
 
 def ft_autocorr_teubner_strey(k, frac_volume, corr_length, repeat_distance):
     """smrt/microstructure_model/teubner_strey.py:45-55."""
-    x = (np.asarray(k, float) * corr_length) ** 2
+    x = (np.asarray(k) * corr_length) ** 2          # (k may be complex: the strong-contrast-expansion emmodels)
     y = (2 * np.pi * corr_length / repeat_distance) ** 2
     return frac_volume * (1.0 - frac_volume) * 8 * np.pi * corr_length**3 / ((1 + y) ** 2 + 2 * (1 - y) * x + x**2)
 
@@ -118,7 +118,7 @@ def ft_autocorr_unified_scaled_exponential(k, frac_volume, porod_length, polydis
 def ft_autocorr_unified_teubner_strey(k, frac_volume, porod_length, polydispersity):
     """smrt/microstructure_model/unified_teubner_strey.py:24-36 (the two lengths) and :63-78 (the transform), as written
     there: two Lorentzians from polydispersity 1 on, the factored Teubner-Strey denominator below."""
-    k = np.asarray(k, float)
+    k = np.asarray(k)                                # (may be complex: the strong-contrast-expansion emmodels)
     k32 = polydispersity ** (3 / 2)
     if polydispersity >= 1:
         b = porod_length * k32
@@ -367,6 +367,10 @@ class SymSCELayer(LayerEM):
                 return lambda k: ft_autocorr_exponential(k, fv, mp["corr_length"])
             if microstructure == "unified_scaled_exponential":
                 return lambda k: ft_autocorr_unified_scaled_exponential(k, fv, mp["porod_length"], mp["polydispersity"])
+            if microstructure == "teubner_strey":
+                return lambda k: ft_autocorr_teubner_strey(k, fv, mp["corr_length"], mp["repeat_distance"])
+            if microstructure == "unified_teubner_strey":
+                return lambda k: ft_autocorr_unified_teubner_strey(k, fv, mp["porod_length"], mp["polydispersity"])
             raise ValueError(microstructure)
 
         self.ft_corr = ft_of(f)

@@ -122,10 +122,10 @@ inline const char* validate(const smrt_batch* b) {
         for (int s = 0; s < b->n_snowpacks; ++s)
             for (int l = 0; l < b->n_layers[s]; ++l) {
                 const int k = b->layer_kind[(long long)s * b->n_layers_max + l], em = k & 15, ms = k >> 4;
-                if (em < SMRT_EM_IBA || em > SMRT_EM_RAYLEIGH_HOST || ms < SMRT_MS_EXPONENTIAL || ms > SMRT_MS_EXPONENTIAL_COMPLEX_K)
+                if (em < SMRT_EM_IBA || em > SMRT_EM_RAYLEIGH_HOST || ms < SMRT_MS_EXPONENTIAL || ms > SMRT_MS_TEUBNER_STREY_COMPLEX_K)
                     return "invalid layer_kind entry";
-                if (ms == SMRT_MS_EXPONENTIAL_COMPLEX_K && (em != SMRT_EM_IBA_HOST || b->mode != SMRT_MODE_PASSIVE))
-                    return "SMRT_MS_EXPONENTIAL_COMPLEX_K goes with SMRT_EM_IBA_HOST layers in passive mode only";
+                if (ms >= SMRT_MS_EXPONENTIAL_COMPLEX_K && (em != SMRT_EM_IBA_HOST || b->mode != SMRT_MODE_PASSIVE))
+                    return "SMRT_MS_*_COMPLEX_K go with SMRT_EM_IBA_HOST layers in passive mode only";
                 if (em == SMRT_EM_HOST) host_layers = true;
                 if (em == SMRT_EM_IBA_HOST) scalar_layers = true;
                 if (em == SMRT_EM_RAYLEIGH_HOST) rayleigh_layers = true;

@@ -133,7 +133,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
                 const double p1 = mp1[l], fv = fracvol[l];
                 if ((kind >> 4) == MS_EXP) { pa = coeff * fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1; pb = 0.5 * kfac * kfac * p1 * p1; }
                 else { pa = coeff; pb = 0.5 * kfac * kfac; }
-                if ((kind >> 4) == MS_EXPC) {   // complex wavenumber: k^2 = 4 k0^2 eps_eff sin^2(Theta / 2); Im / Re travels in pc
+                if ((kind >> 4) >= MS_EXPC) {   // complex wavenumber: k^2 = 4 k0^2 eps_eff sin^2(Theta / 2); Im / Re travels in pc
                     const double k0 = 2.0 * kPi * frequency / kCSpeed;
                     pb = 2.0 * k0 * k0 * ee.re;
                     krho = ee.im / ee.re;
@@ -146,7 +146,7 @@ SMRT_DEV int pair_setup(const DevBatch& b, const Lds& s, double frequency, int L
         s.eps_re[l] = ee.re; s.eps_im[l] = ee.im; s.ks[l] = ks; s.ka[l] = ka; s.pa[l] = pa; s.pb[l] = pb;
         s.pc[l] = (double)(((kind & 15) == EM_IBA_INV || (kind & 15) == EM_IBA_HOST) ? (kind & ~15) | EM_IBA   // the phase function is IBA's either way
                            : (kind & 15) == EM_RAYLEIGH_HOST ? (kind & ~15) | EM_DMRT : kind)                 // ... or Rayleigh's
-                  + krho;   // (MS_EXPC: Im / Re of the squared wavenumber, < 0.5, rides in the fraction; 0 otherwise)
+                  + krho;   // (MS_EXPC / MS_TSC: Im / Re of the squared wavenumber, < 0.5, rides in the fraction; 0 otherwise)
         s.slab_re[l] = s.slab_im[l] = s.slab_th[l] = 0.0; s.lo[l] = (double)l;
         s.thick[l] = thickness[l];
         s.BT[l] = b.rayleigh_jeans ? temperature[l] : planck_radiance(frequency, temperature[l]);
@@ -467,8 +467,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             const double pa = s.pa[l], pb = s.pb[l];
             const int lo = (int)s.lo[l];   // the layer's index in the input arrays
             const int em_l = (int)s.pc[l] & 15, ms_l = (int)s.pc[l] >> 4;   // this layer's emmodel and microstructure
-            const double fv = fracvol[lo], q1 = mp1[lo],
-                         q2 = __builtin_expect(ms_l == MS_EXPC, 0) ? s.pc[l] - (double)(int)s.pc[l] : mp2[lo];
+            const double fv = fracvol[lo], q1 = mp1[lo], q2 = mp2[lo];
+            const double krho = __builtin_expect(ms_l >= MS_EXPC, 0) ? s.pc[l] - (double)(int)s.pc[l] : 0.0;   // Im / Re of k^2 (pair_setup)
             for (int idx = t; idx < T; idx += NT) {
                 int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
                 while ((i + 1) * (i + 2) / 2 <= idx) ++i;
@@ -511,8 +511,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
                             const double q = (pa * wk) * fast_rcp(dp2 * dm2);
                             Cp = dm2 * q; Cm = dp2 * q;
                         } else {
-                            Cp = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_p), fv, q1, q2);
-                            Cm = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_m), fv, q1, q2);
+                            Cp = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_p), fv, q1, q2, krho);
+                            Cm = pa * wk * ft_corr(ms_l, pb * (1.0 - ct_m), fv, q1, q2, krho);
                         }
                         const double fvv_p = c * mm + sisj, fvv_m = -c * mm + sisj;
                         pvv_p += fvv_p * fvv_p * Cp; pvv_m += fvv_m * fvv_m * Cm;

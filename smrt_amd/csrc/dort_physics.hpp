@@ -64,19 +64,26 @@ SMRT_DEV cplx water_permittivity(double frequency, double T) {
 SMRT_DEV double sinc_(double x) { return x == 0.0 ? 1.0 : sin(x) / x; }
 
 // FT of the autocorrelation function at wavenumber k (k2 = k*k)
-SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2) {
+SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2, double krho = 0.0) {
     if (micro == MS_EXP) {  // exponential.py:53-58
         double x = k2 * p1 * p1;
         double den = 1.0 + x;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
     }
-    if (__builtin_expect(micro == MS_EXPC, 0)) {
-        // the exponential model at the COMPLEX wavenumber k^2 (1 + i p2) of the strong-contrast-expansion emmodels, whose
+    if (__builtin_expect(micro >= MS_EXPC, 0)) {
+        // the rational models at the COMPLEX wavenumber k^2 (1 + i krho) of the strong-contrast-expansion emmodels, whose
         // phase function evaluates the transform at 2 k0 sqrt(eps_eff) sin(Theta / 2) with eps_eff complex and keeps the real
-        // part (sce_common.py:222-233, emmodel/common.py:107-117): Re 1 / (1 + X (1 + i p2))^2, X = k2 p1^2
-        const double xr = k2 * p1 * p1, xi = xr * p2;
-        const double a = 1.0 + xr, a2 = a * a, b2 = xi * xi, m = a2 + b2;
-        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * (a2 - b2) / (m * m);
+        // part (sce_common.py:222-233, emmodel/common.py:107-117), X = k2 p1^2:
+        const double xr = k2 * p1 * p1, xi = xr * krho;
+        if (micro == MS_EXPC) {   // exponential: Re 1 / (1 + X (1 + i krho))^2
+            const double a = 1.0 + xr, a2 = a * a, b2 = xi * xi, m = a2 + b2;
+            return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * (a2 - b2) / (m * m);
+        }
+        // Teubner-Strey (p2 = Y): Re 1 / ((1 + Y)^2 + 2 (1 - Y) Xc + Xc^2), Xc = X (1 + i krho)
+        const double y = p2;
+        const double a = (1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * xr + xr * xr - xi * xi;
+        const double b = 2.0 * (1.0 - y) * xi + 2.0 * xr * xi;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * a / (a * a + b * b);
     }
     if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length xi, p2 = Y = (2 pi xi / repeat distance)^2;
         // with a negative Y the same expression is the product of two Lorentzians of unified_teubner_strey.py:69-72

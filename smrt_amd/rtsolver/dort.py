@@ -745,10 +745,13 @@ class DORT(object):
                         name, q1, q2 = _device_microstructure(ms)
                     if name not in MS_CODES:
                         return None
-                    if complex_k:
-                        if MS_CODES[name] != MS_CODES["exponential"]:   # the complex wavenumber: the exponential form only
+                    if complex_k:   # the complex wavenumber: the two rational forms only
+                        if MS_CODES[name] == MS_CODES["exponential"]:
+                            name = "exponential_complex_k"
+                        elif MS_CODES[name] == MS_CODES["teubner_strey"]:
+                            name = "teubner_strey_complex_k"
+                        else:
                             return None
-                        name = "exponential_complex_k"
                     ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
                     ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
                     eps = complex(em.effective_permittivity())

@@ -104,14 +104,15 @@ def packed_batch_from_fixture(d, freqs=None):
                 hc[fi, 0, l] = em.iba_coeff
         host_scalars = (hl, hc)
         emmodel = ["iba_host" if e in family else e for e in names]
-        if "symsce_torquato21" in names:   # ... at the complex wavenumber of the strong-contrast expansion (exponential model)
-            assert ms in ("exponential", "unified_scaled_exponential") and all(e == "symsce_torquato21" for e in names)
-            from smrt_amd.core.layer import device_microstructure_params
-            lc = [device_microstructure_params(ms, 0.0, **{k: float(np.broadcast_to(sp[k], (L,))[l]) for k in
-                                                           (("corr_length",) if ms == "exponential" else ("porod_length", "polydispersity"))})[0]
-                  for l in range(L)]
-            sp = dict(sp, corr_length=np.array(lc))
-            ms = ["exponential_complex_k"] * L
+        if "symsce_torquato21" in names:   # ... at the complex wavenumber of the strong-contrast expansion (rational models)
+            assert all(e == "symsce_torquato21" for e in names)
+            from smrt_amd._native import MS_CODES as _MS
+            complex_ms = {0: "exponential_complex_k", 3: "teubner_strey_complex_k"}[_MS[ms]]
+            from smrt_amd.core.layer import MICROSTRUCTURE_ARGS, device_microstructure_params
+            pq = [device_microstructure_params(ms, float(np.broadcast_to(sp["frac_volume"], (L,))[l]),
+                                               **{k: float(np.broadcast_to(sp[k], (L,))[l]) for k in MICROSTRUCTURE_ARGS[ms]}) for l in range(L)]
+            sp = dict(sp, complex_k_p1=np.array([q[0] for q in pq]), complex_k_p2=np.array([q[1] for q in pq]))
+            ms = [complex_ms] * L
     if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
         L = len(sp["thickness"])
         msl = ms if isinstance(ms, list) else [ms] * L
@@ -122,12 +123,12 @@ def packed_batch_from_fixture(d, freqs=None):
         # stickiness as they are, Teubner-Strey's repeat distance as Y, the unified parameters reparametrised
         from smrt_amd.core.layer import MICROSTRUCTURE_ARGS, device_microstructure_params
         fvl = np.broadcast_to(sp["frac_volume"], (L,))
-        pp = [(float(col("corr_length")[l]), 0.0) if m == "exponential_complex_k" else
+        pp = [(float(col("complex_k_p1")[l]), float(col("complex_k_p2")[l])) if m.endswith("_complex_k") else
               device_microstructure_params(m, float(fvl[l]), **{a: float(col(a)[l]) for a in MICROSTRUCTURE_ARGS[m]})
               for l, m in enumerate(msl)]
         p1, p2 = np.array([q[0] for q in pp]), np.array([q[1] for q in pp])
         ms, emmodel = msl[0], eml[0]
-        ms = "exponential" if ms == "exponential_complex_k" else ms   # (a per-layer code only: the batch-level one is not read)
+        ms = "exponential" if ms.endswith("_complex_k") else ms   # (per-layer codes only: the batch-level one is not read)
     else:
         p1 = sp["corr_length"] if ms == "exponential" else sp["radius"]
         p2 = None if ms == "exponential" else np.broadcast_to(sp["stickiness"], p1.shape)
@@ -205,7 +206,7 @@ MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active", "iba_
 # matrix assembled on the device, the scalars from the emmodel object (SMRT_EM_IBA_HOST)
 IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive",
                        # the symmetrised strong-contrast expansion: IBA's phase function at a complex wavenumber (passive)
-                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive"]
+                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive", "symsce_ts_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

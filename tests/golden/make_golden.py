@@ -65,8 +65,8 @@ def snowpack_arrays(sp):
         out["radius"] = np.array([lay.microstructure.radius for lay in sp.layers], float)
     elif type(ms).__name__ == "Homogeneous":
         out["microstructure"] = "homogeneous"
-    elif type(ms).__name__ == "UnifiedScaledExponential":
-        out["microstructure"] = "unified_scaled_exponential"
+    elif type(ms).__name__ in ("UnifiedScaledExponential", "UnifiedTeubnerStrey"):
+        out["microstructure"] = {"UnifiedScaledExponential": "unified_scaled_exponential", "UnifiedTeubnerStrey": "unified_teubner_strey"}[type(ms).__name__]
         out["porod_length"] = np.array([lay.microstructure.porod_length for lay in sp.layers], float)
         out["polydispersity"] = np.array([lay.microstructure.polydispersity for lay in sp.layers], float)
     elif hasattr(ms, "corr_length"):
@@ -830,6 +830,12 @@ def main():
                                 porod_length=[1.0e-4, 1.6e-4, 2.0e-4], polydispersity=[1.2, 1.1, 1.3])
             save("symsce_unified_L3_n12_passive", run_new("symsce_torquato21", passive([18.7e9, 36.5e9], [55]), spx,
                                                            rtsolver_options=dict(n_max_stream=12)))
+
+    if wanted("symsce_ts_L3_n12_passive"):   # ... and on Teubner-Strey's expression, unified parameters on both sides of polydispersity 1
+        spx = make_snowpack([0.25, 0.35, 100.0], "unified_teubner_strey", density=[220, 310, 390], temperature=[257, 262, 266],
+                            porod_length=[1.0e-4, 1.6e-4, 2.0e-4], polydispersity=[0.8, 1.4, 1.1])
+        save("symsce_ts_L3_n12_passive", run_new("symsce_torquato21", passive([18.7e9, 36.5e9, 89e9], [55]), spx,
+                                                  rtsolver_options=dict(n_max_stream=12)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73
