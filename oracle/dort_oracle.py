@@ -93,7 +93,7 @@ def ft_autocorr_exponential(k, frac_volume, corr_length):
 
 def ft_autocorr_independent_sphere(k, frac_volume, radius):
     """smrt/microstructure_model/independent_sphere.py:54-72."""
-    x = radius * np.asarray(k, float)
+    x = radius * np.asarray(k)                    # (k may be complex: the strong-contrast-expansion emmodels)
     bessel = np.ones_like(x)
     nz = ~np.isclose(x, 0)
     bessel[nz] = 9 * ((np.sin(x[nz]) - x[nz] * np.cos(x[nz])) / x[nz] ** 3) ** 2
@@ -165,7 +165,7 @@ def ft_autocorr_shs(k, frac_volume, radius, stickiness, t=None):
     expression as smrt/microstructure_model/unified_sticky_hard_spheres.py:43-76 evaluates it (its t comes from the
     polydispersity, :24-27, not from a stickiness)."""
     f, tau = frac_volume, stickiness
-    x = np.atleast_1d(np.asarray(k, float)) * radius
+    x = np.atleast_1d(np.asarray(k)) * radius    # (k may be complex: the strong-contrast-expansion emmodels)
     if t is not None:
         pass
     elif np.isfinite(tau) and f > 0:
@@ -369,6 +369,16 @@ class SymSCELayer(LayerEM):
                 return lambda k: ft_autocorr_unified_scaled_exponential(k, fv, mp["porod_length"], mp["polydispersity"])
             if microstructure == "teubner_strey":
                 return lambda k: ft_autocorr_teubner_strey(k, fv, mp["corr_length"], mp["repeat_distance"])
+            if microstructure == "sticky_hard_spheres":
+                return lambda k: ft_autocorr_shs(k, fv, mp["radius"], mp["stickiness"])
+            if microstructure == "unified_sticky_hard_spheres":
+                # (the inverted medium of the reference is a COPY with frac_volume -> 1 - f, autocorrelation.py:146-153: the
+                # radius and the t parameter this model derives from f at construction stay those of the medium itself)
+                radius = 3 / 4 * mp["porod_length"] / (1 - f)
+                t = (1 + 2 * f - 3 / (8 * np.sqrt(2)) * mp["polydispersity"] ** (-3 / 2)) / (f * (1.0 - f))
+                return lambda k: ft_autocorr_shs(k, fv, radius, None, t=t)
+            if microstructure == "independent_sphere":
+                return lambda k: ft_autocorr_independent_sphere(np.atleast_1d(k), fv, mp["radius"]).reshape(np.shape(k))
             if microstructure == "unified_teubner_strey":
                 return lambda k: ft_autocorr_unified_teubner_strey(k, fv, mp["porod_length"], mp["polydispersity"])
             raise ValueError(microstructure)

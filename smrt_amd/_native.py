@@ -22,7 +22,8 @@ EM_CODES = {"iba": 0, "dmrt_qca_shortrange": 1, "dmrt_qcacp_shortrange": 2, "non
 MS_CODES = {"exponential": 0, "sticky_hard_spheres": 1, "independent_sphere": 2, "teubner_strey": 3,   # SMRT_MS_*
             # the models on the unified parameters are reparametrisations (core/layer.py: device_microstructure_params)
             "unified_scaled_exponential": 0, "unified_sticky_hard_spheres": 1, "unified_teubner_strey": 3,
-            "exponential_complex_k": 4, "teubner_strey_complex_k": 5}   # SMRT_MS_*_COMPLEX_K: layers of the strong-contrast-expansion emmodels
+            "exponential_complex_k": 4, "sticky_hard_spheres_complex_k": 5, "independent_sphere_complex_k": 6,
+            "teubner_strey_complex_k": 7}   # SMRT_MS_*_COMPLEX_K: layers of the strong-contrast-expansion emmodels
 SUBSTRATE_CODES = {"flat": 1, "reflector": 2, "host": 3}
 NORM_CODES = {False: 0, None: 0, True: 1, "auto": 1, "forced": 2}
 STATUS_MESSAGES = {

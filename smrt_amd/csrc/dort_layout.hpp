@@ -110,7 +110,7 @@ constexpr double kPi = 3.14159265358979323846;
 
 enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3, EM_HOST = 4, EM_IBA_INV = 5, EM_IBA_HOST = 6, EM_RAYLEIGH_HOST = 7 };  // 1-3 have a Rayleigh phase matrix; 4: host arrays;
 // 5: IBA on the inverted medium (layer_em); pair_setup files such a layer as EM_IBA once its coefficients are computed
-enum { MS_EXP = 0, MS_SHS = 1, MS_SPHERE = 2, MS_TS = 3, MS_EXPC = 4, MS_TSC = 5 };   // 4, 5: exponential / Teubner-Strey at a complex wavenumber (smrt_dort.h)
+enum { MS_EXP = 0, MS_SHS = 1, MS_SPHERE = 2, MS_TS = 3, MS_EXPC = 4, MS_SHSC = 5, MS_SPHEREC = 6, MS_TSC = 7 };   // 4 + model: the model at a complex wavenumber (smrt_dort.h)
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5, ST_COHERENT = 6 };
 enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2, SUB_HOST = 3 };
 

@@ -745,13 +745,9 @@ class DORT(object):
                         name, q1, q2 = _device_microstructure(ms)
                     if name not in MS_CODES:
                         return None
-                    if complex_k:   # the complex wavenumber: the two rational forms only
-                        if MS_CODES[name] == MS_CODES["exponential"]:
-                            name = "exponential_complex_k"
-                        elif MS_CODES[name] == MS_CODES["teubner_strey"]:
-                            name = "teubner_strey_complex_k"
-                        else:
-                            return None
+                    if complex_k:   # the model's transform at the complex wavenumber: 4 + its own code
+                        name = {0: "exponential_complex_k", 1: "sticky_hard_spheres_complex_k", 2: "independent_sphere_complex_k",
+                                3: "teubner_strey_complex_k"}[MS_CODES[name]]
                     ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
                     ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
                     eps = complex(em.effective_permittivity())

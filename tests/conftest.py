@@ -104,15 +104,17 @@ def packed_batch_from_fixture(d, freqs=None):
                 hc[fi, 0, l] = em.iba_coeff
         host_scalars = (hl, hc)
         emmodel = ["iba_host" if e in family else e for e in names]
-        if "symsce_torquato21" in names:   # ... at the complex wavenumber of the strong-contrast expansion (rational models)
+        if "symsce_torquato21" in names:   # ... at the complex wavenumber of the strong-contrast expansion: 4 + the model's code
             assert all(e == "symsce_torquato21" for e in names)
             from smrt_amd._native import MS_CODES as _MS
-            complex_ms = {0: "exponential_complex_k", 3: "teubner_strey_complex_k"}[_MS[ms]]
             from smrt_amd.core.layer import MICROSTRUCTURE_ARGS, device_microstructure_params
-            pq = [device_microstructure_params(ms, float(np.broadcast_to(sp["frac_volume"], (L,))[l]),
-                                               **{k: float(np.broadcast_to(sp[k], (L,))[l]) for k in MICROSTRUCTURE_ARGS[ms]}) for l in range(L)]
+            per_layer = ms if isinstance(ms, list) else [ms] * L
+            at = lambda k, l: float(np.nan_to_num(np.broadcast_to(sp[k], (L,))[l])) if k in sp else 1000.0   # noqa: E731  (stickiness default)
+            pq = [device_microstructure_params(m, float(np.broadcast_to(sp["frac_volume"], (L,))[l]),
+                                               **{k: at(k, l) for k in MICROSTRUCTURE_ARGS[m]}) for l, m in enumerate(per_layer)]
             sp = dict(sp, complex_k_p1=np.array([q[0] for q in pq]), complex_k_p2=np.array([q[1] for q in pq]))
-            ms = [complex_ms] * L
+            ms = [{0: "exponential_complex_k", 1: "sticky_hard_spheres_complex_k", 2: "independent_sphere_complex_k",
+                   3: "teubner_strey_complex_k"}[_MS[m]] for m in per_layer]
     if isinstance(ms, list) or isinstance(emmodel, list):   # heterogeneous snowpack: per-layer codes and parameters
         L = len(sp["thickness"])
         msl = ms if isinstance(ms, list) else [ms] * L
@@ -206,7 +208,8 @@ MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active", "iba_
 # matrix assembled on the device, the scalars from the emmodel object (SMRT_EM_IBA_HOST)
 IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive",
                        # the symmetrised strong-contrast expansion: IBA's phase function at a complex wavenumber (passive)
-                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive", "symsce_ts_L3_n12_passive"]
+                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive", "symsce_ts_L3_n12_passive",
+                       "symsce_spheres_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

@@ -49,10 +49,12 @@ def snowpack_arrays(sp):
                  "UnifiedScaledExponential": "unified_scaled_exponential", "UnifiedTeubnerStrey": "unified_teubner_strey",
                  "UnifiedStickyHardSpheres": "unified_sticky_hard_spheres"}
         out["microstructure"] = np.array([names[type(lay.microstructure).__name__] for lay in sp.layers])
-        unified = any(n.startswith("Unified") for n in kinds)
-        # (the unified models derive corr_length / radius internally: only their own parameters are inputs)
-        for a in ("porod_length", "polydispersity") if unified else ("corr_length", "radius", "stickiness", "repeat_distance"):
-            out[a] = np.array([get(lay, a) for lay in sp.layers])
+        # (the unified models derive corr_length / radius internally: only their own parameters are inputs -- NaN elsewhere)
+        for a in ("corr_length", "radius", "stickiness", "repeat_distance", "porod_length", "polydispersity"):
+            vals = [np.nan if (a in ("corr_length", "radius", "stickiness", "repeat_distance") and
+                               type(lay.microstructure).__name__.startswith("Unified")) else get(lay, a) for lay in sp.layers]
+            if not np.all(np.isnan(vals)):
+                out[a] = np.array(vals)
         return out
     ms = sp.layers[0].microstructure
     if getattr(sp.layers[0], "ks", None) is not None:   # prescribed_kskaeps reads these layer attributes
@@ -836,6 +838,13 @@ def main():
                             porod_length=[1.0e-4, 1.6e-4, 2.0e-4], polydispersity=[0.8, 1.4, 1.1])
         save("symsce_ts_L3_n12_passive", run_new("symsce_torquato21", passive([18.7e9, 36.5e9, 89e9], [55]), spx,
                                                   rtsolver_options=dict(n_max_stream=12)))
+
+    if wanted("symsce_spheres_L3_n12_passive"):   # ... and on the sphere models: sines of a complex argument
+        spx = make_snowpack([0.25, 0.35, 100.0], ["sticky_hard_spheres", "unified_sticky_hard_spheres", "independent_sphere"],
+                            density=[220, 310, 250], temperature=[257, 262, 266], radius=[1.5e-4, None, 2.2e-4],
+                            stickiness=[0.2, None, None], porod_length=[None, 1.6e-4, None], polydispersity=[None, 1.3, None])
+        save("symsce_spheres_L3_n12_passive", run_new("symsce_torquato21", passive([18.7e9, 36.5e9, 89e9], [55]), spx,
+                                                       rtsolver_options=dict(n_max_stream=12)))
 
     # (v) IBA ks table, smrt/emmodel/test_iba.py:111-127 (shs snowpack of setup_func_pc) and the stream-angle
     # known answer smrt/rtsolver/test_rtsolver.py:64-73

@@ -810,10 +810,10 @@ def test_an_emmodel_of_the_iba_family_hands_over_its_scalars():
                "symsce_torquato21": family_member(O.SymSCELayer, "complex_k")}
     for name in IBA_FAMILY_FIXTURES:
         d = load_golden(name)
-        ms = str(d["microstructure"])
-        args = dict(corr_length=d["corr_length"]) if ms == "exponential" else \
-            dict(porod_length=d["porod_length"], polydispersity=d["polydispersity"]) if ms.startswith("unified") else \
-            dict(radius=d["radius"], stickiness=d["stickiness"])
+        none = lambda a: [None if np.isnan(x) else float(x) for x in a]   # noqa: E731
+        ms = str(d["microstructure"]) if np.ndim(d["microstructure"]) == 0 else [str(m) for m in d["microstructure"]]
+        args = {k: none(d[k]) for k in ("corr_length", "radius", "stickiness", "repeat_distance", "porod_length", "polydispersity")
+                if k in d}
         sp = make_snowpack(d["thickness"], ms, density=d["density"], temperature=d["temperature"], **args)
         em = [members.get(str(e), str(e)) for e in np.atleast_1d(d["emmodel"])]
         em = em[0] if len(em) == 1 else em
