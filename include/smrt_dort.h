@@ -63,8 +63,10 @@ typedef struct smrt_dort_ctx smrt_dort_ctx;
 /* The exponential model evaluated at the COMPLEX wavenumber of the strong-contrast-expansion emmodels (smrt/emmodel/
  * sce_common.py:222-233: 2 k0 sqrt(eps_eff) sin(Theta / 2) with the complex eps_eff, real part of the transform kept,
  * emmodel/common.py:107-117): micro_p1 = corr_length; eps_eff comes from host_layer.  Only as the microstructure code of
- * SMRT_EM_IBA_HOST layers (layer_kind), passive mode.  The other models likewise, 4 + their own code, with their own
- * micro_p1 / micro_p2 (sticky hard spheres and independent spheres: sines of the complex k r). */
+ * SMRT_EM_IBA_HOST layers (layer_kind), passive mode.  Teubner-Strey's expression likewise (4 + its own code, micro_p1 /
+ * micro_p2 as for SMRT_MS_TEUBNER_STREY).  The codes of the sphere models are reserved and refused: their complex form
+ * (sines of the complex k r) cost the headline pipeline's prep kernel more than it was worth; such layers take the
+ * SMRT_EM_HOST route. */
 #define SMRT_MS_EXPONENTIAL_COMPLEX_K 4
 #define SMRT_MS_STICKY_HARD_SPHERES_COMPLEX_K 5
 #define SMRT_MS_INDEPENDENT_SPHERE_COMPLEX_K 6

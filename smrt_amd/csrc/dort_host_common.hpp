@@ -126,6 +126,8 @@ inline const char* validate(const smrt_batch* b) {
                     return "invalid layer_kind entry";
                 if (ms >= SMRT_MS_EXPONENTIAL_COMPLEX_K && (em != SMRT_EM_IBA_HOST || b->mode != SMRT_MODE_PASSIVE))
                     return "SMRT_MS_*_COMPLEX_K go with SMRT_EM_IBA_HOST layers in passive mode only";
+                if (ms == SMRT_MS_STICKY_HARD_SPHERES_COMPLEX_K || ms == SMRT_MS_INDEPENDENT_SPHERE_COMPLEX_K)
+                    return "the sphere models have no complex-wavenumber form on the device (exponential and Teubner-Strey do)";
                 if (em == SMRT_EM_HOST) host_layers = true;
                 if (em == SMRT_EM_IBA_HOST) scalar_layers = true;
                 if (em == SMRT_EM_RAYLEIGH_HOST) rayleigh_layers = true;

@@ -70,72 +70,23 @@ SMRT_DEV double ft_corr(int micro, double k2, double fv, double p1, double p2, d
         double den = 1.0 + x;
         return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 / (den * den);
     }
-    if (__builtin_expect(micro >= MS_EXPC, 0)) {
-        // the rational models at the COMPLEX wavenumber k^2 (1 + i krho) of the strong-contrast-expansion emmodels, whose
-        // phase function evaluates the transform at 2 k0 sqrt(eps_eff) sin(Theta / 2) with eps_eff complex and keeps the real
-        // part (sce_common.py:222-233, emmodel/common.py:107-117), X = k2 p1^2:
+    // The rational models at the COMPLEX wavenumber k^2 (1 + i krho) of the strong-contrast-expansion emmodels, whose phase
+    // function evaluates the transform at 2 k0 sqrt(eps_eff) sin(Theta / 2) with eps_eff complex and keeps the real part
+    // (sce_common.py:222-233, emmodel/common.py:107-117), X = k2 p1^2.  (The sphere models at a complex k r were built and
+    // measured: inlined here their complex arithmetic cost the prep kernel of the headline pipeline 44 more spilled
+    // registers and 0.25 ms per step on paths that pipeline never takes, as a function of its own still 21 -- not kept:
+    // such layers go the dense route, rtsolver/dort.py; validate() refuses their codes.)
+    if (__builtin_expect(micro == MS_EXPC, 0)) {   // exponential: Re 1 / (1 + X (1 + i krho))^2
         const double xr = k2 * p1 * p1, xi = xr * krho;
-        if (micro == MS_EXPC) {   // exponential: Re 1 / (1 + X (1 + i krho))^2
-            const double a = 1.0 + xr, a2 = a * a, b2 = xi * xi, m = a2 + b2;
-            return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * (a2 - b2) / (m * m);
-        }
-        if (micro == MS_TSC) {   // Teubner-Strey (p2 = Y): Re 1 / ((1 + Y)^2 + 2 (1 - Y) Xc + Xc^2), Xc = X (1 + i krho)
-            const double y = p2;
-            const double a = (1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * xr + xr * xr - xi * xi;
-            const double b = 2.0 * (1.0 - y) * xi + 2.0 * xr * xi;
-            return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * a / (a * a + b * b);
-        }
-        // the sphere models (the code below in complex arithmetic): x = k r with k^2 complex, sines of a complex argument
-        const double f = fv, vd = 4.0 / 3.0 * kPi * p1 * p1 * p1;
-        const cplx x = csqrt_(cmk(xr, xi));                      // (xr, xi: k^2 r^2 here, p1 = radius)
-        const double ax2 = sqrt(xr * xr + xi * xi);              // |x|^2
-        const cplx x2 = cmk(xr, xi);
-        cplx vint;
-        if (ax2 <= 1e-4) {   // series of vint, as for the real argument
-            vint = csub(cmk(1.0, 0.0), cmul(x2, csub(cmk(0.1, 0.0), cscale(x2, 1.0 / 280.0))));
-        } else {
-            const double sh = sinh(x.im), ch = cosh(x.im), sr = sin(x.re), cr = cos(x.re);
-            const cplx sx = cmk(sr * ch, cr * sh), cx = cmk(cr * ch, -sr * sh);
-            vint = cscale(cdiv(csub(cdiv(sx, x), cx), x2), 3.0);
-            if (micro == MS_SHSC) {
-                double tt = 0.0;
-                if (p2 < 0.0) tt = -p2;
-                else if (isfinite(p2) && f > 0.0) {
-                    const double tau = p2;
-                    const double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
-                                        36 * tau * tau - 12 * f;
-                    tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
-                }
-                const double fr = f / (1.0 - f), c1 = 1.0 - tt * f + 3.0 * fr, c2 = 3.0 - tt * (1.0 - f);
-                const cplx psi = cdiv(cdiv(sx, x), vint);
-                const cplx a = cadd(cadd(cmk(fr * c1, 0.0), cscale(psi, fr * c2)), cdiv(cx, vint));
-                const cplx b = cadd(cscale(x, fr), cdiv(sx, vint));
-                const cplx den = cadd(cmul(a, a), cmul(b, b));
-                return f * vd * den.re / cabs2(den);             // Re 1 / (a^2 + b^2)
-            }
-        }
-        if (micro == MS_SHSC) {   // (|x| <= 1e-2 but above the k = 0 limit: the closed form with the series of vint)
-            double tt = 0.0;
-            if (p2 < 0.0) tt = -p2;
-            else if (isfinite(p2) && f > 0.0) {
-                const double tau = p2;
-                const double disc = 36 * tau * tau * f * f - 72 * tau * f * f - 72 * tau * tau * f + 30 * f * f + 72 * tau * f +
-                                    36 * tau * tau - 12 * f;
-                tt = (6 * tau * f - 6 * f - 6 * tau + sqrt(disc)) / (f * (f - 1.0));
-            }
-            const double fr = f / (1.0 - f), c1 = 1.0 - tt * f + 3.0 * fr, c2 = 3.0 - tt * (1.0 - f);
-            if (ax2 <= 1e-6) { const double den = fr * (c1 + c2) + 1.0; return f * vd / (den * den); }   // |x| <= 1e-3: the k = 0 limit
-            // sin x / x and cos x by their series (|x| <= 1e-2: four terms reach 1e-17)
-            const cplx sc = csub(cmk(1.0, 0.0), cmul(x2, csub(cmk(1.0 / 6.0, 0.0), cscale(x2, 1.0 / 120.0))));
-            const cplx cx = csub(cmk(1.0, 0.0), cmul(x2, csub(cmk(0.5, 0.0), cscale(x2, 1.0 / 24.0))));
-            const cplx psi = cdiv(sc, vint);
-            const cplx a = cadd(cadd(cmk(fr * c1, 0.0), cscale(psi, fr * c2)), cdiv(cx, vint));
-            const cplx b = cadd(cscale(x, fr), cdiv(cmul(sc, x), vint));
-            const cplx den = cadd(cmul(a, a), cmul(b, b));
-            return f * vd * den.re / cabs2(den);
-        }
-        const cplx v2 = cmul(vint, vint);                        // independent spheres: Re vint^2
-        return f * (1.0 - f) * vd * v2.re;
+        const double a = 1.0 + xr, a2 = a * a, b2 = xi * xi, m = a2 + b2;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * (a2 - b2) / (m * m);
+    }
+    if (__builtin_expect(micro == MS_TSC, 0)) {   // Teubner-Strey (p2 = Y): Re 1 / ((1 + Y)^2 + 2 (1 - Y) Xc + Xc^2), Xc = X (1 + i krho)
+        const double xr = k2 * p1 * p1, xi = xr * krho;
+        const double y = p2;
+        const double a = (1.0 + y) * (1.0 + y) + 2.0 * (1.0 - y) * xr + xr * xr - xi * xi;
+        const double b = 2.0 * (1.0 - y) * xi + 2.0 * xr * xi;
+        return fv * (1.0 - fv) * 8.0 * kPi * p1 * p1 * p1 * a / (a * a + b * b);
     }
     if (micro == MS_TS) {   // Teubner-Strey, teubner_strey.py:45-55: p1 = correlation length xi, p2 = Y = (2 pi xi / repeat distance)^2;
         // with a negative Y the same expression is the product of two Lorentzians of unified_teubner_strey.py:69-72

@@ -745,9 +745,10 @@ class DORT(object):
                         name, q1, q2 = _device_microstructure(ms)
                     if name not in MS_CODES:
                         return None
-                    if complex_k:   # the model's transform at the complex wavenumber: 4 + its own code
-                        name = {0: "exponential_complex_k", 1: "sticky_hard_spheres_complex_k", 2: "independent_sphere_complex_k",
-                                3: "teubner_strey_complex_k"}[MS_CODES[name]]
+                    if complex_k:   # the model's transform at the complex wavenumber (4 + its own code): the two rational forms
+                        name = {0: "exponential_complex_k", 3: "teubner_strey_complex_k"}.get(MS_CODES[name])
+                        if name is None:   # the sphere models: the dense route
+                            return None
                     ks = em.ks(one, P) if callable(getattr(em, "ks", None)) else em.ks
                     ka = em.ka(one, P) if callable(getattr(em, "ka", None)) else em.ka
                     eps = complex(em.effective_permittivity())

@@ -208,8 +208,9 @@ MICRO_FIXTURES = ["iba_micro4_L4_n12_passive", "iba_micro4_L4_n10_active", "iba_
 # matrix assembled on the device, the scalars from the emmodel object (SMRT_EM_IBA_HOST)
 IBA_FAMILY_FIXTURES = ["iba_original_L3_n12_passive", "iba_mg_L3_n10_active", "iba_family_L3_n12_passive",
                        # the symmetrised strong-contrast expansion: IBA's phase function at a complex wavenumber (passive)
-                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive", "symsce_ts_L3_n12_passive",
-                       "symsce_spheres_L3_n12_passive"]
+                       "symsce_L3_n12_passive", "symsce_unified_L3_n12_passive", "symsce_ts_L3_n12_passive"]
+# ... on the sphere models (sines of a complex argument: the dense route in the product; the oracle restates it)
+SCE_SPHERES_FIXTURES = ["symsce_spheres_L3_n12_passive"]
 HOST_EMMODEL_FIXTURES = ["rayleigh_L3_n16_passive", "rayleigh_L3_n12_active", "prescribed_L3_n16_passive"]
 # ... together with process_coherent_layers: the phase matrices of the layers that stay live on the streams of the reduced
 # snowpack (a 3 mm and a 6 mm layer leave at these frequencies)

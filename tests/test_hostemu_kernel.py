@@ -238,7 +238,7 @@ def test_blocked_jacobi_kernel_gives_the_singular_values(emu, n_max_stream, N, o
 @pytest.mark.parametrize("name,nt", [(MIXED_FIXTURES[0], 64), (MIXED_FIXTURES[1], 256), (DENSE_AUTO_FIXTURES[0], 256),
                                      (DENSE_AUTO_FIXTURES[1], 128), (WET_FIXTURES[0], 256), (WET_FIXTURES[1], 64), (WET_FIXTURES[2], 128), (MICRO_FIXTURES[0], 256), (MICRO_FIXTURES[1], 64), (MICRO_FIXTURES[2], 256), (MICRO_FIXTURES[3], 64),
                                      (IBA_FAMILY_FIXTURES[0], 256), (IBA_FAMILY_FIXTURES[1], 64), (IBA_FAMILY_FIXTURES[2], 64),
-                                     (IBA_FAMILY_FIXTURES[3], 256), (IBA_FAMILY_FIXTURES[4], 64), (IBA_FAMILY_FIXTURES[5], 64), (IBA_FAMILY_FIXTURES[6], 64)])
+                                     (IBA_FAMILY_FIXTURES[3], 256), (IBA_FAMILY_FIXTURES[4], 64), (IBA_FAMILY_FIXTURES[5], 64)])
 def test_emulated_kernel_heterogeneous_snowpacks(emu, name, nt):
     """Per-layer emmodel and microstructure codes (smrt_batch.layer_kind) through the device code; IBA on the inverted
     medium for layers above half ice (SMRT_EM_IBA_INVERTED, the reference's dense_snow_correction="auto")."""

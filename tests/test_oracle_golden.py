@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, IBA_FAMILY_FIXTURES, COHERENT_HOST_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
+from conftest import (ACTIVE_FIXTURES, COHERENT_FIXTURES, ROUGH_SUBSTRATE_FIXTURES, ROUGH_SUBSTRATE_PASSIVE_FIXTURES, fixture_substrate, HOST_EMMODEL_FIXTURES, IBA_FAMILY_FIXTURES, SCE_SPHERES_FIXTURES, COHERENT_HOST_FIXTURES, MIXED_FIXTURES, DENSE_AUTO_FIXTURES, WET_FIXTURES, MICRO_FIXTURES, PASSIVE_FIXTURES, PRUNE_ACTIVE_FIXTURES, PRUNE_FIXTURES, SUBSTRATE_FIXTURES,
                       assert_backscatter_close, fixture_atmosphere, fixture_options, fixture_substrate, load_golden,
                       fixture_emmodel, reference_method_spread, snowpack_dict)
 from oracle import dort_oracle as O
@@ -212,7 +212,7 @@ def test_albedo_above_one_is_flagged():
     assert ei.value.status == 3
 
 
-@pytest.mark.parametrize("name", MIXED_FIXTURES + HOST_EMMODEL_FIXTURES + DENSE_AUTO_FIXTURES + WET_FIXTURES + MICRO_FIXTURES + IBA_FAMILY_FIXTURES)
+@pytest.mark.parametrize("name", MIXED_FIXTURES + HOST_EMMODEL_FIXTURES + DENSE_AUTO_FIXTURES + WET_FIXTURES + MICRO_FIXTURES + IBA_FAMILY_FIXTURES + SCE_SPHERES_FIXTURES)
 def test_heterogeneous_snowpacks(name):
     """(Also IBA's dense_snow_correction="auto", which changes the medium layer by layer, and the fixtures of the emmodels that smrt_amd evaluates on the host: rayleigh, prescribed_kskaeps.)
     A list of emmodels -- one per layer -- over layers that mix the exponential and the sticky-hard-spheres
