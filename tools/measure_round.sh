@@ -36,6 +36,7 @@ cp profiles/hbm_traffic.json $O/hbm_traffic.json 2>/dev/null
   for s in 51 52 53 54; do python tools/stress_vs_oracle.py $s coherent 2>&1 | tail -n 2; done
   for s in 71 72 73; do python tools/stress_vs_oracle.py $s wetmicro 2>&1 | tail -n 2; done
   for s in 81 82; do python tools/stress_vs_oracle.py $s family 2>&1 | tail -n 2; done
+  for s in 91 92; do python tools/stress_vs_oracle.py $s sce 2>&1 | tail -n 2; done
   echo '# hard passive inputs (tools/stress_reg_extremes.py): register-resident pipeline, then the global-workspace pipeline'
   for s in 1 2 3 4; do python tools/stress_reg_extremes.py $s 2>&1 | tail -n 1; done
   python tools/stress_reg_extremes.py 5 4 big 2>&1 | tail -n 1

@@ -14,6 +14,9 @@ passive / active, with and without substrate and atmosphere, ragged layer counts
         last two reach the device as SMRT_EM_IBA_HOST layers -- effective permittivity, ks, ka and the phase coefficient
         from the oracle's layer objects (what the emmodel objects hand over in the product), the phase matrices
         assembled by the kernels
+        "sce": the passive IBA cases on the exponential model run the symmetrised strong-contrast expansion instead
+        (symsce_torquato21: SMRT_EM_IBA_HOST layers on SMRT_MS_EXPONENTIAL_COMPLEX_K, scalars and phase norm from the
+        oracle's restatement) -- the complex-wavenumber branch of the phase assembly on every pipeline
 """
 import os, sys, time
 import numpy as np
@@ -27,7 +30,8 @@ with_prune = len(sys.argv) > 2 and sys.argv[2] == "prune"
 with_coherent = len(sys.argv) > 2 and sys.argv[2] == "coherent"
 with_wetmicro = len(sys.argv) > 2 and sys.argv[2] == "wetmicro"
 with_family = len(sys.argv) > 2 and sys.argv[2] == "family"
-FAMILY = ["iba", "iba_original", "iba_maxwell_garnett"]
+with_sce = len(sys.argv) > 2 and sys.argv[2] == "sce"
+FAMILY = ["iba", "iba_original", "iba_maxwell_garnett", "symsce_torquato21"]
 n_family = 0
 MS_NAMES = ["exponential", "sticky_hard_spheres", "independent_sphere", "teubner_strey"]   # = MS codes 0 .. 3
 n_wet = n_conditioned = 0
@@ -92,7 +96,7 @@ for mode, n, em, ms in cases:
     host_scalars = eml = None
     if with_family and em == "iba":
         from smrt_amd._native import EM_CODES, MS_CODES
-        eml = rng_prune.integers(0, 3, (S, Lmax))                      # emmodel of every layer: index into FAMILY
+        eml = rng_prune.integers(0, 3, (S, Lmax))                      # emmodel of every layer: index into FAMILY[:3]
         hl = np.zeros((len(freqs), S, Lmax, 4)); hl[..., 2] = 1.0
         hc = np.zeros((len(freqs), S, Lmax))
         for fi, fr in enumerate(freqs):
@@ -106,6 +110,21 @@ for mode, n, em, ms in cases:
         host_scalars = (hl, hc)
         kinds = np.where(eml == 0, EM_CODES["iba"], EM_CODES["iba_host"]) + 16 * MS_CODES[ms]
         n_family += int((eml[:, 0] > 0).sum()) * len(freqs)
+    if with_sce and em == "iba" and ms == "exponential" and mode == "P":
+        from smrt_amd._native import EM_CODES, MS_CODES
+        eml = np.full((S, Lmax), 3)                                    # FAMILY[3]: symsce_torquato21 on every layer
+        hl = np.zeros((len(freqs), S, Lmax, 4)); hl[..., 2] = 1.0
+        hc = np.zeros((len(freqs), S, Lmax))
+        for fi, fr in enumerate(freqs):
+            for s in range(S):
+                k = nl[s]
+                spd = dict(thickness=thick[s, :k], density=dens[s, :k], temperature=temp[s, :k], microstructure=ms, corr_length=p1[s, :k])
+                for l, lay in enumerate(O.make_layers("symsce_torquato21", float(fr), spd)):
+                    hl[fi, s, l] = lay.ks, lay.ka, complex(lay.eps_eff).real, complex(lay.eps_eff).imag
+                    hc[fi, s, l] = lay.iba_coeff
+        host_scalars = (hl, hc)
+        kinds = np.full((S, Lmax), EM_CODES["iba_host"] + 16 * MS_CODES["exponential_complex_k"])
+        n_family += S * len(freqs)
     b = PackedBatch(nl, thick, dens / 916.7, temp, p1, p2, freqs, np.deg2rad(theta), emmodel=em, microstructure=ms, mode=mode,
                     n_max_stream=n, m_max=2, substrate=sub, atmosphere=atm, prune_deep_snowpack=prune,
                     process_coherent_layers=with_coherent, layer_kind=kinds, liquid_water=lw, host_scalars=host_scalars)
@@ -184,6 +203,7 @@ for mode, n, em, ms in cases:
 if with_coherent: print("process_coherent_layers: %d of the checked pairs lost at least one layer, %d pairs refused (status 6) by both" % (n_coherent, n_refused))
 if with_wetmicro: print("wetmicro: microstructure model drawn per layer in the IBA cases, %d of the pairs with wet layers on top; %d active pairs beyond 1e-8 but within 3 x the spread of the oracle's own methods" % (n_wet, n_conditioned))
 if with_family: print("family: emmodel drawn per layer among iba / iba_original / iba_maxwell_garnett in the IBA cases (the last two as SMRT_EM_IBA_HOST layers); %d pairs with such a layer on top" % n_family)
+if with_sce: print("sce: symsce_torquato21 on the passive IBA / exponential cases (complex-wavenumber phase assembly), %d pairs" % n_family)
 if with_prune: print("prune_deep_snowpack drawn per case: %d of the checked pairs were cut above their last layer" % n_pruned)
 print("checked %d pairs: max |dTb| = %.2e K, backscatter max rel (co-pol scale) = %.2e, cross-pol own scale (where cross/co > 1e-3) = %.2e" % (n_checked, worst_tb, worst_co, worst_cx))
 assert worst_tb < 1e-6 and worst_co < 1e-8 and worst_cx < 1e-6
