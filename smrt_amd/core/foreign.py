@@ -28,6 +28,7 @@ import numpy as np
 from .error import SMRTError
 
 NATIVE = "smrt_amd"
+REFERENCE = "smrt"
 
 
 def package_of(x):
@@ -41,7 +42,10 @@ def is_native(x):
 
 def _is_exactly(cls, scope, module, name):
     """Is `cls` the class `name` defined in <package>.<scope>.<module> (not a subclass, not a specialised copy)?"""
-    return getattr(cls, "__name__", None) == name and (getattr(cls, "__module__", "") or "").split(".")[-2:] == [scope, module]
+    parts = (getattr(cls, "__module__", "") or "").split(".")
+    # (the root package must be the reference itself: a third-party plugin that names its class and module alike keeps its
+    # own code and takes the host route)
+    return getattr(cls, "__name__", None) == name and parts[-2:] == [scope, module] and parts[0] == REFERENCE
 
 
 # ---- layers ----------------------------------------------------------------------------------------------------------
@@ -62,7 +66,14 @@ def _device_microstructure(ms):
     for (module, name), (dev, params) in DEVICE_MICROSTRUCTURE_CLASSES.items():
         if _is_exactly(type(ms), "microstructure_model", module, name):
             from .layer import device_microstructure_params
-            return (dev,) + device_microstructure_params(dev, float(ms.frac_volume), **{p: float(getattr(ms, p)) for p in params})
+            args = {p: float(getattr(ms, p)) for p in params}
+            if dev == "unified_sticky_hard_spheres":
+                # the object's OWN derived radius and t: smrt's inverted_medium() is a copy with frac_volume flipped that
+                # keeps the radius and t of the medium it was copied from
+                args["radius"], args["t"] = float(ms.radius), float(ms.t)
+                if not args["t"] > 0:
+                    return None, 0.0, 0.0   # no device encoding: the host route evaluates the layer
+            return (dev,) + device_microstructure_params(dev, float(ms.frac_volume), **args)
     return None, 0.0, 0.0
 
 

@@ -76,8 +76,16 @@ def device_microstructure_params(name, frac_volume, **p):
         return lp, float((lp / z2) ** 2)
     if name == "unified_sticky_hard_spheres":
         f = float(frac_volume)
-        t = (1 + 2 * f - 3 / (8 * np.sqrt(2)) * K ** -1.5) / (f * (1 - f))
-        return 0.75 * lp / (1 - f), float(-t)
+        # (an object that carries its own derived radius / t -- smrt's inverted_medium() copy keeps those of the medium it
+        # was made from while its frac_volume flips -- hands them over as they are)
+        t = float(p["t"]) if p.get("t") is not None else (1 + 2 * f - 3 / (8 * np.sqrt(2)) * K ** -1.5) / (f * (1 - f))
+        radius = float(p["radius"]) if p.get("radius") is not None else 0.75 * lp / (1 - f)
+        if not t > 0:
+            # the sign of micro_p2 is what tells the device "t given" from "stickiness given": a t <= 0 (small
+            # polydispersity) would be read as a stickiness
+            raise SMRTError(f"unified_sticky_hard_spheres: t = {t:g} <= 0 (polydispersity {K:g} at frac_volume {f:g}) "
+                            "has no device encoding; evaluate the layer's emmodel on the host")
+        return radius, float(-t)
     raise SMRTError(f"no device parameters for the microstructure model '{name}'")
 
 

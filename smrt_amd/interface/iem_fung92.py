@@ -60,10 +60,10 @@ class IEM_Fung92(KirchhoffCoherentPart):
 
     def _outside_validity(self, ks, kl, eps_r):
         if ks > 3:
-            return f"Warning, roughness_rms is too high for the given wavelength. Limit is ks < 3. Here ks={ks:g}"
+            return f"iem_fung92: the surface is too rough at this wavelength for the single-scattering series (k * rms height = {ks:g}, the model holds below 3)"
         if ks * kl > np.sqrt(eps_r):
-            return ("Warning, roughness_rms or correlation_length are too high for the given wavelength. Limit is ks * kl "
-                    f"< sqrt(eps_r). Here ks*kl={ks * kl:g} and sqrt(eps_r)={np.sqrt(eps_r):g}")
+            return (f"iem_fung92: (k * rms height)(k * correlation length) = {ks * kl:g} exceeds sqrt(eps_r) = "
+                    f"{np.sqrt(eps_r):g}, the bound of the model's validity for this pair of media")
         return None
 
     def backscatter(self, frequency, eps_1, eps_2, mu):

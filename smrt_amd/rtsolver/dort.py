@@ -309,20 +309,20 @@ class DORT(object):
             for s, w in enumerate(wet):
                 if w is not None:
                     liquid_water[s, :nl[s]] = w
-        self._liquid_water = liquid_water     # (read by the probes of _layer_permittivities for this group)
-        self._host_scalars = scalars
         mode = sensor0.mode
         substrate = atmosphere = None
         sub0 = sps[0].substrate
         if sub0 is not None and substrate_kind(sub0) == "host":
-            substrate = self._substrates_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+            substrate = self._substrates_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host,
+                                                     scalars=scalars, liquid_water=liquid_water)
         elif sub0 is not None:  # one kind per group; permittivity / reflection per (frequency, snowpack)
             q = np.array([[sp.substrate.device_params(f) for sp in sps] for f in freqs])  # (F, S, 2)
             ts = [sp.substrate.temperature if sp.substrate.temperature is not None else 0.0 for sp in sps]
             substrate = (sub0.device_kind, q[:, :, 0], q[:, :, 1], ts)
         host_interfaces = None
         if not all(sp.all_interfaces_flat() for sp in sps):
-            host_interfaces = self._interfaces_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+            host_interfaces = self._interfaces_on_host(sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host,
+                                                            scalars=scalars, liquid_water=liquid_water)
         atm0 = sps[0].atmosphere
         if atm0 is not None and mode == "P":  # one atmosphere object per group; ignored in active mode (reference)
             a = np.array([atm0.device_params(f) for f in freqs])  # (F, 3)
@@ -340,7 +340,7 @@ class DORT(object):
                            process_coherent_layers=self.process_coherent_layers, host_interfaces=host_interfaces,
                            liquid_water=liquid_water)
 
-    def _layer_permittivities(self, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+    def _layer_permittivities(self, sps, freqs, cols, nl, emmodel_names, layer_kind, host, scalars=None, liquid_water=None):
         """Effective permittivity of every layer, (F, S, Lmax): from the host-evaluated emmodels if the group has them,
         otherwise from a cheap pre-pass of the device emmodels (four streams, layer diagnostics only) -- what the streams
         of matrices evaluated on the host (rough substrates / interfaces) are placed with."""
@@ -349,13 +349,13 @@ class DORT(object):
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
         if host is not None:
             return host[0][..., 2] + 1j * host[0][..., 3]
-        scal = getattr(self, "_host_scalars", None)   # emmodels of IBA's family: their scalars travel with the probe
+        scal = scalars   # emmodels of IBA's family: their scalars travel with the probe
         name = "iba" if scal is not None else emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0]
         probe = PackedBatch(nl, cols[0], cols[1], cols[2], cols[3], cols[4], freqs, [0.0], emmodel=name,
                             microstructure=sps[0].layers[0].microstructure_model if scal is None else "exponential",
                             n_max_stream=4, phase_normalization="forced", layer_kind=layer_kind,
                             host_scalars=None if scal is None else scal[:2],
-                            liquid_water=getattr(self, "_liquid_water", None))
+                            liquid_water=liquid_water)
         # on the first of the solver's own devices (the device of this rank), not on GPU 0 whatever the caller chose
         res = get_context((self.devices or [default_device()])[0]).run(probe)
         bad = np.flatnonzero(res.status == 5)   # 5 = invalid layer input: the permittivities below would be meaningless
@@ -460,13 +460,13 @@ class DORT(object):
                    Rbot=diag_of(spec_dn, len(mu_up), 2), Tbot=diag_of(ctr_dn, len(mu_up), 2))
         return modes, coh
 
-    def _interfaces_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+    def _interfaces_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host, scalars=None, liquid_water=None):
         """(slot, matrices, specular diagonals) of PackedBatch(host_interfaces=...) for a group with rough interfaces: every
         interface object that is not Flat is evaluated through the reference's interface protocol on the streams of the
         two media it separates."""
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
-        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host, scalars, liquid_water)
         nm, ne, npol = (self.m_max + 1 if act else 1), 3 * self.n_max_stream, (3 if act else 2)
         rough = [[i for i, itf in enumerate(sp.interfaces) if not isinstance(itf, Flat)] for sp in sps]
         nslots = max(1, max(len(r) for r in rough))
@@ -541,7 +541,7 @@ class DORT(object):
             coh.append(c)
         return dense, coh
 
-    def _substrates_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host):
+    def _substrates_on_host(self, sensor0, sps, freqs, cols, nl, emmodel_names, layer_kind, host, scalars=None, liquid_water=None):
         """("host", R, Rcoh) of PackedBatch for a group whose snowpacks lie on substrates without a device implementation
         (rough ones: geometrical optics, IEM, ...).  Needs the streams of every last layer, hence the effective
         permittivity of every layer: from the host-evaluated emmodels if the group has them, otherwise from a cheap
@@ -550,7 +550,7 @@ class DORT(object):
 
         act = sensor0.mode == "A"
         F, S, Lmax = len(freqs), len(sps), cols.shape[2]
-        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host)
+        eps = self._layer_permittivities(sps, freqs, cols, nl, emmodel_names, layer_kind, host, scalars, liquid_water)
         nm, ne = (self.m_max + 1 if act else 1), 3 * self.n_max_stream
         R = np.zeros((F, S, nm, ne, ne))
         Rc = np.zeros((F, S, nm, ne))

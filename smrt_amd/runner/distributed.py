@@ -6,8 +6,8 @@ the reference fans it out with joblib, smrt/runner/joblib_runner.py:45-72), so n
 
 The product path needs no PyTorch: the gather is `smrt_dort_gather` of the C ABI (RCCL over xGMI, device buffer to
 device buffer) and the ranks find each other with the few lines of TCP below -- rank 0 creates the RCCL id and serves it
-on MASTER_ADDR at a port derived from MASTER_PORT (the variables torchrun / any launcher exports).  `gather_to_root`
-keeps a torch.distributed variant for CPU tests of the sharding logic under gloo."""
+on MASTER_ADDR at a port derived from MASTER_PORT (the variables torchrun / any launcher exports).  The CPU tests of the
+sharding logic drive gloo themselves (tests/test_multirank_cpu.py) on `smrt_dort_gather_plan`."""
 import hashlib
 import os
 import socket
@@ -119,32 +119,3 @@ def init_comm(ctx, rank=None, world=None):
     uid = broadcast_from_root(uid, rank, world)
     ctx.comm_init(world, rank, uid)
     return rank, world
-
-
-def gather_to_root(dist, values, status, dst=0):
-    """torch.distributed variant of the gather (gloo in the CPU tests): per-rank result rows (torch tensors on the
-    collective's device) to `dst`.  Shards may have different lengths: rows are padded to the longest shard for the
-    collective and trimmed afterwards.  Returns (values, status) concatenated in rank order on `dst`, (None, None)
-    elsewhere."""
-    import torch
-
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n_local = torch.tensor([values.shape[0]], dtype=torch.int64, device=values.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
-    n_max = max(counts)
-    pad_v = torch.zeros((n_max,) + tuple(values.shape[1:]), dtype=values.dtype, device=values.device)
-    pad_s = torch.zeros((n_max,), dtype=status.dtype, device=status.device)
-    pad_v[: values.shape[0]] = values
-    pad_s[: status.shape[0]] = status
-    if rank == dst:
-        gv = [torch.empty_like(pad_v) for _ in range(world)]
-        gs = [torch.empty_like(pad_s) for _ in range(world)]
-    else:
-        gv = gs = None
-    dist.gather(pad_v, gv, dst=dst)
-    dist.gather(pad_s, gs, dst=dst)
-    if rank != dst:
-        return None, None
-    return (torch.cat([g[:c] for g, c in zip(gv, counts)], dim=0), torch.cat([g[:c] for g, c in zip(gs, counts)], dim=0))

@@ -962,6 +962,12 @@ def test_unified_microstructure_parameters_are_reparametrisations_of_the_device_
             radius, minus_t = dp("unified_sticky_hard_spheres", f, porod_length=lp, polydispersity=K)
             assert minus_t < 0
             np.testing.assert_allclose(O.ft_autocorr_shs(k, f, radius, None, t=-minus_t), O.ft_autocorr_unified_shs(k, f, lp, K), rtol=1e-13)
+    # t <= 0 (small polydispersity) has no device encoding -- the sign of micro_p2 tells "t given" from "stickiness given" --
+    # and an object's own derived radius / t win over the ones recomputed from frac_volume (smrt's inverted_medium() copy)
+    from smrt_amd.core.error import SMRTError
+    with pytest.raises(SMRTError, match="no device encoding"):
+        dp("unified_sticky_hard_spheres", 0.2, porod_length=1e-4, polydispersity=0.3)
+    assert dp("unified_sticky_hard_spheres", 0.3, porod_length=1e-4, polydispersity=1.0, radius=5e-4, t=10.17) == (5e-4, -10.17)
     # Teubner-Strey itself: micro_p2 is Y = (2 pi xi / d)^2
     xi, Y = dp("teubner_strey", 0.3, corr_length=1.5e-4, repeat_distance=1.2e-3)
     assert xi == 1.5e-4 and Y == (2 * np.pi * 1.5e-4 / 1.2e-3) ** 2
