@@ -291,7 +291,8 @@ enum { SMRT_PIPELINE_FUSED = 0,          /* one kernel per pair, matrices in LDS
        SMRT_PIPELINE_LDS_REG = 3,        /* ... with the register-resident finish kernel (passive default) */
        SMRT_PIPELINE_FUSED_GMEM = 4,     /* one kernel per pair on a global workspace (N > 64) */
        SMRT_PIPELINE_GMEM = 5,           /* prep + Jacobi + finish on the global workspace, 64 < N <= 128 */
-       SMRT_PIPELINE_BIG = 6 };          /* ... with the blocked Jacobi kernel, 128 < N <= 384 */
+       SMRT_PIPELINE_BIG = 6,            /* ... with the blocked Jacobi kernel, 128 < N <= 384 */
+       SMRT_PIPELINE_GMEM_STRIP = 7 };   /* prep + Jacobi on the global workspace + the strip finish kernel, 64 < N <= 128 (passive default) */
 int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n);
 double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset);
 

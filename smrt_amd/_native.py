@@ -458,7 +458,7 @@ class DortContext:
         return cost
 
     # ---- multi-GPU: the RCCL gather of the C ABI (smrt_dort_comm_*, smrt_dort_gather) ----------------------------
-    PIPELINES = ("fused", "lds_two_slot", "lds_four_slot", "lds_reg", "fused_gmem", "gmem", "big")   # SMRT_PIPELINE_*
+    PIPELINES = ("fused", "lds_two_slot", "lds_four_slot", "lds_reg", "fused_gmem", "gmem", "big", "gmem_strip")   # SMRT_PIPELINE_*
 
     def launch_info(self):
         """smrt_dort_launch_info as a dict: pipeline (name), chunk_pairs, chunks, prune_rounds, staged_items (None when

@@ -466,7 +466,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 }
             });
             block_sync();
-            if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, (MODE == 1 && CH == 1) ? stg->Linv + item * 1024 : nullptr)
+            if (!(dense_mfma ? chol2_mfma<NT>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD, (MODE == 1 && CH == 1) ? stg->Linv + item * stg->linv_stride : nullptr)
                           : chol2<NT>(s.M0, s.M1, N, LD))) {
                 if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
                 fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
@@ -520,7 +520,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
                 for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = gL[c * LD + r]; });
                 block_sync();
                 l_times_m_mfma<NT>(s.M3, s.M0, gB, N, LD);                                // Em' = L+ B'
-                lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * 1024, N, LD, true);      // Ep' = L+^-T B'
+                lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * stg->linv_stride, N, LD, true);      // Ep' = L+^-T B'
                 for_2d<NT>(N, N, [&](int i, int c) {
                     const double ep = s.M0[c * LD + i], em = gB[c * LD + i] * s.rsig[c];
                     const double hd = 0.5 * s.d[i];

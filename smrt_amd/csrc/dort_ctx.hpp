@@ -38,6 +38,10 @@ struct smrt_dort_ctx {
     size_t prep_lds_bytes = 0;
     size_t finish2_lds_bytes = 0;
     size_t finish_reg_lds_bytes = 0;
+    size_t prep_wide_lds_bytes = 0;
+    bool prep_wide = false;     // 64 < N <= 128, passive: the LDS-resident prep kernel (packed triangles) with eight wavefronts
+    size_t finish_strip_lds_bytes = 0;
+    bool finish_strip = false;  // strip finish kernel (passive, 64 < N <= 128, Flat interfaces): one workgroup of eight wavefronts per pair
     bool finish_reg = false;    // register-resident finish kernel (passive, N <= 64, Flat interfaces): one wavefront per pair
     int finish_mode = -1;       // -1: the default choice; 0: never the register-resident finish kernel; 1: whenever supported
     bool finish2 = true;        // two-slot finish kernel (set_pipeline(2) selects the LDS-resident one)
@@ -80,10 +84,13 @@ struct smrt_dort_ctx {
 namespace smrt_launch {
 // k_split_passive.hip: prep and finish kernels of the LDS-resident pipeline (N <= 64), nt = 64 or 256
 hipError_t prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
+hipError_t prep_wide(smrt_dort_ctx* ctx, const smrt::DevBatch& c);   // the same for 64 < N <= 128: 512 threads, one workgroup per CU
 hipError_t finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt, bool two_slot);
 void occupancy_report(smrt_dort_ctx* ctx, int nt);
 // k_finish_reg.hip: the register-resident finish kernel of the same pipeline, one wavefront per pair
 hipError_t finish_reg(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
+// k_finish_strip.hip: the strip finish kernel of the 64 < N <= 128 pipeline (passive), one workgroup of eight wavefronts per pair
+hipError_t finish_strip(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
 // k_jacobi.hip: one workgroup per staging item (pair, [azimuth mode,] layer)
 hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_split_active.hip

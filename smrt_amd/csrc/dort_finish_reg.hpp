@@ -565,7 +565,7 @@ SMRT_DEV void dort_pair_passive_reg(const DevBatch& b, long long p, double* lds_
         const long long item = p * (long long)b.Lmax + l;
         const double* gL = stg.L + item * stg.mat_stride;
         const double* gB = stg.B + item * stg.mat_stride;
-        const double* gI = stg.Linv + item * 1024;
+        const double* gI = stg.Linv + item * stg.linv_stride;
         const bool in_e = t < N;
         SMRT_RT(RT_VEC);
         // ---- element t of the vectors of this layer (padding: d = sigma = 1, t = 0)

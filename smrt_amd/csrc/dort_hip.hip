@@ -16,6 +16,7 @@
 #include "dort_host_common.hpp"
 #include "dort_phase_kernel.hpp"
 #include "dort_finish_reg.hpp"      // finish_reg_lds_doubles (device code is inline templates / functions: nothing is instantiated here)
+#include "dort_finish_strip.hpp"    // finish_strip_lds_doubles
 
 using namespace smrt;
 
@@ -54,6 +55,9 @@ static DevBatch chunk_of(const smrt_dort_ctx* ctx, const DevBatch& d, long long 
 #ifndef SMRT_DORT_LANES_DEFAULT
 #define SMRT_DORT_LANES_DEFAULT 1   // concurrent pipeline passes on the LDS pipelines (SMRT_DORT_LANES overrides; measured in profiles/)
 #endif
+#ifndef SMRT_FINISH_STRIP_DEFAULT
+#define SMRT_FINISH_STRIP_DEFAULT 1   // the strip finish kernel where it is supported (64 < N <= 128, passive; set_pipeline(4) / SMRT_DORT_FINISH_STRIP=0: the pivoted one)
+#endif
 #ifndef SMRT_FINISH_REG_DEFAULT
 #define SMRT_FINISH_REG_DEFAULT 1   // the register-resident finish kernel where it is supported (set_pipeline(3) / SMRT_DORT_FINISH_REG=1 force it)
 #endif
@@ -66,11 +70,13 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
     const int rounds = (d.prune_tau > 0.0 && !d.coherent && getenv("SMRT_DORT_NO_PRUNE_ROUNDS") == nullptr) ? std::min(4, d.Lmax) : 1;
     auto prep = [&](const DevBatch& c, unsigned grid) {
         if (ctx->big) return smrt_launch::prep_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->prep_wide) return smrt_launch::prep_wide(ctx, c);
         if (ctx->gmem_split) return smrt_launch::prep_gmem(ctx, c, grid, ctx->active);
         return ctx->active ? smrt_launch::active_prep(ctx, c, ctx->nt) : smrt_launch::prep(ctx, c, ctx->nt);
     };
     auto finish = [&](const DevBatch& c, unsigned grid) {
         if (ctx->big) return smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
+        if (ctx->finish_strip) return smrt_launch::finish_strip(ctx, c);
         if (ctx->gmem_split) return smrt_launch::finish_gmem(ctx, c, grid, ctx->active);
         if (ctx->finish_reg) return smrt_launch::finish_reg(ctx, c);
         return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
@@ -101,7 +107,7 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
             ctx->stage = stage0;
             ctx->stage.L = stage0.L + it0 * stage0.mat_stride; ctx->stage.B = stage0.B + it0 * stage0.mat_stride;
             ctx->stage.d = stage0.d + it0 * stage0.vec_stride; ctx->stage.sigma = stage0.sigma + it0 * stage0.vec_stride;
-            ctx->stage.n = stage0.n + it0; ctx->stage.Linv = stage0.Linv + it0 * 1024;
+            ctx->stage.n = stage0.n + it0; ctx->stage.Linv = stage0.Linv + it0 * stage0.linv_stride;
             if (stage0.ws) ctx->stage.ws = stage0.ws + (long long)lane * ctx->chunk_pairs * rg::kSlotDoubles;
         }
         if (rounds > 1 || d.coherent) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
@@ -291,7 +297,8 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if ((!ctx->gmem_path && ctx->split) || ctx->gmem_split) {
         const size_t nmodes = ctx->active ? (size_t)b->m_max + 1 : 1;   // staging items per layer
         const size_t mat = (size_t)plan.NMAX * plan.LD;
-        const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + 1024) * sizeof(double) + sizeof(int));
+        const int linv_stride = (plan.NMAX > 64) ? 2048 : 1024;   // inverses of the diagonal blocks of L+: four or eight of 256 doubles
+        const size_t per_pair = nmodes * b->n_layers_max * ((2 * mat + 2 * plan.NMAX + linv_stride) * sizeof(double) + sizeof(int));
         // staging budget: 12 GB, or -- for the large matrices of the big pipeline, where 12 GB hold too few pairs to fill
         // the chip -- up to 60 % of the free device memory
         double budget = 12.0e9;
@@ -299,8 +306,15 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::max(budget, 0.6 * (double)(free_b + ctx->d_stL.cap + ctx->d_stB.cap));
         }
+        // 64 < N <= 128: the finish kernels (and the Jacobi kernel) of this pipeline run ONE workgroup per CU, so a pass works in
+        // rounds of 256 pairs and the 598 pairs that 12 GB hold at the configs[2] shape are 2.3 rounds (a third of the last one
+        // idle): 40 GB and whole rounds
+        const bool one_per_cu = ctx->gmem_split && !ctx->big;
+        if (one_per_cu) budget = 40.0e9;
         long long chunk = (long long)(budget / (double)per_pair);
         if (chunk < 1) chunk = 1;
+        if (one_per_cu && chunk >= 512) chunk -= chunk % 256;
+        const long long chunk_cap = chunk;
         if (chunk > pair_count) chunk = pair_count;
         ctx->lanes = 1;
         if (!ctx->gmem_path) {   // (the global-workspace pipelines share one per-workgroup workspace: one pass at a time)
@@ -313,6 +327,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
             long long nchunks = (pair_count + chunk - 1) / chunk;
             if (ctx->lanes > 1) nchunks = ((nchunks + ctx->lanes - 1) / ctx->lanes) * ctx->lanes;
             chunk = (pair_count + nchunks - 1) / nchunks;
+            if (one_per_cu && nchunks > 1) chunk = std::min(chunk_cap, ((chunk + 255) / 256) * 256);   // whole rounds (the last chunk takes the rest)
         }
         ctx->chunk_pairs = chunk;
         for (int k = 0; k < ctx->lanes && ctx->lanes > 1; ++k) {
@@ -326,10 +341,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         HIPCHK(ctx->d_std.reserve(items * plan.NMAX * sizeof(double)));
         HIPCHK(ctx->d_sts.reserve(items * plan.NMAX * sizeof(double)));
         HIPCHK(ctx->d_stn.reserve(items * sizeof(int)));
-        HIPCHK(ctx->d_sti.reserve(items * 1024 * sizeof(double)));
+        HIPCHK(ctx->d_sti.reserve(ctx->big ? 8 : items * linv_stride * sizeof(double)));   // (the N > 128 kernels do not stage them)
         ctx->stage.L = (double*)ctx->d_stL.p; ctx->stage.B = (double*)ctx->d_stB.p;
         ctx->stage.d = (double*)ctx->d_std.p; ctx->stage.sigma = (double*)ctx->d_sts.p;
-        ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = (double*)ctx->d_sti.p;
+        ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = ctx->big ? nullptr : (double*)ctx->d_sti.p;
+        ctx->stage.linv_stride = linv_stride;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
                                    : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
@@ -361,6 +377,25 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->stage.ws = nullptr;
         if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
             HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * ctx->lanes * rg::kSlotDoubles));
+            ctx->stage.ws = (double*)ctx->d_regws.p;
+        }
+    }
+    // the strip finish kernel (one workgroup of eight wavefronts per pair, dort_finish_strip.hpp): the 64 < N <= 128 pipeline in
+    // passive mode under the same conditions
+    {
+        const bool supported = ctx->gmem_split && !ctx->big && !ctx->active && plan.NMAX <= 128 && ctx->chunk_pairs > 0 &&
+                               !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
+        int want = ctx->finish_mode;
+        if (const char* e = getenv("SMRT_DORT_FINISH_STRIP")) want = atoi(e) ? 1 : 0;
+        ctx->finish_strip_lds_bytes = sizeof(double) * (size_t)finish_strip_lds_doubles(b->n_max_stream, b->n_layers_max);
+        ctx->finish_strip = supported && ctx->finish_strip_lds_bytes <= (size_t)ctx->max_lds &&
+                            (want == 1 || (want == -1 && SMRT_FINISH_STRIP_DEFAULT));
+        // ... and the LDS-resident prep kernel of the N <= 64 pipeline where its two packed triangles fit a CU's LDS
+        ctx->prep_wide_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, 0, 3).total * sizeof(double);
+        ctx->prep_wide = ctx->gmem_split && !ctx->big && !ctx->active && plan.NMAX <= 128 && ctx->chunk_pairs > 0 &&
+                         ctx->prep_wide_lds_bytes <= (size_t)ctx->max_lds && getenv("SMRT_DORT_NO_PREP_WIDE") == nullptr;
+        if (ctx->finish_strip) {   // one 128 x 128 matrix per pair of a chunk in global memory (At between its two phases)
+            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * st8::kWsDoubles));
             ctx->stage.ws = (double*)ctx->d_regws.p;
         }
     }
@@ -474,8 +509,9 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     // for experiments.  Passive mode, measured on the headline batch against the oracle (profiles/r3_jacobi_thresholds.txt):
     // 1e-26 / 1e-15 -> 1.4e-10 K, 1e-22 / 1e-12 -> 1.6e-8 K (2.6 % faster), 1e-20 / 1e-10 -> 2.4e-7 K; the requirement is 1e-6 K.
     // The register-resident finish kernel needs the tighter pair on weakly scattering media (dort_host_common.hpp).
-    d.jacobi_skip2 = ctx->active ? 1e-30 : (ctx->finish_reg ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);
-    d.jacobi_exit2 = ctx->active ? 1e-22 : (ctx->finish_reg ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
+    const bool orth = ctx->finish_reg || ctx->finish_strip;   // the finish kernels that use the orthogonality of B' itself
+    d.jacobi_skip2 = ctx->active ? 1e-30 : (orth ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);
+    d.jacobi_exit2 = ctx->active ? 1e-22 : (orth ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
     if (const char* e = getenv("SMRT_DORT_JACOBI_SKIP2")) d.jacobi_skip2 = atof(e);
     if (const char* e = getenv("SMRT_DORT_JACOBI_EXIT2")) d.jacobi_exit2 = atof(e);
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
@@ -583,7 +619,7 @@ int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
     const DevBatch& d = ctx->dev;
     const bool lds_pipeline = !ctx->gmem_path && ctx->split && ctx->chunk_pairs > 0 && (!ctx->active || ctx->finish2);
     int64_t v[SMRT_INFO_COUNT] = {0};
-    v[SMRT_INFO_PIPELINE] = ctx->gmem_split ? (ctx->big ? SMRT_PIPELINE_BIG : SMRT_PIPELINE_GMEM)
+    v[SMRT_INFO_PIPELINE] = ctx->gmem_split ? (ctx->big ? SMRT_PIPELINE_BIG : ctx->finish_strip ? SMRT_PIPELINE_GMEM_STRIP : SMRT_PIPELINE_GMEM)
                           : lds_pipeline ? (ctx->finish_reg ? SMRT_PIPELINE_LDS_REG : ctx->finish2 ? SMRT_PIPELINE_LDS_TWO_SLOT : SMRT_PIPELINE_LDS_FOUR_SLOT)
                           : ctx->gmem_path ? SMRT_PIPELINE_FUSED_GMEM : SMRT_PIPELINE_FUSED;
     const bool three = ctx->gmem_split || lds_pipeline;

@@ -78,8 +78,9 @@ struct DevStage {
     int* n;
     long long mat_stride;  // doubles per matrix slot (NMAX * LD)
     int vec_stride;        // doubles per vector slot (NMAX)
-    double* Linv;          // [item][4][256] inverses of the 16x16 diagonal blocks of L+ (written by the prep kernel)
+    double* Linv;          // [item][linv_stride] inverses of the 16x16 diagonal blocks of L+, 256 doubles each (written by the prep kernel)
     double* ws;            // [pair][4096] one 64 x 64 matrix per pair (register-resident finish kernel), or null
+    int linv_stride;       // 1024 (N <= 64: four blocks) or 2048 (64 < N <= 128: eight blocks)
 };
 
 // index into the flattened (frequency-major) pair list of the batch for the p-th workgroup of a launch

@@ -565,7 +565,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         block_sync();
         SMRT_STAGE(SG_CHOL);
         if (!(dense_mfma ? chol2_mfma<NT, PK>(s.M0, s.M1, dense_scratch, &s.ints[2], N, LD,
-                                       (MODE == 1 && CH == 1) ? stg->Linv + (p * (long long)b.Lmax + l) * 1024 : nullptr)
+                                       (MODE == 1 && CH <= 2 && stg->Linv) ? stg->Linv + (p * (long long)b.Lmax + l) * stg->linv_stride : nullptr)
                       : chol2<NT>(s.M0, s.M1, N, LD))) {
             if (MODE == 1) { layer_failed(l, ST_ALBEDO); continue; }
             fail_pair<NT>(b, p, ST_ALBEDO, out_stride); return;
@@ -627,7 +627,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             for_2d<NT>(N, N, [&](int r, int c) { s.M3[c * LD + r] = gL[c * LD + r]; });
             block_sync();
             l_times_m_mfma<NT>(s.M3, s.M0, gB, N, LD);                                          // Em' = L+ B'
-            lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * 1024, N, LD, true);                // Ep' = L+^-T B'
+            lt_solve_mfma<NT>(s.M3, s.M0, stg->Linv + item * stg->linv_stride, N, LD, true);    // Ep' = L+^-T B'
             // F, G to global memory (A operands and elementwise terms of the second GEMM pass) and to slots R, X
             // (B operands of the first one)
             for_2d<NT>(N, N, [&](int i, int c) {

@@ -1,0 +1,25 @@
+// Strip finish kernel of the 64 < N <= 128 pipeline (passive): one workgroup of eight wavefronts per pair, see dort_finish_strip.hpp.
+#include <cstdio>
+#include "dort_ctx.hpp"
+#include "dort_device.hpp"
+#include "dort_finish_strip.hpp"
+
+using namespace smrt;
+
+// eight wavefronts, two per SIMD: 256 registers each; the LDS of the CU belongs to the one resident workgroup
+__global__ __launch_bounds__(512, 2) void dort_finish_strip_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive_strip(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, st);
+}
+
+namespace smrt_launch {
+
+hipError_t finish_strip(smrt_dort_ctx* ctx, const DevBatch& c) {
+    const size_t lds = ctx->finish_strip_lds_bytes;
+    hipError_t e = hipFuncSetAttribute((const void*)dort_finish_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dort_finish_strip_kernel, dim3((unsigned)c.pair_count), dim3(512), lds, ctx->stream, c, ctx->stage);
+    return hipGetLastError();
+}
+
+}  // namespace smrt_launch

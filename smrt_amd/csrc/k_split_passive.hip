@@ -14,6 +14,12 @@ __global__ __launch_bounds__(NT, SMRT_PREP_WAVES) void dort_prep_kernel(DevBatch
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     dort_pair_passive<NT, 1, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
 }
+// the same kernel for 64 < N <= 128: the two packed lower triangles of a 64-stream layer (N = 128) are 134 KB, one
+// workgroup of eight wavefronts per CU (two per SIMD) instead of the global-workspace prep kernel's two of four
+__global__ __launch_bounds__(512, 2) void dort_prep_kernel_wide(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_pair_passive<512, 1, 1>(b, dispatched_pair(b, (long long)blockIdx.x), smrt_lds, nullptr, &st);
+}
 // four N x N matrices in LDS: one workgroup per CU (kept for A/B runs, smrt_dort_set_pipeline(ctx, 2))
 template <int NT>
 __global__ __launch_bounds__(NT) void dort_finish_kernel(DevBatch b, DevStage st) {
@@ -37,6 +43,8 @@ static hipError_t go(K kern, smrt_dort_ctx* ctx, const DevBatch& c, int nt, size
     hipLaunchKernelGGL(kern, dim3((unsigned)c.pair_count), dim3(nt), lds, ctx->stream, c, ctx->stage);
     return hipGetLastError();
 }
+
+hipError_t prep_wide(smrt_dort_ctx* ctx, const DevBatch& c) { return go(dort_prep_kernel_wide, ctx, c, 512, ctx->prep_wide_lds_bytes); }
 
 hipError_t prep(smrt_dort_ctx* ctx, const DevBatch& c, int nt) {
     return nt == 64 ? go(dort_prep_kernel<64>, ctx, c, 64, ctx->prep_lds_bytes)

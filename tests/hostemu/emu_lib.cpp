@@ -9,6 +9,7 @@
 #include "../../smrt_amd/csrc/dort_host_common.hpp"
 #include "../../smrt_amd/csrc/dort_phase_kernel.hpp"
 #include "../../smrt_amd/csrc/dort_finish_reg.hpp"
+#include "../../smrt_amd/csrc/dort_finish_strip.hpp"
 
 using namespace smrt;
 
@@ -50,8 +51,9 @@ struct Staging {
     std::vector<int> n;
     DevStage st;
     Staging(size_t items, const LdsPlan& plan) : L(items * (size_t)plan.NMAX * plan.LD, NAN), B(L.size(), NAN), d(items * plan.NMAX, NAN),
-                                                 sigma(items * plan.NMAX, NAN), inv(items * 1024, NAN), ws(plan.NMAX <= 64 ? items * 4096 : 0, NAN), n(items, -1) {
-        st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, inv.data(), ws.data()};
+                                                 sigma(items * plan.NMAX, NAN), inv(items * (plan.NMAX <= 64 ? 1024 : 2048), NAN), ws(plan.NMAX <= 128 ? items * 16384 : 0, NAN), n(items, -1) {
+        st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, plan.NMAX <= 128 ? inv.data() : nullptr, ws.data(),
+                      plan.NMAX <= 64 ? 1024 : 2048};
     }
 };
 
@@ -86,18 +88,28 @@ template <int NT, bool ACTIVE>
 static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     const int nmodes = ACTIVE ? d.m_max + 1 : 1;
     Staging sg((size_t)d.pair_count * d.Lmax * nmodes, plan);
-    std::vector<double> lds(2 * plan.total), ws((size_t)plan.mat_doubles + plan.scratch_doubles);   // generous: the kernels lay out LDS differently
+    std::vector<double> lds(2 * plan.total + finish_strip_lds_doubles(d.n_max_stream, d.Lmax)), ws((size_t)plan.mat_doubles + plan.scratch_doubles);   // generous: the kernels lay out LDS differently
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, ACTIVE ? 3 : 2);
+    // the strip finish kernel (one workgroup of eight wavefronts per pair) where the library uses it
+    const bool strip = !ACTIVE && smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST;
     std::vector<double> jl(jp.total);
     auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };
+    // (passive: the LDS-resident prep kernel with eight wavefronts where its two packed triangles fit, like the library)
+    const size_t wide_lds = (size_t)make_plan(d.n_max_stream, 2, d.Lmax, d.n_theta, 9, 1, 0, 3).total;
+    const bool wide = !ACTIVE && wide_lds * sizeof(double) <= 160 * 1024;
+    if (wide && lds.size() < wide_lds) lds.resize(wide_lds);
     return run_rounds(d, order, nmodes, sg,
-        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); })
-                                                  : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
+        [&](long long p) { fresh();
+                           if (wide) return emu::run_block(512, order, [&]() { dort_pair_passive<512, 1, 1>(d, p, lds.data(), nullptr, &sg.st); });
+                           return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); })
+                                         : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
         // (the product launches the Jacobi kernel of this pipeline with 512 threads: k_jacobi.hip)
         [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(512, order, [&]() { dort_jacobi_item<512>(d, sg.st, it, jl.data()); }); },
         // (and the finish kernel with 512 threads too: k_gmem_split.hip)
-        [&](long long p) { fresh(); return ACTIVE ? emu::run_block(512, order, [&]() { dort_pair_active<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
-                                                  : emu::run_block(512, order, [&]() { dort_pair_passive<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
+        [&](long long p) { fresh();
+                           if (strip) return emu::run_block(512, order, [&]() { dort_pair_passive_strip(d, p, lds.data(), sg.st); });
+                           return ACTIVE ? emu::run_block(512, order, [&]() { dort_pair_active<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); })
+                                         : emu::run_block(512, order, [&]() { dort_pair_passive<512, 2, 2>(d, p, lds.data(), ws.data(), &sg.st); }); });
 }
 
 // 128 < N <= 384: prep / finish with CH row chunks on the global workspace, the blocked Jacobi kernel in between
@@ -174,7 +186,12 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     if (why) { fprintf(stderr, "smrt_emu_run: %s\n", why); return -1; }
     const bool active = (b->mode == SMRT_MODE_ACTIVE);
     const int P = active ? 3 : 2;
-    const bool gmem = b->n_max_stream * P > 64;
+    // (pipeline 5, tests only: the global-workspace pipeline with the strip finish kernel whatever the size, so that the
+    // small fixtures exercise it; it then behaves like pipeline 3)
+    const bool force_gmem = (smrt_emu_pipeline == 5);
+    struct Restore { int v; ~Restore() { smrt_emu_pipeline = v; } } restore_pipeline{smrt_emu_pipeline};
+    if (force_gmem) smrt_emu_pipeline = 3;
+    const bool gmem = b->n_max_stream * P > 64 || force_gmem;
     auto plan_with = [&](int jac) {
         return active ? make_plan(b->n_max_stream, 3, b->n_layers_max, b->n_theta, azimuth_samples(b->m_max) / 2 + 1,
                                   gmem ? 0 : 1, active_doubles(b->n_max_stream, b->n_layers_max, b->n_theta), 0, jac)
@@ -211,7 +228,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
     d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
-    const bool reg_thr = !active && smrt_emu_pipeline == 3 && b->n_max_stream * 2 <= 64 && !b->host_interface_slot &&
+    const bool reg_thr = !active && smrt_emu_pipeline == 3 && b->n_max_stream * 2 <= 128 && !b->host_interface_slot &&
                          !b->process_coherent_layers && b->substrate_kind != SUB_HOST;   // where the register-resident finish kernel runs
     d.jacobi_skip2 = active ? 1e-30 : (reg_thr ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);   // like smrt_dort_upload
     d.jacobi_exit2 = active ? 1e-22 : (reg_thr ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);

@@ -196,10 +196,19 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
     try:
         ctx.upload(batch)
         info = ctx.launch_info()
-        assert info["pipeline"] == "gmem" and info["n_max"] == 128, info
+        # (passive, Flat interfaces: the strip finish kernel behind the prep and Jacobi kernels of the global-workspace pipeline)
+        assert info["pipeline"] == "gmem_strip" and info["n_max"] == 128, info
         assert info["chunks"] * info["chunk_pairs"] >= batch.n_pairs > (info["chunks"] - 1) * info["chunk_pairs"], info
         ctx.launch(); ctx.sync()
-        assert (ctx.download().status == 0).all()
+        strip = ctx.download()
+        assert (strip.status == 0).all()
+        # ... and the pivoted finish kernel of that pipeline (set_pipeline(4)) gives the same brightness temperatures
+        ctx.set_pipeline(4); ctx.upload(batch)
+        assert ctx.launch_info()["pipeline"] == "gmem"
+        ctx.launch(); ctx.sync()
+        pivoted = ctx.download()
+        ctx.set_pipeline(1)
+        assert (pivoted.status == 0).all() and np.abs(strip.values - pivoted.values).max() < 1e-6
         # the other shapes take the kernels DESIGN.md section 4 names
         rng = np.random.default_rng(4)
         for n_stream, mode, want in ((32, "P", "lds_reg"), (16, "A", "lds_two_slot"), (96, "P", "big")):

@@ -899,7 +899,7 @@ def test_cfg3_full_batch_size(ctx):
     full = ctx.run(b)
     assert b.n_pairs == 57344 and (full.status == 0).all()
     info = ctx.launch_info()
-    assert info["pipeline"] == "gmem" and info["chunks"] > 1
+    assert info["pipeline"] == "gmem_strip" and info["chunks"] > 1
     mine = full.values.reshape(len(freqs), S, *full.values.shape[1:])[:, k]
     assert np.abs(mine - d["result"]).max() < TB_TOL
     lo, hi = info["chunk_pairs"] - 700, 2 * info["chunk_pairs"] + 300

@@ -110,6 +110,38 @@ def test_emulated_register_resident_finish_is_schedule_independent(emu):
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+STRIP_FIXTURES = ["cfg1_iba_onelayer", "iba_L6_n8_angles", "dmrt_L8_n16", "mixed_L4_n16_passive", "iba_L3_n16_substrate_atmosphere",
+                  "dmrt_L4_n12_reflector", "iba_L2_n10_mirror_atmosphere_only", "iba_L8_n12_prune", "dmrt_L6_n10_prune_over_bad_layer"]
+
+
+@pytest.mark.parametrize("name,order", [(n, i % 3) for i, n in enumerate(STRIP_FIXTURES)])
+def test_emulated_strip_finish_kernel(emu, name, order):
+    """The strip finish kernel of the 64 < N <= 128 pipeline (one workgroup of eight wavefronts per pair, the pivot-free
+    recursion on tile columns, dort_finish_strip.hpp) on the small reference fixtures -- the emulator's pipeline 5 forces
+    the global-workspace pipeline whatever the size --: layers of 1 to 2 tiles, ragged stream counts, substrates,
+    atmosphere, pruning, in three fiber orders.  Its own size is covered by the configs[2] fixture below."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 5
+    try:
+        out, st, ref = run_fixture(emu, name, nt=256, order=order)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st == 0).all()
+    assert np.abs(out - ref).max() < 1e-6
+
+
+def test_emulated_strip_finish_kernel_at_its_own_size_and_any_schedule(emu):
+    """50 layers x 64 streams (one frequency of the configs[2] fixture: up to 8 x 8 tiles) and schedule independence."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 3
+    try:
+        out, st, ref = run_fixture(emu, "cfg3_dmrt_L50_n64_sp0", nt=256, order=1, freqs=[1])
+        assert (st == 0).all() and np.abs(out - ref).max() < 1e-6
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 5
+        outs = [run_fixture(emu, "iba_L3_n16_flat_substrate", nt=256, order=o)[0] for o in (0, 1, 2)]
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("name,nt,pipeline,order", [("rough_iem_surface_L3_n10_passive", 256, 1, 0), ("rough_iem_inner_L3_n10_passive", 64, 0, 1),
                                                     ("rough_go_surface_L3_n10_active", 256, 1, 2), ("rough_iem_inner_L3_n10_active", 64, 0, 0)])
 def test_emulated_kernel_rough_interfaces(emu, name, nt, pipeline, order):
