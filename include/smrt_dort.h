@@ -292,7 +292,8 @@ enum { SMRT_PIPELINE_FUSED = 0,          /* one kernel per pair, matrices in LDS
        SMRT_PIPELINE_FUSED_GMEM = 4,     /* one kernel per pair on a global workspace (N > 64) */
        SMRT_PIPELINE_GMEM = 5,           /* prep + Jacobi + finish on the global workspace, 64 < N <= 128 */
        SMRT_PIPELINE_BIG = 6,            /* ... with the blocked Jacobi kernel, 128 < N <= 384 */
-       SMRT_PIPELINE_GMEM_STRIP = 7 };   /* prep + Jacobi on the global workspace + the strip finish kernel, 64 < N <= 128 (passive default) */
+       SMRT_PIPELINE_GMEM_STRIP = 7,     /* LDS-resident prep + Jacobi + the strip finish kernel (eight wavefronts), 64 < N <= 128 (passive default) */
+       SMRT_PIPELINE_LDS_STRIP = 8 };    /* prep + Jacobi + the strip finish kernel (four wavefronts), N <= 64 (passive default) */
 int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n);
 double smrt_dort_total_kernel_ms(smrt_dort_ctx* ctx, int64_t* n_launches, int32_t reset);
 
@@ -306,10 +307,15 @@ int32_t smrt_dort_set_block_threads(smrt_dort_ctx* ctx, int32_t threads);
  *   64 < N <= 128:  per-workgroup global workspace, Jacobi kernel on a 128-column LDS matrix;
  *   128 < N <= 384: global workspace, blocked Jacobi kernel (the limit of this build: n_max_stream <= 192 passive,
  *                   <= 128 active; smrt_dort_upload fails beyond).
- * 3 = like 1, the register-resident finish kernel wherever it is supported (what 1 does today); 4 = like 1, never the
- * register-resident finish kernel (A/B runs); 2 = like 4 with the four-matrix LDS finish kernel (one workgroup per CU;
+ * In passive mode with Flat interfaces the finish kernel of 1 is the pivot-free recursion: the STRIP kernel (one workgroup
+ * of four wavefronts per pair for N <= 64 while three of them share a CU, of eight for 64 < N <= 128), else the
+ * register-resident one (one wavefront per pair, N <= 64).
+ * 3 = like 1 with the register-resident finish kernel wherever it is supported (N <= 64) instead of the four-wavefront
+ * strip kernel; 5 = like 1, the strip kernels wherever they are supported (also at two workgroups per CU); 4 = like 1,
+ * never a pivot-free finish kernel (A/B runs); 2 = like 4 with the four-matrix LDS finish kernel (one workgroup per CU;
  * N <= 64 passive only, otherwise like 0); 0 = everything fused in one kernel, one workgroup per pair (no
- * prune_deep_snowpack).  Call before smrt_dort_upload.  SMRT_DORT_FINISH_REG=0|1 in the environment overrides 3 / 4. */
+ * prune_deep_snowpack).  Call before smrt_dort_upload.  In the environment SMRT_DORT_FINISH_REG=0|1 overrides 3 / 4 for
+ * the register-resident kernel, SMRT_DORT_FINISH_STRIP=0|1 and SMRT_DORT_FINISH_STRIP4=0|1 for the two strip kernels. */
 int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
 
 /* LDS bytes one workgroup (= one wavefront) of the register-resident finish kernel takes for a batch with this
@@ -317,6 +323,11 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split);
  * three up to 160 KB / 3 (~140 layers) -- the range in which the default pipeline takes this kernel --, two up to the
  * 64 KB a workgroup may have, where only smrt_dort_set_pipeline(ctx, 3) selects it (it ties with the two-slot kernel). */
 int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max);
+
+/* LDS bytes one workgroup of the strip finish kernel takes: wavefronts = 4 (N <= 64; the default pipeline takes it while
+ * three workgroups share a CU, i.e. up to 160 KB / 3) or 8 (64 < N <= 128: one workgroup per CU, taken while it fits the
+ * 160 KB at all).  Returns -1 for other wavefront counts. */
+int32_t smrt_dort_finish_strip_lds_bytes(int32_t n_max_stream, int32_t n_layers_max, int32_t wavefronts);
 
 /* LDS bytes one workgroup of the Jacobi kernel takes in the three-kernel pipelines of up to 128 columns (n_pol = 2
  * passive, 3 active).  The N <= 64 pipelines launch one kernel per SIZE CLASS of items (at most 32 / 33-48 / 49-56 /

@@ -299,6 +299,8 @@ def load_library():
     lib.smrt_dort_gather_plan.restype = C.c_int32
     lib.smrt_dort_finish_reg_lds_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.smrt_dort_finish_reg_lds_bytes.restype = C.c_int32
+    lib.smrt_dort_finish_strip_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.smrt_dort_finish_strip_lds_bytes.restype = C.c_int32
     lib.smrt_dort_jacobi_lds_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.smrt_dort_jacobi_lds_bytes.restype = C.c_int32
     lib.smrt_dort_sum_n3.argtypes = [C.c_void_p]
@@ -338,7 +340,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_launch_info", "smrt_dort_comm_library", "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
-    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_jacobi_lds_bytes", "smrt_dort_gather_plan",
+    "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_finish_strip_lds_bytes", "smrt_dort_jacobi_lds_bytes", "smrt_dort_gather_plan",
 ]
 
 
@@ -386,9 +388,9 @@ class DortContext:
         self._check(self._lib.smrt_dort_set_block_threads(self._h, int(n)), "smrt_dort_set_block_threads")
 
     def set_pipeline(self, split=1):
-        """1 (default): prep / Jacobi / finish kernels (N <= 64 passive: the register-resident finish kernel); 3: the same,
-        4: never the register-resident finish kernel; 2: the four-matrix LDS finish kernel; 0: one fused kernel per pair
-        (include/smrt_dort.h)."""
+        """1 (default): prep / Jacobi / finish kernels (passive, Flat interfaces: the strip finish kernels); 3: the
+        register-resident finish kernel instead (N <= 64); 5: the strip kernels wherever supported; 4: no pivot-free finish
+        kernel; 2: the four-matrix LDS finish kernel; 0: one fused kernel per pair (include/smrt_dort.h)."""
         self._check(self._lib.smrt_dort_set_pipeline(self._h, int(split)), "smrt_dort_set_pipeline")
 
     def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1, pairs=None) -> BatchOutput:
@@ -458,7 +460,7 @@ class DortContext:
         return cost
 
     # ---- multi-GPU: the RCCL gather of the C ABI (smrt_dort_comm_*, smrt_dort_gather) ----------------------------
-    PIPELINES = ("fused", "lds_two_slot", "lds_four_slot", "lds_reg", "fused_gmem", "gmem", "big", "gmem_strip")   # SMRT_PIPELINE_*
+    PIPELINES = ("fused", "lds_two_slot", "lds_four_slot", "lds_reg", "fused_gmem", "gmem", "big", "gmem_strip", "lds_strip")   # SMRT_PIPELINE_*
 
     def launch_info(self):
         """smrt_dort_launch_info as a dict: pipeline (name), chunk_pairs, chunks, prune_rounds, staged_items (None when

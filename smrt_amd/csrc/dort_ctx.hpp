@@ -40,7 +40,8 @@ struct smrt_dort_ctx {
     size_t finish_reg_lds_bytes = 0;
     size_t prep_wide_lds_bytes = 0;
     bool prep_wide = false;     // 64 < N <= 128, passive: the LDS-resident prep kernel (packed triangles) with eight wavefronts
-    size_t finish_strip_lds_bytes = 0;
+    size_t finish_strip_lds_bytes = 0, finish_strip4_lds_bytes = 0;
+    bool finish_strip4 = false; // ... its four-wavefront instance on the LDS pipeline (N <= 64) instead of the register-resident kernel
     bool finish_strip = false;  // strip finish kernel (passive, 64 < N <= 128, Flat interfaces): one workgroup of eight wavefronts per pair
     bool finish_reg = false;    // register-resident finish kernel (passive, N <= 64, Flat interfaces): one wavefront per pair
     int finish_mode = -1;       // -1: the default choice; 0: never the register-resident finish kernel; 1: whenever supported
@@ -91,6 +92,7 @@ void occupancy_report(smrt_dort_ctx* ctx, int nt);
 hipError_t finish_reg(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
 // k_finish_strip.hip: the strip finish kernel of the 64 < N <= 128 pipeline (passive), one workgroup of eight wavefronts per pair
 hipError_t finish_strip(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
+hipError_t finish_strip4(smrt_dort_ctx* ctx, const smrt::DevBatch& c);   // N <= 64: four wavefronts per pair
 // k_jacobi.hip: one workgroup per staging item (pair, [azimuth mode,] layer)
 hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_split_active.hip

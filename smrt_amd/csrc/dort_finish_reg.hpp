@@ -137,7 +137,56 @@ SMRT_DEV void inv16_step2(double (&d)[4], const LaneId& L) {
         d[r] = old - m0 * rk0 - m1 * rk1;
     }
 }
+// The same elimination with the NEXT pivot row carried one step ahead.  In inv16_step every step is one dependent chain:
+// update of the tile -> row K to all lane rows (two lane-row swaps) -> pivot -> reciprocal (seed + two Newton steps) ->
+// multipliers -> update, about 290 cycles of latency for some 45 instructions.  Here row K + 1 is fetched as it stands at
+// the beginning of step K (that fetch hangs on step K - 1 only), eliminated in its broadcast copy with the same two
+// operations the tile applies to it (rn' = rn - m rk': bitwise the row the tile will hold), and the reciprocal of ITS
+// pivot is started at once -- behind it runs the update of the tile, which no longer sits between two reciprocals.  What
+// is left of the recurrence from one reciprocal to the next: multiplier, update of the copy, pivot broadcast, reciprocal.
+// State between the steps: rk (row K in every lane row), piv, pinv.  Same results as inv16_step, bit for bit.
+SMRT_DEV void inv16_la_begin(const double (&d)[4], double& rk, double& piv, double& pinv) {
+    rk = rows_bcast<0>(d[0]);
+    piv = row_bcast16<0>(rk);
+    pinv = fast_rcp(piv);
+}
+template <int K>
+SMRT_DEV void inv16_la_step(double (&d)[4], double& rk, double& piv, double& pinv, const LaneId& L) {
+    constexpr int r0 = K >> 2, g0 = K & 3;
+    constexpr int K1 = (K < 15) ? K + 1 : 15;
+    double rn = 0.0, pn = 1.0, pinvn = 1.0;
+    if (K < 15) rn = rows_bcast<(K1 & 3)>(d[K1 >> 2]);     // row K + 1 before this step, every lane row
+    const double rkp = (L.c == K) ? piv + 1.0 : rk;         // (the unit-vector trick of inv16_step)
+    if (K < 15) {
+        const double mn = row_bcast16<K>(rn) * pinv;
+        rn -= mn * rkp;                                     // row K + 1 after this step
+        pn = row_bcast16<K1>(rn);
+        pinvn = fast_rcp(pn);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double f = row_bcast16<K>(d[r]);              // D[4 r + g][K]
+        double m = f * pinv;
+        if (r == r0) m = (L.g == g0) ? (1.0 - pinv) : m;
+        d[r] -= m * rkp;
+    }
+    rk = rn; piv = pn; pinv = pinvn;
+}
+SMRT_DEV void inv16_la(double (&d)[4], const LaneId& L) {
+    double rk, piv, pinv;
+    inv16_la_begin(d, rk, piv, pinv);
+    inv16_la_step<0>(d, rk, piv, pinv, L); inv16_la_step<1>(d, rk, piv, pinv, L); inv16_la_step<2>(d, rk, piv, pinv, L);
+    inv16_la_step<3>(d, rk, piv, pinv, L); inv16_la_step<4>(d, rk, piv, pinv, L); inv16_la_step<5>(d, rk, piv, pinv, L);
+    inv16_la_step<6>(d, rk, piv, pinv, L); inv16_la_step<7>(d, rk, piv, pinv, L); inv16_la_step<8>(d, rk, piv, pinv, L);
+    inv16_la_step<9>(d, rk, piv, pinv, L); inv16_la_step<10>(d, rk, piv, pinv, L); inv16_la_step<11>(d, rk, piv, pinv, L);
+    inv16_la_step<12>(d, rk, piv, pinv, L); inv16_la_step<13>(d, rk, piv, pinv, L); inv16_la_step<14>(d, rk, piv, pinv, L);
+    inv16_la_step<15>(d, rk, piv, pinv, L);
+}
 SMRT_DEV void inv16(double (&d)[4], const LaneId& L) {
+#if !defined(SMRT_INV16_NO_LOOKAHEAD) && !defined(SMRT_INV16_TWO_COLUMNS)
+    inv16_la(d, L);
+    return;
+#endif
 #ifndef SMRT_INV16_TWO_COLUMNS   // (two columns per step: same instruction count, same time -- 42.5 vs 42.3 ms per step: the
                                   // elimination is issue bound, not latency bound; kept as an opt-in build)
     inv16_step<0>(d, L); inv16_step<1>(d, L); inv16_step<2>(d, L); inv16_step<3>(d, L);

@@ -25,25 +25,41 @@
 #include "dort_finish_reg.hpp"
 
 namespace smrt {
-namespace st8 {
 
-using rg::LaneId;
-using rg::tile_tn_acc;
+#ifdef SMRT_STRIP_TIMING_INV
+#define SMRT_SI_PTR (b.stage_out + p * 16)
+#else
+#define SMRT_SI_PTR nullptr
+#endif
+// Optional phase timing (profiling builds, -DSMRT_STRIP_TIMING): shader-clock deltas per phase as thread 0 sees them (the
+// barriers make every wavefront's view the same to a few hundred cycles), summed per pair into stage_out
+#ifdef SMRT_STRIP_TIMING
+#define SMRT_ST(k) do { const long long now_ = cycle_counter(); st_acc[st_cur] += (double)(now_ - st_t0); st_t0 = now_; st_cur = (k); } while (0)
+#else
+#define SMRT_ST(k) do {} while (0)
+#endif
+enum { STP_SETUP = 0, STP_LOAD, STP_TRI, STP_AT, STP_T1, STP_H, STP_INV1, STP_INV2, STP_T2, STP_CP, STP_IFACE, STP_INV3, STP_Z, STP_SURF, STP_COUNT };
 
-constexpr int NTT = 8;               // 16 x 16 tiles per side: N <= 128
-constexpr int NW = 8;                // wavefronts of the workgroup: one tile column each
-constexpr int NTH = NW * SMRT_LANES;
-constexpr int TROW = 17;             // doubles per tile row in LDS
-constexpr int TS = 16 * TROW;        // doubles per tile in LDS
-constexpr int kBig = NTT * NTT * TS; // the matrix region
-constexpr int kVecLen = 16 * NTT;    // 128
-constexpr int kVectors = 12;         // exchange vectors
-constexpr int kWsDoubles = NTT * NTT * 256;   // one matrix per pair in global memory (DevStage.ws): At between its phases
+// NTT_: 16 x 16 tiles per side = wavefronts of the workgroup.  8: the 64 < N <= 128 pipeline (one workgroup per CU);
+// 4: N <= 64 (three workgroups per CU).
+template <int NTT_>
+struct StripFinish {
+
+static constexpr int NTT = NTT_;             // 16 x 16 tiles per side: N <= 16 NTT
+static constexpr int NW = NTT_;              // wavefronts of the workgroup: one tile column each
+static constexpr int NTH = NW * SMRT_LANES;
+static constexpr int TROW = 17;              // doubles per tile row in LDS
+static constexpr int TS = 16 * TROW;         // doubles per tile in LDS
+static constexpr int kBig = NTT * NTT * TS;  // the matrix region
+static constexpr int kVecLen = 16 * NTT;     // elements of a vector (128 / 64)
+static constexpr int kVectors = 12;          // exchange vectors
+static constexpr int kWsDoubles = NTT * NTT * 256;   // one matrix per pair in global memory (DevStage.ws): At between its phases
+using LaneId = rg::LaneId;
 
 // tile column of a matrix: tile ti, register r, lane 16 g + c of wavefront w holds X[16 ti + 4 r + g][16 w + c]
 struct Strip { double v[NTT][4]; };
 
-SMRT_DEV void zero(Strip& S) {
+static SMRT_DEV void zero(Strip& S) {
 #pragma unroll
     for (int i = 0; i < NTT; ++i)
 #pragma unroll
@@ -55,7 +71,7 @@ SMRT_DEV void zero(Strip& S) {
 // spills them (600 registers in the first version).  Here the lane part of an address exists THREE times -- once per
 // window of 30 tiles (65 280 bytes) -- and a tile is reached by a compile-time offset inside its window; the values are
 // laundered once per layer so that nothing derived from them is loop-invariant.
-constexpr int kWinTiles = 30;
+static constexpr int kWinTiles = 30;
 struct Lane {
     LaneId id;
     double* d[3];   // window base + (g * 17 + c): the walk of the accumulator layout
@@ -63,13 +79,13 @@ struct Lane {
     double* col[3]; // the tiles (3 k + i, w) of this wavefront's own column, accumulator walk (windows of three tile rows)
     double* rowt;   // the tiles (w, j) of this wavefront's tile row, transposed walk
 };
-SMRT_DEV int launder(int v) {
+static SMRT_DEV int launder(int v) {
 #if !defined(SMRT_HOST_EMU)
     asm volatile("" : "+v"(v));
 #endif
     return v;
 }
-SMRT_DEV Lane make_lane(double* big, const LaneId& id, int w) {
+static SMRT_DEV Lane make_lane(double* big, const LaneId& id, int w) {
     Lane L;
     L.id = id;
     const int od = launder(id.g * TROW + id.c), ot = launder(id.c * TROW + id.g);
@@ -81,44 +97,44 @@ SMRT_DEV Lane make_lane(double* big, const LaneId& id, int w) {
     L.rowt = big + w * NTT * TS + ot;
     return L;
 }
-SMRT_DEV int tile_index(int ti, int tj) { return ti * NTT + tj; }
+static SMRT_DEV int tile_index(int ti, int tj) { return ti * NTT + tj; }
 // accumulator layout <-> LDS tile T (= tile_index(ti, tj), a compile-time constant after unrolling)
-SMRT_DEV void put_tile(int T, const double (&x)[4], const Lane& L) {
+static SMRT_DEV void put_tile(int T, const double (&x)[4], const Lane& L) {
     double* p = L.d[T / kWinTiles] + (T % kWinTiles) * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[4 * r * TROW] = x[r];
 }
 // the tile in accumulator layout (= the A operand of its transpose)
-SMRT_DEV void get_tile(double (&x)[4], int T, const Lane& L) {
+static SMRT_DEV void get_tile(double (&x)[4], int T, const Lane& L) {
     const double* p = L.d[T / kWinTiles] + (T % kWinTiles) * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = p[4 * r * TROW];
 }
 // the transpose of the tile in accumulator layout (= the A operand of the tile itself)
-SMRT_DEV void get_tile_t(double (&x)[4], int T, const Lane& L) {
+static SMRT_DEV void get_tile_t(double (&x)[4], int T, const Lane& L) {
     const double* p = L.t[T / kWinTiles] + (T % kWinTiles) * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = p[4 * r];
 }
 // tile (ti, w) of this wavefront's own column
-SMRT_DEV void put_own(int ti, const double (&x)[4], const Lane& L) {
+static SMRT_DEV void put_own(int ti, const double (&x)[4], const Lane& L) {
     double* p = L.col[ti / 3] + (ti % 3) * NTT * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[4 * r * TROW] = x[r];
 }
 // the transpose of tile (w, tj) of this wavefront's tile row
-SMRT_DEV void get_row_t(double (&x)[4], int tj, const Lane& L) {
+static SMRT_DEV void get_row_t(double (&x)[4], int tj, const Lane& L) {
     const double* p = L.rowt + tj * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = p[4 * r];
 }
 // the same with a run-time tile index inside the first window (the broadcast buffers of the elimination)
-SMRT_DEV void put_tile_rt(int T, const double (&x)[4], const Lane& L) {
+static SMRT_DEV void put_tile_rt(int T, const double (&x)[4], const Lane& L) {
     double* p = L.d[0] + T * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[4 * r * TROW] = x[r];
 }
-SMRT_DEV void get_tile_t_rt(double (&x)[4], int T, const Lane& L) {
+static SMRT_DEV void get_tile_t_rt(double (&x)[4], int T, const Lane& L) {
     const double* p = L.t[0] + T * TS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = p[4 * r];
@@ -127,7 +143,7 @@ SMRT_DEV void get_tile_t_rt(double (&x)[4], int T, const Lane& L) {
 // Z = op(A) Y on the leading nt x nt tiles: A in the LDS matrix region, Y / Z tile columns of this wavefront.
 // TRANS: op(A) = A^T.  LOWER: A is lower triangular by tiles (tiles above the diagonal are not read).
 template <bool TRANS, bool LOWER = false>
-SMRT_DEV void strip_gemm(Strip& Z, const Strip& Y, int nt, const Lane& L) {
+static SMRT_DEV void strip_gemm(Strip& Z, const Strip& Y, int nt, const Lane& L) {
 #pragma unroll
     for (int ti = 0; ti < NTT; ++ti) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -140,7 +156,7 @@ SMRT_DEV void strip_gemm(Strip& Z, const Strip& Y, int nt, const Lane& L) {
                     double a[4];
                     if (TRANS) get_tile(a, tile_index(tk, ti), L);
                     else get_tile_t(a, tile_index(ti, tk), L);
-                    tile_tn_acc(acc, a, Y.v[tk]);
+                    rg::tile_tn_acc(acc, a, Y.v[tk]);
                 }
             }
         }
@@ -150,14 +166,14 @@ SMRT_DEV void strip_gemm(Strip& Z, const Strip& Y, int nt, const Lane& L) {
 }
 
 // the tile column of this wavefront into the LDS matrix
-SMRT_DEV void put_strip(const Strip& S, int nt, const Lane& L) {
+static SMRT_DEV void put_strip(const Strip& S, int nt, const Lane& L) {
 #pragma unroll
     for (int ti = 0; ti < NTT; ++ti)
         if (ti < nt) put_own(ti, S.v[ti], L);
 }
 
 // y[j] = sum_i X[i][j] v[i] for the 16 columns of this wavefront -> out[16 w + c] (LDS); v: LDS vector
-SMRT_DEV void strip_matvec_t(const Strip& X, const double* v, double* out, int nt, int w, const LaneId& L) {
+static SMRT_DEV void strip_matvec_t(const Strip& X, const double* v, double* out, int nt, int w, const LaneId& L) {
     double acc = 0.0;
 #pragma unroll
     for (int ti = 0; ti < NTT; ++ti)
@@ -171,7 +187,7 @@ SMRT_DEV void strip_matvec_t(const Strip& X, const double* v, double* out, int n
 }
 // partial row sums of this wavefront's 16 columns: part[row] = sum_c X[row][16 w + c] colf[16 w + c] (LDS, one row of
 // the [NW][128] partial table per wavefront)
-SMRT_DEV void strip_row_partial(const Strip& X, const double* colf, double* part, int ntr, int w, const LaneId& L) {
+static SMRT_DEV void strip_row_partial(const Strip& X, const double* colf, double* part, int ntr, int w, const LaneId& L) {
     const double f = colf[16 * w + L.c];
 #pragma unroll
     for (int ti = 0; ti < NTT; ++ti)
@@ -185,7 +201,7 @@ SMRT_DEV void strip_row_partial(const Strip& X, const double* colf, double* part
 }
 
 // X[i][j] <- factor rowf[i] X[i][j] colf[j] + (i == j) diag[i] on this wavefront's columns (null pointers: factor 1 / nothing)
-SMRT_DEV void strip_scale_add_diag(Strip& X, const double* rowf, const double* colf, const double* diag, double factor, int nt,
+static SMRT_DEV void strip_scale_add_diag(Strip& X, const double* rowf, const double* colf, const double* diag, double factor, int nt,
                                    int w, const LaneId& L) {
     const double cf = (colf ? colf[16 * w + L.c] : 1.0) * factor;
 #pragma unroll
@@ -203,7 +219,7 @@ SMRT_DEV void strip_scale_add_diag(Strip& X, const double* rowf, const double* c
 }
 
 // cyclic shift of the leading nt tiles of the column: new[i] = old[(i + 1) % nt]
-SMRT_DEV void rotate_strip(Strip& M, int nt) {
+static SMRT_DEV void rotate_strip(Strip& M, int nt) {
     double t0[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) t0[r] = M.v[0][r];
@@ -223,8 +239,16 @@ SMRT_DEV void rotate_strip(Strip& M, int nt) {
 // After every step the tiles of a column are rotated so that the running block row is always tile 0 (one copy of the
 // step code in a run-time loop); nt rotations restore the order.  The caller provides the barrier in front (the region is
 // free, the matrix complete) and must put one behind before the region is reused.
-SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L) {
+#ifdef SMRT_STRIP_TIMING_INV
+#define SMRT_SI(slot) do { if (L.id.lane == 0) { const long long n_ = cycle_counter(); gmem_add(&si_dbg[slot], (double)(n_ - si_t)); si_t = n_; } } while (0)
+#define SMRT_SI0() long long si_t = cycle_counter()
+#else
+#define SMRT_SI(slot) do {} while (0)
+#define SMRT_SI0() do {} while (0)
+#endif
+static SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L, double* si_dbg = nullptr) {
     double D[4] = {0.0, 0.0, 0.0, 0.0};
+    SMRT_SI0();
     if (w == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) D[r] = M.v[0][r];
@@ -240,31 +264,75 @@ SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L) {
     for (int k = 0; k < nt; ++k) {
         const int buf = k & 1;
         const int colb = buf * NTT, nxtb = (buf ^ 1) * NTT;        // tiles (buf, i) / (buf ^ 1, i): run-time index inside the first window
+        if (w == 0) SMRT_SI(k == 0 ? 0 : 1);     // wavefront 0: prologue / its step work
         block_sync();
+        if (w == 0) SMRT_SI(2);                  // wavefront 0: waiting at the barrier
         if (w < nt) {
             if (w != k) {
                 double a[4], R[4] = {0.0, 0.0, 0.0, 0.0};
                 get_tile_t_rt(a, (2 + buf) * NTT, L);
-                tile_tn_acc(R, a, M.v[0]);                                   // row of the block step: D M[k][w]
+                rg::tile_tn_acc(R, a, M.v[0]);                                   // row of the block step: D M[k][w]
                 const bool next = (w == k + 1);
+#ifdef SMRT_STRIP_TIMING_INV
+                if (next) si_t = cycle_counter();
+#endif
                 double Dn[4] = {0.0, 0.0, 0.0, 0.0};
-                if (next) {   // the diagonal tile of the next step first; its inversion runs behind the others' updates
+                if (next) {
+                    // The owner of the next block column: its diagonal tile first, then the 16 x 16 elimination -- one long
+                    // dependent chain on the vector unit -- with the updates of its other tiles issued INTO that chain, one tile
+                    // every other elimination step (operands requested a step ahead): the matrix core works in the shadow
+                    // of the chain instead of behind it.  No branches in the sequence: a tile beyond nt is read from tile 1's
+                    // place and its result is never used (the tiles of a column beyond nt are dead storage).
                     double u[4] = {0.0, 0.0, 0.0, 0.0};
                     get_tile_t_rt(a, colb + 1, L);
-                    tile_tn_acc(u, a, R);
+                    rg::tile_tn_acc(u, a, R);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { M.v[1][r] -= u[r]; Dn[r] = M.v[1][r]; }
-                    rg::inv16(Dn, L.id);
+#ifdef SMRT_STRIP_TIMING_INV
+                    if (w != 0) SMRT_SI(4);      // next owner: diagonal tile update (from the end of R)
+#endif
+                    double a2[4];
+                    auto want = [&](int i, double (&dst)[4]) { if (i < NTT) get_tile_t_rt(dst, colb + (i < nt ? i : 1), L); };
+                    auto upd = [&](int i, const double (&src)[4]) {
+                        if (i < NTT) {
+                            double v[4] = {0.0, 0.0, 0.0, 0.0};
+                            rg::tile_tn_acc(v, src, R);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) M.v[i < NTT ? i : 0][r] -= v[r];
+                        }
+                    };
+                    want(2, a);
+                    double rk, piv, pinv;
+                    rg::inv16_la_begin(Dn, rk, piv, pinv);
+#define SMRT_LA(K) rg::inv16_la_step<K>(Dn, rk, piv, pinv, L.id)
+                    SMRT_LA(0); want(3, a2);
+                    SMRT_LA(1); upd(2, a);
+                    SMRT_LA(2); want(4, a);
+                    SMRT_LA(3); upd(3, a2);
+                    SMRT_LA(4); want(5, a2);
+                    SMRT_LA(5); upd(4, a);
+                    SMRT_LA(6); want(6, a);
+                    SMRT_LA(7); upd(5, a2);
+                    SMRT_LA(8); want(7, a2);
+                    SMRT_LA(9); upd(6, a);
+                    SMRT_LA(10);
+                    SMRT_LA(11); upd(7, a2);
+                    SMRT_LA(12); SMRT_LA(13); SMRT_LA(14); SMRT_LA(15);
+#undef SMRT_LA
+#ifdef SMRT_STRIP_TIMING_INV
+                    if (w != 0) SMRT_SI(5);      // next owner: elimination + interleaved updates
+#endif
+                } else {
+#pragma unroll
+                    for (int i = 1; i < NTT; ++i)
+                        if (i < nt) {
+                            double u[4] = {0.0, 0.0, 0.0, 0.0};
+                            get_tile_t_rt(a, colb + i, L);
+                            rg::tile_tn_acc(u, a, R);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) M.v[i][r] -= u[r];
+                        }
                 }
-#pragma unroll
-                for (int i = 1; i < NTT; ++i)
-                    if (i < nt && !(next && i == 1)) {
-                        double u[4] = {0.0, 0.0, 0.0, 0.0};
-                        get_tile_t_rt(a, colb + i, L);
-                        tile_tn_acc(u, a, R);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) M.v[i][r] -= u[r];
-                    }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) M.v[0][r] = R[r];
                 if (next) {   // broadcast for step k + 1, in its (rotated) order: tile i of then is tile i + 1 of now, the last one tile 0
@@ -275,6 +343,9 @@ SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L) {
                     if (nt > 1) put_tile_rt(nxtb + nt - 1, M.v[0], L);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) D[r] = Dn[r];
+#ifdef SMRT_STRIP_TIMING_INV
+                    if (w != 0) SMRT_SI(6);      // next owner: broadcast stores
+#endif
                 }
             } else {   // the column of the block step itself: M[i][k] = -M[i][k] D, M[k][k] = D
 #pragma unroll
@@ -282,7 +353,7 @@ SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L) {
                     if (i < nt) {
                         double a[4], u[4] = {0.0, 0.0, 0.0, 0.0};
                         get_tile_t_rt(a, colb + i, L);
-                        tile_tn_acc(u, a, D);
+                        rg::tile_tn_acc(u, a, D);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) M.v[i][r] = -u[r];
                     }
@@ -294,24 +365,16 @@ SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L) {
     }
 }
 
-// LDS layout of the strip finish kernel: the matrix region, the exchange vectors, then the tables pair_setup fills (stream
-// tables 3 x n_max_stream, layer tables 15 x Lmax, 8 doubles of flags)
-}  // namespace st8
-
-SMRT_HD int finish_strip_lds_doubles(int n_max_stream, int Lmax) {
-    return st8::kBig + st8::kVectors * st8::kVecLen + 3 * n_max_stream + 15 * Lmax + 8;
-}
 
 // ------------------------------------------------------------------------------------------------------------
-// the per-pair driver: one workgroup of eight wavefronts
+// the per-pair driver: one workgroup of NTT wavefronts
 // ------------------------------------------------------------------------------------------------------------
-// Supported: passive mode, N <= 128, Flat interfaces, no / Flat / Reflector substrate, atmosphere, prune_deep_snowpack.
+// Supported: passive mode, N <= 16 NTT, Flat interfaces, no / Flat / Reflector substrate, atmosphere, prune_deep_snowpack.
 // The host routes batches with process_coherent_layers (T != 1 - R), a host-evaluated dense substrate or rough interfaces
-// to the pivoted finish kernel of the global-workspace pipeline (dort_hip.hip).
-SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
-    using namespace st8;
+// to the pivoted finish kernels (dort_hip.hip).
+static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
     constexpr int NT = NTH, P = 2;
-    const LaneId Ln = rg::lane_id();
+    const LaneId Ln0 = rg::lane_id();
     const int t = tid();
     const int w = t >> 6;
     const int nmax = b.n_max_stream;
@@ -378,12 +441,20 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
     }
     const int LD = (nmax * P + 1) | 1;   // leading dimension of the staged matrices (make_plan)
 
+#ifdef SMRT_STRIP_TIMING
+    double st_acc[STP_COUNT];
+    for (int k = 0; k < STP_COUNT; ++k) st_acc[k] = 0.0;
+    long long st_t0 = cycle_counter();
+    int st_cur = STP_SETUP;
+#endif
     double n3 = 0.0;
-    // element t (< 128: the first two wavefronts) of the vectors carried from layer to layer: source c of the relation
-    // (physical coordinates of the layer it is used in) and u = C^ 1^
-    double c_e = 0.0, u_e = 0.0;
+    // element t (< 16 NTT: the first wavefronts) of the source c of the relation delta = -C s + c carried from layer to layer
+    // (physical coordinates of the layer it is used in).  The matrix is carried TRANSPOSED, Ct = C^^T as tile columns: every
+    // matrix-vector product of the recursion is then a sum down the columns of a wavefront's own tile column (strip_matvec_t),
+    // and the only use of C^ as a matrix, T1 = C^^T A+, reads it from LDS in either orientation anyway.
+    double c_e = 0.0;
     double tb_e = 0.0;
-    Strip C;   // C^ of the layer at hand, tile column of this wavefront (carried in registers between the layers)
+    Strip C;   // C^^T of the layer at hand, tile column of this wavefront (carried in registers between the layers)
     zero(C);
 
     for (int l = Lk - 1; l >= 0; --l) {
@@ -398,23 +469,59 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
         const double* gB = stg.B + item * stg.mat_stride;
         const double* gI = stg.Linv + item * stg.linv_stride;
         const bool in_e = t < N;
-        // ---- element t of the vectors of this layer (padding: d = sigma = 1, t = 0)
-        const double d_e = in_e ? stg.d[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
-        const double sg_e = in_e ? stg.sigma[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
-        const double di_e = fast_rcp(d_e);
-        const double nrs_e = -fast_rcp(sg_e);                      // -1 / sigma
-        const double tt_e = in_e ? exp(-sg_e * s.thick[l]) : 0.0;
-        const double st_e = sg_e * tt_e;                           // sigma t
-        const double m3_e = in_e ? sg_e * (1.0 - tt_e * tt_e) : 1.0;
-
-        // (LDS addresses: laundered once per layer, see make_lane)
+        SMRT_ST(STP_LOAD);
+        // (LDS addresses: laundered once per layer, see make_lane; the lane coordinates too -- the row indices and diagonal
+        // masks derived from them are cheap to recompute and were hoisted out of the layer loop by the dozen, and spilled)
+        LaneId Ln = Ln0;
+        Ln.g = launder(Ln0.g); Ln.c = launder(Ln0.c);
         const Lane Lw = make_lane(big, Ln, w);
         double* const lb = big + launder(0);   // for the element-wise walks below
         double* const V = lb + kBig;           // (the exchange vectors through the laundered base too)
         double* const E0 = V, * const E1 = V + kVecLen, * const E2 = V + 2 * kVecLen, * const E3 = V + 3 * kVecLen;
         double* const E4 = V + 4 * kVecLen, * const E5 = V + 5 * kVecLen, * const E6 = V + 6 * kVecLen, * const E7 = V + 7 * kVecLen;
-        double* const E8 = V + 8 * kVecLen, * const E9 = V + 9 * kVecLen, * const E10 = V + 10 * kVecLen;
-        // ---- B' (tile column of this wavefront) requested first: the loads fly while L+ moves into LDS
+        double* const E8 = V + 8 * kVecLen, * const E9 = V + 9 * kVecLen, * const E10 = V + 10 * kVecLen, * const E11 = V + 11 * kVecLen;
+        // ---- element t of the vectors of this layer (padding: d = sigma = 1, t = 0)
+        const double d_e = in_e ? stg.d[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
+        const double sg_e = in_e ? stg.sigma[item * stg.vec_stride + (in_e ? t : 0)] : 1.0;
+        // ---- L+ -> LDS (lower tiles, zero above the diagonal and beyond N); the inverses of its diagonal blocks into
+        //      free tiles above the diagonal: block i in tile (i, i + 1), the last one in tile (0, 2).  Eight requests in
+        //      flight per thread before the first store (a load per iteration waited for its own latency: 45 k cycles per layer).
+        {
+            const int NP = 16 * nt;
+            constexpr int CPP = NTH / kVecLen, U = 8;   // columns per pass of the workgroup, passes per batch
+            const int r = t % kVecLen, cq = t / kVecLen;
+            for (int c0 = 0; c0 < NP; c0 += CPP * U) {
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc = c0 + u * CPP + cq;
+                    const bool in = r < N && cc < N && r >= cc;
+                    v[u] = gL[in ? cc * LD + r : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc = c0 + u * CPP + cq;
+                    const bool in = r < N && cc < N && r >= cc;
+                    if (r < NP && cc < NP && (r >> 4) >= (cc >> 4))
+                        lb[((r >> 4) * NTT + (cc >> 4)) * TS + (r & 15) * TROW + (cc & 15)] = in ? v[u] : 0.0;
+                }
+            }
+            constexpr int UI = (256 * NTT + NT - 1) / NT;   // passes over the block inverses (4)
+            double vi[UI];
+#pragma unroll
+            for (int u = 0; u < UI; ++u) { const int e = t + u * NT; vi[u] = gI[e < 256 * nt ? e : 0]; }
+#pragma unroll
+            for (int u = 0; u < UI; ++u) {
+                const int e = t + u * NT;
+                if (e < 256 * nt) {   // element e = blk 256 + j 16 + i of the prep kernel's table: (L_blk^-1)[i][j]
+                    const int blk = e >> 8, j = (e >> 4) & 15, i = e & 15;
+                    const int T = (blk < NTT - 1) ? blk * NTT + blk + 1 : 2;
+                    lb[T * TS + i * TROW + j] = vi[u];
+                }
+            }
+        }
+        // ---- B' (tile column of this wavefront) requested behind the copy -- with it in flight during the copy the batch
+        //      above spills -- and in front of the vector arithmetic, which covers most of its latency
         Strip X;
         zero(X);
         const rg::LaneOffsets lo = rg::lane_offsets(LD, N, Ln);
@@ -422,28 +529,11 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
 #pragma unroll
             for (int ti = 0; ti < NTT; ++ti) rg::load_tile_raw(X.v[ti], gB, LD, ti, w, ti < nt, lo);
         }
-        // ---- L+ -> LDS (lower tiles, zero above the diagonal and beyond N); the inverses of its diagonal blocks into
-        //      free tiles above the diagonal: block i in tile (i, i + 1), the last one in tile (0, 2)
-        {
-            const int NP = 16 * nt;
-            for (int c0 = 0; c0 < NP; c0 += 4) {
-                const int r = t & 127, cc = c0 + (t >> 7);
-                if (r < NP && cc < NP && (r >> 4) >= (cc >> 4)) {
-                    const bool in = r < N && cc < N && r >= cc;
-                    const double v = gL[in ? cc * LD + r : 0];
-                    lb[((r >> 4) * NTT + (cc >> 4)) * TS + (r & 15) * TROW + (cc & 15)] = in ? v : 0.0;
-                }
-            }
-            for (int e = t; e < 256 * nt; e += NT) {
-                const int blk = e >> 8, j = (e >> 4) & 15, i = e & 15;
-                const int T = (blk < NTT - 1) ? blk * NTT + blk + 1 : 2;
-                lb[T * TS + i * TROW + j] = gI[blk * 256 + j * 16 + i];
-            }
-        }
-        if (t < kVecLen) {
-            E0[t] = nrs_e; E1[t] = sg_e; E2[t] = st_e; E3[t] = m3_e; E4[t] = di_e; E5[t] = d_e;
-            E6[t] = c_e * di_e - 2.0 * Bl * u_e;                   // z = c^ - 2 B C^ 1^
-        }
+        const double di_e = fast_rcp(d_e);
+        const double nrs_e = -fast_rcp(sg_e);                      // -1 / sigma
+        const double tt_e = in_e ? exp(-sg_e * s.thick[l]) : 0.0;
+        const double st_e = sg_e * tt_e;                           // sigma t
+        const double m3_e = in_e ? sg_e * (1.0 - tt_e * tt_e) : 1.0;
         if (l == Lk - 1) {
             // what the last layer sees below (rtsolver_utils.py:544-551,579-584,601-603; dort.py:429-441,446-452):
             // I_up = R I_dn + src  ->  C = (1 - R) / (1 + R) (diagonal: C^ = C), c = (C + 1) src
@@ -460,8 +550,11 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
             }
             const double cd = in_e ? (1.0 - Rs) * fast_rcp(1.0 + Rs) : 0.0;
             c_e = in_e ? (cd + 1.0) * src : 0.0;
-            u_e = cd * di_e;
-            if (t < kVecLen) { E7[t] = cd; E6[t] = c_e * di_e - 2.0 * Bl * u_e; }
+            if (t < kVecLen) E7[t] = cd;
+        }
+        if (t < kVecLen) {
+            E0[t] = nrs_e; E1[t] = sg_e; E2[t] = st_e; E3[t] = m3_e; E4[t] = di_e; E5[t] = d_e;
+            E6[t] = c_e * di_e;                                    // c^ = D^-1 c
         }
         block_sync();
         if (l == Lk - 1) {
@@ -470,6 +563,7 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
 #pragma unroll
                 for (int r = 0; r < 4; ++r) C.v[ti][r] = (ti == w && ti < nt && 4 * r + Ln.g == Ln.c) ? E7[16 * ti + Ln.c] : 0.0;
         }
+        SMRT_ST(STP_TRI);
         Strip At;   // W = L+ B' -> At = A-^T = -Sigma^-1 W^T
         zero(At);
         if (w < nt) {
@@ -485,70 +579,77 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
                         if (tk < nt) {
                             double a[4], u[4] = {0.0, 0.0, 0.0, 0.0};
                             get_tile(a, tile_index(tk, ti), Lw);            // L+[tk][ti]^T X[tk]
-                            tile_tn_acc(u, a, X.v[tk]);
+                            rg::tile_tn_acc(u, a, X.v[tk]);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) X.v[ti][r] -= u[r];
                         }
                     double a[4], u[4] = {0.0, 0.0, 0.0, 0.0};
                     get_tile(a, (ti < NTT - 1) ? tile_index(ti, ti + 1) : tile_index(0, 2), Lw);
-                    tile_tn_acc(u, a, X.v[ti]);
+                    rg::tile_tn_acc(u, a, X.v[ti]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X.v[ti][r] = u[r];
                 }
             }
-            strip_matvec_t(X, E6, E8, nt, w, Ln);                           // r = A+^T z -> E8
+            strip_matvec_t(X, E6, E8, nt, w, Ln);                           // A+^T c^ -> E8
+            strip_matvec_t(At, E4, E9, nt, w, Ln);                          // W^T D^-1 1 -> E9  (x1 = A-^T D^-1 1 = -Sigma^-1 W^T D^-1 1)
         }
         block_sync();                                                       // L+ is dead
+        SMRT_ST(STP_AT);
         if (w < nt) put_strip(At, nt, Lw);                                  // W, to be read back transposed
         block_sync();
+        // At waits in this pair's matrix in global memory (lane-contiguous, the wavefront's own part) until Theta exists:
+        // fewer tile columns in registers through the two inversions
+        // (uniform base + a laundered 32-bit lane offset: as 64-bit addresses the 32 slots were hoisted out of the layer loop and spilled)
+        double* const wsb = stg.ws + p * (long long)kWsDoubles;
+        const int wso = launder((w * NTT * 4) * SMRT_LANES + Ln.lane);
         if (w < nt) {
 #pragma unroll
             for (int tj = 0; tj < NTT; ++tj)
                 if (tj < nt) {
                     get_row_t(At.v[tj], tj, Lw);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) At.v[tj][r] *= E0[16 * tj + 4 * r + Ln.g];
-                }
-        }
-        // At waits in this pair's matrix in global memory (lane-contiguous, the wavefront's own 16 KB) until Theta exists: three
-        // tile columns in registers at most, the fourth was 300 spilled registers
-        double* const wsw = stg.ws + p * (long long)kWsDoubles + (w * NTT * 4) * SMRT_LANES + Ln.lane;
-        if (w < nt) {
-#pragma unroll
-            for (int ti = 0; ti < NTT; ++ti)
-                if (ti < nt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) wsw[(ti * 4 + r) * SMRT_LANES] = At.v[ti][r];
+                    for (int r = 0; r < 4; ++r) {
+                        At.v[tj][r] *= E0[16 * tj + 4 * r + Ln.g];
+                        wsb[wso + (tj * 4 + r) * SMRT_LANES] = At.v[tj][r];
+                    }
                 }
         }
         block_sync();
-        if (w < nt) put_strip(C, nt, Lw);                                   // C^
+        if (w < nt) put_strip(C, nt, Lw);                                   // C^^T
         block_sync();
-        Strip X2;   // T1 = C^^T A+, then H^T and the matrices that are inverted
+        SMRT_ST(STP_T1);
+        Strip X2;   // T1 = C^^T A+, then the work column of the products
         zero(X2);
-        if (w < nt) strip_gemm<true>(X2, X, nt, Lw);
+        if (w < nt) {
+            strip_gemm<false>(X2, X, nt, Lw);                               // (the region holds C^^T as it is)
+            strip_matvec_t(X2, E4, E10, nt, w, Ln);                         // A+^T C^ D^-1 1 = T1^T D^-1 1 -> E10
+        }
         block_sync();
+        SMRT_ST(STP_H);
+        if (t < kVecLen) E8[t] -= 2.0 * Bl * E10[t];                        // r = A+^T (c^ - 2 B C^ 1^)
         if (w < nt) put_strip(X, nt, Lw);                                   // A+
         block_sync();
         if (w < nt) {
-            strip_gemm<true>(C, X2, nt, Lw);                                // H^T = A+^T (C^^T A+)   (C is free: reused as the work column)
+            strip_gemm<true>(C, X2, nt, Lw);                                // H^T = A+^T (C^^T A+)   (C is free: the work column)
             strip_scale_add_diag(C, nullptr, nullptr, E1, 1.0, nt, w, Ln);  // H^T + Sigma
         }
-        // (the barrier at the top of the elimination loop separates the reads of A+ from the broadcasts)
         block_sync();
-        strip_invert(C, nt, w, Lw);                                         // P^T
-        if (w < nt) strip_matvec_t(C, E8, E9, nt, w, Ln);                   // q = P r -> E9
+        SMRT_ST(STP_INV1);
+        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // P^T
+        if (w < nt) strip_matvec_t(C, E8, E10, nt, w, Ln);                  // q = P r -> E10
         block_sync();
-        const double q_e = (t < kVecLen) ? E9[t] : 0.0;
-        if (t < kVecLen) E10[t] = st_e * q_e;
+        if (t < kVecLen) { E11[t] = st_e * E10[t]; E9[t] *= nrs_e; }        // Sigma t q;  x1
         if (w < nt) strip_scale_add_diag(C, E2, E2, E3, 2.0, nt, w, Ln);    // M3^T
         block_sync();
-        strip_invert(C, nt, w, Lw);                                         // M3^-T
+        SMRT_ST(STP_INV2);
+        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // M3^-T
         if (w < nt) {
-            strip_matvec_t(C, E10, E9, nt, w, Ln);                          // y = M3^-1 (Sigma t q) -> E9
+            strip_matvec_t(C, E11, E10, nt, w, Ln);                         // y = M3^-1 (Sigma t q) -> E10
             strip_scale_add_diag(C, nullptr, nullptr, E0, 2.0, nt, w, Ln);  // Theta^T = 2 M3^-T - Sigma^-1
+            strip_matvec_t(C, E9, E6, nt, w, Ln);                           // x2 = Theta x1 -> E6 (free since the first phase; E11 is still being read)
         }
         block_sync();
+        SMRT_ST(STP_T2);
         zero(At);
         if (w < nt) {
             put_strip(C, nt, Lw);                                           // Theta^T
@@ -556,28 +657,23 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
             for (int ti = 0; ti < NTT; ++ti)
                 if (ti < nt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) At.v[ti][r] = wsw[(ti * 4 + r) * SMRT_LANES];
+                    for (int r = 0; r < 4; ++r) At.v[ti][r] = wsb[wso + (ti * 4 + r) * SMRT_LANES];
                 }
-            strip_matvec_t(At, E9, E8, nt, w, Ln);                          // A- y = At^T y -> E8
+            strip_matvec_t(At, E10, E8, nt, w, Ln);                         // A- y = At^T y -> E8
+            strip_matvec_t(At, E6, E9, nt, w, Ln);                          // C^' D^-1 1 = A- Theta A-^T D^-1 1 = At^T x2 -> E9
         }
         block_sync();
-        if (w < nt) strip_gemm<true>(X2, At, nt, Lw);                       // T2 = Theta At
+        if (t < kVecLen) c_e = d_e * (2.0 * Bl * E9[t] - 2.0 * E8[t]);      // c' (physical coordinates)
+        if (w < nt) strip_gemm<false>(X2, At, nt, Lw);                      // T2' = Theta^T At
         block_sync();
+        SMRT_ST(STP_CP);
         if (w < nt) put_strip(At, nt, Lw);
         block_sync();
-        if (w < nt) strip_gemm<true>(C, X2, nt, Lw);                        // C^' = At^T T2 = A- Theta A-^T
-        block_sync();                                                       // At is dead: the partial sums may take its place
-        double* const part = lb;                                            // [NW][128] partial row sums, twice
-        if (w < nt) strip_row_partial(C, E4, part + w * kVecLen, nt, w, Ln);   // C^' D^-1 1 (this wavefront's columns)
-        block_sync();
-        if (t < kVecLen) {
-            double a = 0.0;
-            for (int k = 0; k < nt; ++k) a += part[k * kVecLen + t];
-            c_e = d_e * (2.0 * Bl * a - 2.0 * E8[t]);                       // c' (physical coordinates)
+        if (w < nt) {
+            strip_gemm<true>(C, X2, nt, Lw);                                // C^'^T = At^T Theta^T At
+            strip_scale_add_diag(C, E4, E5, nullptr, 1.0, nt, w, Ln);       // C'^T = D^-1 C^'^T D
         }
-        if (w < nt) strip_scale_add_diag(C, E5, E4, nullptr, 1.0, nt, w, Ln);  // C' = D C^' D^-1
-        block_sync();
-
+        SMRT_ST(l == 0 ? STP_SURF : STP_IFACE);
         if (l == 0) {
             // surface (dort.py:391-395,484): I_dn = r2 I_up + t2 I_sky just below it;
             // S I_up = c' + (I - C') t2 I_sky,  S = (1 - r2) + C' (1 + r2);  I0 = R_air I_sky + t1 I_up
@@ -585,6 +681,7 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
             const double Idn = atm ? (b.rayleigh_jeans ? b.atm_down[fi] : planck_radiance(frequency, b.atm_down[fi])) : 0.0;
             double Tair = 0.0, r2s = 0.0, t1s_e = 0.0, Rair_e = 0.0;
             const cplx one = cmk(1.0, 0.0);
+            block_sync();                                                   // (E8, E9 are read)
             if (t < kVecLen) {
                 if (in_e) { r2s = flat_R(el, one, s.ri[0] * s.gsin[t >> 1], t & 1); t1s_e = 1.0 - r2s; }
                 if (t < n_air * P) {
@@ -596,23 +693,17 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
                 E7[t] = in_e ? 1.0 + r2s : 0.0; E8[t] = in_e ? 1.0 - r2s : 1.0;
             }
             block_sync();
-            if (w < nt) strip_row_partial(C, E6, part + w * kVecLen, nt, w, Ln);   // C' (t2 I_sky)
-            block_sync();
-            if (t < kVecLen) {
-                double a = 0.0;
-                for (int k = 0; k < nt; ++k) a += part[k * kVecLen + t];
-                E9[t] = in_e ? c_e + E6[t] - a : 0.0;                       // right-hand side
+            if (w < nt) {
+                strip_matvec_t(C, E6, E9, nt, w, Ln);                       // C' (t2 I_sky) -> E9
+                strip_scale_add_diag(C, E7, nullptr, E8, 1.0, nt, w, Ln);   // S^T = (1 - r2) + (1 + r2) C'^T
             }
-            if (w < nt) strip_scale_add_diag(C, nullptr, E7, E8, 1.0, nt, w, Ln);   // S
             block_sync();
-            strip_invert(C, nt, w, Lw);
-            block_sync();
-            if (w < nt) strip_row_partial(C, E9, part + w * kVecLen, nt, w, Ln);   // I_up just below the surface
+            if (t < kVecLen) E10[t] = in_e ? c_e + E6[t] - E9[t] : 0.0;     // right-hand side
+            strip_invert(C, nt, w, Lw, SMRT_SI_PTR);
+            if (w < nt) strip_matvec_t(C, E10, E9, nt, w, Ln);              // I_up just below the surface
             block_sync();
             if (t < n_air * P) {
-                double a = 0.0;
-                for (int k = 0; k < nt; ++k) a += part[k * kVecLen + t];
-                double I0 = Rair_e * Idn + t1s_e * a;
+                double I0 = Rair_e * Idn + t1s_e * E9[t];
                 if (atm) I0 = (b.rayleigh_jeans ? b.atm_up[fi] : planck_radiance(frequency, b.atm_up[fi])) + b.atm_trans[fi] * I0;
                 tb_e = b.rayleigh_jeans ? I0 : planck_inverse(frequency, I0);
             }
@@ -625,7 +716,8 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
         const int ntm = nt > ntu ? nt : ntu;
         const long long item_u = item - 1;
         const bool in_u = t < Nu;
-        double cb_e = 0.0, cd_e = 0.0, it2_e = 0.0;
+        double cd_e = 0.0, it2_e = 0.0;
+        block_sync();                                                       // (E0 ... E5 of the layer are read)
         if (t < kVecLen) {
             const cplx eup = cmk(s.eps_re[l - 1], s.eps_im[l - 1]);
             double r1 = 1.0, t2 = 0.0, r2 = 0.0, t1 = 0.0, extra_e = 0.0;
@@ -641,22 +733,24 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
             const double tt2 = t1 * t2;
             const double ca = 0.5 * (tt2 + (1.0 + r1) * (1.0 - r2));
             const double cc = 0.5 * (tt2 - (1.0 - r1) * (1.0 - r2));
-            cb_e = 0.5 * (tt2 - (1.0 + r1) * (1.0 + r2));
+            const double cb_e = 0.5 * (tt2 - (1.0 + r1) * (1.0 + r2));
             cd_e = 0.5 * (tt2 + (1.0 - r1) * (1.0 + r2));
             const double t2_e = (t < nc) ? t2 : 0.0;
             it2_e = (t < nc) ? fast_rcp(t2) : 0.0;
             const double du_e = in_u ? stg.d[item_u * stg.vec_stride + (in_u ? t : 0)] : 1.0;
             const double dui_e = fast_rcp(du_e);
-            // Y = a - b C', Nn = c - d C' (row factors and diagonals); then the factors of the result
+            // Y^T = a - C'^T b, Nn^T = c - C'^T d (column factors and diagonals); then the factors of the result
             E0[t] = in_e ? -cb_e : 0.0; E1[t] = in_e ? ca : 1.0;
             E2[t] = in_e ? -cd_e : 0.0; E3[t] = in_e ? cc : 0.0;
             E6[t] = in_e ? cb_e * c_e : 0.0;                                // b c'
-            E7[t] = -it2_e * dui_e; E8[t] = t2_e * du_e; E9[t] = extra_e; E10[t] = dui_e;
+            E7[t] = -it2_e * dui_e; E8[t] = t2_e * du_e; E9[t] = extra_e;
         }
         block_sync();
-        Strip Nn;
+        Strip Nn;   // Nn^T
         zero(Nn);
         if (w < nt) {
+            const int col = 16 * w + Ln.c;
+            const double f0 = E0[col], f2 = E2[col];
 #pragma unroll
             for (int ti = 0; ti < NTT; ++ti)
                 if (ti < nt) {
@@ -665,55 +759,43 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
                         const int row = 16 * ti + 4 * r + Ln.g;
                         const bool dg = (ti == w && 4 * r + Ln.g == Ln.c);
                         const double cv = C.v[ti][r];
-                        C.v[ti][r] = cv * E0[row] + (dg ? E1[row] : 0.0);
-                        Nn.v[ti][r] = cv * E2[row] + (dg ? E3[row] : 0.0);
+                        C.v[ti][r] = cv * f0 + (dg ? E1[row] : 0.0);
+                        Nn.v[ti][r] = cv * f2 + (dg ? E3[row] : 0.0);
                     }
                 }
         }
-        block_sync();                                                       // (the partial sums above are read; the region is free)
-        strip_invert(C, nt, w, Lw);                                         // Y^-1
+        block_sync();                                                       // (At in the region is read)
+        SMRT_ST(STP_INV3);
+        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // Y^-T
         block_sync();
-        if (w < nt) put_strip(Nn, nt, Lw);
+        SMRT_ST(STP_Z);
+        if (w < nt) put_strip(C, nt, Lw);
         block_sync();
-        // ---- Z = Nn Y^-1;  C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the upper layer's
-        //      extra streams;  c_u = (d c' - Z b c') / t2;  in the hats of the layer above, C^ = D^-1 C D
+        // ---- Z^T = Y^-T Nn^T;  C_u = -t2^-1 Z t2 on the common streams, (1 - R) / (1 + R) on the diagonal of the upper layer's
+        //      extra streams;  c_u = (d c' - Z b c') / t2;  in the hats of the layer above, C^ = D^-1 C D -- transposed
         zero(X2);
-        if (w < nt) strip_gemm<false>(X2, C, nt, Lw);
-        block_sync();                                                       // Nn is dead: partial sums again
-        {
-            Strip Cu;
-            zero(Cu);
-            if (w < ntm) {
-                const int col = 16 * w + Ln.c;
-                const double wb = E6[col], cf = E8[col], wu = E10[col];
-#pragma unroll
-                for (int ti = 0; ti < NTT; ++ti)
-                    if (ti < ntm) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * ti + 4 * r + Ln.g;
-                            const double h = X2.v[ti][r];                   // (zero outside nt x nt)
-                            double x = (row < nc && col < nc) ? h * E7[row] * cf : 0.0;
-                            if (row == col) x += E9[row];
-                            Cu.v[ti][r] = x;
-                            const double zb = group_sum<16>(h * wb);
-                            const double ur = group_sum<16>(x * wu);
-                            if (Ln.c == 0) { part[w * kVecLen + row] = zb; part[(NW + w) * kVecLen + row] = ur; }
-                        }
-                    }
-            }
+        if (w < nt) {
+            strip_gemm<false>(X2, Nn, nt, Lw);
+            strip_matvec_t(X2, E6, E10, nt, w, Ln);                         // Z b c' -> E10
+        }
+        if (w < ntm) {
+            const int col = 16 * w + Ln.c;
+            const double cf = E7[col];                                      // (-1 / (t2 d_u)) of the column = row of C_u
 #pragma unroll
             for (int ti = 0; ti < NTT; ++ti)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) C.v[ti][r] = Cu.v[ti][r];
-        }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + Ln.g;
+                    double x = 0.0;
+                    if (ti < ntm) {
+                        x = (row < nc && col < nc) ? X2.v[ti][r] * E8[row] * cf : 0.0;   // (X2 is zero outside nt x nt)
+                        if (row == col) x += E9[row];
+                    }
+                    C.v[ti][r] = x;
+                }
+        } else zero(C);
         block_sync();
-        if (t < kVecLen) {
-            double a = 0.0, u2 = 0.0;
-            for (int k = 0; k < ntm; ++k) { a += part[k * kVecLen + t]; u2 += part[(NW + k) * kVecLen + t]; }
-            c_e = (t < nc) ? (cd_e * c_e - a) * it2_e : 0.0;
-            u_e = in_u ? u2 : 0.0;
-        }
+        if (t < kVecLen) c_e = (t < nc) ? (cd_e * c_e - E10[t]) * it2_e : 0.0;
         block_sync();
     }
 
@@ -739,6 +821,24 @@ SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* ld
         b.out[p * out_stride + idx] = y0 + (y1 - y0) * ((um - x0) / (x1 - x0));
     }
     if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+#ifdef SMRT_STRIP_TIMING
+    SMRT_ST(STP_SETUP);
+    if (t == 0 && b.stage_out) for (int k = 0; k < 16; ++k) b.stage_out[p * 16 + k] = (k < STP_COUNT) ? st_acc[k] : 0.0;
+#endif
+}
+
+};   // StripFinish
+
+// LDS layout of the strip finish kernels: the matrix region, the exchange vectors, then the tables pair_setup fills (stream
+// tables 3 x n_max_stream, layer tables 15 x Lmax, 8 doubles of flags)
+SMRT_HD int finish_strip_lds_doubles(int n_max_stream, int Lmax, int ntt = 8) {
+    return ntt * ntt * 16 * 17 + 12 * 16 * ntt + 3 * n_max_stream + 15 * Lmax + 8;
+}
+SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
+    StripFinish<8>::run(b, p, lds_base, stg);
+}
+SMRT_DEV void dort_pair_passive_strip4(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
+    StripFinish<4>::run(b, p, lds_base, stg);
 }
 
 }  // namespace smrt

@@ -78,6 +78,7 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         if (ctx->big) return smrt_launch::finish_gmem_big(ctx, c, grid, ctx->active, ctx->nmax_rows <= 256 ? 4 : 6);
         if (ctx->finish_strip) return smrt_launch::finish_strip(ctx, c);
         if (ctx->gmem_split) return smrt_launch::finish_gmem(ctx, c, grid, ctx->active);
+        if (ctx->finish_strip4) return smrt_launch::finish_strip4(ctx, c);
         if (ctx->finish_reg) return smrt_launch::finish_reg(ctx, c);
         return ctx->active ? smrt_launch::active_finish(ctx, c, ctx->nt) : smrt_launch::finish(ctx, c, ctx->nt, ctx->finish2);
     };
@@ -203,13 +204,18 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
     if (!ctx) return -1;
     ctx->split = (split != 0);
     ctx->finish2 = (split != 2);
-    ctx->finish_mode = (split == 3) ? 1 : (split == 4 ? 0 : -1);   // 3: register-resident finish wherever supported, 4: never
+    ctx->finish_mode = (split == 3) ? 1 : (split == 4 ? 0 : (split == 5 ? 2 : -1));   // 3: register-resident finish wherever supported, 4: no pivot-free kernel, 5: strip kernels wherever supported
     ctx->uploaded = false;  // the staging area is sized at upload time
     return 0;
 }
 
 int32_t smrt_dort_finish_reg_lds_bytes(int32_t n_max_stream, int32_t n_layers_max) {
     return (int32_t)(sizeof(double) * (size_t)finish_reg_lds_doubles(n_max_stream, n_layers_max));
+}
+
+int32_t smrt_dort_finish_strip_lds_bytes(int32_t n_max_stream, int32_t n_layers_max, int32_t wavefronts) {
+    if (wavefronts != 4 && wavefronts != 8) return -1;
+    return (int32_t)(sizeof(double) * (size_t)finish_strip_lds_doubles(n_max_stream, n_layers_max, wavefronts));
 }
 
 int32_t smrt_dort_jacobi_lds_bytes(int32_t n_max_stream, int32_t n_pol, int32_t size_class_columns) {
@@ -361,7 +367,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     {
         const bool supported = !ctx->gmem_path && ctx->split && ctx->finish2 && !ctx->active && ctx->chunk_pairs > 0 &&
                                !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
-        int want = ctx->finish_mode;
+        int want = (ctx->finish_mode == 2) ? -1 : ctx->finish_mode;
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
         ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
         // (its per-layer tables grow with n_layers_max: beyond the LDS of a workgroup the two-slot kernel takes over)
@@ -375,6 +381,21 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->finish_reg = supported && ctx->finish_reg_lds_bytes <= cap &&
                           (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));
         ctx->stage.ws = nullptr;
+        // The strip kernel's four-wavefront instance under the same conditions: the default while three of its workgroups
+        // share a CU (160 KB / 3; 44 KB at 32 streams and 20 layers), with set_pipeline(5) up to the 64 KB a workgroup may
+        // take; set_pipeline(3) keeps the register-resident kernel.  11.1 against 13.7 ms on the headline batch.
+        ctx->finish_strip4 = false;
+        {
+            int want4 = (ctx->finish_mode == 2) ? 1 : (ctx->finish_mode == -1 ? -1 : 0);
+            if (const char* e = getenv("SMRT_DORT_FINISH_STRIP4")) want4 = atoi(e) ? 1 : 0;
+            const size_t lds4 = sizeof(double) * (size_t)finish_strip_lds_doubles(b->n_max_stream, b->n_layers_max, 4);
+            const size_t cap4 = (want4 == 1) ? (size_t)64 * 1024 : (size_t)160 * 1024 / 3;
+            if (supported && lds4 <= cap4 && (want4 == 1 || (want4 == -1 && SMRT_FINISH_STRIP_DEFAULT))) {
+                ctx->finish_strip4 = true; ctx->finish_strip4_lds_bytes = lds4; ctx->finish_reg = false;
+                HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * ctx->lanes * StripFinish<4>::kWsDoubles));
+                ctx->stage.ws = (double*)ctx->d_regws.p;
+            }
+        }
         if (ctx->finish_reg) {   // one 64 x 64 matrix per pair of a chunk in global memory (At between its two phases)
             HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * ctx->lanes * rg::kSlotDoubles));
             ctx->stage.ws = (double*)ctx->d_regws.p;
@@ -385,7 +406,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     {
         const bool supported = ctx->gmem_split && !ctx->big && !ctx->active && plan.NMAX <= 128 && ctx->chunk_pairs > 0 &&
                                !b->process_coherent_layers && b->substrate_kind != SUB_HOST && !b->host_interface_slot;
-        int want = ctx->finish_mode;
+        int want = (ctx->finish_mode == 2) ? 1 : ctx->finish_mode;
         if (const char* e = getenv("SMRT_DORT_FINISH_STRIP")) want = atoi(e) ? 1 : 0;
         ctx->finish_strip_lds_bytes = sizeof(double) * (size_t)finish_strip_lds_doubles(b->n_max_stream, b->n_layers_max);
         ctx->finish_strip = supported && ctx->finish_strip_lds_bytes <= (size_t)ctx->max_lds &&
@@ -395,7 +416,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->prep_wide = ctx->gmem_split && !ctx->big && !ctx->active && plan.NMAX <= 128 && ctx->chunk_pairs > 0 &&
                          ctx->prep_wide_lds_bytes <= (size_t)ctx->max_lds && getenv("SMRT_DORT_NO_PREP_WIDE") == nullptr;
         if (ctx->finish_strip) {   // one 128 x 128 matrix per pair of a chunk in global memory (At between its two phases)
-            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * st8::kWsDoubles));
+            HIPCHK(ctx->d_regws.reserve(sizeof(double) * (size_t)ctx->chunk_pairs * StripFinish<8>::kWsDoubles));
             ctx->stage.ws = (double*)ctx->d_regws.p;
         }
     }
@@ -509,7 +530,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     // for experiments.  Passive mode, measured on the headline batch against the oracle (profiles/r3_jacobi_thresholds.txt):
     // 1e-26 / 1e-15 -> 1.4e-10 K, 1e-22 / 1e-12 -> 1.6e-8 K (2.6 % faster), 1e-20 / 1e-10 -> 2.4e-7 K; the requirement is 1e-6 K.
     // The register-resident finish kernel needs the tighter pair on weakly scattering media (dort_host_common.hpp).
-    const bool orth = ctx->finish_reg || ctx->finish_strip;   // the finish kernels that use the orthogonality of B' itself
+    const bool orth = ctx->finish_reg || ctx->finish_strip || ctx->finish_strip4;   // the finish kernels that use the orthogonality of B' itself
     d.jacobi_skip2 = ctx->active ? 1e-30 : (orth ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);
     d.jacobi_exit2 = ctx->active ? 1e-22 : (orth ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);
     if (const char* e = getenv("SMRT_DORT_JACOBI_SKIP2")) d.jacobi_skip2 = atof(e);
@@ -620,7 +641,7 @@ int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
     const bool lds_pipeline = !ctx->gmem_path && ctx->split && ctx->chunk_pairs > 0 && (!ctx->active || ctx->finish2);
     int64_t v[SMRT_INFO_COUNT] = {0};
     v[SMRT_INFO_PIPELINE] = ctx->gmem_split ? (ctx->big ? SMRT_PIPELINE_BIG : ctx->finish_strip ? SMRT_PIPELINE_GMEM_STRIP : SMRT_PIPELINE_GMEM)
-                          : lds_pipeline ? (ctx->finish_reg ? SMRT_PIPELINE_LDS_REG : ctx->finish2 ? SMRT_PIPELINE_LDS_TWO_SLOT : SMRT_PIPELINE_LDS_FOUR_SLOT)
+                          : lds_pipeline ? (ctx->finish_strip4 ? SMRT_PIPELINE_LDS_STRIP : ctx->finish_reg ? SMRT_PIPELINE_LDS_REG : ctx->finish2 ? SMRT_PIPELINE_LDS_TWO_SLOT : SMRT_PIPELINE_LDS_FOUR_SLOT)
                           : ctx->gmem_path ? SMRT_PIPELINE_FUSED_GMEM : SMRT_PIPELINE_FUSED;
     const bool three = ctx->gmem_split || lds_pipeline;
     v[SMRT_INFO_CHUNK_PAIRS] = three ? ctx->chunk_pairs : d.pair_count;

@@ -83,6 +83,7 @@ SMRT_DEV double group_sum(double v) {
 SMRT_DEV void lds_or(int* p, int v) { *p |= v; }
 SMRT_DEV void lds_max(int* p, int v) { if (v > *p) *p = v; }
 SMRT_DEV void gmem_max(int* p, int v) { if (v > *p) *p = v; }
+SMRT_DEV void gmem_add(double* p, double v) { *p += v; }
 }  // namespace smrt
 
 #else
@@ -146,8 +147,11 @@ SMRT_DEV double dpp_move(double v) {
 }
 // value of lane K of the caller's 16-lane row, K a compile-time constant: DPP row_newbcast (gfx90a and later), two
 // v_mov_b32_dpp, no LDS traffic
+// (ONE v_mov_b64_dpp: gfx90a and later take 64-bit operands under this DPP control -- and only this one --, which halves the
+// cross-lane instructions of the in-register eliminations; a wavefront issues about one vector instruction every 4.5
+// cycles whatever it is, tools/micro/inv16_cost.hip)
 template <int K>
-SMRT_DEV double row_bcast16(double v) { return dpp_move<0x150 + K>(v); }
+SMRT_DEV double row_bcast16(double v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xF, 0xF, false); }
 // value of lane 16 G0 + c in every lane 16 g + c (the 16-lane row G0 copied to all four rows), G0 a compile-time constant:
 // v_permlane16_swap / v_permlane32_swap (gfx950) -- the first makes rows {0, 1} and {2, 3} equal, the second the halves
 template <int G0>
@@ -264,6 +268,7 @@ SMRT_DEV double group_sum(double v) {
 SMRT_DEV void lds_or(int* p, int v) { atomicOr(p, v); }
 SMRT_DEV void lds_max(int* p, int v) { atomicMax(p, v); }
 SMRT_DEV void gmem_max(int* p, int v) { atomicMax(p, v); }
+SMRT_DEV void gmem_add(double* p, double v) { atomicAdd(p, v); }   // (profiling builds only)
 }  // namespace smrt
 
 #endif

@@ -165,13 +165,15 @@ static long run_split_active(DevBatch& d, int order, size_t lds_doubles, const L
 template <int NT>
 static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan& plan) {
     Staging sg((size_t)d.pair_count * d.Lmax, plan);
-    std::vector<double> lds(lds_doubles + finish_reg_lds_doubles(d.n_max_stream, d.Lmax));
+    std::vector<double> lds(lds_doubles + finish_reg_lds_doubles(d.n_max_stream, d.Lmax) + finish_strip_lds_doubles(d.n_max_stream, d.Lmax, 4));
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
     return run_rounds(d, order, 1, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
         [&](long long it) { return run_jacobi_classes(d, sg.st, it, 2, order, jl); },
         [&](long long p) { for (auto& x : lds) x = NAN;
+                           if (smrt_emu_pipeline == 6 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the strip finish kernel on four wavefronts
+                               return emu::run_block(256, order, [&]() { dort_pair_passive_strip4(d, p, lds.data(), sg.st); });
                            if (smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the register-resident finish kernel: one wavefront per pair (where the library uses it)
                                return emu::run_block(64, order, [&]() { dort_pair_passive_reg(d, p, lds.data(), sg.st); });
                            return smrt_emu_pipeline == 2 ? emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &sg.st); })
@@ -228,7 +230,7 @@ extern "C" int smrt_emu_run(const smrt_batch* b, long long pair_begin, long long
     d.atm_trans = has_atm ? b->atm_transmittance : nullptr;
     d.prune_tau = (b->prune_optical_depth > 0.0) ? b->prune_optical_depth : 0.0;
     d.layer_lo = 0; d.layer_hi = b->n_layers_max; d.pair_done = nullptr;
-    const bool reg_thr = !active && smrt_emu_pipeline == 3 && b->n_max_stream * 2 <= 128 && !b->host_interface_slot &&
+    const bool reg_thr = !active && (smrt_emu_pipeline == 3 || smrt_emu_pipeline == 6) && b->n_max_stream * 2 <= 128 && !b->host_interface_slot &&
                          !b->process_coherent_layers && b->substrate_kind != SUB_HOST;   // where the register-resident finish kernel runs
     d.jacobi_skip2 = active ? 1e-30 : (reg_thr ? SMRT_JACOBI_REG_SKIP_COS2 : SMRT_JACOBI_PASSIVE_SKIP_COS2);   // like smrt_dort_upload
     d.jacobi_exit2 = active ? 1e-22 : (reg_thr ? SMRT_JACOBI_REG_EXIT_COS2 : SMRT_JACOBI_PASSIVE_EXIT_COS2);

@@ -211,7 +211,7 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
         assert (pivoted.status == 0).all() and np.abs(strip.values - pivoted.values).max() < 1e-6
         # the other shapes take the kernels DESIGN.md section 4 names
         rng = np.random.default_rng(4)
-        for n_stream, mode, want in ((32, "P", "lds_reg"), (16, "A", "lds_two_slot"), (96, "P", "big")):
+        for n_stream, mode, want in ((32, "P", "lds_strip"), (16, "A", "lds_two_slot"), (96, "P", "big")):
             b = PackedBatch([4] * 8, rng.uniform(0.05, 0.3, (8, 4)), rng.uniform(0.2, 0.45, (8, 4)), rng.uniform(235, 268, (8, 4)),
                             rng.uniform(5e-5, 3e-4, (8, 4)), None, [18.7e9], np.deg2rad([40.0]), n_max_stream=n_stream, mode=mode)
             ctx.upload(b)
@@ -221,8 +221,11 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
         # limit is reached the per-layer tables of the OTHER kernels have already sent the batch to the global-workspace
         # pipeline: the kernel never runs at two per CU by default.  Same brightness temperatures as the
         # two-slot kernel at a depth where it runs three per CU.
+        # The strip finish kernel (four wavefronts) is the default while three of its workgroups share a CU -- up to ~95 layers
+        # at 32 streams --, then the register-resident one takes over under its own rule.
         lib = ctx._lib
         assert lib.smrt_dort_finish_reg_lds_bytes(32, 40) <= 40 * 1024 < lib.smrt_dort_finish_reg_lds_bytes(32, 41)
+        assert lib.smrt_dort_finish_strip_lds_bytes(32, 60, 4) <= 160 * 1024 // 3 < lib.smrt_dort_finish_strip_lds_bytes(32, 110, 4)
         seen = {}
         for deep in (60, 100, 150):
             th = rng.uniform(0.01, 0.05, (2, deep)); th[:, -1] = 100.0
@@ -237,8 +240,15 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
                 ctx.set_pipeline(4); ctx.upload(b)
                 assert ctx.launch_info()["pipeline"] == "lds_two_slot"
                 ctx.launch(); ctx.sync(); two_slot = ctx.download()
+                ctx.set_pipeline(3); ctx.upload(b)
+                assert ctx.launch_info()["pipeline"] == "lds_reg"
+                ctx.launch(); ctx.sync(); reg = ctx.download()
                 ctx.set_pipeline(1)
                 assert (by_default.status == 0).all() and np.abs(by_default.values - two_slot.values).max() < 1e-6
-        assert seen[60] == "lds_reg" and seen[150] == "gmem", seen
+                assert np.abs(by_default.values - reg.values).max() < 1e-6
+        # (before the strip kernel's limit is reached the four LDS matrices of the FUSED plan have sent the batch to the
+        # global-workspace pipeline -- 91 layers at 32 streams --, whose strip kernel needs the tables of 100 layers beside its
+        # 136 KB matrix region: the pivoted kernel there)
+        assert seen[60] == "lds_strip" and seen[100] in ("gmem", "gmem_strip") and seen[150] == "gmem", seen
     finally:
         ctx.close()

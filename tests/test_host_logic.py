@@ -427,7 +427,9 @@ def test_kernel_occupancy_as_designed():
             "dort_active_finish_kernelILi256E": 2, "dort_active_prep_kernelILi256E": 2, "dort_finish_kernel_gmemILi256E": 2,
             "dort_active_finish_kernel_gmemILi256E": 2, "dort_passive_big_kernelILi256ELi6ELi2E": 2,
             "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3,
-            "dort_finish_reg_kernel": 1}   # one wavefront per SIMD by design: the whole register file
+            "dort_finish_reg_kernel": 1,   # one wavefront per SIMD by design: the whole register file
+            # the strip finish kernels: eight wavefronts, one workgroup per CU / four wavefronts, three workgroups per CU
+            "dort_finish_strip_kernel": 2, "dort_finish_strip4_kernel": 3, "dort_prep_kernel_wide": 2}
     for key, minimum in want.items():
         hits = [v for k, v in waves.items() if key in k]
         assert hits, key
@@ -437,6 +439,10 @@ def test_kernel_occupancy_as_designed():
     from smrt_amd import _native
     lib = _native.load_library()
     assert lib.smrt_dort_finish_reg_lds_bytes(32, 20) <= 40 * 1024
+    # the strip finish kernels: three four-wavefront workgroups per CU at the headline shape, the eight-wavefront one within
+    # the 160 KB of a CU at the configs[2] shape (64 streams, 50 layers)
+    assert 3 * lib.smrt_dort_finish_strip_lds_bytes(32, 20, 4) <= 160 * 1024
+    assert lib.smrt_dort_finish_strip_lds_bytes(64, 50, 8) <= 160 * 1024 and lib.smrt_dort_finish_strip_lds_bytes(64, 50, 3) == -1
     # the size classes of the Jacobi kernel at the headline shape: 7 / 6 / 4 workgroups in the 160 KB of a CU, each with
     # the layout of its own largest item (one layout for all would hold 4), bank-conflict-free leading dimensions
     for columns, per_cu in ((32, 14), (48, 7), (56, 6), (64, 4), (0, 4)):

@@ -114,13 +114,15 @@ STRIP_FIXTURES = ["cfg1_iba_onelayer", "iba_L6_n8_angles", "dmrt_L8_n16", "mixed
                   "dmrt_L4_n12_reflector", "iba_L2_n10_mirror_atmosphere_only", "iba_L8_n12_prune", "dmrt_L6_n10_prune_over_bad_layer"]
 
 
-@pytest.mark.parametrize("name,order", [(n, i % 3) for i, n in enumerate(STRIP_FIXTURES)])
-def test_emulated_strip_finish_kernel(emu, name, order):
-    """The strip finish kernel of the 64 < N <= 128 pipeline (one workgroup of eight wavefronts per pair, the pivot-free
-    recursion on tile columns, dort_finish_strip.hpp) on the small reference fixtures -- the emulator's pipeline 5 forces
-    the global-workspace pipeline whatever the size --: layers of 1 to 2 tiles, ragged stream counts, substrates,
-    atmosphere, pruning, in three fiber orders.  Its own size is covered by the configs[2] fixture below."""
-    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 5
+@pytest.mark.parametrize("name,order,pipeline", [(n, i % 3, 5 + (i + k) % 2) for i, n in enumerate(STRIP_FIXTURES) for k in (0, 1)
+                                                 if k == 0 or i % 2 == 0])
+def test_emulated_strip_finish_kernel(emu, name, order, pipeline):
+    """The strip finish kernels (the pivot-free recursion on tile columns, one matrix at a time through LDS,
+    dort_finish_strip.hpp) on the small reference fixtures: the eight-wavefront instance of the 64 < N <= 128 pipeline
+    (the emulator's pipeline 5 forces that pipeline whatever the size) and the four-wavefront instance of the N <= 64
+    pipeline (6) -- layers of 1 to 2 tiles, ragged stream counts, substrates, atmosphere, pruning, in three fiber orders.
+    The eight-wavefront kernel's own size is covered by the configs[2] fixture below, the other's by the headline one."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
     try:
         out, st, ref = run_fixture(emu, name, nt=256, order=order)
     finally:
@@ -135,11 +137,17 @@ def test_emulated_strip_finish_kernel_at_its_own_size_and_any_schedule(emu):
     try:
         out, st, ref = run_fixture(emu, "cfg3_dmrt_L50_n64_sp0", nt=256, order=1, freqs=[1])
         assert (st == 0).all() and np.abs(out - ref).max() < 1e-6
-        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 5
-        outs = [run_fixture(emu, "iba_L3_n16_flat_substrate", nt=256, order=o)[0] for o in (0, 1, 2)]
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 6
+        out, st, ref = run_fixture(emu, "cfg2_iba_L20_n32_sp1", nt=256, order=2, freqs=[0, 3])   # the headline shape: 3 - 4 tiles
+        assert (st == 0).all() and np.abs(out - ref).max() < 1e-6
+        outs = {}
+        for pipeline in (5, 6):
+            C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+            outs[pipeline] = [run_fixture(emu, "iba_L3_n16_flat_substrate", nt=256, order=o)[0] for o in (0, 1, 2)]
     finally:
         C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    for o in outs.values():
+        assert np.array_equal(o[0], o[1]) and np.array_equal(o[0], o[2])
 
 
 @pytest.mark.parametrize("name,nt,pipeline,order", [("rough_iem_surface_L3_n10_passive", 256, 1, 0), ("rough_iem_inner_L3_n10_passive", 64, 0, 1),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The register-resident finish kernel (pivot-free recursion) on deliberately hard passive inputs, every pair
+"""The pivot-free finish kernels (strip kernels and the register-resident one) on deliberately hard passive inputs, every pair
 against the CPU oracle: layers from 0.1 mm to 100 m, ice volume fractions 0.05 ... 0.49, correlation lengths up to the
 30 % renormalisation limit, 1.4 ... 183 GHz, 4 ... 32 streams, with and without a substrate / atmosphere.  Pairs the
 oracle refuses must come back with the same status.
@@ -15,6 +15,7 @@ from smrt_amd._native import DortContext, PackedBatch
 
 
 WORST_TWO = [0.0]   # the same pairs through the two-slot finish kernel (set_pipeline(4)), filled by run()
+WORST_REG = [0.0]   # ... and through the register-resident finish kernel (set_pipeline(3); N <= 64 only)
 
 
 def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_layers=8):
@@ -22,6 +23,7 @@ def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_la
   rng = np.random.default_rng(seed)
   worst, checked, refused, mism = 0.0, 0, 0, 0
   WORST_TWO[0] = 0.0
+  WORST_REG[0] = 0.0
   for case in range(n_cases):
       S, L = 6, int(rng.integers(1, max_layers + 1))
       n_str = int(rng.choice(list(streams)))
@@ -36,8 +38,10 @@ def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_la
       if rng.random() < 0.4:
           atm = (rng.uniform(3, 80, 3), rng.uniform(2, 60, 3), rng.uniform(0.4, 1.0, 3))
       b = PackedBatch([L] * S, thick, fv, temp, lc, None, freqs, np.deg2rad(theta), n_max_stream=n_str, substrate=sub, atmosphere=atm)
-      ctx.set_pipeline(3)
+      ctx.set_pipeline(1)   # the default: the strip finish kernels (four wavefronts for N <= 64, eight above)
       out = ctx.run(b)
+      ctx.set_pipeline(3)   # the register-resident finish kernel (N <= 64; above, the strip kernel again)
+      reg = ctx.run(b)
       ctx.set_pipeline(4)
       two = ctx.run(b)
       for fi, f in enumerate(freqs):
@@ -51,9 +55,9 @@ def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_la
                   st = 0
               except O.OracleError as e:
                   st = e.status
-              if st != out.status[p] or st != two.status[p]:
+              if st != out.status[p] or st != two.status[p] or st != reg.status[p]:
                   mism += 1
-                  if verbose: print("status mismatch: case %d pair %d oracle %d reg %d two-slot %d" % (case, p, st, out.status[p], two.status[p]))
+                  if verbose: print("status mismatch: case %d pair %d oracle %d strip %d reg %d two-slot %d" % (case, p, st, out.status[p], reg.status[p], two.status[p]))
                   continue
               if st != 0:
                   refused += 1
@@ -61,6 +65,7 @@ def run(seed, n_cases, ctx, verbose=True, streams=(4, 7, 12, 16, 24, 32), max_la
               e = float(np.abs(out.values[p] - ref).max())
               worst = max(worst, e); checked += 1
               WORST_TWO[0] = max(WORST_TWO[0], float(np.abs(two.values[p] - ref).max()))
+              WORST_REG[0] = max(WORST_REG[0], float(np.abs(reg.values[p] - ref).max()))
               if e > 1e-6:
                   print("case %d pair %d: |dTb| = %.2e K (two-slot kernel: %.2e K), L = %d, n = %d, f = %.1f GHz, thinnest %.2e m" % (
                       case, p, e, float(np.abs(two.values[p] - ref).max()), L, n_str, f / 1e9, thick[s].min()))
@@ -75,5 +80,6 @@ if __name__ == "__main__":
     deep = len(sys.argv) > 3 and sys.argv[3] == "deep"   # up to 45 layers
     worst, checked, refused, mism = run(seed, n_cases, DortContext(0), streams=(40, 64) if big else (4, 7, 12, 16, 24, 32),
                                         max_layers=45 if deep else 8)
-    print("seed %d: %d pairs checked, max |dTb| = %.2e K (two-slot / global-workspace finish kernel on the same pairs: %.2e K); %d refused by "
-          "both (renormalisation / albedo); %d status mismatches" % (seed, checked, worst, WORST_TWO[0], refused, mism))
+    print("seed %d: %d pairs checked, max |dTb| = %.2e K with the strip finish kernels (register-resident kernel on the same pairs: %.2e K, "
+          "two-slot / pivoted global-workspace kernel: %.2e K); %d refused by all (renormalisation / albedo); %d status mismatches"
+          % (seed, checked, worst, WORST_REG[0], WORST_TWO[0], refused, mism))
