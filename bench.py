@@ -354,6 +354,19 @@ def main():
         allv = ctx.allreduce_max(mine)
         per_rank = {"kernel_ms": [float(v) for v in allv[:world]], "pairs": [int(v) for v in allv[world:]]}
 
+    # which kernel the time goes to: three more launches with an event pair around every kernel (outside the timed region)
+    per_kernel = None
+    if not use_comm:
+        ctx.kernel_breakdown(True)
+        acc = {"prep": 0.0, "jacobi": 0.0, "finish": 0.0}
+        for _ in range(3):
+            ctx.launch()
+            bd = ctx.kernel_breakdown()
+            for k in acc:
+                acc[k] += bd[k] / 3.0
+        ctx.kernel_breakdown(False)
+        if sum(acc.values()) > 0:
+            per_kernel = {k: {"ms": v} for k, v in acc.items()}
     res = ctx.download()
     n_fail = int((res.status != 0).sum())
     if use_comm and rank == 0:
@@ -418,6 +431,12 @@ def main():
                 "kernel": desc["kernel"] + " (one launch each per step; kernel_ms is their summed HIP-event time on the "
                                             "launch stream)",
                 "per_rank": per_rank,
+                # HIP-event time per kernel kind (three instrumented launches after the timed region) with the share of the
+                # algorithmic flops SURVEY 8(d) books on it: assembly + Cholesky x 2 + B = L+^T L- ~ 2 N^3 (prep), the
+                # one-sided Jacobi ~ 25 N^3, eigenvector recovery + layer recursion ~ 41 N^3 (finish)
+                "per_kernel": (None if per_kernel is None else
+                               {k: dict(v, flop_share=fs, tflops=fs * flops_per_launch / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None)
+                                for (k, v), fs in zip(per_kernel.items(), (2.0 / 68.0, 25.0 / 68.0, 41.0 / 68.0))}),
                 "kernel_ms": kernel_ms,
                 "flops_per_launch": flops_per_launch,
                 "note": "FP64 compute roofline: vector FMA and FP64 MFMA share one 78.6 TFLOP/s pipe on gfx950 "

@@ -275,6 +275,13 @@ int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, dou
  * and accumulated over all launches since the last reset (count returned through n_launches). */
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
 
+/* Per-kernel HIP-event time of the three-kernel pipelines.  enable != 0: every prep / Jacobi / finish kernel launch of the
+ * following smrt_dort_launch calls is bracketed by an event pair on its stream (a few microseconds per launch: for
+ * measurement runs, not for the timed region of a benchmark).  ms3 != NULL: the intervals of the LAST launch summed per kind
+ * -- ms3[0] prep, [1] Jacobi (all size classes), [2] finish -- after a stream synchronisation; zeros when that launch was not
+ * instrumented or the batch runs on a fused kernel.  Returns the number of intervals of the last launch, -1 on error. */
+int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* ms3);
+
 /* What the uploaded batch runs on, as numbers (tests assert the designed kernel choice with these instead of wall-clock
  * ratios): info[SMRT_INFO_*], at most n entries written; returns SMRT_INFO_COUNT, -1 on error.
  *   PIPELINE      SMRT_PIPELINE_*: the kernels a launch of this batch consists of

@@ -288,6 +288,8 @@ def load_library():
     lib.smrt_dort_download.restype = C.c_int32
     lib.smrt_dort_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smrt_dort_last_kernel_ms.restype = C.c_double
+    lib.smrt_dort_kernel_breakdown.argtypes = [C.c_void_p, C.c_int32, P(C.c_double)]
+    lib.smrt_dort_kernel_breakdown.restype = C.c_int32
     lib.smrt_dort_total_kernel_ms.argtypes = [C.c_void_p, P(C.c_int64), C.c_int32]
     lib.smrt_dort_total_kernel_ms.restype = C.c_double
     lib.smrt_dort_set_block_threads.argtypes = [C.c_void_p, C.c_int32]
@@ -338,7 +340,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_out_stride", "smrt_dort_create", "smrt_dort_destroy", "smrt_dort_last_error", "smrt_dort_run",
     "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost", "smrt_dort_ft_even_phase",
     "smrt_dort_launch_info", "smrt_dort_comm_library", "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
-    "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms",
+    "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms", "smrt_dort_kernel_breakdown",
     "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_finish_strip_lds_bytes", "smrt_dort_jacobi_lds_bytes", "smrt_dort_gather_plan",
 ]
@@ -540,6 +542,17 @@ class DortContext:
 
     STAGE_NAMES = ["setup", "assemble", "cholesky", "LtL", "jacobi", "triangular", "R1", "LU1", "R45", "LU2", "R78",
                    "out"]
+
+    def kernel_breakdown(self, enable=None):
+        """Per-kernel HIP-event times: kernel_breakdown(True) instruments the following launches, kernel_breakdown() returns
+        {"prep", "jacobi", "finish"} in ms for the last launch (include/smrt_dort.h)."""
+        if enable is not None:
+            self._check(min(self._lib.smrt_dort_kernel_breakdown(self._h, 1 if enable else 0, None), 0), "smrt_dort_kernel_breakdown")
+            return None
+        a = np.zeros(3)
+        n = self._lib.smrt_dort_kernel_breakdown(self._h, 1, _dptr(a))
+        self._check(min(n, 0), "smrt_dort_kernel_breakdown")
+        return {"prep": float(a[0]), "jacobi": float(a[1]), "finish": float(a[2]), "intervals": int(n)}
 
     def stage_cycles(self):
         a = np.zeros(16)

@@ -34,6 +34,7 @@ class Snowpack:
         self._packed = None
         self._micro = self._overrides = None
         self._wet = self._flat = None
+        self._facts = None
         self.substrate = substrate
         self.atmosphere = atmosphere
 
@@ -75,7 +76,7 @@ class Snowpack:
         self._check_interface(interface)
         self.layers.append(layer)
         self.interfaces.append(interface or Flat())
-        self._packed = self._micro = self._overrides = self._wet = self._flat = None
+        self._packed = self._micro = self._overrides = self._wet = self._flat = self._facts = None
 
     def packed(self):
         """The per-layer columns of the device batch for this snowpack -- thickness, ice volume fraction, temperature,
@@ -87,6 +88,16 @@ class Snowpack:
                     for lay in self.layers]
             self._packed = np.array(cols, dtype=np.float64).T.reshape(5, len(self.layers))
         return self._packed
+
+    def layer_facts(self):
+        """What the batching solver asks of every snowpack of every run, behind ONE freshness check: (packed columns,
+        microstructure model names, any per-layer emmodel setting?, liquid-water column or None).  The solver reads it once
+        per run and snowpack (rtsolver/dort.py keeps it for the duration of a solve)."""
+        fresh = self._fresh("_facts_key")
+        f = self.__dict__.get("_facts")
+        if f is None or not fresh:
+            f = self._facts = (self.packed(), frozenset(self.microstructure_models), self.has_layer_emmodels(), self.liquid_water())
+        return f
 
     def liquid_water(self):
         """Per-layer liquid water (water / (ice + water) volume) as one array, or None for a dry snowpack -- the optional

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 
 #include "dort_layout.hpp"
 
@@ -50,6 +51,12 @@ struct smrt_dort_ctx {
     double total_ms = 0.0;
     int64_t n_launch = 0;
     bool timing_pending = false;
+    // per-kernel HIP-event time of the three-kernel pipelines (smrt_dort_kernel_breakdown: events around every prep / Jacobi /
+    // finish launch of the NEXT smrt_dort_launch; summed per kind when it is read)
+    bool breakdown_on = false;
+    std::vector<hipEvent_t> bd_events;   // pool, reused
+    std::vector<int> bd_kind;            // per recorded interval [2 k, 2 k + 1]: 0 prep, 1 Jacobi, 2 finish
+    size_t bd_used = 0;
     int max_lds = 0;
     bool split = true;          // three-kernel pipeline on the LDS path (fused single kernel if false)
     long long chunk_pairs = 0;  // pairs per pipeline pass (bounds the staging area)
@@ -61,6 +68,7 @@ struct smrt_dort_ctx {
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     size_t jacobi_lds = 0;
+    size_t jacobi16_lds = 0;    // 64 < N <= 128: LDS of the sixteen-wavefront Jacobi kernel (sixteen lanes per column pair), 0: it does not fit
     smrt::DevStage stage{};
     bool gmem_path = false;
     bool gmem_split = false;    // 64 < N: three-kernel pipeline on the global workspace

@@ -150,27 +150,38 @@ SMRT_DEV void inv16_la_begin(const double (&d)[4], double& rk, double& piv, doub
     piv = row_bcast16<0>(rk);
     pinv = fast_rcp(piv);
 }
+// (the two halves of a step separately, for callers that issue matrix-core work between them: state of the half step in s)
+struct Inv16Half { double rn, pn, pinvn, rkp; };
 template <int K>
-SMRT_DEV void inv16_la_step(double (&d)[4], double& rk, double& piv, double& pinv, const LaneId& L) {
-    constexpr int r0 = K >> 2, g0 = K & 3;
+SMRT_DEV void inv16_la_pivot(const double (&d)[4], const double& rk, const double& piv, const double& pinv, Inv16Half& s, const LaneId& L) {
     constexpr int K1 = (K < 15) ? K + 1 : 15;
-    double rn = 0.0, pn = 1.0, pinvn = 1.0;
-    if (K < 15) rn = rows_bcast<(K1 & 3)>(d[K1 >> 2]);     // row K + 1 before this step, every lane row
-    const double rkp = (L.c == K) ? piv + 1.0 : rk;         // (the unit-vector trick of inv16_step)
+    s.rn = 0.0; s.pn = 1.0; s.pinvn = 1.0;
+    if (K < 15) s.rn = rows_bcast<(K1 & 3)>(d[K1 >> 2]);   // row K + 1 before this step, every lane row
+    s.rkp = (L.c == K) ? piv + 1.0 : rk;                    // (the unit-vector trick of inv16_step)
     if (K < 15) {
-        const double mn = row_bcast16<K>(rn) * pinv;
-        rn -= mn * rkp;                                     // row K + 1 after this step
-        pn = row_bcast16<K1>(rn);
-        pinvn = fast_rcp(pn);
+        const double mn = row_bcast16<K>(s.rn) * pinv;
+        s.rn -= mn * s.rkp;                                 // row K + 1 after this step
+        s.pn = row_bcast16<K1>(s.rn);
+        s.pinvn = fast_rcp(s.pn);
     }
+}
+template <int K>
+SMRT_DEV void inv16_la_update(double (&d)[4], double& rk, double& piv, double& pinv, const Inv16Half& s, const LaneId& L) {
+    constexpr int r0 = K >> 2, g0 = K & 3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const double f = row_bcast16<K>(d[r]);              // D[4 r + g][K]
         double m = f * pinv;
         if (r == r0) m = (L.g == g0) ? (1.0 - pinv) : m;
-        d[r] -= m * rkp;
+        d[r] -= m * s.rkp;
     }
-    rk = rn; piv = pn; pinv = pinvn;
+    rk = s.rn; piv = s.pn; pinv = s.pinvn;
+}
+template <int K>
+SMRT_DEV void inv16_la_step(double (&d)[4], double& rk, double& piv, double& pinv, const LaneId& L) {
+    Inv16Half s;
+    inv16_la_pivot<K>(d, rk, piv, pinv, s, L);
+    inv16_la_update<K>(d, rk, piv, pinv, s, L);
 }
 SMRT_DEV void inv16_la(double (&d)[4], const LaneId& L) {
     double rk, piv, pinv;

@@ -291,34 +291,35 @@ static SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L, double
 #ifdef SMRT_STRIP_TIMING_INV
                     if (w != 0) SMRT_SI(4);      // next owner: diagonal tile update (from the end of R)
 #endif
-                    double a2[4];
-                    auto want = [&](int i, double (&dst)[4]) { if (i < NTT) get_tile_t_rt(dst, colb + (i < nt ? i : 1), L); };
-                    auto upd = [&](int i, const double (&src)[4]) {
+                    // tile i = 2 + j / 4, k-slab j % 4: ONE matrix-core instruction (64 cycles of the pipe) per half step, so
+                    // that the wavefront never waits for the pipe in the middle of the chain; the operands of a tile are
+                    // requested two half steps before its first slab
+                    double ta[2][4], tv[2][4];
+                    auto want = [&](int i) { if (i < NTT) get_tile_t_rt(ta[i & 1], colb + (i < nt ? i : 1), L); };
+                    auto slab = [&](int j) {
+                        const int i = 2 + j / 4, kk = j % 4;
                         if (i < NTT) {
-                            double v[4] = {0.0, 0.0, 0.0, 0.0};
-                            rg::tile_tn_acc(v, src, R);
+                            if (kk == 0) { tv[i & 1][0] = tv[i & 1][1] = tv[i & 1][2] = tv[i & 1][3] = 0.0; }
+                            mfma_f64_16x16x4(ta[i & 1][kk], R[kk], tv[i & 1]);
+                            if (kk == 3) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) M.v[i < NTT ? i : 0][r] -= v[r];
+                                for (int r = 0; r < 4; ++r) M.v[i < NTT ? i : 0][r] -= tv[i & 1][r];
+                            }
                         }
                     };
-                    want(2, a);
                     double rk, piv, pinv;
+                    rg::Inv16Half hs;
+                    want(2);
                     rg::inv16_la_begin(Dn, rk, piv, pinv);
-#define SMRT_LA(K) rg::inv16_la_step<K>(Dn, rk, piv, pinv, L.id)
-                    SMRT_LA(0); want(3, a2);
-                    SMRT_LA(1); upd(2, a);
-                    SMRT_LA(2); want(4, a);
-                    SMRT_LA(3); upd(3, a2);
-                    SMRT_LA(4); want(5, a2);
-                    SMRT_LA(5); upd(4, a);
-                    SMRT_LA(6); want(6, a);
-                    SMRT_LA(7); upd(5, a2);
-                    SMRT_LA(8); want(7, a2);
-                    SMRT_LA(9); upd(6, a);
-                    SMRT_LA(10);
-                    SMRT_LA(11); upd(7, a2);
-                    SMRT_LA(12); SMRT_LA(13); SMRT_LA(14); SMRT_LA(15);
+                    // half steps 2 K (pivot look-ahead) and 2 K + 1 (tile update): slab j after half step j + 1; tile i wanted
+                    // before half step 4 (i - 2) - 1
+#define SMRT_LA(K) rg::inv16_la_pivot<K>(Dn, rk, piv, pinv, hs, L.id); if (2 * (K) >= 1) slab(2 * (K) - 1); \
+                   if ((2 * (K) + 2) % 4 == 0) want(2 + (2 * (K) + 2) / 4); \
+                   rg::inv16_la_update<K>(Dn, rk, piv, pinv, hs, L.id); slab(2 * (K));
+                    SMRT_LA(0) SMRT_LA(1) SMRT_LA(2) SMRT_LA(3) SMRT_LA(4) SMRT_LA(5) SMRT_LA(6) SMRT_LA(7)
+                    SMRT_LA(8) SMRT_LA(9) SMRT_LA(10) SMRT_LA(11) SMRT_LA(12) SMRT_LA(13) SMRT_LA(14) SMRT_LA(15)
 #undef SMRT_LA
+                    slab(31);
 #ifdef SMRT_STRIP_TIMING_INV
                     if (w != 0) SMRT_SI(5);      // next owner: elimination + interleaved updates
 #endif

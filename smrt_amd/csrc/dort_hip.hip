@@ -94,6 +94,26 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         for (int k = 0; k < lanes; ++k)
             if ((e = hipStreamWaitEvent(ctx->lane_stream[k], ctx->fork_ev, 0)) != hipSuccess) return e;
     }
+    // optional per-kernel timing: an event pair around every launch of a kind (on the stream the kernel goes to)
+    auto timed = [&](int kind, auto&& launch) -> hipError_t {
+        if (!ctx->breakdown_on) return launch();
+        for (int k = 0; k < 2; ++k)
+            if (ctx->bd_used + k >= ctx->bd_events.size()) {
+                hipEvent_t ev;
+                hipError_t e = hipEventCreate(&ev);
+                if (e != hipSuccess) return e;
+                ctx->bd_events.push_back(ev);
+            }
+        hipError_t e = hipEventRecord(ctx->bd_events[ctx->bd_used], ctx->stream);
+        if (e != hipSuccess) return e;
+        e = launch();
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(ctx->bd_events[ctx->bd_used + 1], ctx->stream);
+        ctx->bd_used += 2;
+        ctx->bd_kind.push_back(kind);
+        return e;
+    };
+    if (ctx->breakdown_on) { ctx->bd_used = 0; ctx->bd_kind.clear(); }
     long long chunk_index = 0;
     for (long long c0 = 0; c0 < d.pair_count; c0 += ctx->chunk_pairs, ++chunk_index) {
         const long long cn = std::min<long long>(ctx->chunk_pairs, d.pair_count - c0);
@@ -121,13 +141,13 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
         for (int r = 0; r < rounds; ++r) {
             c.layer_lo = (int)((long long)d.Lmax * r / rounds);
             c.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
-            if ((e = prep(c, grid)) != hipSuccess) return e;
+            if ((e = timed(0, [&]() { return prep(c, grid); })) != hipSuccess) return e;
             const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
-            if ((e = ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems)) != hipSuccess) return e;
+            if ((e = timed(1, [&]() { return ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems); })) != hipSuccess) return e;
             if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, done_lane)) != hipSuccess) return e;
         }
         c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
-        if ((e = finish(c, grid)) != hipSuccess) return e;
+        if ((e = timed(2, [&]() { return finish(c, grid); })) != hipSuccess) return e;
     }
     if (lanes > 1) {   // join: whatever follows on the context's stream (timing event, download, gather) waits for every lane
         for (int k = 0; k < lanes; ++k) {
@@ -194,6 +214,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
         if (ctx->lane_stream[k]) (void)hipStreamDestroy(ctx->lane_stream[k]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    for (hipEvent_t ev : ctx->bd_events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -355,6 +376,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
         ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
                                    : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
+        ctx->jacobi16_lds = 0;
+        if (ctx->gmem_split && !ctx->big) {
+            const size_t l16 = (size_t)make_jacobi_plan(b->n_max_stream, P, 0, 16).total * sizeof(double);
+            if (l16 <= (size_t)ctx->max_lds) ctx->jacobi16_lds = l16;
+        }
         // (the LDS-resident passive prep kernel stores its two matrices as packed lower triangles: plan 3)
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd,
                                                 (!ctx->gmem_split && !ctx->active) ? 3 : 1).total * sizeof(double);
@@ -633,6 +659,23 @@ int32_t smrt_dort_sync(smrt_dort_ctx* ctx) {
 }
 
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx) { return ctx ? (double)ctx->last_ms : -1.0; }
+
+int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* ms3) {
+    if (!ctx) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ms3) {   // the intervals recorded by the last launch, summed per kind (synchronises)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ms3[0] = ms3[1] = ms3[2] = 0.0;
+        for (size_t k = 0; k < ctx->bd_kind.size() && 2 * k + 1 < ctx->bd_used; ++k) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->bd_events[2 * k], ctx->bd_events[2 * k + 1]));
+            ms3[ctx->bd_kind[k]] += ms;
+        }
+    }
+    ctx->breakdown_on = (enable != 0);
+    if (!ctx->breakdown_on) { ctx->bd_used = 0; ctx->bd_kind.clear(); }
+    return (int32_t)ctx->bd_kind.size();
+}
 
 int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
     if (!ctx || !info || n < 0) return -1;

@@ -136,11 +136,11 @@ SMRT_DEV void rotate_resident(double* Bm, int LD, int CP, int nslots, int steps,
 // wavefront per 16 columns keeps every lane group busy (NB = 2 JW column blocks of m = ceil(N / NB) <= 8 columns).  With
 // the fixed four wavefronts of the first versions a 42 ... 48-column item (60 % of the headline batch) left a quarter
 // of every wavefront rotating the padding column.
-SMRT_HD int jacobi_waves(int N, int jw_max) {
+SMRT_HD int jacobi_waves(int N, int jw_max, int gs = SMRT_JACOBI_GS) {
 #ifdef SMRT_JACOBI_ALL_WAVES   // ablation build (tools/build_variant.py): the fixed wavefront count of the first versions
     return jw_max;
 #endif
-    const int w = (N + 2 * (SMRT_LANES / SMRT_JACOBI_GS) - 1) / (2 * (SMRT_LANES / SMRT_JACOBI_GS));
+    const int w = (N + 2 * (SMRT_LANES / gs) - 1) / (2 * (SMRT_LANES / gs));
     return w < 1 ? 1 : (w > jw_max ? jw_max : w);
 }
 
@@ -261,22 +261,25 @@ SMRT_HD int jacobi_padded_rows(int N) {
 }
 // cap > 0: the LDS layout of a SIZE CLASS -- items of at most `cap` columns (the staged matrices in global memory keep
 // the layout of the batch maximum) -- so that the small items of a batch do not pay the LDS of its largest one.
-SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P, int cap = 0) {
+// gs = 16 (64 < N <= 128 only): the layout of the sixteen-wavefront kernel -- sixteen lanes per column pair, four pairs per
+// wavefront, so that one 128-column matrix (64 disjoint pairs per step, the whole LDS of a CU) keeps 1024 threads busy
+// instead of 512: the leading dimension is == 16 (mod 32) (the two column pairs of a 32-lane group are adjacent columns).
+SMRT_HD JacobiPlan make_jacobi_plan(int n_max_stream, int P, int cap = 0, int gs = SMRT_JACOBI_GS) {
     JacobiPlan p;
     p.NMAX = n_max_stream * P;
     p.LD = (p.NMAX + 1) | 1;                            // layout of the staged matrices in global memory (make_plan)
     const int nmax = (cap > 0 && cap < p.NMAX) ? cap : p.NMAX;   // columns of the largest item held in this layout
     // leading dimension: the first value >= the padded rows that is == 8 or == 24 (mod 32) -- four adjacent columns
     // then start at bank slots {0, 8, 16, 24} in one order or the other
-    int ldj = jacobi_padded_rows(nmax);
-    while ((ldj & 31) != SMRT_JACOBI_GS && (ldj & 31) != 32 - SMRT_JACOBI_GS) ++ldj;
+    int ldj = (gs == 16) ? ((nmax + 15) / 16) * 16 : jacobi_padded_rows(nmax);
+    while ((ldj & 31) != gs && (ldj & 31) != 32 - gs) ++ldj;
     p.LDJ = ldj;
     // NB * ceil(N / NB) <= this - 1 for every N <= nmax and its NB = 2 * jacobi_waves(N) column blocks (the padded column
     // count grows with N inside a wavefront count and reaches 16 JW at its upper end, so nmax decides), for workgroups of
     // four and of eight wavefronts (k_jacobi.hip launches either on 64 < N <= 128); plus the idle-slot column
     int cpmax = 0;
-    for (int jw_max = 4; jw_max <= 8; jw_max += 4) {
-        const int nb = 2 * jacobi_waves(nmax, jw_max);
+    for (int jw_max = (gs == 16 ? 16 : 4); jw_max <= (gs == 16 ? 16 : 8); jw_max += 4) {
+        const int nb = 2 * jacobi_waves(nmax, jw_max, gs);
         const int cp = nb * ((nmax + nb - 1) / nb);
         if (cp > cpmax) cpmax = cp;
     }
@@ -307,10 +310,9 @@ SMRT_HD int jacobi_classes(int NMAX, JacobiClass* out) {
     return n;
 }
 
-template <int NT, int RPL>
+template <int NT, int RPL, int GS = SMRT_JACOBI_GS>
 SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long long item, double* lds, int cap = 0) {
-    constexpr int JWMAX = (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: at most 4, or 8 (N > 64)
-    constexpr int GS = SMRT_JACOBI_GS;
+    constexpr int JWMAX = (GS == 16) ? NT / SMRT_LANES : (NT / SMRT_LANES >= 8) ? 8 : NT / SMRT_LANES;   // wavefronts rotating block pairs: at most 4, or 8 (N > 64); 16 with sixteen lanes per pair
     const int t = tid();
     const int nmodes = (b.mode == 1) ? b.m_max + 1 : 1;   // active: items are (pair, azimuth mode, layer)
     const long long p = item / ((long long)b.Lmax * nmodes);
@@ -319,7 +321,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     const int si = (int)(gp % b.S);
     if (l >= b.n_layers[si]) return;          // uniform
     if (b.status[p] != ST_OK) return;         // the prep kernel flagged this pair (uniform)
-    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2, cap);
+    const JacobiPlan plan = make_jacobi_plan(b.n_max_stream, b.mode == 1 ? 3 : 2, cap, GS);
     const int LD = plan.LD, LDJ = plan.LDJ;
     const int N = stg.n[item];
     if (N <= 0) return;                       // the prep kernel flagged this layer (uniform)
@@ -330,7 +332,7 @@ SMRT_DEV void dort_jacobi_item_impl(const DevBatch& b, const DevStage& stg, long
     double* gB = stg.B + item * stg.mat_stride;
     // load B and zero the padding: rows N..RPL*GS-1 of every used column, columns N..CP (CP = NB*m, plus the idle
     // slot column CP itself)
-    const int JW = jacobi_waves(N, JWMAX);
+    const int JW = jacobi_waves(N, JWMAX, GS);
     const int NB = 2 * JW;
     const int m = (N + NB - 1) / NB;
     const int CP = NB * m;
@@ -377,6 +379,22 @@ SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long
     SMRT_JACOBI_ROWS(40, 48) SMRT_JACOBI_ROWS(48, 56) SMRT_JACOBI_ROWS(56, 64) SMRT_JACOBI_ROWS(64, 80)
     SMRT_JACOBI_ROWS(80, 96) SMRT_JACOBI_ROWS(96, 112) SMRT_JACOBI_ROWS(112, 128)
 #undef SMRT_JACOBI_ROWS
+}
+
+// The same with SIXTEEN lanes per column pair (64 < N <= 128, 1024 threads): rows per lane from the item's own size in steps of
+// sixteen rows.
+template <int NT>
+SMRT_DEV void dort_jacobi_item16(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
+    const int rows = stg.n[item];       // <= 0: nothing to do
+    if (rows <= 0) return;
+    if (rows <= 16) { dort_jacobi_item_impl<NT, 1, 16>(b, stg, item, lds); return; }
+    if (rows <= 32) { dort_jacobi_item_impl<NT, 2, 16>(b, stg, item, lds); return; }
+    if (rows <= 48) { dort_jacobi_item_impl<NT, 3, 16>(b, stg, item, lds); return; }
+    if (rows <= 64) { dort_jacobi_item_impl<NT, 4, 16>(b, stg, item, lds); return; }
+    if (rows <= 80) { dort_jacobi_item_impl<NT, 5, 16>(b, stg, item, lds); return; }
+    if (rows <= 96) { dort_jacobi_item_impl<NT, 6, 16>(b, stg, item, lds); return; }
+    if (rows <= 112) { dort_jacobi_item_impl<NT, 7, 16>(b, stg, item, lds); return; }
+    dort_jacobi_item_impl<NT, 8, 16>(b, stg, item, lds);
 }
 
 }  // namespace smrt

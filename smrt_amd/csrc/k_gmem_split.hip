@@ -1,4 +1,6 @@
 // Three-kernel pipeline for 64 < N <= 128 (passive and active): prep and the four-matrix finish on the per-workgroup
+// hipcc-flags: -mllvm -disable-machine-licm
+// (fewer loop-invariant values hoisted and spilled: active 32 streams 1496 -> 1573 solves/s, profiles/r5_nolicm_ab.txt)
 // global workspace (L2 / Infinity-Cache resident, grid-stride over the pairs so that it stays bounded); the shared
 // Jacobi kernel with its 128-column LDS matrix runs in between.
 #include <cstdlib>

@@ -12,7 +12,19 @@ __global__ __launch_bounds__(NT) void dort_jacobi_kernel(DevBatch b, DevStage st
     dort_jacobi_item<NT, LO, HI>(b, st, jacobi_item_of_block(b, (long long)blockIdx.x), smrt_lds);
 }
 
+// 64 < N <= 128 with sixteen lanes per column pair: sixteen wavefronts (four per SIMD) on the one matrix a CU's LDS holds
+__global__ __launch_bounds__(1024) void dort_jacobi_kernel16(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    dort_jacobi_item16<1024>(b, st, jacobi_item_of_block(b, (long long)blockIdx.x), smrt_lds);
+}
+
 namespace smrt_launch {
+static hipError_t go16(smrt_dort_ctx* ctx, const DevBatch& c, long long items, size_t lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)dort_jacobi_kernel16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dort_jacobi_kernel16, dim3((unsigned)items), dim3(1024), lds, ctx->stream, c, ctx->stage);
+    return hipGetLastError();
+}
 template <int NT, int LO, int HI>
 static hipError_t go(smrt_dort_ctx* ctx, const DevBatch& c, long long items, size_t lds) {
     auto kern = dort_jacobi_kernel<NT, LO, HI>;
@@ -35,6 +47,12 @@ static hipError_t go(smrt_dort_ctx* ctx, const DevBatch& c, long long items, siz
 hipError_t jacobi(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
     static const bool wide = getenv("SMRT_DORT_JACOBI_256") == nullptr;
     static const bool one = getenv("SMRT_DORT_JACOBI_ONE") != nullptr;
+    // SMRT_DORT_JACOBI_1024=1: sixteen wavefronts with sixteen lanes per column pair.  Measured (round 5, configs[2] shape,
+    // profiles/r5_jacobi_n128.txt): 101.9 against 102.3 ms per 1792-pair chunk -- nothing: at N = 128 a step moves 64 J columns
+    // of 1 KB through LDS each way, and 64 KB of ds_write_b64 at ~85 B / clk are ~770 of the step's ~1000 cycles whatever the
+    // number of lanes that issue them.  Kept as an experiment switch, off by default.
+    static const bool sixteen = getenv("SMRT_DORT_JACOBI_1024") != nullptr;
+    if (ctx->nmax_rows > 64 && sixteen && ctx->jacobi16_lds > 0) return go16(ctx, c, items, ctx->jacobi16_lds);
     if (ctx->nmax_rows > 64) return wide ? go<512, 0, 128>(ctx, c, items, ctx->jacobi_lds) : go<SMRT_JACOBI_NT, 0, 128>(ctx, c, items, ctx->jacobi_lds);
     if (one) return go<SMRT_JACOBI_NT, 0, 128>(ctx, c, items, ctx->jacobi_lds);
     const int P = c.mode == 1 ? 3 : 2;

@@ -1,4 +1,6 @@
 // Kernels of the LDS-resident passive pipeline (streams x polarisations N <= 64): prep and finish, see dort_passive.hpp.
+// hipcc-flags: -mllvm -disable-machine-licm
+// (fewer loop-invariant values hoisted and spilled: prep kernel 6.15 -> 6.02 ms on the headline batch, profiles/r5_nolicm_ab.txt)
 #include <cstdio>
 #include "dort_ctx.hpp"
 #include "dort_device.hpp"

@@ -12,6 +12,7 @@ streams, interfaces, eigen-decomposition, boundary conditions) runs in the HIP k
   objects, distinct snowpacks packed once, the stacked Result built from the output array without per-pair objects.
 """
 import threading
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -134,6 +135,8 @@ class DORT(object):
         """The whole plan of a Model.run: returns the nested Result directly."""
         from ..core.model import nest_results
 
+        for sp in plan.snowpacks:   # (one freshness check per snowpack and run; the passes below read the attribute)
+            sp._f = sp.layer_facts()
         names = self.emmodel_names(model, plan)
         sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, names)
         stacked = sol.stacked_result(plan)
@@ -161,8 +164,9 @@ class DORT(object):
         simple_name = getattr(emmodel, "device_name", None) if simple else None
         simple_options = None
         for sp in plan.snowpacks:
-            n = sp.nlayer
-            plain = (simple and not sp.has_layer_emmodels() and not is_sequence(all_options)
+            f = sp.__dict__.get("_f") or sp.layer_facts()
+            n = f[0].shape[1]
+            plain = (simple and not f[2] and not is_sequence(all_options)
                      and all_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
             if plain and simple_name is not None and simple_options is not None and not hasattr(sp, "source"):
                 # the common case -- one device emmodel, no per-layer settings, options already validated, smrt_amd's own
@@ -247,10 +251,11 @@ class DORT(object):
         from .._native import EM_CODES, MS_CODES
 
         S = len(sps)
-        nl = np.fromiter((sp.nlayer for sp in sps), np.int32, S)
+        facts = [sp.__dict__.get("_f") or sp.layer_facts() for sp in sps]   # (packed, microstructures, overrides, liquid water)
+        nl = np.fromiter((f[0].shape[1] for f in facts), np.int32, S)
         Lmax = int(nl.max())
         # emmodel + 16 * microstructure per layer; handed to the device only when the batch really mixes them
-        micro = [sp.microstructure_models for sp in sps]
+        micro = [f[1] for f in facts]
         uniform_micro = len(set().union(*micro)) == 1
         layer_kind = host = None
         if not isinstance(emmodel_names, str):
@@ -284,12 +289,12 @@ class DORT(object):
         device_name = "host" if host is not None else "iba" if scalars is not None else \
             (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
-            cols = np.stack([sp.packed() for sp in sps], axis=1)      # (5, S, L)
+            cols = np.stack([f[0] for f in facts], axis=1)      # (5, S, L)
         else:
             cols = np.empty((5, S, Lmax))
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
             for s, sp in enumerate(sps):
-                cols[:, s, :nl[s]] = sp.packed()
+                cols[:, s, :nl[s]] = facts[s][0]
         if scalars is not None:
             # the medium every emmodel object works on (its own frac_volume and microstructure: inverted above half ice
             # under dense_snow_correction="auto"), read while the scalars were taken
@@ -302,7 +307,7 @@ class DORT(object):
         elif device_name == "iba_inverted":   # every layer of the batch
             cols[1] = 1.0 - cols[1]
         # wet snow: the optional liquid-water column (water / (ice + water) volume; the frac_volume column is ice + water)
-        wet = [sp.liquid_water() for sp in sps]
+        wet = [f[3] for f in facts]
         liquid_water = None
         if any(w is not None for w in wet):
             liquid_water = np.zeros((S, Lmax))
@@ -930,6 +935,11 @@ class _Solution:
         if int(np.prod(shape)) != len(order):
             return None
         data = LabeledArray(out.values[order].reshape(shape + out.values.shape[1:]), lead + self._coords(sensor0))
+        # the layer / stream diagnostics of Result.other_data are built when somebody asks for them: on a 1024 x 5 batch
+        # they are a third of the host time of Model.run, and most callers only read the brightness temperatures
+        return make_result(sensor0, data, other_data=_LazyOther(lambda: self._stacked_other(out, order, lead, shape, sensor0)))
+
+    def _stacked_other(self, out, order, lead, shape, sensor0):
         nl = np.fromiter((sp.nlayer for sp in self.packs), np.int64, len(self.packs))[self.pack_idx]
         Lmax = int(nl.max())
         lay = out.layers[order][:, :Lmax].copy()
@@ -969,7 +979,33 @@ class _Solution:
             "ka": stack(lay[:, :, 3], "ka"),
             "thickness": stack(thick_rows, "thickness"),
         }
-        return make_result(sensor0, data, other_data=other)
+        return other
+
+
+class _LazyOther(Mapping):
+    """Result.other_data of a stacked result, built on first access (a read-only mapping with the six keys of the reference:
+    smrt/rtsolver/rtsolver_utils.py:338-342,373-398)."""
+    KEYS = ("stream_angles", "effective_permittivity", "ks", "ke", "ka", "thickness")
+
+    def __init__(self, build):
+        self._build, self._data = build, None
+
+    def _get(self):
+        if self._data is None:
+            self._data, self._build = self._build(), None
+        return self._data
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
+
+    def __reduce__(self):   # (pickling / deep copies: as the plain dictionary it stands for)
+        return (dict, (dict(self._get()),))
 
 
 # ---- contexts and the multi-GPU fan-out ----------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 // logic (and check it is barrier-order independent) in a container without a GPU.  Never loaded by smrt_amd.
 #define SMRT_HOST_EMU 1
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../smrt_amd/csrc/dort_active.hpp"
@@ -103,8 +104,14 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
                            if (wide) return emu::run_block(512, order, [&]() { dort_pair_passive<512, 1, 1>(d, p, lds.data(), nullptr, &sg.st); });
                            return ACTIVE ? emu::run_block(NT, order, [&]() { dort_pair_active<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); })
                                          : emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 2, 1>(d, p, lds.data(), ws.data(), &sg.st); }); },
-        // (the product launches the Jacobi kernel of this pipeline with 512 threads: k_jacobi.hip)
-        [&](long long it) { for (auto& x : jl) x = NAN; return emu::run_block(512, order, [&]() { dort_jacobi_item<512>(d, sg.st, it, jl.data()); }); },
+        // (the product launches the Jacobi kernel of this pipeline with eight wavefronts, eight lanes per column pair; sixteen and
+        // sixteen behind an experiment switch: k_jacobi.hip)
+        [&](long long it) { const size_t l16 = (size_t)make_jacobi_plan(d.n_max_stream, ACTIVE ? 3 : 2, 0, 16).total;
+                            if (getenv("SMRT_EMU_JACOBI_1024") && l16 * sizeof(double) <= 160 * 1024) {   // (the library's experiment switch SMRT_DORT_JACOBI_1024)
+                                std::vector<double> j16(l16, NAN);
+                                return emu::run_block(1024, order, [&]() { dort_jacobi_item16<1024>(d, sg.st, it, j16.data()); });
+                            }
+                            for (auto& x : jl) x = NAN; return emu::run_block(512, order, [&]() { dort_jacobi_item<512>(d, sg.st, it, jl.data()); }); },
         // (and the finish kernel with 512 threads too: k_gmem_split.hip)
         [&](long long p) { fresh();
                            if (strip) return emu::run_block(512, order, [&]() { dort_pair_passive_strip(d, p, lds.data(), sg.st); });
