@@ -54,6 +54,8 @@ static constexpr int kBig = NTT * NTT * TS;  // the matrix region
 static constexpr int kVecLen = 16 * NTT;     // elements of a vector (128 / 64)
 static constexpr int kVectors = 12;          // exchange vectors
 static constexpr int kWsDoubles = NTT * NTT * 256;   // one matrix per pair in global memory (DevStage.ws): At between its phases
+static constexpr bool kPark = NTT > 4;               // (four wavefronts: a tile column is 16 doubles per lane, At stays in registers -- the
+                                                     //  round trip was half of the kernel's 13.5 GB of HBM traffic on the headline batch)
 using LaneId = rg::LaneId;
 
 // tile column of a matrix: tile ti, register r, lane 16 g + c of wavefront w holds X[16 ti + 4 r + g][16 w + c]
@@ -611,7 +613,7 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         At.v[tj][r] *= E0[16 * tj + 4 * r + Ln.g];
-                        wsb[wso + (tj * 4 + r) * SMRT_LANES] = At.v[tj][r];
+                        if (kPark) wsb[wso + (tj * 4 + r) * SMRT_LANES] = At.v[tj][r];
                     }
                 }
         }
@@ -651,15 +653,17 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         }
         block_sync();
         SMRT_ST(STP_T2);
-        zero(At);
+        if (kPark) zero(At);
         if (w < nt) {
             put_strip(C, nt, Lw);                                           // Theta^T
+            if (kPark) {
 #pragma unroll
-            for (int ti = 0; ti < NTT; ++ti)
-                if (ti < nt) {
+                for (int ti = 0; ti < NTT; ++ti)
+                    if (ti < nt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) At.v[ti][r] = wsb[wso + (ti * 4 + r) * SMRT_LANES];
-                }
+                        for (int r = 0; r < 4; ++r) At.v[ti][r] = wsb[wso + (ti * 4 + r) * SMRT_LANES];
+                    }
+            }
             strip_matvec_t(At, E10, E8, nt, w, Ln);                         // A- y = At^T y -> E8
             strip_matvec_t(At, E6, E9, nt, w, Ln);                          // C^' D^-1 1 = A- Theta A-^T D^-1 1 = At^T x2 -> E9
         }

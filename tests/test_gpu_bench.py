@@ -227,7 +227,7 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
         assert lib.smrt_dort_finish_reg_lds_bytes(32, 40) <= 40 * 1024 < lib.smrt_dort_finish_reg_lds_bytes(32, 41)
         assert lib.smrt_dort_finish_strip_lds_bytes(32, 60, 4) <= 160 * 1024 // 3 < lib.smrt_dort_finish_strip_lds_bytes(32, 110, 4)
         seen = {}
-        for deep in (60, 100, 150):
+        for deep in (60, 93, 100, 150):
             th = rng.uniform(0.01, 0.05, (2, deep)); th[:, -1] = 100.0
             b = PackedBatch([deep] * 2, th, rng.uniform(0.2, 0.45, (2, deep)), rng.uniform(235, 268, (2, deep)),
                             rng.uniform(5e-5, 3e-4, (2, deep)), None, [18.7e9], np.deg2rad([40.0]), n_max_stream=32)
@@ -235,6 +235,14 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
             seen[deep] = ctx.launch_info()["pipeline"]
             if seen[deep] == "lds_reg":
                 assert lib.smrt_dort_finish_reg_lds_bytes(32, deep) <= 160 * 1024 // 3, deep
+            if deep == 93:   # the window in which a 32-stream batch runs on the eight-wavefront strip kernel (global-workspace pipeline)
+                assert seen[deep] == "gmem_strip", seen
+                ctx.launch(); ctx.sync(); strip8 = ctx.download()
+                ctx.set_pipeline(4); ctx.upload(b)
+                assert ctx.launch_info()["pipeline"] == "gmem"
+                ctx.launch(); ctx.sync(); pivoted = ctx.download()
+                ctx.set_pipeline(1)
+                assert (strip8.status == 0).all() and np.abs(strip8.values - pivoted.values).max() < 1e-6
             if deep == 60:
                 ctx.launch(); ctx.sync(); by_default = ctx.download()
                 ctx.set_pipeline(4); ctx.upload(b)
