@@ -1,8 +1,9 @@
-// The strip finish kernel of the 64 < N <= 128 pipeline (passive mode, Flat interfaces): the pivot-free admittance
-// recursion of dort_finish_reg.hpp (same algebra) with every N x N matrix spread over the EIGHT wavefronts
-// of one workgroup -- wavefront w keeps tile column w (16 columns, up to 8 tiles of 16 x 16, 32 registers per matrix) in
-// the accumulator layout of v_mfma_f64_16x16x4_f64 -- and ONE matrix at a time broadcast through LDS as the A operand of
-// the products.  Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
+// The strip finish kernels (passive mode, Flat interfaces): the pivot-free admittance recursion of dort_finish_reg.hpp (same
+// algebra) with every N x N matrix spread over the wavefronts of ONE workgroup per (snowpack, frequency)
+// pair -- wavefront w keeps tile column w (16 columns, up to NTT tiles of 16 x 16, 4 NTT doubles per lane and matrix) in the
+// accumulator layout of v_mfma_f64_16x16x4_f64 -- and ONE matrix at a time broadcast through LDS as the A operand of the
+// products.  Two instances: eight wavefronts for 64 < N <= 128 (one workgroup per CU), four for N <= 64 (three per CU).
+// Part of the DORT device code (see dort_device.hpp for the overview and the reference map).
 //
 // What is solved is the boundary system of smrt/rtsolver/dort.py:263-488 (the same linear system as the other finish
 // kernels, eliminated in the order of dort_finish_reg.hpp; tests/studies/admittance_recursion.py is the NumPy statement).
@@ -12,11 +13,12 @@
 // doubles: 136 KB).  A tile in LDS can be read as the A operand of itself (lane (g, c), k-slab r: element (c, 4 r + g))
 // or of its transpose (element (4 r + g, c), which is also the accumulator layout): both walks touch 31 of the 32
 // eight-byte banks with the row stride of 17, so every product of the chain is written in its natural orientation and
-// nothing is transposed on the matrix core.  The three inversions of a layer are block Gauss-Jordan WITHOUT pivoting on
-// the strips: the owner of block column k broadcasts the inverse of the diagonal block (16 x 16, in registers: rg::inv16)
-// and its column through LDS, every other wavefront updates its own column; the owner of column k + 1 updates its diagonal
-// tile first and inverts it behind the matrix-core work of the others (look-ahead), double-buffered: one workgroup
-// barrier per block step.
+// nothing is transposed on the matrix core.  The matrix carried from layer to layer is C^^T: every matrix-vector product of
+// the recursion is then a sum down the columns of a wavefront's own tile column (no row sums, no cross-wavefront
+// reductions).  The three inversions of a layer are block Gauss-Jordan WITHOUT pivoting on the tile columns: the owner of
+// block column k broadcasts the inverse of the diagonal block (16 x 16, in registers: rg::inv16_la) and its column through
+// LDS, every other wavefront updates its own column; the owner of column k + 1 updates its diagonal tile first and
+// eliminates it while the others update (look-ahead), double-buffered: one workgroup barrier per block step.
 #pragma once
 #include "spmd.hpp"
 #include <math.h>

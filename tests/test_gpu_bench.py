@@ -49,6 +49,13 @@ def test_bench_single_gpu_line():
     # the secondary rates of the same run: host buffers through smrt_dort_run, and the plugin surface end to end
     assert 0 < d["pcie_inclusive"]["value"] <= d["value"] * 1.05
     assert d["model_run"]["bitwise_equal_to_c_abi_run"] and 0 < d["model_run"]["value"] <= d["value"] * 1.05
+    # per-kernel HIP-event times of three instrumented launches behind the timed region (smrt_dort_kernel_breakdown): the three
+    # kinds add up to the pipeline's own event time within launch gaps, and carry SURVEY 8(d)'s flop shares
+    pk = d["roofline"]["per_kernel"]
+    assert set(pk) == {"prep", "jacobi", "finish"} and all(v["ms"] > 0 for v in pk.values())
+    total = sum(v["ms"] for v in pk.values())
+    assert 0.9 * d["roofline"]["kernel_ms"] < total <= 1.05 * d["roofline"]["kernel_ms"], (total, d["roofline"]["kernel_ms"])
+    assert abs(sum(v["flop_share"] for v in pk.values()) - 1.0) < 1e-12
 
 
 def test_bench_distributed_path_one_rank():
@@ -258,5 +265,33 @@ def test_cfg3_shape_runs_on_the_three_kernel_pipeline():
         # global-workspace pipeline -- 91 layers at 32 streams --, whose strip kernel needs the tables of 100 layers beside its
         # 136 KB matrix region: the pivoted kernel there)
         assert seen[60] == "lds_strip" and seen[100] in ("gmem", "gmem_strip") and seen[150] == "gmem", seen
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_kernel_breakdown_entry_point():
+    """(Kept at the END of this module: the tests above that import torch must do so before the process has loaded the
+    library -- two HIP runtimes in one process only get along in that order.)  smrt_dort_kernel_breakdown through ctypes: off by default (zeros), three positive intervals per chunk once enabled, on
+    the strip pipeline of a small passive batch and on the fused path (nothing to report)."""
+    from smrt_amd._native import DortContext, PackedBatch
+
+    rng = np.random.default_rng(5)
+    b = PackedBatch([4] * 64, rng.uniform(0.05, 0.3, (64, 4)), rng.uniform(0.2, 0.45, (64, 4)), rng.uniform(235, 268, (64, 4)),
+                    rng.uniform(5e-5, 3e-4, (64, 4)), None, [18.7e9, 36.5e9], np.deg2rad([40.0]), n_max_stream=16)
+    ctx = DortContext(0)
+    try:
+        ctx.upload(b); ctx.launch(); ctx.sync()
+        off = ctx.kernel_breakdown()          # (reading also switches it on for the following launches)
+        assert off["intervals"] == 0 and off["prep"] == off["jacobi"] == off["finish"] == 0.0
+        ctx.launch()
+        on = ctx.kernel_breakdown()
+        ctx.sync()
+        assert on["intervals"] >= 3 and min(on["prep"], on["jacobi"], on["finish"]) > 0.0
+        assert on["prep"] + on["jacobi"] + on["finish"] <= 1.05 * ctx.last_kernel_ms() + 0.05
+        ctx.kernel_breakdown(False)
+        ctx.set_pipeline(0); ctx.upload(b); ctx.launch()      # fused kernel: no kinds to tell apart
+        assert ctx.kernel_breakdown()["intervals"] == 0
+        ctx.set_pipeline(1)
     finally:
         ctx.close()
