@@ -72,7 +72,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const int nmax = b.n_max_stream;
     const LdsPlan plan = make_plan(nmax, 3, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0,
                                    active_doubles(nmax, b.Lmax, b.n_theta, MODE < 2), MODE == 1 ? 1 : (MODE == 3 ? 2 : 0),
-                                   (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
+                                   (gmem_mat != nullptr && MODE != 1) ? ((CH > 2 && MODE == 2) ? 3 : (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds)) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
@@ -80,6 +80,16 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
     const bool dense_mfma = (CH == 1) || (CH == 2 && (plan.o_jac >= 0 || MODE == 1)) || (CH > 2);
     double* dense_scratch = (CH > 2) ? gmem_mat + plan.mat_doubles
                                      : ((CH == 1 || MODE == 1) ? s.gj : lds_base + (plan.o_jac >= 0 ? plan.o_jac : 0));
+#ifdef SMRT_STAGE_TIMING
+    double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    s.sub_acc = sub_acc_store;
+    double stage_acc[SG_COUNT];
+    for (int k = 0; k < SG_COUNT; ++k) stage_acc[k] = 0.0;
+    long long stage_t0 = cycle_counter();
+    int stage_cur = SG_SETUP;
+#endif
+    // N > 128 finish kernel: LDS staging buffers of the matrix-core products (make_plan jac_in_lds = 3)
+    double* big_stage = (CH > 2 && MODE == 2 && plan.o_jac >= 0) ? lds_base + plan.o_jac : nullptr;
     const int LD = plan.LD;
     const int out_stride = 9 * b.n_theta;
     const int NI = 2 * b.n_theta;                 // capacity of the incident stream list
@@ -279,6 +289,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             const double ks = s.ks[l], ke = s.ks[l] + s.ka[l];
             const int nu = (l > 0) ? (int)s.nl[l - 1] : 0;
             const int Nu = nu * P;
+            SMRT_STAGE(SG_SETUP);
 
             for (int j = t; j < n; j += NT) { const double rs = s.ri[l] * s.gsin[j]; s.mu[j] = sqrt(1.0 - rs * rs); }
             if (l > 0)
@@ -492,6 +503,7 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             }
             }  // MODE < 2
             double* F = s.M2; double* G = s.M1; double* Rt = s.M3; double* Wk = s.M0;
+            SMRT_STAGE(SG_TRI);
             double r1a[RowTiles<NT>::RPW][16];   // MODE 3: rows of R~ D of this wavefront's row tile
             if (MODE == 2) {  // four-matrix finish (global workspace): pick up L+, B' = B V, d and the singular values
                 const double* gL = stg->L + item * stg->mat_stride;
@@ -544,12 +556,14 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             }
             for (int c = t; c < N; c += NT) s.t[c] = exp(-s.sigma[c] * s.thick[l]);
             block_sync();
+            SMRT_STAGE(SG_R1);
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
             if (MODE == 3) r1_compute<NT>(s.M3, s.M0, r1a, N, LD);
             else if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else if (CH >= 2 && dense_mfma) r1_mfma_big<NT, 16 * CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;
+            SMRT_STAGE(SG_LU1);
             if (MODE == 3) {
                 if (!gj_solve_b16<NT, false, CH>(Wk, Rt, nullptr, s, N, LD, true, s.t, s.t, true)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
                 // -- Y = F tQt + G -> slot R ; W = (D G - Rtop F) tQt + (D F - Rtop G) -> slot X (over tQt) ; K = Y W^-1
@@ -558,17 +572,20 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             } else {
             if (!gj_solve<NT, false, CH>(Wk, Rt, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             double* Q = Rt;
+            SMRT_STAGE(SG_R45);
             for_2d<NT>(N, N, [&](int r, int c) { Q[c * LD + r] *= s.t[r] * s.t[c]; });
             block_sync();
             // -- Y = F tQt + G ; W = (D G - Rtop F) tQt + (D F - Rtop G) ; K = Y W^-1
             if (CH == 1) r45_mfma<NT, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else if (CH > 2) {   // two passes with one operand array each (register budget, see r45_mfma_big)
-                r45_mfma_big<NT, true, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
-                r45_mfma_big<NT, true, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+                r45_mfma_big<NT, true, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
+                r45_mfma_big<NT, true, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
             } else if (CH == 2 && dense_mfma) r45_mfma_big<NT, true, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
             else r45_rows<NT, CH, true>(F, G, Q, Wk, s.Rtop, s.tq, s.up, s.cvec, 0.0, N, LD, dsg);
+            SMRT_STAGE(SG_LU2);
             if (!gj_solve<NT, true, CH>(F, Wk, nullptr, s, N, LD, MODE == 2)) { fail_pair<NT>(b, p, ST_SINGULAR, out_stride); return; }
             }
+            SMRT_STAGE(SG_R78);
             if (l > 0 || hs >= 0) {
                 const int Nue = (hs >= 0) ? N : Nu;
                 const int nc = (N < Nue) ? N : Nue;
@@ -645,6 +662,13 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
         b.out[p * out_stride + idx] = res;
     }
     if (t == 0) { b.status[p] = ST_OK; if (b.n3_out) b.n3_out[p] = n3; }
+#ifdef SMRT_STAGE_TIMING
+    SMRT_STAGE(SG_OUT);
+    if (t == 0 && b.stage_out) {
+        for (int k = 4; k < 16; ++k) b.stage_out[p * 16 + k] = (k < SG_COUNT) ? stage_acc[k] : 0.0;
+        for (int k = 0; k < 3; ++k) b.stage_out[p * 16 + 13 + k] = sub_acc_store[k];
+    }
+#endif
 }
 
 }  // namespace smrt

@@ -790,16 +790,43 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
 // PASS 0: Y and W together (two A-operand arrays per lane); PASS 1: Y = F tQt + G -> Wk and upb only; PASS 2:
 // W -> over F and gvec only.  For N > 128 the caller runs PASS 1 then PASS 2: one array of KG doubles per lane instead
 // of two keeps the kernel within 256 VGPRs, i.e. two workgroups per CU.
+// stage (N > 128 only, or nullptr): stage_bufs = two LDS buffers of 64 KG doubles (one if two do not fit).  Every wavefront needs the whole operand tile
+// Q[:, 16 tj .. 16 tj + 15] for its row tile, and a tile (48 KB at N = 384) does not fit the vector L1: read straight from
+// global memory it crossed L2 -> L1 once per wavefront.  With the buffers the workgroup copies each tile once, in
+// matrix-core lane order (stage[64 kk + lane] = the B operand of lane `lane` for k-group kk), double-buffered: the
+// loads of tile tj + 1 are in flight during the matrix-core passes of tile tj, one workgroup barrier per tile (two
+// with a single buffer).
 template <int NT, bool SIGNED, int KG = 32, int PASS = 0>
 SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* Wk, const double* Rtop, const double* tq,
-                           double* upb, double* gvec, double Bl, int N, int LD, const double* dsg) {
+                           double* upb, double* gvec, double Bl, int N, int LD, const double* dsg, double* stage = nullptr,
+                           int stage_bufs = 2, int stage_stride = 64 * KG /* doubles per buffer (LdsPlan) */) {
     constexpr int NW = NT / SMRT_LANES;
     constexpr int MAXRT = KG / 4;
     constexpr int RPW = (NW >= MAXRT) ? 1 : (MAXRT + NW - 1) / NW;
     constexpr int CS = (NW > MAXRT) ? NW / MAXRT : 1;
     constexpr bool DO_Y = (PASS != 2), DO_W = (PASS != 1);
+    constexpr int QPT = (KG + NW - 1) / NW;   // k-groups of a staged tile each wavefront copies
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
+    const bool staged = (stage != nullptr) && CS == 1;
+    double qn[QPT];
+    auto fetch = [&](int tj) {   // this wavefront's share of operand tile tj into registers
+        const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int kk = wave + NW * i;
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double qv = Q[jc * LD + kc];
+            qn[i] = (j < N && k < N) ? qv : 0.0;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int kk = wave + NW * i;
+            if (kk < KG && 4 * kk < N) stage[buf * stage_stride + kk * 64 + lane] = qn[i];
+        }
+    };
     for (int o = 0; o < RPW; ++o) {
         const int ti = (NW >= MAXRT) ? (wave % MAXRT) : (wave + o * NW);
         const int cs = (NW >= MAXRT) ? (wave / MAXRT) : 0;
@@ -826,8 +853,40 @@ SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* 
             if (DO_Y) upb[i] = vy + Bl;
             if (DO_W) gvec[i] = vg + (1.0 - rt) * Bl;
         }
+        if (staged) { fetch(0); put(0); }
         block_sync();
-        if (ti < RT) {
+        auto epilogue = [&](int tj, const double (&cy)[4], const double (&cw)[4]) {
+            tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                const double gic = G[col * LD + row];
+                if (DO_Y) Wk[col * LD + row] = cy[reg] + gic;
+                if (DO_W) {
+                    const double fic = F[col * LD + row];
+                    F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
+                }
+            });
+        };
+        if (staged) {
+            for (int tj = 0; tj < RT; ++tj) {
+                const int nxt = (stage_bufs == 2) ? ((tj + 1) & 1) : 0;
+                const double* cur = stage + ((stage_bufs == 2) ? (tj & 1) : 0) * stage_stride;
+                if (tj + 1 < RT) fetch(tj + 1);
+                if (ti < RT) {
+                    double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) {
+                        if (4 * kk < N) {
+                            const double bop = cur[kk * 64 + lane];
+                            if (DO_Y) mfma_f64_16x16x4(af[kk], bop, cy);
+                            if (DO_W) mfma_f64_16x16x4(aw[kk], bop, cw);
+                        }
+                    }
+                    epilogue(tj, cy, cw);
+                }
+                if (stage_bufs != 2) block_sync();   // one buffer: everybody has read the tile before it is overwritten
+                if (tj + 1 < RT) put(nxt);
+                block_sync();
+            }
+        } else if (ti < RT) {
             for (int tj = cs; tj < RT; tj += CS) {
                 double cy[4] = {0.0, 0.0, 0.0, 0.0}, cw[4] = {0.0, 0.0, 0.0, 0.0};
                 const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
@@ -841,14 +900,7 @@ SMRT_DEV void r45_mfma_big(double* F, const double* G, const double* Q, double* 
                         if (DO_W) mfma_f64_16x16x4(aw[kk], bop, cw);
                     }
                 }
-                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
-                    const double gic = G[col * LD + row];
-                    if (DO_Y) Wk[col * LD + row] = cy[reg] + gic;
-                    if (DO_W) {
-                        const double fic = F[col * LD + row];
-                        F[col * LD + row] = cw[reg] + (SIGNED ? dsg[row] * fic : fic) - Rtop[row] * gic;
-                    }
-                });
+                epilogue(tj, cy, cw);
             }
         }
     }

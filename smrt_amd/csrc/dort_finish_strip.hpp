@@ -189,21 +189,6 @@ static SMRT_DEV void strip_matvec_t(const Strip& X, const double* v, double* out
     acc += shfl_xor(acc, 32);
     if (L.g == 0) out[16 * w + L.c] = acc;
 }
-// partial row sums of this wavefront's 16 columns: part[row] = sum_c X[row][16 w + c] colf[16 w + c] (LDS, one row of
-// the [NW][128] partial table per wavefront)
-static SMRT_DEV void strip_row_partial(const Strip& X, const double* colf, double* part, int ntr, int w, const LaneId& L) {
-    const double f = colf[16 * w + L.c];
-#pragma unroll
-    for (int ti = 0; ti < NTT; ++ti)
-        if (ti < ntr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double a = group_sum<16>(X.v[ti][r] * f);
-                if (L.c == 0) part[16 * ti + 4 * r + L.g] = a;
-            }
-        }
-}
-
 // X[i][j] <- factor rowf[i] X[i][j] colf[j] + (i == j) diag[i] on this wavefront's columns (null pointers: factor 1 / nothing)
 static SMRT_DEV void strip_scale_add_diag(Strip& X, const double* rowf, const double* colf, const double* diag, double factor, int nt,
                                    int w, const LaneId& L) {

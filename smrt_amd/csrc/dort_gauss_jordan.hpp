@@ -4,6 +4,7 @@
 #include "spmd.hpp"
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 #include "dort_dense.hpp"
 
 namespace smrt {
@@ -319,6 +320,12 @@ inline long smrt_emu_panels[2] = {0, 0};   // emulator builds count [0] fast and
 // one).  The LDS-resident kernels (N <= 64) pass false: the panels are separate (noinline) functions whose register
 // footprint counts against the kernel's even when they are never called, and the two-workgroups-per-CU finish kernel
 // has none to spare (<= 256 VGPRs).
+#ifndef SMRT_GJ_TILES_IN_FLIGHT
+#define SMRT_GJ_TILES_IN_FLIGHT 4
+#endif
+#ifndef SMRT_GJ_WIDE_BLOCKS
+#define SMRT_GJ_WIDE_BLOCKS 2   // blocks of 16 columns whose updates are applied together when N > 128 (1: one by one; 2 | 3 | 4 measured)
+#endif
 template <int NT, bool TR, int CHN = 2>   // CHN = the kernel's CH: N <= 64 CHN
 SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N, int LD, bool result_in_A = false,
                            const double* rs = nullptr, const double* cs = nullptr, bool allow_fast = false) {
@@ -335,13 +342,18 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     const int RT = (N + 15) >> 4;
     const int lr = lane & 15, lk = lane >> 4;
     for (int r = t; r < NMX; r += NT) rowblk[r] = -1;
-#ifndef SMRT_GJ_FAST_PANEL
     // Measured on MI355X (profiles/r2_gj_fast_panel.txt): inside the finish kernel the diagonal-block panel costs as
     // much as the full-pivot one (its ds_bpermute traffic queues behind the LDS reads of the other wavefronts' tile
     // updates: ~1300 cycles per column in situ against 350-425 alone), so the default build keeps the full-pivot panel,
     // whose numerics do not depend on the order of the eigenpairs.  -DSMRT_GJ_FAST_PANEL builds take the fast one.
-    allow_fast = false;
+    // (Round 5, N = 384 with the eigenpairs sorted on the way in: a group of four blocks took 1.17 M cycles with the
+    // fast panel against 0.93 M with the full-pivot one, profiles/r5_cfg3_gauss_jordan.txt.)
+#ifdef SMRT_GJ_FAST_PANEL
+    constexpr bool kFastPanel = true;
+#else
+    constexpr bool kFastPanel = false;
 #endif
+    if (!kFastPanel) allow_fast = false;
     if (t == 0) { *fail = 0; *fast = allow_fast ? 1 : 0; }
     block_sync();
 #ifdef SMRT_STAGE_TIMING
@@ -359,7 +371,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             return true;
         }
 #endif
-#ifdef SMRT_GJ_FAST_PANEL
+        if constexpr (kFastPanel) {
         if (*fast) {
             int took;
             if constexpr (CHN >= 2) took = (N > 64) ? gj_panel16_fast<TR, 4 * CHN>(A, N, LD, kb, lane, perm, rowblk, pinv, SMRT_GJ_GROWTH_MAX)
@@ -369,7 +381,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             if (lane == 0) *fast = 0;
             wave_sync_lds();
         }
-#endif
+        }
         SMRT_COUNT_PANEL(1);
         if constexpr (CHN > 2) {          // rows lane + 64 r, r < CHN, of the panel in registers (inlined, see gj_panel16)
             if (N > 128) return gj_panel16_impl<TR, CHN>(A, N, LD, kb, lane, perm, rowblk);
@@ -380,6 +392,190 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
             return gj_panel16<TR, 1>(A, N, LD, kb, lane, perm, rowblk);
         }
     };
+    if constexpr (CHN > 2 && SMRT_GJ_WIDE_BLOCKS > 1) {
+    // ---- N > 128, matrices in the global workspace: the updates of SB = SMRT_GJ_WIDE_BLOCKS consecutive blocks are
+    // applied to a column tile in ONE pass (rank 16 SB instead of SB passes of rank 16: the tile is read and written once
+    // per 64 eliminated columns -- at N = 384 the rank-16 passes moved ~85 MB per solve through HBM and ran at its
+    // bandwidth).  The blocks of a group are factorised one after the other by one wavefront, each applied at once to
+    // the group's OTHER column tiles only -- the live ones to its right and the dead ones to its left, whose multiplier
+    // columns U_q thereby become T_k U_q: with T_k = I + U_k E_k^T (E_k^T = the pivot rows of block k),
+    //     T_2 T_1 M = M + (T_2 U_1) (E_1^T M) + U_2 (E_2^T M),
+    // so after the group its columns hold U_tot and every other tile is M + U_tot (E^T M) with the pivot rows of M as
+    // they were BEFORE the group.  The group after the running one is factorised (look-ahead) by the wavefront that owns
+    // it, after it has brought that group's tiles up to date.
+    constexpr int SB = SMRT_GJ_WIDE_BLOCKS;
+    constexpr int PF1 = SMRT_GJ_TILES_IN_FLIGHT, PFW = 2;
+    // blocks [kf, kf + nb) applied to the absolute column tile g of [A | B] (NB = capacity of the operand arrays)
+    auto apply = [&](auto nbcap, int g, int kf, int nb) {
+        constexpr int NB = decltype(nbcap)::value;
+        constexpr int PF = (NB == 1) ? PF1 : PFW;
+        double* Mat = (g < RT) ? A : Bm;
+        const int col = ((g < RT) ? g : g - RT) * 16 + lr;
+        const bool cin = col < N;
+        const int colc = cin ? col : 0;
+        double bop[NB][4];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int k0q = 16 * (kf + q);
+            const int nbq = (q < nb) ? ((N - k0q < 16) ? N - k0q : 16) : 0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int j = 4 * kk + lk;
+                const int pr = (j < nbq) ? perm[k0q + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                bop[q][kk] = (cin && j < nbq) ? x : 0.0;
+            }
+        }
+        for (int t0 = 0; t0 < RT; t0 += PF) {
+            double c[PF][4], av[PF][NB][4];
+            bool keep[PF][4];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int ti = t0 + u;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = ti * 16 + lk + 4 * reg;
+                    const int rowc = row < N ? row : 0;
+                    const double x = at<TR>(Mat, rowc, colc, LD);
+                    const int rb = rowblk[rowc];
+                    keep[u][reg] = cin && row < N && !(rb >= kf && rb < kf + nb);
+                    c[u][reg] = keep[u][reg] ? x : 0.0;
+                }
+                const int arow = ti * 16 + lr;
+                const int arowc = arow < N ? arow : 0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int k0q = 16 * (kf + q);
+                    const int nbq = (q < nb) ? ((N - k0q < 16) ? N - k0q : 16) : 0;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int j = 4 * kk + lk;
+                        const int jc = (j < nbq) ? j : 0;
+                        const double x = at<TR>(A, arowc, (nbq > 0 ? k0q : 0) + jc, LD);
+                        av[u][q][kk] = (arow < N && j < nbq) ? x : 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) mfma_f64_16x16x4(av[u][q][kk], bop[q][kk], c[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = (t0 + u) * 16 + lk + 4 * reg;
+                    if (keep[u][reg]) at<TR>(Mat, row, col, LD) = c[u][reg];
+                }
+            }
+        }
+        // the new pivot rows of every block of the group: R_P' + U_tot[P', :] R_P
+        double pvt[NB][4];
+#pragma unroll
+        for (int q2 = 0; q2 < NB; ++q2) {
+            const int k0p = 16 * (kf + q2);
+            const int nbp = (q2 < nb) ? ((N - k0p < 16) ? N - k0p : 16) : 0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                const int pr = (j < nbp) ? perm[k0p + j] : 0;
+                const double x = at<TR>(Mat, pr, colc, LD);
+                pvt[q2][reg] = (cin && j < nbp) ? x : 0.0;
+            }
+            const int prl = (lr < nbp) ? perm[k0p + lr] : 0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int k0q = 16 * (kf + q);
+                const int nbq = (q < nb) ? ((N - k0q < 16) ? N - k0q : 16) : 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int j = 4 * kk + lk;
+                    const int jc = (j < nbq) ? j : 0;
+                    const double x = at<TR>(A, prl, (nbq > 0 ? k0q : 0) + jc, LD);
+                    mfma_f64_16x16x4((lr < nbp && j < nbq) ? x : 0.0, bop[q][kk], pvt[q2]);
+                }
+            }
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int q2 = 0; q2 < NB; ++q2) {
+            const int k0p = 16 * (kf + q2);
+            const int nbp = (q2 < nb) ? ((N - k0p < 16) ? N - k0p : 16) : 0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = lk + 4 * reg;
+                if (col < N && j < nbp) at<TR>(Mat, perm[k0p + j], col, LD) = pvt[q2][reg];
+            }
+        }
+        wave_sync_lds();
+    };
+    using One = std::integral_constant<int, 1>;
+    using Cap = std::integral_constant<int, SB>;
+    // the blocks of group gi, one after the other, by the calling wavefront
+    auto factor_group = [&](int gi) -> bool {
+        const int kf = SB * gi, kl = (kf + SB < RT) ? kf + SB : RT;
+        for (int kb = kf; kb < kl; ++kb) {
+            if (!panel(kb)) return false;
+            wave_sync_lds();
+            for (int g = kf; g < kl; ++g)
+                if (g != kb) apply(One{}, g, kb, 1);
+        }
+        return true;
+    };
+    const int NG = (RT + SB - 1) / SB;
+    if (wave == 0) { if (!factor_group(0) && lane == 0) *fail = 1; }
+    SMRT_GSUB(0);
+    block_sync();
+    if (*fail) return false;  // uniform
+    for (int gi = 0; gi < NG; ++gi) {
+        const int kf = SB * gi, kl = (kf + SB < RT) ? kf + SB : RT, nb = kl - kf;
+        const bool has_next = gi + 1 < NG;
+        const int owner = has_next ? ((gi + 1) % NW) : -1;
+        const int kl2 = has_next ? ((kl + SB < RT) ? kl + SB : RT) : RT;
+        if (has_next && wave == owner) {
+            for (int g = kl; g < kl2; ++g) apply(Cap{}, g, kf, nb);
+            if (!factor_group(gi + 1) && lane == 0) *fail = 1;
+        }
+        const bool worker = (NW == 1) || !has_next || wave != owner;
+        const int nworkers = (NW == 1 || !has_next) ? NW : NW - 1;
+        const int widx = (NW == 1 || !has_next) ? wave : (wave - owner - 1 + NW) % NW;
+        if (worker) {
+            int idx = 0;
+            for (int g = kl2; g < 2 * RT; ++g, ++idx) {
+                if (idx % nworkers != widx) continue;
+                apply(Cap{}, g, kf, nb);
+            }
+            if (has_v && widx == 0) {  // extra right-hand side: v + U_tot v[P], rows lane + 64 r2
+                double acc[CHN];
+#pragma unroll
+                for (int r2 = 0; r2 < CHN; ++r2) {
+                    const int row = lane + 64 * r2;
+                    acc[r2] = 0.0;
+                    if (row < N) {
+                        acc[r2] = v[row];
+                        for (int c2 = 16 * kf; c2 < 16 * kl && c2 < N; ++c2) acc[r2] += at<TR>(A, row, c2, LD) * v[perm[c2]];
+                    }
+                }
+                wave_sync_lds();
+#pragma unroll
+                for (int r2 = 0; r2 < CHN; ++r2)
+                    if (lane + 64 * r2 < N) v[lane + 64 * r2] = acc[r2];
+            }
+        }
+#ifdef SMRT_GJ_TIMING_SPLIT
+        SMRT_GSUB(1);   // (experiment: [1] = wavefront 0's own work, [2] = its wait at the group barrier)
+        block_sync();
+        SMRT_GSUB(2);
+#else
+        block_sync();
+#endif
+        if (*fail) return false;  // uniform
+    }
+    } else {
     if (wave == 0) { if (!panel(0) && lane == 0) *fail = 1; }
     SMRT_GSUB(0);
     block_sync();
@@ -402,30 +598,46 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
                 const double x = at<TR>(Mat, pr, colc, LD);
                 bop[kk] = (cin && j < nbk) ? x : 0.0;
             }
-            for (int ti = 0; ti < RT; ++ti) {
-                double c[4];
-                bool keep[4];
+            // PF row tiles in flight: with the matrices in the global workspace (CHN > 2) a tile's loads take a couple
+            // of thousand cycles under load, and the compiler cannot move the next tile's loads above this tile's stores
+            // (same array).  The loads of PF tiles are issued together, then their matrix-core passes, then the stores.
+            constexpr int PF = (CHN > 2) ? SMRT_GJ_TILES_IN_FLIGHT : 1;
+            for (int t0 = 0; t0 < RT; t0 += PF) {
+                double c[PF][4], av[PF][4];
+                bool keep[PF][4];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = ti * 16 + lk + 4 * reg;
-                    const int rowc = row < N ? row : 0;
-                    const double x = at<TR>(Mat, rowc, colc, LD);
-                    keep[reg] = cin && row < N && rowblk[rowc] != k;
-                    c[reg] = keep[reg] ? x : 0.0;
+                for (int u = 0; u < PF; ++u) {
+                    const int ti = t0 + u;   // (past the last row tile: nothing kept, zero operands)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = ti * 16 + lk + 4 * reg;
+                        const int rowc = row < N ? row : 0;
+                        const double x = at<TR>(Mat, rowc, colc, LD);
+                        keep[u][reg] = cin && row < N && rowblk[rowc] != k;
+                        c[u][reg] = keep[u][reg] ? x : 0.0;
+                    }
+                    const int arow = ti * 16 + lr;
+                    const int arowc = arow < N ? arow : 0;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int j = 4 * kk + lk;
+                        const int jc = (j < nbk) ? j : 0;
+                        const double x = at<TR>(A, arowc, k0 + jc, LD);
+                        av[u][kk] = (arow < N && j < nbk) ? x : 0.0;
+                    }
                 }
-                const int arow = ti * 16 + lr;
-                const int arowc = arow < N ? arow : 0;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int j = 4 * kk + lk;
-                    const int jc = (j < nbk) ? j : 0;
-                    const double x = at<TR>(A, arowc, k0 + jc, LD);
-                    mfma_f64_16x16x4((arow < N && j < nbk) ? x : 0.0, bop[kk], c);
+                for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) mfma_f64_16x16x4(av[u][kk], bop[kk], c[u]);
                 }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = ti * 16 + lk + 4 * reg;
-                    if (keep[reg]) at<TR>(Mat, row, col, LD) = c[reg];
+                for (int u = 0; u < PF; ++u) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = (t0 + u) * 16 + lk + 4 * reg;
+                        if (keep[u][reg]) at<TR>(Mat, row, col, LD) = c[u][reg];
+                    }
                 }
             }
             // new pivot rows: R_P + U_P R_P with U_P[j][i] = u_i[p_j]
@@ -508,6 +720,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
         }
         block_sync();
         if (*fail) return false;  // uniform
+    }
     }
     block_sync();
     SMRT_GSUB(1);

@@ -385,7 +385,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->prep_lds_bytes = (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, ctx->gmem_split ? 0 : 1, actd,
                                                 (!ctx->gmem_split && !ctx->active) ? 3 : 1).total * sizeof(double);
         ctx->finish2_lds_bytes = ctx->gmem_split
-            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 0 : 2).total * sizeof(double)
+            ? (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 0, actd_fin, 0, ctx->big ? 3 : 2).total * sizeof(double)
             : (size_t)make_plan(b->n_max_stream, P, b->n_layers_max, b->n_theta, nphi, 1, actd_fin, 2).total * sizeof(double);
     }
     // the register-resident finish kernel (one wavefront per pair, dort_finish_reg.hpp): LDS pipeline, passive mode, Flat

@@ -133,6 +133,7 @@ struct LdsPlan {
     int o_int;      // 16 ints (8 doubles)
     int o_gj;       // scratch of the blocked solvers (block inverses of Cholesky / triangular solve, Gauss-Jordan bookkeeping)
     int o_act;      // active mode only: per-layer mode-0 normalisation, mode totals, incident stream list
+    int stage_bufs; // N > 128 finish kernels: operand staging buffers at o_jac (make_plan jac_in_lds = 3), else 0
     int o_jac;      // global-workspace kernels: an NMAX x LD LDS buffer for the Jacobi stage, or -1 if it does not fit
     int total;      // doubles
 };
@@ -177,7 +178,8 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     const int nmat = slim ? 2 : 4;
     const int one = packed ? (p.LD * (p.LD + 1)) / 2 : p.NMAX * p.LD;
     p.mat_doubles = nmat * one;
-    p.scratch_doubles = !matrices_in_lds ? 16 * p.NMAX : 0;
+    // (one 16 x 16 block inverse per block row of the triangular solve: whole blocks, also when 16 does not divide NMAX)
+    p.scratch_doubles = !matrices_in_lds ? 256 * ((p.NMAX + 15) / 16) : 0;
     int o = 0;
     for (int i = 0; i < 4; ++i) { p.o_M[i] = (i < nmat ? i : 0) * one; }
     if (slim == 2) p.o_M[3] = p.NMAX * p.LD;  // the two-slot finish kernel: M0 = X, M3 = R (M1, M2 live in global memory)
@@ -198,7 +200,18 @@ SMRT_HD LdsPlan make_plan(int n_max_stream, int P, int Lmax, int ntheta, int nph
     p.o_jac = -1;
     // 1: a whole matrix (Jacobi stage of the fused kernel); 2: only the 16 NMAX doubles of scratch that the blocked
     // triangular solve needs (finish half of the global-workspace pipeline: small LDS, several workgroups per CU)
-    if (jac_in_lds && !matrices_in_lds) { p.o_jac = o; o += (jac_in_lds == 2) ? 16 * p.NMAX : p.NMAX * p.LD; }
+    // 3: the operand staging of the N > 128 finish kernels (r45_mfma_big): buffers of one 16-column operand tile in
+    // matrix-core lane order, 64 doubles per group of four rows
+    // (two buffers while they fit the 160 KB of a CU next to the rest, else one)
+    p.stage_bufs = 0;
+    if (jac_in_lds && !matrices_in_lds) {
+        p.o_jac = o;
+        if (jac_in_lds == 3) {
+            const int one = 64 * ((p.NMAX + 3) / 4);
+            p.stage_bufs = ((o + 2 * one) * 8 <= 160 * 1024) ? 2 : 1;
+            o += p.stage_bufs * one;
+        } else o += (jac_in_lds == 2) ? 16 * p.NMAX : p.NMAX * p.LD;
+    }
     p.total = o;
     return p;
 }

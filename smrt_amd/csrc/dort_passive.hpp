@@ -262,7 +262,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     const int nphi = 9;  // m_max = 0 -> 16 azimuth samples (emmodel/common.py:401-414), 9 distinct by symmetry
     const LdsPlan plan = make_plan(b.n_max_stream, P, b.Lmax, b.n_theta, nphi, gmem_mat == nullptr ? 1 : 0, 0,
                                    MODE == 1 ? (CH == 1 ? 3 : 1) : (MODE == 3 ? 2 : 0),
-                                   (gmem_mat != nullptr && MODE != 1) ? (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds) : 0);
+                                   (gmem_mat != nullptr && MODE != 1) ? ((CH > 2 && MODE == 2) ? 3 : (MODE == 2 && b.jac_in_lds ? 2 : b.jac_in_lds)) : 0);
     Lds s = carve(lds_base, gmem_mat == nullptr ? lds_base : gmem_mat, plan);
     // matrix-core variants of the dense steps: always on the LDS path; on the global-workspace path for N <= 128 when
     // the LDS Jacobi buffer exists (it doubles as the scratch of the blocked Cholesky / triangular solve)
@@ -275,6 +275,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
     double sub_acc_store[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     s.sub_acc = sub_acc_store;
 #endif
+    // N > 128 finish kernel: LDS staging buffers of the matrix-core products (make_plan jac_in_lds = 3)
+    double* big_stage = (CH > 2 && MODE == 2 && plan.o_jac >= 0) ? lds_base + plan.o_jac : nullptr;
     const int LD = plan.LD;
     const int nmax = b.n_max_stream;
     const int out_stride = P * b.n_theta;
@@ -684,8 +686,8 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             r45_mfma<NT>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD);
         } else if (CH >= 2 && dense_mfma) {
             if (CH > 2) {   // two passes with one operand array each (register budget, see r45_mfma_big)
-                r45_mfma_big<NT, false, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
-                r45_mfma_big<NT, false, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
+                r45_mfma_big<NT, false, 16 * CH, 1>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
+                r45_mfma_big<NT, false, 16 * CH, 2>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
             } else r45_mfma_big<NT, false, 16 * CH>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);
         } else {
             r45_rows<NT, CH, false>(F, G, Q, Wk, s.Rtop, s.tq, s.upb, s.g, Bl, N, LD, nullptr);

@@ -124,7 +124,8 @@ template <int CH, bool ACTIVE>
 static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
     const int nmodes = ACTIVE ? d.m_max + 1 : 1;
     Staging sg((size_t)d.pair_count * d.Lmax * nmodes, plan);
-    std::vector<double> lds(2 * plan.total), ws((size_t)plan.mat_doubles + plan.scratch_doubles);
+    // (the finish kernels add their operand staging buffers: make_plan jac_in_lds = 3)
+    std::vector<double> lds(2 * plan.total + 2 * 64 * ((plan.NMAX + 3) / 4)), ws((size_t)plan.mat_doubles + plan.scratch_doubles);
     const JacobiBigPlan jp = make_jacobi_big_plan(d.n_max_stream, ACTIVE ? 3 : 2);
     std::vector<double> jl(jp.total);
     auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };

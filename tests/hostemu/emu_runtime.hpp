@@ -159,6 +159,9 @@ inline long run_block(int nt, int order, std::function<void()> body) {
         }
         if (ndone < nt && R.progress == progress_before) {
             fprintf(stderr, "emu: DEADLOCK -- a full scheduler pass made no progress (non-uniform barrier?)\n");
+            fprintf(stderr, "emu: %d of %d threads at the workgroup barrier; wavefront rendezvous counts:", R.bar_count, nt);
+            for (size_t w = 0; w < R.wave_count.size(); ++w) fprintf(stderr, " %d", R.wave_count[w]);
+            fprintf(stderr, "\n");
             abort();
         }
     }
