@@ -560,7 +560,10 @@ SMRT_DEV void dort_pair_active(const DevBatch& b, long long p, double* lds_base,
             // -- Q = (F - R~ D G)^-1 (R~ D F - G)
             if (MODE == 3) r1_compute<NT>(s.M3, s.M0, r1a, N, LD);
             else if (CH == 1) r1_mfma<NT>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
-            else if (CH >= 2 && dense_mfma) r1_mfma_big<NT, 16 * CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
+            else if (CH > 2 && big_stage) {   // one staged operand matrix per pass (dort_dense.hpp)
+                r1_mfma_big<NT, 16 * CH, 1>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
+                r1_mfma_big<NT, 16 * CH, 2>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD, big_stage, plan.stage_bufs, 64 * ((plan.NMAX + 3) / 4));
+            } else if (CH >= 2 && dense_mfma) r1_mfma_big<NT, 16 * CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             else r1_rows<NT, CH>(F, G, Rt, Wk, s.cvec, s.svec, 0.0, N, LD);
             double* K = Wk;
             SMRT_STAGE(SG_LU1);

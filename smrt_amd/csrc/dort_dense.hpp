@@ -407,25 +407,54 @@ SMRT_DEV void lt_times_l_mfma(const double* Lp, const double* Lm, double* C, int
     block_sync();
 }
 
-// C = Lp * Bm (Lp lower triangular)
+// C = Lp * Bm (Lp lower triangular).  A wavefront carries TPW output tiles of one tile row together: the operand of
+// Lp is loaded once for the three, and the loads of a chunk of 16 columns (4 + 4 TPW) are all in flight before its
+// matrix-core passes (operands from global memory for N > 64: two dependent loads per pass was the latency of L2 every
+// four columns).
 template <int NT>
 SMRT_DEV void l_times_m_mfma(const double* Lp, const double* Bm, double* C, int N, int LD) {
     const int wave = tid() / SMRT_LANES;
     constexpr int NW = NT / SMRT_LANES;
+    constexpr int TPW = 3;
     const int RT = (N + 15) >> 4;
-    for (int tix = wave; tix < RT * RT; tix += NW) {
-        const int ti = tix % RT, tj = tix / RT;
-        double c[4] = {0.0, 0.0, 0.0, 0.0};
-        const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
-        const int i = ti * 16 + lr, j = tj * 16 + lr;
-        const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+    const int NG = (RT + TPW - 1) / TPW;
+    const int lane = tid() & (SMRT_LANES - 1), lr = lane & 15, lk = lane >> 4;
+    for (int u = wave; u < RT * NG; u += NW) {
+        const int ti = u % RT, tg = u / RT;
+        double c[TPW][4];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) c[q][reg] = 0.0;
+        const int i = ti * 16 + lr, ic = i < N ? i : N - 1;
         const int kend = (ti * 16 + 16 < N) ? ti * 16 + 16 : N;  // k <= i
-        for (int k0 = 0; k0 < kend; k0 += 4) {
-            const int k = k0 + lk, kc = k < N ? k : N - 1;
-            const double av = Lp[kc * LD + ic], bv = Bm[jc * LD + kc];
-            mfma_f64_16x16x4((i < N && k <= i) ? av : 0.0, (j < N && k < N) ? bv : 0.0, c);
+        const int nq = (RT - tg * TPW < TPW) ? RT - tg * TPW : TPW;   // tiles of this group (uniform)
+        for (int k0 = 0; k0 < kend; k0 += 16) {
+            double av[4], bv[TPW][4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + 4 * kk + lk, kc = k < N ? k : N - 1;
+                const double x = Lp[kc * LD + ic];
+                av[kk] = (i < N && k <= i && k < N) ? x : 0.0;
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    bv[q][kk] = 0.0;
+                    if (q < nq) {
+                        const int j = (tg * TPW + q) * 16 + lr, jc = j < N ? j : N - 1;
+                        const double y = Bm[jc * LD + kc];
+                        bv[q][kk] = (j < N && k < N) ? y : 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                    if (q < nq) mfma_f64_16x16x4(av[kk], bv[q][kk], c[q]);
         }
-        tile_foreach(ti, tj, N, [&](int reg, int row, int col) { C[col * LD + row] = c[reg]; });
+#pragma unroll
+        for (int q = 0; q < TPW; ++q)
+            if (tg * TPW + q < RT) tile_foreach(ti, tg * TPW + q, N, [&](int reg, int row, int col) { C[col * LD + row] = c[q][reg]; });
     }
     block_sync();
 }
@@ -737,15 +766,40 @@ SMRT_DEV void r45_mfma2(const double* F, const double* G, const double* Q, doubl
 // the matrices live (all pointers are generic).
 // KG = k-groups of four columns a row block spans = 16 per 64 rows (N <= 4 KG): the A operands of one 16-row tile, KG
 // doubles per lane, are pulled into registers before anything of that tile is written (in-place row updates).
-template <int NT, int KG = 32>
+// PASS 0: both products in one sweep (operands straight from memory).  PASS 1: Wk = F - Rt G and cvec only; PASS 2:
+// Rt <- Rt F - G only -- the N > 128 finish kernels run 1 then 2, each with its ONE operand matrix (G, then F) staged
+// through LDS like r45_mfma_big below (stage / stage_bufs / stage_stride: see there).
+template <int NT, int KG = 32, int PASS = 0>
 SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* Wk, double* cvec, const double* svec,
-                          double Bl, int N, int LD) {
+                          double Bl, int N, int LD, double* stage = nullptr, int stage_bufs = 2, int stage_stride = 64 * KG) {
     constexpr int NW = NT / SMRT_LANES;
     constexpr int MAXRT = KG / 4;
     constexpr int RPW = (NW >= MAXRT) ? 1 : (MAXRT + NW - 1) / NW;
     constexpr int CS = (NW > MAXRT) ? NW / MAXRT : 1;
+    constexpr bool DO_W = (PASS != 2), DO_R = (PASS != 1);
+    constexpr int QPT = (KG + NW - 1) / NW;   // k-groups of a staged tile each wavefront copies
     const int t = tid(), lane = t & (SMRT_LANES - 1), wave = t / SMRT_LANES, lr = lane & 15, lk = lane >> 4;
     const int RT = (N + 15) >> 4;
+    const bool staged = (stage != nullptr) && CS == 1 && PASS != 0;
+    const double* Bop = (PASS == 2) ? F : G;   // the staged operand matrix
+    double qn[QPT];
+    auto fetch = [&](int tj) {
+        const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int kk = wave + NW * i;
+            const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
+            const double qv = Bop[jc * LD + kc];
+            qn[i] = (j < N && k < N) ? qv : 0.0;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int kk = wave + NW * i;
+            if (kk < KG && 4 * kk < N) stage[buf * stage_stride + kk * 64 + lane] = qn[i];
+        }
+    };
     for (int o = 0; o < RPW; ++o) {
         const int ti = (NW >= MAXRT) ? (wave % MAXRT) : (wave + o * NW);
         const int cs = (NW >= MAXRT) ? (wave / MAXRT) : 0;
@@ -759,11 +813,40 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
             a[kk] = (ti < RT && i < N && k < N) ? x : 0.0;
             rs += a[kk];
         }
-        rs += shfl_xor(rs, 16);
-        rs += shfl_xor(rs, 32);
-        if (cs == 0 && ti < RT && lk == 0 && i < N) cvec[i] = rs * Bl - Bl + svec[i];
+        if (DO_W) {
+            rs += shfl_xor(rs, 16);
+            rs += shfl_xor(rs, 32);
+            if (cs == 0 && ti < RT && lk == 0 && i < N) cvec[i] = rs * Bl - Bl + svec[i];
+        }
+        if (staged) { fetch(0); put(0); }
         block_sync();  // column-split wavefronts share a row tile: everybody has its A operands before anybody writes
-        if (ti < RT) {
+        auto epilogue = [&](int tj, const double (&c1)[4], const double (&c2)[4]) {
+            tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
+                if (DO_W) Wk[col * LD + row] = F[col * LD + row] - c1[reg];
+                if (DO_R) Rt[col * LD + row] = c2[reg] - G[col * LD + row];
+            });
+        };
+        if (staged) {
+            for (int tj = 0; tj < RT; ++tj) {
+                const int nxt = (stage_bufs == 2) ? ((tj + 1) & 1) : 0;
+                const double* cur = stage + ((stage_bufs == 2) ? (tj & 1) : 0) * stage_stride;
+                if (tj + 1 < RT) fetch(tj + 1);
+                if (ti < RT) {
+                    double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < KG; ++kk) {
+                        if (4 * kk < N) {
+                            const double bop = cur[kk * 64 + lane];
+                            if (DO_W) mfma_f64_16x16x4(a[kk], bop, c1); else mfma_f64_16x16x4(a[kk], bop, c2);
+                        }
+                    }
+                    epilogue(tj, c1, c2);
+                }
+                if (stage_bufs != 2) block_sync();
+                if (tj + 1 < RT) put(nxt);
+                block_sync();
+            }
+        } else if (ti < RT) {
             for (int tj = cs; tj < RT; tj += CS) {
                 double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
                 const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
@@ -772,15 +855,11 @@ SMRT_DEV void r1_mfma_big(const double* F, const double* G, double* Rt, double* 
                     if (4 * kk < N) {
                         const int k = 4 * kk + lk, kc = k < N ? k : N - 1;
                         const bool in = (j < N && k < N);
-                        const double gv = G[jc * LD + kc], fv = F[jc * LD + kc];
-                        mfma_f64_16x16x4(a[kk], in ? gv : 0.0, c1);
-                        mfma_f64_16x16x4(a[kk], in ? fv : 0.0, c2);
+                        if (DO_W) { const double gv = G[jc * LD + kc]; mfma_f64_16x16x4(a[kk], in ? gv : 0.0, c1); }
+                        if (DO_R) { const double fv = F[jc * LD + kc]; mfma_f64_16x16x4(a[kk], in ? fv : 0.0, c2); }
                     }
                 }
-                tile_foreach(ti, tj, N, [&](int reg, int row, int col) {
-                    Wk[col * LD + row] = F[col * LD + row] - c1[reg];
-                    Rt[col * LD + row] = c2[reg] - G[col * LD + row];
-                });
+                epilogue(tj, c1, c2);
             }
         }
     }
@@ -1201,38 +1280,72 @@ SMRT_DEV void lt_solve_mfma(const double* Lp, double* Bm, double* inv /* [4][16*
         }
     }
     if (!have_inv) block_sync();
-    for (int I = RT - 1; I >= 0; --I) {
-        for (int tj = wave; tj < RT; tj += NW) {
-            double c[4] = {0.0, 0.0, 0.0, 0.0};
-            const int i = I * 16 + lr, j = tj * 16 + lr;
-            const int ic = i < N ? i : N - 1, jc = j < N ? j : N - 1;
+    // A column tile of the solution depends on nothing but itself: a wavefront carries TPW of them from the bottom block
+    // row to the top without a workgroup barrier, the operand of Lp loaded once for the three and the loads of a chunk
+    // of 16 rows all in flight before its matrix-core passes.
+    constexpr int TPW = 3;
+    for (int tb = wave; tb < RT; tb += NW * TPW) {
+        for (int I = RT - 1; I >= 0; --I) {
+            double c[TPW][4];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) c[q][reg] = 0.0;
+            const int i = I * 16 + lr, ic = i < N ? i : N - 1;
+            const int nq = (RT - tb + NW - 1) / NW < TPW ? (RT - tb + NW - 1) / NW : TPW;   // tiles carried (uniform)
             // acc = sum_{k in later blocks} L[k][i] X[k][j]
-            for (int k0 = (I + 1) * 16; k0 < N; k0 += 4) {
-                const int k = k0 + lk, kc = k < N ? k : N - 1;
-                const double av = Lp[ic * LD + kc], bv = Bm[jc * LD + kc];
-                mfma_f64_16x16x4((i < N && k < N) ? av : 0.0, (j < N && k < N) ? bv : 0.0, c);
-            }
-            // R = B_I - acc in accumulator layout
-            double r[4];
+            for (int k0 = (I + 1) * 16; k0 < N; k0 += 16) {
+                double av[4], bv[TPW][4];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = I * 16 + lk + 4 * reg;
-                const int rowc = row < N ? row : N - 1;
-                const double bv = Bm[jc * LD + rowc];
-                r[reg] = ((row < N && j < N) ? bv : 0.0) - c[reg];
-            }
-            // X = inv(L_II)^T R : A[i][k] = inv[k][i]
-            double x[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = k0 + 4 * kk + lk, kc = k < N ? k : N - 1;
+                    const double a = Lp[ic * LD + kc];
+                    av[kk] = (i < N && k < N) ? a : 0.0;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = 4 * kk + lk;                          // row of inv(L_II)
-                const double av = inv[I * 256 + lr * 16 + k];       // (L_II^-1)[k][lr]
-                mfma_f64_16x16x4(av, r[kk], x);
+                    for (int q = 0; q < TPW; ++q) {
+                        bv[q][kk] = 0.0;
+                        if (q < nq) {
+                            const int j = (tb + q * NW) * 16 + lr, jc = j < N ? j : N - 1;
+                            const double y = Bm[jc * LD + kc];
+                            bv[q][kk] = (j < N && k < N) ? y : 0.0;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q)
+                        if (q < nq) mfma_f64_16x16x4(av[kk], bv[q][kk], c[q]);
             }
-            tile_foreach(I, tj, N, [&](int reg, int row, int col) { Bm[col * LD + row] = x[reg]; });
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int tj = tb + q * NW;
+                if (tj < RT) {   // uniform
+                    const int j = tj * 16 + lr, jc = j < N ? j : N - 1;
+                    // R = B_I - acc in accumulator layout
+                    double r[4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = I * 16 + lk + 4 * reg;
+                        const int rowc = row < N ? row : N - 1;
+                        const double bvr = Bm[jc * LD + rowc];
+                        r[reg] = ((row < N && j < N) ? bvr : 0.0) - c[q][reg];
+                    }
+                    // X = inv(L_II)^T R : A[i][k] = inv[k][i]
+                    double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + lk;                          // row of inv(L_II)
+                        const double a = inv[I * 256 + lr * 16 + k];       // (L_II^-1)[k][lr]
+                        mfma_f64_16x16x4(a, r[kk], x);
+                    }
+                    tile_foreach(I, tj, N, [&](int reg, int row, int col) { Bm[col * LD + row] = x[reg]; });
+                }
+            }
+            wave_sync();   // the rows just written are operands of this wavefront's next block row
         }
-        block_sync();
     }
+    block_sync();
 }
 
 }  // namespace smrt
