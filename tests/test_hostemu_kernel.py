@@ -211,6 +211,29 @@ def test_emulated_active_kernel_high_azimuth_order(emu):
     assert_backscatter_close(out[0], ref, spread=oracle_method_spread(sp, 10e9, th, ref, **kw))
 
 
+@pytest.mark.parametrize("order", [0, 2])
+def test_emulated_big_pipeline_against_the_oracle(emu, order):
+    """The N > 128 pipeline (k_gmem_split_big.hip: CH = 4 row chunks, 512 threads) on a two-layer passive pair with 66
+    streams -- N = 132, nine blocks of 16 with a ragged last one: the grouped Gauss-Jordan updates (two blocks per pass,
+    last group of one), the LDS-staged operand tiles of the row-block products, the triangular product / solve with three
+    column tiles per wavefront, the solver scratch of whole 16 x 16 blocks -- under two fiber schedules."""
+    from oracle import dort_oracle as O
+
+    sp = dict(thickness=np.array([0.15, 20.0]), density=np.array([230.0, 380.0]), temperature=np.array([255.0, 268.0]),
+              microstructure="exponential", corr_length=np.array([2.2e-4, 0.9e-4]))
+    th = np.array([30.0, 50.0])
+    ref = O.solve(sp, 36.5e9, th, n_max_stream=66, method="schur_forcedtriu")
+    b = PackedBatch([2], sp["thickness"], sp["density"] / 916.7, sp["temperature"], sp["corr_length"], None, [36.5e9],
+                    np.deg2rad(th), emmodel="iba", microstructure="exponential", mode="P", n_max_stream=66)
+    out = np.empty((1,) + b.out_shape())
+    st = np.empty(1, np.int32)
+    nb = C.c_long()
+    rc = emu.smrt_emu_run(C.byref(b.struct), 0, 1, 256, order, out.ctypes.data_as(C.POINTER(C.c_double)),
+                          st.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, C.byref(nb))
+    assert rc == 0 and st[0] == 0
+    assert np.abs(out[0] - ref).max() < 1e-7
+
+
 def test_emulated_kernel_flags_albedo_above_one(emu):
     out, st, _ = run_fixture(emu, "dmrt_2layer_passive37")
     assert st[0] == 3 and np.isnan(out).all()
