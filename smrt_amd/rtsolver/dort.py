@@ -289,7 +289,8 @@ class DORT(object):
         device_name = "host" if host is not None else "iba" if scalars is not None else \
             (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
-            cols = np.stack([f[0] for f in facts], axis=1)      # (5, S, L)
+            # (5, S, L); one concatenate + reshape: np.stack reshapes every one of the S small arrays in Python first
+            cols = np.concatenate([f[0] for f in facts], axis=1).reshape(5, S, Lmax)
         else:
             cols = np.empty((5, S, Lmax))
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
