@@ -11,6 +11,7 @@ streams, interfaces, eigen-decomposition, boundary conditions) runs in the HIP k
 * `solve_plan(model, plan)` -- a whole `SimulationPlan` (smrt_amd/core/model.py): index vectors instead of pair
   objects, distinct snowpacks packed once, the stacked Result built from the output array without per-pair objects.
 """
+import operator
 import threading
 from collections.abc import Mapping
 
@@ -23,6 +24,10 @@ from ..core.foreign import result_factory
 from ..core.result import LabeledArray, make_result
 from ..core.snowpack import Snowpack, substrate_kind
 from ..interface.flat import Flat
+
+# the row blocks and the stacked columns of the last group that was packed (DORT._pack): a repeated Model.run on the same,
+# unchanged snowpacks copies the columns instead of stacking thousands of small arrays again
+_LAST_COLUMNS = [None]
 
 _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
 
@@ -163,11 +168,12 @@ class DORT(object):
         per_pack, distinct = [], set()
         simple_name = getattr(emmodel, "device_name", None) if simple else None
         simple_options = None
+        # (dense_snow_correction="auto" is checked layer by layer)
+        plain_model = simple and not is_sequence(all_options) and all_options.get("dense_snow_correction") != "auto"
         for sp in plan.snowpacks:
             f = sp.__dict__.get("_f") or sp.layer_facts()
             n = f[0].shape[1]
-            plain = (simple and not f[2] and not is_sequence(all_options)
-                     and all_options.get("dense_snow_correction") != "auto")   # (that option is checked layer by layer)
+            plain = plain_model and not f[2]
             if plain and simple_name is not None and simple_options is not None and not hasattr(sp, "source"):
                 # the common case -- one device emmodel, no per-layer settings, options already validated, smrt_amd's own
                 # layers (nothing the device could not compute): no per-layer work
@@ -289,8 +295,15 @@ class DORT(object):
         device_name = "host" if host is not None else "iba" if scalars is not None else \
             (emmodel_names if isinstance(emmodel_names, str) else emmodel_names[0][0])
         if int(nl.min()) == Lmax:
-            # (5, S, L); one concatenate + reshape: np.stack reshapes every one of the S small arrays in Python first
-            cols = np.concatenate([f[0] for f in facts], axis=1).reshape(5, S, Lmax)
+            # (5, S, L); one concatenate + reshape (np.stack reshapes every one of the S small arrays in Python first), and
+            # not even that when the row blocks are the very objects of the previous run (unchanged snowpacks keep theirs)
+            rows = [f[0] for f in facts]
+            kept = _LAST_COLUMNS[0]
+            if kept is not None and len(kept[0]) == S and all(map(operator.is_, rows, kept[0])):
+                cols = kept[1].copy()
+            else:
+                cols = np.concatenate(rows, axis=1).reshape(5, S, Lmax)
+                _LAST_COLUMNS[0] = (rows, cols.copy()) if S >= 256 else None
         else:
             cols = np.empty((5, S, Lmax))
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding

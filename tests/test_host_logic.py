@@ -999,3 +999,43 @@ def test_snowpack_caches_follow_in_place_changes():
     assert sp.all_interfaces_flat()
     sp.append(make_snow_layer(1.0, "exponential", density=400, temperature=273.15, corr_length=2e-4, volumetric_liquid_water=0.01), rough)
     assert sp.liquid_water()[3] > 0 and not sp.all_interfaces_flat()
+
+
+def test_packed_columns_of_a_repeated_run_follow_changed_snowpacks(emulated):
+    """DORT._pack keeps the stacked columns of the last group and copies them when a run comes with the very same,
+    unchanged snowpacks (rtsolver/dort.py: _LAST_COLUMNS): the next batch must be the same bytes, a layer changed in place
+    or a snowpack swapped must show in it, and the rows of the others must not move."""
+    import smrt_amd.rtsolver.dort as dort
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    emulated.compute = False   # host side only: the batches as packed
+    rng = np.random.default_rng(5)
+    S = 300
+    sps = [make_snowpack([0.1, 0.3, 20.0], "exponential", density=rng.uniform(200, 400, 3), temperature=rng.uniform(240, 270, 3),
+                         corr_length=rng.uniform(5e-5, 3e-4, 3)) for _ in range(S)]
+    sensor = sensor_list.passive([19e9, 37e9], 55.0)
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=8))
+    dort._LAST_COLUMNS[0] = None
+    cols = ("thickness", "frac_volume", "temperature", "micro_p1", "micro_p2")
+
+    def packed():
+        del emulated.batches[:]
+        m.run(sensor, sps, runner=HipBatchRunner())
+        b = emulated.batches[-1][0]
+        return {c: np.array(getattr(b, c), copy=True) for c in cols}
+
+    first = packed()
+    assert dort._LAST_COLUMNS[0] is not None and len(dort._LAST_COLUMNS[0][0]) == S
+    again = packed()                       # served from the kept columns
+    assert all(first[c].tobytes() == again[c].tobytes() for c in cols)
+    sps[7].layers[1].update(temperature=251.25)          # a layer changed in place
+    sps[200] = make_snowpack([0.5, 20.0, 30.0], "exponential", density=[310, 320, 330], temperature=[255, 256, 257], corr_length=1e-4)
+    third = packed()
+    assert third["temperature"][7, 1] == 251.25 and first["temperature"][7, 1] != 251.25
+    assert np.array_equal(third["thickness"][200], [0.5, 20.0, 30.0])
+    keep = np.ones(S, bool); keep[[7, 200]] = False
+    assert all(np.array_equal(third[c][keep], first[c][keep]) for c in cols)
+    fresh = dict(first)
+    dort._LAST_COLUMNS[0] = None
+    fresh = packed()                       # packed from scratch: the same bytes as with the kept columns
+    assert all(fresh[c].tobytes() == third[c].tobytes() for c in cols)
