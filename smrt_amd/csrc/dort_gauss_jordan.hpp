@@ -395,7 +395,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     if constexpr (CHN > 2 && SMRT_GJ_WIDE_BLOCKS > 1) {
     // ---- N > 128, matrices in the global workspace: the updates of SB = SMRT_GJ_WIDE_BLOCKS consecutive blocks are
     // applied to a column tile in ONE pass (rank 16 SB instead of SB passes of rank 16: the tile is read and written once
-    // per 64 eliminated columns -- at N = 384 the rank-16 passes moved ~85 MB per solve through HBM and ran at its
+    // per 16 SB eliminated columns -- at N = 384 the rank-16 passes moved ~85 MB per solve through HBM and ran at its
     // bandwidth).  The blocks of a group are factorised one after the other by one wavefront, each applied at once to
     // the group's OTHER column tiles only -- the live ones to its right and the dead ones to its left, whose multiplier
     // columns U_q thereby become T_k U_q: with T_k = I + U_k E_k^T (E_k^T = the pivot rows of block k),
