@@ -323,6 +323,9 @@ inline long smrt_emu_panels[2] = {0, 0};   // emulator builds count [0] fast and
 #ifndef SMRT_GJ_TILES_IN_FLIGHT
 #define SMRT_GJ_TILES_IN_FLIGHT 4
 #endif
+#ifndef SMRT_GJ_WIDE_TILES_IN_FLIGHT
+#define SMRT_GJ_WIDE_TILES_IN_FLIGHT 4   // row tiles in flight in a grouped pass (2 | 3 | 4 measured: 2297 / 2291 / 2261 ms)
+#endif
 #ifndef SMRT_GJ_WIDE_BLOCKS
 #define SMRT_GJ_WIDE_BLOCKS 2   // blocks of 16 columns whose updates are applied together when N > 128 (1: one by one; 2 | 3 | 4 measured)
 #endif
@@ -404,7 +407,7 @@ SMRT_DEV bool gj_solve_b16(double* A, double* Bm, double* v, const Lds& s, int N
     // they were BEFORE the group.  The group after the running one is factorised (look-ahead) by the wavefront that owns
     // it, after it has brought that group's tiles up to date.
     constexpr int SB = SMRT_GJ_WIDE_BLOCKS;
-    constexpr int PF1 = SMRT_GJ_TILES_IN_FLIGHT, PFW = 2;
+    constexpr int PF1 = SMRT_GJ_TILES_IN_FLIGHT, PFW = SMRT_GJ_WIDE_TILES_IN_FLIGHT;
     // blocks [kf, kf + nb) applied to the absolute column tile g of [A | B] (NB = capacity of the operand arrays)
     auto apply = [&](auto nbcap, int g, int kf, int nb) {
         constexpr int NB = decltype(nbcap)::value;
