@@ -282,6 +282,13 @@ double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
  * instrumented or the batch runs on a fused kernel.  Returns the number of intervals of the last launch, -1 on error. */
 int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* ms3);
 
+/* How the layer eigenproblems are diagonalised on the three-kernel pipelines -- the device counterpart of the reference's
+ * DORT option diagonalization_method (smrt/rtsolver/dort.py:614,821-962: eig / schur / half_rank_eig / stamnes88; all of them
+ * work on the squared problem, like SMRT_DIAG_SYMMETRIC).  mode: SMRT_DIAG_JACOBI, SMRT_DIAG_SYMMETRIC (wherever it is
+ * built: passive mode, streams x polarisations <= 64; other batches keep the Jacobi kernels), or -1: the default (SMRT_DIAG_SYMMETRIC;
+ * the environment variable SMRT_DORT_EIG=0 / 1 overrides it for experiments).  Takes effect at the next upload. */
+int32_t smrt_dort_set_diagonalisation(smrt_dort_ctx* ctx, int32_t mode);
+
 /* What the uploaded batch runs on, as numbers (tests assert the designed kernel choice with these instead of wall-clock
  * ratios): info[SMRT_INFO_*], at most n entries written; returns SMRT_INFO_COUNT, -1 on error.
  *   PIPELINE      SMRT_PIPELINE_*: the kernels a launch of this batch consists of
@@ -289,9 +296,12 @@ int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* m
  *   PRUNE_ROUNDS  layer ranges the prep + Jacobi kernels run over under prune_deep_snowpack (1: all layers at once)
  *   STAGED_ITEMS  (pair, azimuth mode, layer) items the LAST chunk of the last launch diagonalised -- known when the
  *                 staging counts are reset per chunk (prune rounds, process_coherent_layers), else -1; synchronises
- *   BLOCK_THREADS workgroup size of the per-pair kernels, N_MAX: padded matrix order (streams x polarisations) */
+ *   BLOCK_THREADS workgroup size of the per-pair kernels, N_MAX: padded matrix order (streams x polarisations)
+ *   DIAGONALISATION  SMRT_DIAG_*: what runs between the prep and the finish kernels of the three-kernel pipelines */
 enum { SMRT_INFO_PIPELINE = 0, SMRT_INFO_CHUNK_PAIRS, SMRT_INFO_CHUNKS, SMRT_INFO_PRUNE_ROUNDS, SMRT_INFO_STAGED_ITEMS,
-       SMRT_INFO_BLOCK_THREADS, SMRT_INFO_N_MAX, SMRT_INFO_COUNT };
+       SMRT_INFO_BLOCK_THREADS, SMRT_INFO_N_MAX, SMRT_INFO_DIAGONALISATION, SMRT_INFO_COUNT };
+enum { SMRT_DIAG_JACOBI = 0,      /* one-sided Jacobi on B = L+^T L- (singular values to high relative accuracy) */
+       SMRT_DIAG_SYMMETRIC = 1 }; /* Householder tridiagonalisation + implicit QL on S = B B^T (passive, N <= 64: the default) */
 enum { SMRT_PIPELINE_FUSED = 0,          /* one kernel per pair, matrices in LDS (N <= 64) */
        SMRT_PIPELINE_LDS_TWO_SLOT = 1,   /* prep + Jacobi + two-slot finish, matrices in LDS */
        SMRT_PIPELINE_LDS_FOUR_SLOT = 2,  /* ... with the four-slot finish kernel (set_pipeline(2)) */

@@ -296,6 +296,8 @@ def load_library():
     lib.smrt_dort_set_block_threads.restype = C.c_int32
     lib.smrt_dort_set_pipeline.argtypes = [C.c_void_p, C.c_int32]
     lib.smrt_dort_set_pipeline.restype = C.c_int32
+    lib.smrt_dort_set_diagonalisation.argtypes = [C.c_void_p, C.c_int32]
+    lib.smrt_dort_set_diagonalisation.restype = C.c_int32
     lib.smrt_dort_gather_plan.argtypes = [C.c_int32, C.c_int32, C.c_int32, P(C.c_int64), C.c_void_p, C.c_int32,
                                           P(C.c_int64), P(C.c_int64)]
     lib.smrt_dort_gather_plan.restype = C.c_int32
@@ -341,7 +343,7 @@ EXPORTED_SYMBOLS = [
     "smrt_dort_upload", "smrt_dort_upload_pairs", "smrt_dort_run_pairs", "smrt_dort_abi", "smrt_dort_pair_cost", "smrt_dort_ft_even_phase",
     "smrt_dort_launch_info", "smrt_dort_comm_library", "smrt_dort_comm_unique_id", "smrt_dort_comm_init", "smrt_dort_comm_init_all", "smrt_dort_comm_destroy", "smrt_dort_gather",
     "smrt_dort_comm_allreduce_max", "smrt_dort_launch", "smrt_dort_sync", "smrt_dort_download", "smrt_dort_last_kernel_ms", "smrt_dort_kernel_breakdown",
-    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
+    "smrt_dort_total_kernel_ms", "smrt_dort_set_block_threads", "smrt_dort_set_pipeline", "smrt_dort_set_diagonalisation", "smrt_dort_sum_n3", "smrt_dort_stage_cycles", "smrt_dort_device_count", "smrt_gauss_legendre_positive",
     "smrt_dort_version", "smrt_dort_finish_reg_lds_bytes", "smrt_dort_finish_strip_lds_bytes", "smrt_dort_jacobi_lds_bytes", "smrt_dort_gather_plan",
 ]
 
@@ -394,6 +396,14 @@ class DortContext:
         register-resident finish kernel instead (N <= 64); 5: the strip kernels wherever supported; 4: no pivot-free finish
         kernel; 2: the four-matrix LDS finish kernel; 0: one fused kernel per pair (include/smrt_dort.h)."""
         self._check(self._lib.smrt_dort_set_pipeline(self._h, int(split)), "smrt_dort_set_pipeline")
+
+    DIAGONALISATIONS = ("jacobi", "symmetric")   # SMRT_DIAG_*
+
+    def set_diagonalisation(self, mode="default"):
+        """How the layer eigenproblems are diagonalised on the three-kernel pipelines: "jacobi" (one-sided Jacobi on
+        B = L+^T L-), "symmetric" (tridiagonalisation + implicit QL on B B^T where it is built: N <= 64) or "default"."""
+        code = -1 if mode in (None, "default") else self.DIAGONALISATIONS.index(mode)
+        self._check(self._lib.smrt_dort_set_diagonalisation(self._h, code), "smrt_dort_set_diagonalisation")
 
     def run(self, batch: PackedBatch, pair_begin=0, pair_count=-1, pairs=None) -> BatchOutput:
         """One shot (H2D, kernels, D2H) for the pair range, or for the listed pair indices (row i = pairs[i])."""
@@ -470,9 +480,10 @@ class DortContext:
         v = (C.c_int64 * 16)()
         n = self._lib.smrt_dort_launch_info(self._h, v, 16)
         self._check(0 if n > 0 else -1, "smrt_dort_launch_info")
-        keys = ("pipeline", "chunk_pairs", "chunks", "prune_rounds", "staged_items", "block_threads", "n_max")
+        keys = ("pipeline", "chunk_pairs", "chunks", "prune_rounds", "staged_items", "block_threads", "n_max", "diagonalisation")
         d = {k: int(v[i]) for i, k in enumerate(keys[:n])}
         d["pipeline"] = self.PIPELINES[d["pipeline"]]
+        d["diagonalisation"] = self.DIAGONALISATIONS[d["diagonalisation"]]
         if d.get("staged_items", -1) < 0:
             d["staged_items"] = None
         return d

@@ -30,7 +30,7 @@ struct smrt_dort_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase, d_done, d_hostlayer, d_hostcoeff, d_hoststreams, d_hostphase, d_dispatch, d_regws, d_itfslot, d_itf, d_itfcoh, d_lw;
+    DevBuf d_nl, d_thick, d_fv, d_temp, d_p1, d_p2, d_freq, d_theta, d_gl, d_out, d_status, d_layer, d_stream, d_n3, d_stage, d_work, d_stL, d_stB, d_std, d_sts, d_stn, d_sti, d_sub1, d_sub2, d_subT, d_atm, d_pairmap, d_kind, d_phase, d_done, d_hostlayer, d_hostcoeff, d_hoststreams, d_hostphase, d_dispatch, d_regws, d_itfslot, d_itf, d_itfcoh, d_lw, d_ste, d_strot;
     smrt::DevBatch dev{};
     bool uploaded = false;
     int out_stride = 0;
@@ -68,6 +68,8 @@ struct smrt_dort_ctx {
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr;
     size_t jacobi_lds = 0;
+    int diag_mode = -1;         // smrt_dort_set_diagonalisation: -1 default, 0 Jacobi, 1 symmetric eigensolver where built
+    bool eig = false;           // this batch: the symmetric eigensolver (k_eig.hip) between prep and finish
     size_t jacobi16_lds = 0;    // 64 < N <= 128: LDS of the sixteen-wavefront Jacobi kernel (sixteen lanes per column pair), 0: it does not fit
     smrt::DevStage stage{};
     bool gmem_path = false;
@@ -103,6 +105,8 @@ hipError_t finish_strip(smrt_dort_ctx* ctx, const smrt::DevBatch& c);
 hipError_t finish_strip4(smrt_dort_ctx* ctx, const smrt::DevBatch& c);   // N <= 64: four wavefronts per pair
 // k_jacobi.hip: one workgroup per staging item (pair, [azimuth mode,] layer)
 hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
+// k_eig.hip: the symmetric eigensolver on the same items (N <= 64): tridiag, chase, vectors
+hipError_t eig(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_split_active.hip
 hipError_t active_prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
 hipError_t active_finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dort_ctx.hpp"
+#include "dort_eig_kernel.hpp"      // eig_rot_doubles
 #include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
 #include "dort_phase_kernel.hpp"
@@ -129,6 +130,7 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
             ctx->stage.L = stage0.L + it0 * stage0.mat_stride; ctx->stage.B = stage0.B + it0 * stage0.mat_stride;
             ctx->stage.d = stage0.d + it0 * stage0.vec_stride; ctx->stage.sigma = stage0.sigma + it0 * stage0.vec_stride;
             ctx->stage.n = stage0.n + it0; ctx->stage.Linv = stage0.Linv + it0 * stage0.linv_stride;
+            if (stage0.eig_rot) { ctx->stage.eig_e = stage0.eig_e + it0 * 2 * stage0.vec_stride; ctx->stage.eig_rot = stage0.eig_rot + it0 * stage0.rot_stride; }
             if (stage0.ws) ctx->stage.ws = stage0.ws + (long long)lane * ctx->chunk_pairs * rg::kSlotDoubles;
         }
         if (rounds > 1 || d.coherent) {   // unprocessed layers must read as "nothing staged", pairs as "not cut yet"
@@ -143,7 +145,7 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
             c.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
             if ((e = timed(0, [&]() { return prep(c, grid); })) != hipSuccess) return e;
             const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
-            if ((e = timed(1, [&]() { return ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems); })) != hipSuccess) return e;
+            if ((e = timed(1, [&]() { return ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : ctx->eig ? smrt_launch::eig(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems); })) != hipSuccess) return e;
             if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, done_lane)) != hipSuccess) return e;
         }
         c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
@@ -203,7 +205,7 @@ void smrt_dort_destroy(smrt_dort_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     DevBuf* bufs[] = {&ctx->d_nl, &ctx->d_thick, &ctx->d_fv, &ctx->d_temp, &ctx->d_p1, &ctx->d_p2, &ctx->d_freq,
                       &ctx->d_theta, &ctx->d_gl, &ctx->d_out, &ctx->d_status, &ctx->d_layer, &ctx->d_stream, &ctx->d_n3, &ctx->d_stage, &ctx->d_work,
-                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_regws, &ctx->d_itfslot, &ctx->d_itf, &ctx->d_itfcoh,
+                      &ctx->d_stL, &ctx->d_stB, &ctx->d_std, &ctx->d_sts, &ctx->d_stn, &ctx->d_sti, &ctx->d_ste, &ctx->d_strot, &ctx->d_regws, &ctx->d_itfslot, &ctx->d_itf, &ctx->d_itfcoh,
                       &ctx->d_sub1, &ctx->d_sub2, &ctx->d_subT, &ctx->d_atm, &ctx->d_pairmap, &ctx->d_kind, &ctx->d_hostlayer, &ctx->d_hoststreams, &ctx->d_hostphase, &ctx->d_dispatch, &ctx->d_phase, &ctx->d_done, &ctx->d_lw, &ctx->d_gather_out, &ctx->d_gather_status,
                       &ctx->d_scalar};
     for (DevBuf* b : bufs) b->release();
@@ -226,6 +228,14 @@ int32_t smrt_dort_set_pipeline(smrt_dort_ctx* ctx, int32_t split) {
     ctx->split = (split != 0);
     ctx->finish2 = (split != 2);
     ctx->finish_mode = (split == 3) ? 1 : (split == 4 ? 0 : (split == 5 ? 2 : -1));   // 3: register-resident finish wherever supported, 4: no pivot-free kernel, 5: strip kernels wherever supported
+    ctx->uploaded = false;  // the staging area is sized at upload time
+    return 0;
+}
+
+int32_t smrt_dort_set_diagonalisation(smrt_dort_ctx* ctx, int32_t mode) {
+    if (!ctx) return -1;
+    if (mode < -1 || mode > SMRT_DIAG_SYMMETRIC) { ctx->err = "unknown diagonalisation mode"; return -1; }
+    ctx->diag_mode = mode;
     ctx->uploaded = false;  // the staging area is sized at upload time
     return 0;
 }
@@ -374,6 +384,23 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->stage.n = (int*)ctx->d_stn.p; ctx->stage.Linv = ctx->big ? nullptr : (double*)ctx->d_sti.p;
         ctx->stage.linv_stride = linv_stride;
         ctx->stage.mat_stride = (long long)mat; ctx->stage.vec_stride = plan.NMAX;
+        // the symmetric eigensolver in place of the Jacobi kernel (N <= 64: the LDS pipelines): its tridiagonal forms and
+        // rotation lists (not counted in the staging budget above: 148 KB per item at N = 64 on top of the 67 KB of L+ and B)
+        {
+            int want = ctx->diag_mode < 0 ? SMRT_DIAG_SYMMETRIC : ctx->diag_mode;
+            if (const char* e = getenv("SMRT_DORT_EIG")) want = atoi(e) ? SMRT_DIAG_SYMMETRIC : SMRT_DIAG_JACOBI;
+            // (passive mode: the backscatter is a small difference of intensities and needs the singular vectors of the
+            // small singular values to the relative accuracy only the Jacobi iteration gives -- 3e-8 against 1e-8 relative
+            // on the cross-polarised fixture of test_emulated_active_kernel_high_azimuth_order)
+            ctx->eig = !ctx->gmem_path && !ctx->active && plan.NMAX <= 64 && want == SMRT_DIAG_SYMMETRIC;
+            ctx->stage.eig_e = nullptr; ctx->stage.eig_rot = nullptr; ctx->stage.rot_stride = 0;
+            if (ctx->eig) {
+                const long long rs = eig_rot_doubles(plan.NMAX);
+                HIPCHK(ctx->d_ste.reserve(items * 2 * plan.NMAX * sizeof(double)));
+                HIPCHK(ctx->d_strot.reserve(items * (size_t)rs * sizeof(double)));
+                ctx->stage.eig_e = (double*)ctx->d_ste.p; ctx->stage.eig_rot = (double*)ctx->d_strot.p; ctx->stage.rot_stride = rs;
+            }
+        }
         ctx->jacobi_lds = ctx->big ? (size_t)make_jacobi_big_plan(b->n_max_stream, P).total * sizeof(double)
                                    : (size_t)make_jacobi_plan(b->n_max_stream, P).total * sizeof(double);
         ctx->jacobi16_lds = 0;
@@ -709,6 +736,7 @@ int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
     }
     v[SMRT_INFO_BLOCK_THREADS] = ctx->nt;
     v[SMRT_INFO_N_MAX] = ctx->nmax_rows;
+    v[SMRT_INFO_DIAGONALISATION] = (three && ctx->eig) ? SMRT_DIAG_SYMMETRIC : SMRT_DIAG_JACOBI;
     for (int k = 0; k < n && k < SMRT_INFO_COUNT; ++k) info[k] = v[k];
     return SMRT_INFO_COUNT;
 }

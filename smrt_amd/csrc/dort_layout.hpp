@@ -81,6 +81,10 @@ struct DevStage {
     double* Linv;          // [item][linv_stride] inverses of the 16x16 diagonal blocks of L+, 256 doubles each (written by the prep kernel)
     double* ws;            // [pair][4096] one 64 x 64 matrix per pair (register-resident finish kernel), or null
     int linv_stride;       // 1024 (N <= 64: four blocks) or 2048 (64 < N <= 128: eight blocks)
+    // the symmetric eigensolver (dort_eig_kernel.hpp), or null / 0: the Jacobi kernel diagonalises
+    double* eig_e;         // [item][2 * vec_stride] off-diagonal of the tridiagonal form (+ the scale), then the tau of the reflectors
+    double* eig_rot;       // [item][rot_stride] the plane rotations of the QL iterations
+    long long rot_stride;
 };
 
 // index into the flattened (frequency-major) pair list of the batch for the p-th workgroup of a launch

@@ -1,0 +1,87 @@
+// The symmetric eigensolver of the N <= 64 pipelines (dort_eig_kernel.hpp): tridiag -> chase -> vectors in place of the
+// one-sided Jacobi kernel, on the same staging items (pair, [azimuth mode,] layer).
+#include <cstdlib>
+#include "dort_ctx.hpp"
+#include "dort_device.hpp"
+#include "dort_eig_kernel.hpp"
+
+using namespace smrt;
+
+// One wavefront per item; a launch holds the instantiations of the padded row counts of ITS size class (LO, HI] only, so
+// that the small items run with the registers (and, in tridiag, the LDS) of their own size; an item of another class
+// leaves at once (like dort_jacobi_kernel).
+#define SMRT_EIG_ROWS(NP_, CALL) \
+    if constexpr (LO < (NP_) && (NP_) - 8 < HI) if (rows <= (NP_)) { CALL; return; }
+
+template <int LO, int HI>
+__global__ __launch_bounds__(64) void dort_eig_tridiag_kernel(DevBatch b, DevStage st) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    const long long item = uniform(jacobi_item_of_block(b, (long long)blockIdx.x));
+    const int rows = uniform(st.n[item]);
+    if (rows <= LO || rows > HI) return;
+    SMRT_EIG_ROWS(8, (eig_tridiag_item<8>(st, item, smrt_lds))) SMRT_EIG_ROWS(16, (eig_tridiag_item<16>(st, item, smrt_lds)))
+    SMRT_EIG_ROWS(24, (eig_tridiag_item<24>(st, item, smrt_lds))) SMRT_EIG_ROWS(32, (eig_tridiag_item<32>(st, item, smrt_lds)))
+    SMRT_EIG_ROWS(40, (eig_tridiag_item<40>(st, item, smrt_lds))) SMRT_EIG_ROWS(48, (eig_tridiag_item<48>(st, item, smrt_lds)))
+    SMRT_EIG_ROWS(56, (eig_tridiag_item<56>(st, item, smrt_lds))) SMRT_EIG_ROWS(64, (eig_tridiag_item<64>(st, item, smrt_lds)))
+}
+
+template <int LO, int HI>
+__global__ __launch_bounds__(64) void dort_eig_vectors_kernel(DevBatch b, DevStage st) {
+    const long long item = uniform(jacobi_item_of_block(b, (long long)blockIdx.x));
+    const int rows = uniform(st.n[item]);
+    if (rows <= LO || rows > HI) return;
+    SMRT_EIG_ROWS(8, (eig_vectors_item<8>(st, item))) SMRT_EIG_ROWS(16, (eig_vectors_item<16>(st, item)))
+    SMRT_EIG_ROWS(24, (eig_vectors_item<24>(st, item))) SMRT_EIG_ROWS(32, (eig_vectors_item<32>(st, item)))
+    SMRT_EIG_ROWS(40, (eig_vectors_item<40>(st, item))) SMRT_EIG_ROWS(48, (eig_vectors_item<48>(st, item)))
+    SMRT_EIG_ROWS(56, (eig_vectors_item<56>(st, item))) SMRT_EIG_ROWS(64, (eig_vectors_item<64>(st, item)))
+}
+
+// one LANE per item: d and e of the 64 items of a wavefront in LDS, element i of lane t at [64 i + t]
+__global__ __launch_bounds__(64) void dort_eig_chase_kernel(DevBatch b, DevStage st, long long items) {
+    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
+    const long long blk = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (blk >= items) return;
+    const long long item = jacobi_item_of_block(b, blk);
+    if (st.n[item] <= 0) return;
+    const int nmax = st.vec_stride;
+    eig_chase_lane(st, item, smrt_lds + threadIdx.x, smrt_lds + 64 * nmax + threadIdx.x);
+}
+
+namespace smrt_launch {
+template <int LO, int HI>
+static hipError_t go_tridiag(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
+    constexpr int NPMAX = ((HI + 7) / 8) * 8;
+    const size_t lds = (size_t)eig_tridiag_lds_doubles<NPMAX>() * sizeof(double);
+    auto kern = dort_eig_tridiag_kernel<LO, HI>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(64), lds, ctx->stream, c, ctx->stage);
+    return hipGetLastError();
+}
+template <int LO, int HI>
+static hipError_t go_vectors(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
+    hipLaunchKernelGGL((dort_eig_vectors_kernel<LO, HI>), dim3((unsigned)items), dim3(64), 0, ctx->stream, c, ctx->stage);
+    return hipGetLastError();
+}
+
+// Size classes by row count: (0, 32], (32, 48], (48, 64] -- tridiag's LDS is 8.4 / 18.8 / 33.3 KB per wavefront, the register
+// rows of tridiag / vectors 64 / 96 / 128 registers.
+hipError_t eig(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
+    const int nmax = ctx->nmax_rows;
+    hipError_t e;
+    if ((e = go_tridiag<0, 32>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 32 && (e = go_tridiag<32, 48>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 48 && (e = go_tridiag<48, 64>(ctx, c, items)) != hipSuccess) return e;
+    {
+        const size_t lds = (size_t)2 * 64 * nmax * sizeof(double);
+        e = hipFuncSetAttribute((const void*)dort_eig_chase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(dort_eig_chase_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), lds, ctx->stream, c, ctx->stage, items);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if ((e = go_vectors<0, 32>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 32 && (e = go_vectors<32, 48>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 48 && (e = go_vectors<48, 64>(ctx, c, items)) != hipSuccess) return e;
+    return hipSuccess;
+}
+}  // namespace smrt_launch

@@ -11,12 +11,43 @@
 #include "../../smrt_amd/csrc/dort_phase_kernel.hpp"
 #include "../../smrt_amd/csrc/dort_finish_reg.hpp"
 #include "../../smrt_amd/csrc/dort_finish_strip.hpp"
+#include "../../smrt_amd/csrc/dort_eig_kernel.hpp"
 
 using namespace smrt;
 
 // 1: three-kernel pipeline with the two-slot finish kernel (default, like the library), 2: three-kernel pipeline with
 // the LDS-resident finish kernel, 3: ... with the register-resident finish kernel (passive, N <= 64), 0: fused kernel
 extern "C" { int smrt_emu_pipeline = 1; }
+// 1: the symmetric eigensolver (dort_eig_kernel.hpp) in place of the Jacobi kernel on the N <= 64 pipelines, like the library's default
+extern "C" { int smrt_emu_eig = 1; }
+
+// tridiag -> chase -> vectors on one staging item, as k_eig.hip launches them (one wavefront, one lane, one wavefront)
+template <int NP>
+static long run_eig_np(const DevStage& st, long long it, int order) {
+    long nb = 0;
+    std::vector<double> lds((size_t)eig_tridiag_lds_doubles<NP>(), NAN);
+    nb += emu::run_block(64, order, [&]() { eig_tridiag_item<NP>(st, it, lds.data()); });
+    if (st.n[it] <= 0) return nb;
+    std::vector<double> cl((size_t)2 * 64 * st.vec_stride, NAN);
+    nb += emu::run_block(64, order, [&]() { if (emu::tid() == 5) eig_chase_lane(st, it, cl.data() + 5, cl.data() + 64 * st.vec_stride + 5); });
+    if (st.n[it] <= 0) return nb;
+    nb += emu::run_block(64, order, [&]() { eig_vectors_item<NP>(st, it); });
+    return nb;
+}
+static long run_eig_item(const DevStage& st, long long it, int order) {
+    const int rows = st.n[it];
+    if (rows <= 0) return 0;
+    switch ((rows + 7) / 8) {
+        case 1: return run_eig_np<8>(st, it, order);
+        case 2: return run_eig_np<16>(st, it, order);
+        case 3: return run_eig_np<24>(st, it, order);
+        case 4: return run_eig_np<32>(st, it, order);
+        case 5: return run_eig_np<40>(st, it, order);
+        case 6: return run_eig_np<48>(st, it, order);
+        case 7: return run_eig_np<56>(st, it, order);
+        default: return run_eig_np<64>(st, it, order);
+    }
+}
 
 template <int NT, int CH>
 static long run_pairs(DevBatch& d, int order, size_t lds_doubles, size_t mat_doubles) {
@@ -48,13 +79,17 @@ static long run_active(DevBatch& d, int order, size_t lds_doubles, size_t mat_do
 // staged item, finish for every pair -- in up to four rounds over successive layer ranges with the pruning marks in
 // between when prune_deep_snowpack is set (the layers below a cut are never staged).
 struct Staging {
-    std::vector<double> L, B, d, sigma, inv, ws;
+    std::vector<double> L, B, d, sigma, inv, ws, eig_e, eig_rot;
     std::vector<int> n;
     DevStage st;
     Staging(size_t items, const LdsPlan& plan) : L(items * (size_t)plan.NMAX * plan.LD, NAN), B(L.size(), NAN), d(items * plan.NMAX, NAN),
                                                  sigma(items * plan.NMAX, NAN), inv(items * (plan.NMAX <= 64 ? 1024 : 2048), NAN), ws(plan.NMAX <= 128 ? items * 16384 : 0, NAN), n(items, -1) {
         st = DevStage{L.data(), B.data(), d.data(), sigma.data(), n.data(), (long long)plan.NMAX * plan.LD, plan.NMAX, plan.NMAX <= 128 ? inv.data() : nullptr, ws.data(),
                       plan.NMAX <= 64 ? 1024 : 2048};
+        if (plan.NMAX <= 64) {   // the symmetric eigensolver's own staging
+            eig_e.assign(items * 2 * plan.NMAX, NAN); eig_rot.assign(items * (size_t)eig_rot_doubles(plan.NMAX), NAN);
+            st.eig_e = eig_e.data(); st.eig_rot = eig_rot.data(); st.rot_stride = eig_rot_doubles(plan.NMAX);
+        }
     }
 };
 
@@ -142,6 +177,7 @@ static long run_split_big(DevBatch& d, int order, const LdsPlan& plan) {
 // The Jacobi stage of the N <= 64 pipelines as the library launches it (k_jacobi.hip): one pass per size class of
 // jacobi_classes over the item, each with the LDS layout of its class; an item outside the class leaves at once.
 static long run_jacobi_classes(DevBatch& d, const DevStage& st, long long it, int P, int order, std::vector<double>& jl) {
+    if (smrt_emu_eig && st.eig_rot && P == 2) return run_eig_item(st, it, order);   // passive mode only, like the library
     JacobiClass cls[4];
     const int n = jacobi_classes(d.n_max_stream * P, cls);
     long nb = 0;
@@ -329,6 +365,27 @@ extern "C" int smrt_emu_jacobi_big(int n_max_stream, int P, int N, double* Bm, d
     DevStage st{nullptr, Bm, nullptr, sigma, &n, (long long)jp.NMAX * jp.LD, jp.NMAX, nullptr};
     std::vector<double> jl(jp.total, NAN);
     emu::run_block(SMRT_JACOBI_BIG_NT, order, [&]() { dort_jacobi_big_item<SMRT_JACOBI_BIG_NT>(d, st, 0, jl.data()); });
+    return n;
+}
+
+// The symmetric eigensolver on one matrix: Bm is [N][LD] column-major with LD = (NMAX + 1) | 1, replaced by B' = U Sigma;
+// sigma [NMAX] out.  Returns N, or the negative status the kernels left in the staging slot.
+extern "C" int smrt_emu_eig_item(int NMAX, int N, double* Bm, double* sigma, int order, long long* n_rotations) {
+    int n = N;
+    std::vector<double> e((size_t)2 * NMAX, NAN), rot((size_t)eig_rot_doubles(NMAX), NAN);
+    DevStage st{nullptr, Bm, nullptr, sigma, &n, (long long)NMAX * ((NMAX + 1) | 1), NMAX, nullptr, nullptr, 1024, e.data(), rot.data(), eig_rot_doubles(NMAX)};
+    run_eig_item(st, 0, order);
+    if (n_rotations) {   // records of the list (identity padding included)
+        long long cnt = 0;
+        const double* list = rot.data();
+        while (n > 0) {
+            const int gt = ((const int*)list)[0], gb = ((const int*)list)[1];
+            if (gt < 0) break;
+            cnt += 4 * (gt - gb + 1);
+            list += 2 + 8 * (gt - gb + 1);
+        }
+        *n_rotations = cnt;
+    }
     return n;
 }
 
