@@ -86,7 +86,7 @@ def make_workload(config, rank, strong, n_snowpacks):
             metric="snowpack x frequency DORT solves/sec (20 layers, 32 streams)",
             what="BASELINE configs[1]: IBA + DORT passive, 20 layers, 32 streams, 5 AMSR-E channels (10.65-89 GHz, 55 deg), "
                  "%d synthetic snowpacks" % S,
-            kernel="dort pipeline = dort_prep_kernel + dort_jacobi_kernel (one launch per size class of items: <= 32 | 33-48 | 49-56 | 57-64 columns) + dort_finish_reg_kernel")
+            )
     if config == 2:
         S, L = n_snowpacks or 1024, 50
         arrays = synthetic_snowpacks(seed=3 if strong else 3 + rank, S=S, L=L, size_range=(5e-5, 1.5e-4))
@@ -98,7 +98,7 @@ def make_workload(config, rank, strong, n_snowpacks):
             metric="snowpack x frequency DORT solves/sec (50 layers, 64 streams)",
             what="BASELINE configs[2] shape: DMRT-QCA short-range + DORT passive, 50 layers, 64 streams, 7 AMSR2 frequencies "
                  "(stickiness 0.2), %d synthetic snowpacks" % S,
-            kernel="64 < N <= 128 pipeline = prep_gmem + jacobi<512> + finish_gmem<512>")
+            )
     if config == 3:
         S, L = n_snowpacks or 512, 30
         arrays = synthetic_snowpacks(seed=4 if strong else 4 + rank, S=S, L=L, thick_range=(0.02, 0.10), last=1000.0)
@@ -109,8 +109,35 @@ def make_workload(config, rank, strong, n_snowpacks):
             metric="snowpack x frequency DORT solves/sec (active, 30 layers, 128 streams, m_max 2)",
             what="BASELINE configs[3] shape: IBA + DORT active, Sentinel-1 C band (5.405 GHz, 20..45 deg), 30 layers, "
                  "128 streams, m_max 2, %d synthetic snowpacks" % S,
-            kernel="128 < N <= 384 pipeline = active_big prep + jacobi_big + active_big finish")
+            )
     raise SystemExit("bench.py: --config must be 1, 2 or 3")
+
+
+PIPELINE_KERNELS = {   # smrt_dort_launch_info's pipeline -> the kernels of a launch (prep, finish; the diagonalisation between them below)
+    "fused": ("dort_fused_kernel (everything of a pair in one workgroup)", None),
+    "lds_two_slot": ("dort_prep_kernel", "dort_finish2_kernel"),
+    "lds_four_slot": ("dort_prep_kernel", "dort_finish_kernel"),
+    "lds_reg": ("dort_prep_kernel", "dort_finish_reg_kernel"),
+    "lds_strip": ("dort_prep_kernel", "dort_finish_strip4_kernel"),
+    "fused_gmem": ("dort_fused_gmem_kernel (everything of a pair in one workgroup, global workspace)", None),
+    "gmem": ("dort_prep_kernel_gmem", "dort_finish_kernel_gmem"),
+    "gmem_strip": ("dort_prep_kernel_wide", "dort_finish_strip_kernel"),
+    "big": ("dort_passive_big_kernel / dort_active_big_kernel (prep)", "dort_passive_big_kernel / dort_active_big_kernel (finish)"),
+}
+DIAG_KERNELS = {
+    "jacobi": "dort_jacobi_kernel (one launch per size class of items; dort_jacobi_big_kernel above 128 rows)",
+    "symmetric": "dort_eig_gram_kernel + dort_eig_tridiag_kernel + dort_eig_chase_kernel + dort_eig_vectors_kernel "
+                 "(symmetric eigensolver of B B^T, one launch per size class)",
+}
+
+
+def describe_kernels(info):
+    """What a launch of the uploaded batch consists of, from smrt_dort_launch_info (not a hard-coded string)."""
+    prep, finish = PIPELINE_KERNELS[info["pipeline"]]
+    if finish is None:
+        return "pipeline '%s': %s" % (info["pipeline"], prep)
+    return "pipeline '%s': %s + %s + %s; %d pipeline pass(es) of <= %d pairs per launch" % (
+        info["pipeline"], prep, DIAG_KERNELS[info["diagonalisation"]], finish, info["chunks"], info["chunk_pairs"])
 
 
 # ---- CPU baseline ------------------------------------------------------------------------------------------------
@@ -204,7 +231,9 @@ def model_run_rate(thick, dens, temp, lc, reference_values, reps=3):
     build_s = time.perf_counter() - t0
     sensor = passive(list(FREQS), THETA_DEG)
     m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=N_STREAMS, devices=[int(os.environ.get("LOCAL_RANK", "0"))]))
+    t0 = time.perf_counter()
     res = m.run(sensor, sps)
+    first_ms = 1e3 * (time.perf_counter() - t0)
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -212,10 +241,41 @@ def model_run_rate(thick, dens, temp, lc, reference_values, reps=3):
         times.append(time.perf_counter() - t0)
     ms = 1e3 * float(np.median(times))
     same = bool(np.array_equal(res.data.values.reshape(reference_values.shape), reference_values))
-    return dict(value=len(sps) * len(FREQS) / (ms * 1e-3), unit="solves/s", ms=ms, bitwise_equal_to_c_abi_run=same,
+    return dict(value=len(sps) * len(FREQS) / (ms * 1e-3), unit="solves/s", ms=ms, repeated_run_ms=ms, first_run_ms=first_ms,
+                first_run_value=len(sps) * len(FREQS) / (first_ms * 1e-3), bitwise_equal_to_c_abi_run=same,
                 snowpack_objects_built_in_s=build_s,
-                what="make_model('iba','dort').run(passive(5 freqs), 1024 Snowpack objects) -> stacked Result, "
-                     "median of %d (objects built once, outside)" % reps)
+                what="make_model('iba','dort').run(passive(5 freqs), 1024 Snowpack objects) -> stacked Result: `first_run_ms` is "
+                     "the first call on fresh objects (context creation, packing and the device's buffer allocation included), "
+                     "`value` / `repeated_run_ms` the median of %d more calls on the same objects (built once, outside)" % reps)
+
+
+def other_config(config, n_snowpacks, steps, local_rank):
+    """A short driver-timed run of another BASELINE shape on its own context (inputs resident, like the headline)."""
+    from smrt_amd._native import DortContext
+
+    batch, _, desc = make_workload(config, 0, False, n_snowpacks)
+    ctx = DortContext(local_rank)
+    try:
+        ctx.upload(batch)
+        ctx.launch(); ctx.sync()      # warm-up (first-touch of the staging area)
+        ctx.total_kernel_ms(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.launch()
+        ctx.sync()
+        elapsed = time.perf_counter() - t0
+        kernel_ms_total, n_launch = ctx.total_kernel_ms()
+        res = ctx.download()
+        flops = FLOPS_PER_N3 * ctx.sum_n3()
+        kernel_ms = kernel_ms_total / max(n_launch, 1)
+        info = ctx.launch_info()
+        return dict(workload=desc["what"], value=batch.n_pairs * steps / elapsed, unit="solves/s", steps=steps, warmup=1,
+                    ms_per_step=1e3 * elapsed / steps, solves_per_step=batch.n_pairs, failed_solves=int((res.status != 0).sum()),
+                    roofline=dict(bound="mfma", achieved=flops / (kernel_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                                  frac=flops / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, kernel_ms=kernel_ms,
+                                  flops_per_launch=flops, kernel=describe_kernels(info)))
+    finally:
+        ctx.close()
 
 
 def spawn_ranks(n):
@@ -267,7 +327,8 @@ def main():
     ap.add_argument("--snowpacks", type=int, default=0, help="snowpacks per GPU (default 1024 / 1024 / 512 by --config)")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size of the per-pair kernels (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the pcie_inclusive / model_run measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the pcie_inclusive / model_run / other_configs measurements")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs[2] and configs[3] on the headline line")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {1: 20, 2: 5, 3: 3}.get(args.config, 20)
@@ -355,8 +416,15 @@ def main():
         per_rank = {"kernel_ms": [float(v) for v in allv[:world]], "pairs": [int(v) for v in allv[world:]]}
 
     # which kernel the time goes to: three more launches with an event pair around every kernel (outside the timed region)
+    res = ctx.download()
+    info = ctx.launch_info()
     per_kernel = None
     if not use_comm:
+        # (one pipeline pass at a time for this: the intervals of concurrent passes overlap and would not add up)
+        lanes_env = os.environ.get("SMRT_DORT_LANES")
+        os.environ["SMRT_DORT_LANES"] = "1"
+        ctx.upload(batch, lo, hi - lo)
+        ctx.launch(); ctx.sync()
         ctx.kernel_breakdown(True)
         acc = {"prep": 0.0, "jacobi": 0.0, "finish": 0.0}
         for _ in range(3):
@@ -365,9 +433,13 @@ def main():
             for k in acc:
                 acc[k] += bd[k] / 3.0
         ctx.kernel_breakdown(False)
+        if lanes_env is None:
+            del os.environ["SMRT_DORT_LANES"]
+        else:
+            os.environ["SMRT_DORT_LANES"] = lanes_env
+        ctx.upload(batch, lo, hi - lo)
         if sum(acc.values()) > 0:
-            per_kernel = {k: {"ms": v} for k, v in acc.items()}
-    res = ctx.download()
+            per_kernel = {"prep": {"ms": acc["prep"]}, "diagonalise": {"ms": acc["jacobi"]}, "finish": {"ms": acc["finish"]}}
     n_fail = int((res.status != 0).sum())
     if use_comm and rank == 0:
         n_fail = int((gathered[1] != 0).sum())
@@ -411,8 +483,9 @@ def main():
                 "failed_solves": n_fail,
                 "timed_region": "smrt_dort_launch of the resident batch (+ smrt_dort_gather when N > 1), "
                                 "barrier + stream sync on both sides, max over ranks",
-                "value_is": "the resident-input rate (inputs in HBM when the timed region starts); SURVEY 8(d)'s rate "
-                            "including H2D of the packed inputs and D2H of the results is `pcie_inclusive` of this line",
+                "value_is": "the resident-input rate (inputs in HBM when the timed region starts, as the bench contract asks); "
+                            "SURVEY 8(d)'s rate including H2D of the packed inputs and D2H of the results is `pcie_inclusive` "
+                            "of this line, the plugin surface end to end is `model_run`",
             },
             "roofline": {
                 "bound": "mfma",
@@ -428,12 +501,13 @@ def main():
                 "hbm": (None if traffic is None or kernel_ms <= 0 else
                         {"achieved": traffic / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}),
-                "kernel": desc["kernel"] + " (one launch each per step; kernel_ms is their summed HIP-event time on the "
-                                            "launch stream)",
+                "kernel": describe_kernels(info) + " (kernel_ms: HIP events around the whole launch on the context's stream)",
                 "per_rank": per_rank,
-                # HIP-event time per kernel kind (three instrumented launches after the timed region) with the share of the
-                # algorithmic flops SURVEY 8(d) books on it: assembly + Cholesky x 2 + B = L+^T L- ~ 2 N^3 (prep), the
-                # one-sided Jacobi ~ 25 N^3, eigenvector recovery + layer recursion ~ 41 N^3 (finish)
+                # HIP-event time per kernel kind (three instrumented launches after the timed region, ONE pipeline pass at a
+                # time -- the timed region may run several concurrently, so these need not add up to ms_per_step) with the
+                # share of the algorithmic flops SURVEY 8(d) books on it: assembly + Cholesky x 2 + B = L+^T L- ~ 2 N^3
+                # (prep), the diagonalisation ~ 25 N^3 (the reference's count, whatever algorithm runs), eigenvector
+                # recovery + layer recursion ~ 41 N^3 (finish)
                 "per_kernel": (None if per_kernel is None else
                                {k: dict(v, flop_share=fs, tflops=fs * flops_per_launch / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else None)
                                 for (k, v), fs in zip(per_kernel.items(), (2.0 / 68.0, 25.0 / 68.0, 41.0 / 68.0))}),
@@ -454,6 +528,11 @@ def main():
             line["cpu_baseline"] = cb
             line["config"]["max_abs_dTb_vs_oracle_K"] = err
         assert line["n_gpus"] == args.gpus
+        if world == 1 and headline and not args.no_secondary and not args.no_other_configs:
+            # the other two BASELINE shapes, timed by whoever runs this command (short: 2 steps of configs[2] at 1024
+            # snowpacks, 1 step of configs[3] at 512 -- their own contexts, this one's buffers released first)
+            ctx.close()
+            line["other_configs"] = {"2": other_config(2, 1024, 2, local_rank), "3": other_config(3, 512, 1, local_rank)}
         print(json.dumps(line), flush=True)
     if use_comm:
         ctx.barrier()

@@ -275,11 +275,14 @@ int32_t smrt_dort_download(smrt_dort_ctx* ctx, double* out, int32_t* status, dou
  * and accumulated over all launches since the last reset (count returned through n_launches). */
 double smrt_dort_last_kernel_ms(smrt_dort_ctx* ctx);
 
-/* Per-kernel HIP-event time of the three-kernel pipelines.  enable != 0: every prep / Jacobi / finish kernel launch of the
- * following smrt_dort_launch calls is bracketed by an event pair on its stream (a few microseconds per launch: for
- * measurement runs, not for the timed region of a benchmark).  ms3 != NULL: the intervals of the LAST launch summed per kind
- * -- ms3[0] prep, [1] Jacobi (all size classes), [2] finish -- after a stream synchronisation; zeros when that launch was not
- * instrumented or the batch runs on a fused kernel.  Returns the number of intervals of the last launch, -1 on error. */
+/* Per-kernel HIP-event time of the three-kernel pipelines.  enable > 0: every prep / diagonalisation / finish kernel launch
+ * of the following smrt_dort_launch calls is bracketed by an event pair on its stream (a few microseconds per launch: for
+ * measurement runs, not for the timed region of a benchmark); enable == 0: off; enable < 0: leave it as it is (read only).
+ * ms3 != NULL: the intervals of the LAST launch summed per kind -- ms3[0] prep, [1] diagonalisation (the Jacobi launches
+ * of all size classes, or the gram / tridiag / chase / vectors kernels of the symmetric eigensolver), [2] finish -- after a
+ * stream synchronisation; zeros when that launch was not instrumented or the batch runs on a fused kernel.  (With several
+ * concurrent pipeline passes the intervals of different passes overlap: the sums then exceed the wall time of the launch.)
+ * Returns the number of intervals of the last launch, -1 on error. */
 int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* ms3);
 
 /* How the layer eigenproblems are diagonalised on the three-kernel pipelines -- the device counterpart of the reference's

@@ -556,12 +556,13 @@ class DortContext:
 
     def kernel_breakdown(self, enable=None):
         """Per-kernel HIP-event times: kernel_breakdown(True) instruments the following launches, kernel_breakdown() returns
-        {"prep", "jacobi", "finish"} in ms for the last launch (include/smrt_dort.h)."""
+        {"prep", "jacobi", "finish"} in ms for the last launch ("jacobi": the diagonalisation stage, whichever kernels run
+        it -- include/smrt_dort.h)."""
         if enable is not None:
             self._check(min(self._lib.smrt_dort_kernel_breakdown(self._h, 1 if enable else 0, None), 0), "smrt_dort_kernel_breakdown")
             return None
         a = np.zeros(3)
-        n = self._lib.smrt_dort_kernel_breakdown(self._h, 1, _dptr(a))
+        n = self._lib.smrt_dort_kernel_breakdown(self._h, -1, _dptr(a))   # read only: the instrumentation stays as it is
         self._check(min(n, 0), "smrt_dort_kernel_breakdown")
         return {"prep": float(a[0]), "jacobi": float(a[1]), "finish": float(a[2]), "intervals": int(n)}
 

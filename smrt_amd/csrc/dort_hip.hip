@@ -315,6 +315,7 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     }
     ctx->nmax_rows = plan.NMAX;
     ctx->chunk_pairs = 0;
+    ctx->eig = false;
     // N > 128: the pipeline with the blocked Jacobi kernel (matrix in the staging area, column blocks through LDS)
     int big_min = 128;   // SMRT_DORT_BIG_MIN_N: experiments with the big pipeline on smaller matrices
     if (const char* e = getenv("SMRT_DORT_BIG_MIN_N")) big_min = std::max(64, atoi(e));
@@ -353,12 +354,25 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         if (one_per_cu && chunk >= 512) chunk -= chunk % 256;
         const long long chunk_cap = chunk;
         if (chunk > pair_count) chunk = pair_count;
+        // the symmetric eigensolver in place of the Jacobi kernel (smrt_dort_set_diagonalisation): passive mode, N <= 64.
+        // (Passive only: the backscatter is a small difference of intensities and needs the singular vectors of the small
+        // singular values to the relative accuracy only the Jacobi iteration gives -- 3e-8 against 1e-8 relative on the
+        // cross-polarised fixture of test_emulated_active_kernel_high_azimuth_order.)
+        {
+            int want = ctx->diag_mode < 0 ? SMRT_DIAG_SYMMETRIC : ctx->diag_mode;
+            if (const char* e = getenv("SMRT_DORT_EIG")) want = atoi(e) ? SMRT_DIAG_SYMMETRIC : SMRT_DIAG_JACOBI;
+            ctx->eig = !ctx->gmem_path && !ctx->active && plan.NMAX <= 64 && want == SMRT_DIAG_SYMMETRIC;
+        }
         ctx->lanes = 1;
         if (!ctx->gmem_path) {   // (the global-workspace pipelines share one per-workgroup workspace: one pass at a time)
-            int want = SMRT_DORT_LANES_DEFAULT;
+            // With the eigensolver, three concurrent passes by default: its chase kernel is a latency chain of two wavefronts
+            // per CU (64 KB of LDS each) that leaves the vector pipes to the tridiag / vectors kernels of the other passes --
+            // 160 k -> 169 k solves/s on the headline batch (profiles/r6_eig_steps.txt); the Jacobi pipeline gains nothing
+            // from it (round 4: profiles/r4_pipeline_lanes.txt)
+            int want = ctx->eig ? 3 : SMRT_DORT_LANES_DEFAULT;
             if (const char* e = getenv("SMRT_DORT_LANES")) want = atoi(e);
             ctx->lanes = std::max(1, std::min(4, want));
-            if (pair_count < 1024LL * ctx->lanes) ctx->lanes = 1;   // small batches: one pass fills the chip at most once
+            while (ctx->lanes > 1 && pair_count < 1024LL * ctx->lanes) --ctx->lanes;   // small batches: a pass should fill the chip
         }
         {   // equal chunks: a short last chunk would leave most of the chip idle for a whole pipeline pass
             long long nchunks = (pair_count + chunk - 1) / chunk;
@@ -387,12 +401,6 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         // the symmetric eigensolver in place of the Jacobi kernel (N <= 64: the LDS pipelines): its tridiagonal forms and
         // rotation lists (not counted in the staging budget above: 148 KB per item at N = 64 on top of the 67 KB of L+ and B)
         {
-            int want = ctx->diag_mode < 0 ? SMRT_DIAG_SYMMETRIC : ctx->diag_mode;
-            if (const char* e = getenv("SMRT_DORT_EIG")) want = atoi(e) ? SMRT_DIAG_SYMMETRIC : SMRT_DIAG_JACOBI;
-            // (passive mode: the backscatter is a small difference of intensities and needs the singular vectors of the
-            // small singular values to the relative accuracy only the Jacobi iteration gives -- 3e-8 against 1e-8 relative
-            // on the cross-polarised fixture of test_emulated_active_kernel_high_azimuth_order)
-            ctx->eig = !ctx->gmem_path && !ctx->active && plan.NMAX <= 64 && want == SMRT_DIAG_SYMMETRIC;
             ctx->stage.eig_e = nullptr; ctx->stage.eig_rot = nullptr; ctx->stage.rot_stride = 0;
             if (ctx->eig) {
                 const long long rs = eig_rot_doubles(plan.NMAX);
@@ -699,9 +707,12 @@ int32_t smrt_dort_kernel_breakdown(smrt_dort_ctx* ctx, int32_t enable, double* m
             ms3[ctx->bd_kind[k]] += ms;
         }
     }
-    ctx->breakdown_on = (enable != 0);
-    if (!ctx->breakdown_on) { ctx->bd_used = 0; ctx->bd_kind.clear(); }
-    return (int32_t)ctx->bd_kind.size();
+    const int32_t recorded = (int32_t)ctx->bd_kind.size();
+    if (enable >= 0) {   // (negative: read only, the instrumentation stays as it is)
+        ctx->breakdown_on = (enable != 0);
+        if (!ctx->breakdown_on) { ctx->bd_used = 0; ctx->bd_kind.clear(); }
+    }
+    return recorded;
 }
 
 int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {

@@ -12,28 +12,39 @@ using namespace smrt;
 // leaves at once (like dort_jacobi_kernel).
 #define SMRT_EIG_ROWS(NP_, CALL) \
     if constexpr (LO < (NP_) && (NP_) - 8 < HI) if (rows <= (NP_)) { CALL; return; }
+#define SMRT_EIG_ROWS16(NP_, CALL) \
+    if constexpr (LO < (NP_) && (NP_) - 16 < HI) if (rows <= (NP_)) { CALL; return; }
+
+template <int LO, int HI>
+__global__ __launch_bounds__(64) void dort_eig_gram_kernel(DevBatch b, DevStage st) {
+    const long long item = uniform(jacobi_item_of_block(b, (long long)blockIdx.x));
+    const int rows = uniform(eig_item_rows(b, st, item));
+    if (rows <= LO || rows > HI) return;
+    SMRT_EIG_ROWS16(16, (eig_gram_item<16>(st, item))) SMRT_EIG_ROWS16(32, (eig_gram_item<32>(st, item)))
+    SMRT_EIG_ROWS16(48, (eig_gram_item<48>(st, item))) SMRT_EIG_ROWS16(64, (eig_gram_item<64>(st, item)))
+}
 
 template <int LO, int HI>
 __global__ __launch_bounds__(64) void dort_eig_tridiag_kernel(DevBatch b, DevStage st) {
-    extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     const long long item = uniform(jacobi_item_of_block(b, (long long)blockIdx.x));
-    const int rows = uniform(st.n[item]);
+    const int rows = uniform(eig_item_rows(b, st, item));
     if (rows <= LO || rows > HI) return;
-    SMRT_EIG_ROWS(8, (eig_tridiag_item<8>(st, item, smrt_lds))) SMRT_EIG_ROWS(16, (eig_tridiag_item<16>(st, item, smrt_lds)))
-    SMRT_EIG_ROWS(24, (eig_tridiag_item<24>(st, item, smrt_lds))) SMRT_EIG_ROWS(32, (eig_tridiag_item<32>(st, item, smrt_lds)))
-    SMRT_EIG_ROWS(40, (eig_tridiag_item<40>(st, item, smrt_lds))) SMRT_EIG_ROWS(48, (eig_tridiag_item<48>(st, item, smrt_lds)))
-    SMRT_EIG_ROWS(56, (eig_tridiag_item<56>(st, item, smrt_lds))) SMRT_EIG_ROWS(64, (eig_tridiag_item<64>(st, item, smrt_lds)))
+    SMRT_EIG_ROWS(8, (eig_tridiag_item<8>(st, item))) SMRT_EIG_ROWS(16, (eig_tridiag_item<16>(st, item)))
+    SMRT_EIG_ROWS(24, (eig_tridiag_item<24>(st, item))) SMRT_EIG_ROWS(32, (eig_tridiag_item<32>(st, item)))
+    SMRT_EIG_ROWS(40, (eig_tridiag_item<40>(st, item))) SMRT_EIG_ROWS(48, (eig_tridiag_item<48>(st, item)))
+    SMRT_EIG_ROWS(56, (eig_tridiag_item<56>(st, item))) SMRT_EIG_ROWS(64, (eig_tridiag_item<64>(st, item)))
 }
 
 template <int LO, int HI>
 __global__ __launch_bounds__(64) void dort_eig_vectors_kernel(DevBatch b, DevStage st) {
+    __shared__ __attribute__((aligned(16))) double ring[2 * kEigRingSlots];
     const long long item = uniform(jacobi_item_of_block(b, (long long)blockIdx.x));
-    const int rows = uniform(st.n[item]);
+    const int rows = uniform(eig_item_rows(b, st, item));
     if (rows <= LO || rows > HI) return;
-    SMRT_EIG_ROWS(8, (eig_vectors_item<8>(st, item))) SMRT_EIG_ROWS(16, (eig_vectors_item<16>(st, item)))
-    SMRT_EIG_ROWS(24, (eig_vectors_item<24>(st, item))) SMRT_EIG_ROWS(32, (eig_vectors_item<32>(st, item)))
-    SMRT_EIG_ROWS(40, (eig_vectors_item<40>(st, item))) SMRT_EIG_ROWS(48, (eig_vectors_item<48>(st, item)))
-    SMRT_EIG_ROWS(56, (eig_vectors_item<56>(st, item))) SMRT_EIG_ROWS(64, (eig_vectors_item<64>(st, item)))
+    SMRT_EIG_ROWS(8, (eig_vectors_item<8>(st, item, ring))) SMRT_EIG_ROWS(16, (eig_vectors_item<16>(st, item, ring)))
+    SMRT_EIG_ROWS(24, (eig_vectors_item<24>(st, item, ring))) SMRT_EIG_ROWS(32, (eig_vectors_item<32>(st, item, ring)))
+    SMRT_EIG_ROWS(40, (eig_vectors_item<40>(st, item, ring))) SMRT_EIG_ROWS(48, (eig_vectors_item<48>(st, item, ring)))
+    SMRT_EIG_ROWS(56, (eig_vectors_item<56>(st, item, ring))) SMRT_EIG_ROWS(64, (eig_vectors_item<64>(st, item, ring)))
 }
 
 // one LANE per item: d and e of the 64 items of a wavefront in LDS, element i of lane t at [64 i + t]
@@ -42,20 +53,20 @@ __global__ __launch_bounds__(64) void dort_eig_chase_kernel(DevBatch b, DevStage
     const long long blk = (long long)blockIdx.x * 64 + threadIdx.x;
     if (blk >= items) return;
     const long long item = jacobi_item_of_block(b, blk);
-    if (st.n[item] <= 0) return;
+    if (eig_item_rows(b, st, item) <= 0) return;
     const int nmax = st.vec_stride;
     eig_chase_lane(st, item, smrt_lds + threadIdx.x, smrt_lds + 64 * nmax + threadIdx.x);
 }
 
 namespace smrt_launch {
 template <int LO, int HI>
+static hipError_t go_gram(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
+    hipLaunchKernelGGL((dort_eig_gram_kernel<LO, HI>), dim3((unsigned)items), dim3(64), 0, ctx->stream, c, ctx->stage);
+    return hipGetLastError();
+}
+template <int LO, int HI>
 static hipError_t go_tridiag(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
-    constexpr int NPMAX = ((HI + 7) / 8) * 8;
-    const size_t lds = (size_t)eig_tridiag_lds_doubles<NPMAX>() * sizeof(double);
-    auto kern = dort_eig_tridiag_kernel<LO, HI>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(64), lds, ctx->stream, c, ctx->stage);
+    hipLaunchKernelGGL((dort_eig_tridiag_kernel<LO, HI>), dim3((unsigned)items), dim3(64), 0, ctx->stream, c, ctx->stage);
     return hipGetLastError();
 }
 template <int LO, int HI>
@@ -69,6 +80,9 @@ static hipError_t go_vectors(smrt_dort_ctx* ctx, const DevBatch& c, long long it
 hipError_t eig(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
     const int nmax = ctx->nmax_rows;
     hipError_t e;
+    if ((e = go_gram<0, 32>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 32 && (e = go_gram<32, 48>(ctx, c, items)) != hipSuccess) return e;
+    if (nmax > 48 && (e = go_gram<48, 64>(ctx, c, items)) != hipSuccess) return e;
     if ((e = go_tridiag<0, 32>(ctx, c, items)) != hipSuccess) return e;
     if (nmax > 32 && (e = go_tridiag<32, 48>(ctx, c, items)) != hipSuccess) return e;
     if (nmax > 48 && (e = go_tridiag<48, 64>(ctx, c, items)) != hipSuccess) return e;

@@ -36,8 +36,9 @@ class DORT(object):
     """Discrete-ordinate and eigenvalue solver (Picard et al. 2018), device implementation.
 
     Arguments as smrt/rtsolver/dort.py:148-161.  `diagonalization_method` and `diagonalization_cache` are accepted for
-    compatibility: the device always uses its own symmetric reduction (every reference method agrees with it to
-    ~1e-11 K) and has nothing to cache.  `devices` (list of GPU indices, default: all visible ones for large batches)
+    compatibility: the device always uses its own symmetric reduction -- Cholesky + a symmetric eigensolver of B B^T
+    (passive mode up to 32 streams) or a one-sided Jacobi iteration on B (everything else); every reference method
+    agrees with it to ~1e-9 K -- and has nothing to cache.  `devices` (list of GPU indices, default: all visible ones for large batches)
     and `block_threads` are smrt_amd's own knobs."""
 
     _broadcast_capability = {"theta_inc", "polarization_inc", "theta", "phi", "polarization"}
@@ -62,7 +63,7 @@ class DORT(object):
             # not silently: 'stamnes88' in the reference differs from its other methods by up to ~1 K
             # (smrt/test/test_integration_iba.py atol table); the device has ONE route, equal to the default to 1e-8 K
             smrt_warn(f"diagonalization_method='{diagonalization_method}' is ignored: smrt_amd's DORT always diagonalises with "
-                      "its own symmetric reduction (Cholesky x 2 + one-sided Jacobi), which reproduces the reference's "
+                      "its own symmetric reduction (Cholesky + a symmetric eigensolver or a one-sided Jacobi iteration), which reproduces the reference's "
                       "default 'schur_forcedtriu'" + (" -- NOT the 'stamnes88' variant" if diagonalization_method == "stamnes88" else ""))
         if error_handling not in ("exception", "nan"):
             raise SMRTError("error_handling must be 'exception' or 'nan'")

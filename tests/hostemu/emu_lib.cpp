@@ -25,13 +25,15 @@ extern "C" { int smrt_emu_eig = 1; }
 template <int NP>
 static long run_eig_np(const DevStage& st, long long it, int order) {
     long nb = 0;
-    std::vector<double> lds((size_t)eig_tridiag_lds_doubles<NP>(), NAN);
-    nb += emu::run_block(64, order, [&]() { eig_tridiag_item<NP>(st, it, lds.data()); });
+    constexpr int NG = ((NP + 15) / 16) * 16;
+    nb += emu::run_block(64, order, [&]() { eig_gram_item<NG>(st, it); });
+    nb += emu::run_block(64, order, [&]() { eig_tridiag_item<NP>(st, it); });
     if (st.n[it] <= 0) return nb;
     std::vector<double> cl((size_t)2 * 64 * st.vec_stride, NAN);
     nb += emu::run_block(64, order, [&]() { if (emu::tid() == 5) eig_chase_lane(st, it, cl.data() + 5, cl.data() + 64 * st.vec_stride + 5); });
     if (st.n[it] <= 0) return nb;
-    nb += emu::run_block(64, order, [&]() { eig_vectors_item<NP>(st, it); });
+    std::vector<double> ring((size_t)2 * kEigRingSlots, NAN);
+    nb += emu::run_block(64, order, [&]() { eig_vectors_item<NP>(st, it, ring.data()); });
     return nb;
 }
 static long run_eig_item(const DevStage& st, long long it, int order) {
@@ -382,7 +384,7 @@ extern "C" int smrt_emu_eig_item(int NMAX, int N, double* Bm, double* sigma, int
             const int gt = ((const int*)list)[0], gb = ((const int*)list)[1];
             if (gt < 0) break;
             cnt += 4 * (gt - gb + 1);
-            list += 2 + 8 * (gt - gb + 1);
+            list += 2 + 32 * ((gt >> 2) - (gb >> 2) + 1);
         }
         *n_rotations = cnt;
     }

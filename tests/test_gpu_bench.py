@@ -52,10 +52,22 @@ def test_bench_single_gpu_line():
     # per-kernel HIP-event times of three instrumented launches behind the timed region (smrt_dort_kernel_breakdown): the three
     # kinds add up to the pipeline's own event time within launch gaps, and carry SURVEY 8(d)'s flop shares
     pk = d["roofline"]["per_kernel"]
-    assert set(pk) == {"prep", "jacobi", "finish"} and all(v["ms"] > 0 for v in pk.values())
+    assert set(pk) == {"prep", "diagonalise", "finish"} and all(v["ms"] > 0 for v in pk.values())
+    # (measured one pipeline pass at a time; the timed region runs up to three concurrently and is a few percent faster)
     total = sum(v["ms"] for v in pk.values())
-    assert 0.9 * d["roofline"]["kernel_ms"] < total <= 1.05 * d["roofline"]["kernel_ms"], (total, d["roofline"]["kernel_ms"])
+    assert 0.9 * d["roofline"]["kernel_ms"] < total <= 1.3 * d["roofline"]["kernel_ms"], (total, d["roofline"]["kernel_ms"])
     assert abs(sum(v["flop_share"] for v in pk.values()) - 1.0) < 1e-12
+    # the kernels named are the ones smrt_dort_launch_info reports for this batch
+    assert "dort_eig_tridiag_kernel" in d["roofline"]["kernel"] and "dort_finish_strip4_kernel" in d["roofline"]["kernel"]
+    # the other two BASELINE shapes, short runs in the same command
+    oc = d["other_configs"]
+    assert set(oc) == {"2", "3"}
+    for k, solves in (("2", 7168), ("3", 512)):
+        assert oc[k]["solves_per_step"] == solves and oc[k]["failed_solves"] == 0 and oc[k]["value"] > 0
+        assert 0.0 < oc[k]["roofline"]["frac"] < 1.0
+    assert "dort_finish_strip_kernel" in oc["2"]["roofline"]["kernel"] and "big" in oc["3"]["roofline"]["kernel"]
+    mr = d["model_run"]
+    assert mr["first_run_ms"] >= 0.9 * mr["repeated_run_ms"] > 0
 
 
 def test_bench_distributed_path_one_rank():
@@ -282,8 +294,11 @@ def test_kernel_breakdown_entry_point():
     ctx = DortContext(0)
     try:
         ctx.upload(b); ctx.launch(); ctx.sync()
-        off = ctx.kernel_breakdown()          # (reading also switches it on for the following launches)
+        off = ctx.kernel_breakdown()          # (reading leaves the instrumentation as it is: off)
         assert off["intervals"] == 0 and off["prep"] == off["jacobi"] == off["finish"] == 0.0
+        ctx.launch()
+        assert ctx.kernel_breakdown()["intervals"] == 0
+        ctx.kernel_breakdown(True)
         ctx.launch()
         on = ctx.kernel_breakdown()
         ctx.sync()
