@@ -528,7 +528,7 @@ def main():
             line["cpu_baseline"] = cb
             line["config"]["max_abs_dTb_vs_oracle_K"] = err
         assert line["n_gpus"] == args.gpus
-        if world == 1 and headline and not args.no_secondary and not args.no_other_configs:
+        if world == 1 and not use_comm and headline and not args.no_secondary and not args.no_other_configs:
             # the other two BASELINE shapes, timed by whoever runs this command (short: 2 steps of configs[2] at 1024
             # snowpacks, 1 step of configs[3] at 512 -- their own contexts, this one's buffers released first)
             ctx.close()
