@@ -429,11 +429,19 @@ def test_kernel_occupancy_as_designed():
             "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3,
             "dort_finish_reg_kernel": 1,   # one wavefront per SIMD by design: the whole register file
             # the strip finish kernels: eight wavefronts, one workgroup per CU / four wavefronts, three workgroups per CU
-            "dort_finish_strip_kernel": 2, "dort_finish_strip4_kernel": 3, "dort_prep_kernel_wide": 2}
+            "dort_finish_strip_kernel": 2, "dort_finish_strip4_kernel": 3, "dort_prep_kernel_wide": 2,
+            # the symmetric eigensolver (k_eig.hip), one wavefront per item and no scratch: the register rows of its largest
+            # size class (64 rows: 128 registers for the row alone) still leave two wavefronts per SIMD
+            "dort_eig_tridiag_kernel": 2, "dort_eig_vectors_kernel": 2, "dort_eig_gram_kernel": 2, "dort_eig_chase_kernel": 4}
     for key, minimum in want.items():
         hits = [v for k, v in waves.items() if key in k]
         assert hits, key
         assert min(hits) >= minimum, (key, hits)
+    scratch = {}
+    for f in files:
+        for blk in open(f).read().split(" Function Name: ")[1:]:
+            scratch[blk.split()[0]] = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+    assert all(v == 0 for k, v in scratch.items() if "dort_eig_" in k), {k: v for k, v in scratch.items() if "dort_eig_" in k}
     # the register-resident finish kernel must fit four wavefronts in the LDS of a CU at the headline shape (32 streams,
     # 20 layers): matrix slot + exchange vectors + tables <= 40 KB
     from smrt_amd import _native

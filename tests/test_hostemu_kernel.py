@@ -472,3 +472,79 @@ def test_emulated_rough_interfaces_under_prune_and_coherent_options(name, emulat
     from conftest import ROUGH_OPTION_CASES
 
     check_rough_option_case(name, ROUGH_OPTION_CASES[name])
+
+
+def _eig_item(emu, NMAX, N, A, order):
+    emu.smrt_emu_eig_item.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_longlong)]
+    LD = (NMAX + 1) | 1
+    buf = np.full((NMAX, LD), np.nan)
+    buf[:N, :N] = A.T                       # column c of the matrix at buf[c, :N]
+    sig = np.zeros(NMAX)
+    nrec = C.c_longlong()
+    rc = emu.smrt_emu_eig_item(NMAX, N, buf.ctypes.data_as(C.POINTER(C.c_double)), sig.ctypes.data_as(C.POINTER(C.c_double)), order,
+                               C.byref(nrec))
+    return rc, buf[:N, :N].T.copy(), sig[:N].copy(), nrec.value
+
+
+@pytest.mark.parametrize("NMAX,N,order", [(64, 48, 0), (64, 64, 1), (64, 57, 2), (64, 33, 1), (48, 40, 0), (21, 21, 2), (64, 7, 0),
+                                          (64, 3, 1), (64, 2, 0), (64, 1, 0)])
+def test_symmetric_eigensolver_kernels(emu, NMAX, N, order):
+    """The symmetric eigensolver of the N <= 64 pipelines (dort_eig_kernel.hpp: gram -> tridiag -> chase -> vectors, as
+    k_eig.hip launches them) on one matrix B: the columns it returns are B' = U Sigma with U the eigenvectors of B B^T --
+    orthonormal to rounding, the residual of the eigen-equation at rounding level, sigma the singular values of B --
+    whatever the order in which the emulated lanes run between their rendezvous, for every padded size and for staging
+    layouts whose leading dimension is not a multiple of eight."""
+    rng = np.random.default_rng(100 * NMAX + N)
+    A = rng.standard_normal((N, N)) @ np.diag(np.linspace(1, 30, N)) * 1e-3    # graded columns, small units
+    rc, Bp, sig, nrec = _eig_item(emu, NMAX, N, A, order)
+    assert rc == N
+    sv = np.linalg.svd(A, compute_uv=False)
+    U = Bp / sig[None, :]
+    assert np.abs(U.T @ U - np.eye(N)).max() < 2e-14
+    assert np.abs(A @ A.T @ U - U * sig[None, :] ** 2).max() < 5e-15 * sv.max() ** 2
+    # (the price of the squared problem: eps * condition^2 on the small singular values)
+    np.testing.assert_allclose(np.sort(sig)[::-1], sv, rtol=1e-16 * (sv.max() / sv.min()) ** 2 + 1e-13)
+    if N > 8:
+        assert 0.5 * N * N < nrec < 1.5 * N * N      # ~0.85 N^2 plane rotations + the identity padding of the groups
+
+
+def test_symmetric_eigensolver_on_degenerate_and_diagonal_matrices(emu):
+    """Inputs a QL iteration can stumble over: an exactly diagonal B (no scattering: every reflector is skipped, every
+    eigenvalue stands alone), exactly repeated singular values (V / H pairs of a non-scattering layer), a rank-one
+    perturbation of the identity, and singular values spread over eight decades."""
+    N, NMAX = 24, 32
+    rng = np.random.default_rng(3)
+    Q1, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    cases = {
+        "diagonal": np.diag(np.linspace(0.5, 40.0, N)),
+        "pairs": Q1 @ np.diag(np.repeat(np.linspace(1.0, 12.0, N // 2), 2)) @ Q2,
+        "rank one": np.eye(N) + 0.3 * np.outer(np.ones(N), np.ones(N)) / N,
+        "graded": Q1 @ np.diag(np.logspace(0, -4, N)) @ Q2,
+    }
+    for name, A in cases.items():
+        rc, Bp, sig, _ = _eig_item(emu, NMAX, N, A, 0)
+        assert rc == N, name
+        sv = np.linalg.svd(A, compute_uv=False)
+        U = Bp / sig[None, :]
+        assert np.abs(U.T @ U - np.eye(N)).max() < 2e-14, name
+        assert np.abs(A @ A.T @ U - U * sig[None, :] ** 2).max() < 1e-14 * sv.max() ** 2, name
+        np.testing.assert_allclose(np.sort(sig)[::-1], sv, rtol=0, atol=2e-15 * sv.max() ** 2 / sv.min(), err_msg=name)
+
+
+@pytest.mark.parametrize("name", ["iba_2layer_passive37", "iba_L6_n8_angles", "dmrt_L8_n16"])
+def test_jacobi_kernel_still_runs_the_passive_pipeline(emu, name):
+    """The one-sided Jacobi kernel stays the diagonalisation of active mode and of N > 64; with smrt_emu_eig = 0 (the
+    library's smrt_dort_set_diagonalisation(SMRT_DIAG_JACOBI)) it runs the passive N <= 64 pipeline too, and the two
+    diagonalisations agree far inside the parity bar."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 6
+    try:
+        sym, st_s, ref = run_fixture(emu, name)
+        C.c_int.in_dll(emu, "smrt_emu_eig").value = 0
+        jac, st_j, _ = run_fixture(emu, name)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_eig").value = 1
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st_s == 0).all() and (st_j == 0).all()
+    assert np.abs(sym - ref).max() < 1e-6 and np.abs(jac - ref).max() < 1e-6
+    assert np.abs(sym - jac).max() < 1e-8
