@@ -18,7 +18,11 @@ class Microstructure:
     def __setattr__(self, key, value):
         # every write bumps the object's own version: Snowpack's per-run caches (packed columns, microstructure set,
         # per-layer emmodel flag) compare the versions of THEIR layers, nobody else's
-        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
+        # (an object still under construction is in nobody's cache: its writes do not touch the process-wide count, so
+        # building more snowpacks leaves the caches of the existing ones on their fast path)
+        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+        if self.__dict__.get("_constructed"):
+            WRITES[0] += 1
         object.__setattr__(self, key, value)
 
     def __init__(self, name, frac_volume, **params):
@@ -26,6 +30,7 @@ class Microstructure:
         self.frac_volume = frac_volume
         for k, v in params.items():
             setattr(self, k, v)
+        object.__setattr__(self, "_constructed", True)
 
     @property
     def device_params(self):
@@ -110,11 +115,17 @@ class Layer:
         if key in READ_ONLY_AFTER_INIT and self.__dict__.get("_constructed"):
             raise SMRTError(f"The attribute '{key}' is read-only, setting it would make the layer inconsistent "
                             "(frac_volume derives from it). Use the update method instead: layer.update(density=...).")
-        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1); WRITES[0] += 1
+        constructed = self.__dict__.get("_constructed")
+        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+        if constructed:   # (writes of __init__: the object is in nobody's cache yet)
+            WRITES[0] += 1
         object.__setattr__(self, key, value)
         ms = self.__dict__.get("microstructure")
         if ms is not None and key in MICROSTRUCTURE_ARGS.get(self.__dict__.get("microstructure_model"), ()):
-            setattr(ms, key, float(value))
+            if constructed:
+                setattr(ms, key, float(value))
+            else:
+                object.__setattr__(ms, key, float(value))
 
     def __init__(self, thickness, microstructure_model, density, temperature=FREEZING_POINT, medium="snow",
                  liquid_water=None, volumetric_liquid_water=None, salinity=0, emmodel=None, emmodel_options=None,

@@ -12,6 +12,7 @@ the plan as a whole (`runner.run_plan`): it packs the distinct snowpacks once, l
 stacked result directly; any other runner is fed the reference's `(function, argument_list)` protocol and the per-pair
 results are nested afterwards by `nest_results`."""
 import inspect
+import threading
 from collections.abc import Mapping, Sequence
 from dataclasses import dataclass, field
 
@@ -195,6 +196,9 @@ class Model(object):
         else:
             self.emmodel = None if emmodel is None else make_emmodel(emmodel)
         self.rtsolver = import_class("rtsolver", rtsolver) if isinstance(rtsolver, str) else rtsolver
+        # [lock, (row blocks, stacked columns) of the last large run]: the batching rtsolver skips the concatenation of
+        # thousands of row blocks when a run meets the very objects of the previous one (rtsolver/dort.py:_pack)
+        self._kept_columns = [threading.Lock(), None]
         self.emmodel_options = self._checked_options(emmodel_options)
         self.rtsolver_options = dict(rtsolver_options or {})
 

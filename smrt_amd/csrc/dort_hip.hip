@@ -448,6 +448,9 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         ctx->finish_strip4 = false;
         {
             int want4 = (ctx->finish_mode == 2) ? 1 : (ctx->finish_mode == -1 ? -1 : 0);
+            // (an explicit SMRT_DORT_FINISH_REG=1 asks for the register-resident kernel: it is not to lose against this
+            // kernel's default -- ADVICE r5; SMRT_DORT_FINISH_STRIP4 still has the last word)
+            if (getenv("SMRT_DORT_FINISH_REG") && want == 1 && want4 == -1) want4 = 0;
             if (const char* e = getenv("SMRT_DORT_FINISH_STRIP4")) want4 = atoi(e) ? 1 : 0;
             const size_t lds4 = sizeof(double) * (size_t)finish_strip_lds_doubles(b->n_max_stream, b->n_layers_max, 4);
             const size_t cap4 = (want4 == 1) ? (size_t)64 * 1024 : (size_t)160 * 1024 / 3;

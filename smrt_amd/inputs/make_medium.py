@@ -97,4 +97,6 @@ def make_snowpack(thickness, microstructure_model, density, interface=None, surf
         sp.append(layer, interface=as_interface(itf))
     if sp.nlayer == 0:
         raise SMRTError("a snowpack needs at least one layer with a positive thickness")
-    return sp
+    sp.all_interfaces_flat()
+    sp.layer_facts()   # the per-layer columns the batching solver stacks, packed once here: a FIRST Model.run on a fresh
+    return sp          # ensemble costs what a repeated one does (the caches stand until one of these layers is written to)

@@ -27,7 +27,6 @@ from ..interface.flat import Flat
 
 # the row blocks and the stacked columns of the last group that was packed (DORT._pack): a repeated Model.run on the same,
 # unchanged snowpacks copies the columns instead of stacking thousands of small arrays again
-_LAST_COLUMNS = [None]
 
 _DIAG_METHODS = ("eig", "schur", "schur_forcedtriu", "half_rank_eig", "stamnes88")
 
@@ -141,17 +140,24 @@ class DORT(object):
         """The whole plan of a Model.run: returns the nested Result directly."""
         from ..core.model import nest_results
 
-        for sp in plan.snowpacks:   # (one freshness check per snowpack and run; the passes below read the attribute)
-            sp._f = sp.layer_facts()
-        names = self.emmodel_names(model, plan)
-        sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, names)
-        stacked = sol.stacked_result(plan)
+        # one freshness check per snowpack and run: the snapshot lives on THIS solver for the duration of the solve (never on
+        # the snowpack: a layer changed after the run must not meet a stale tuple in a later solve_batch / solve)
+        self._plan_facts = {id(sp): sp.layer_facts() for sp in plan.snowpacks}
+        self._plan_model = model
+        try:
+            names = self.emmodel_names(model, plan, self._plan_facts)
+            sol = self._solve_indexed(plan.sensors, plan.snowpacks, plan.sensor_index, plan.snowpack_index, names)
+            stacked = sol.stacked_result(plan)
+        finally:
+            self._plan_facts = self._plan_model = None
         if stacked is not None:
             return stacked
         return nest_results([sol.result(i) for i in range(len(plan))], plan.dimensions)
 
+    _plan_facts = _plan_model = None   # (set by solve_plan for the duration of one solve)
+
     @classmethod
-    def emmodel_names(cls, model, plan):
+    def emmodel_names(cls, model, plan, facts=None):
         """The emmodel of every layer as the device knows it, after the same checks the per-simulation route applies
         through Model.prepare_emmodels (per-layer overrides, lists / dicts of emmodels and emmodel options are honoured
         or refused, never dropped): one device name when all the layers of all the snowpacks share it, otherwise a list
@@ -172,7 +178,7 @@ class DORT(object):
         # (dense_snow_correction="auto" is checked layer by layer)
         plain_model = simple and not is_sequence(all_options) and all_options.get("dense_snow_correction") != "auto"
         for sp in plan.snowpacks:
-            f = sp.__dict__.get("_f") or sp.layer_facts()
+            f = (facts.get(id(sp)) if facts else None) or sp.layer_facts()
             n = f[0].shape[1]
             plain = plain_model and not f[2]
             if plain and simple_name is not None and simple_options is not None and not hasattr(sp, "source"):
@@ -250,7 +256,7 @@ class DORT(object):
             if len(bad) and self.error_handling == "exception":
                 st = int(out.status[bad[0]])
                 raise SMRTError(STATUS_MESSAGES.get(st, f"DORT failed with status {st}"))
-            sol.add_group(sel, out, sp0)
+            sol.add_group(sel, out, sp0, (u_packs, np.array(batch.n_layers, np.int64), np.array(batch.thickness, float)))
         return sol
 
     def _pack(self, sensor0, sps, freqs, emmodel_names, sensor_of=None):
@@ -258,7 +264,8 @@ class DORT(object):
         from .._native import EM_CODES, MS_CODES
 
         S = len(sps)
-        facts = [sp.__dict__.get("_f") or sp.layer_facts() for sp in sps]   # (packed, microstructures, overrides, liquid water)
+        known = self._plan_facts or {}
+        facts = [known.get(id(sp)) or sp.layer_facts() for sp in sps]   # (packed, microstructures, overrides, liquid water)
         nl = np.fromiter((f[0].shape[1] for f in facts), np.int32, S)
         Lmax = int(nl.max())
         # emmodel + 16 * microstructure per layer; handed to the device only when the batch really mixes them
@@ -298,13 +305,21 @@ class DORT(object):
         if int(nl.min()) == Lmax:
             # (5, S, L); one concatenate + reshape (np.stack reshapes every one of the S small arrays in Python first), and
             # not even that when the row blocks are the very objects of the previous run (unchanged snowpacks keep theirs)
+            # (kept on the MODEL of the run, behind its lock -- never process-wide: two models on two threads do not share a
+            # slot, and the arrays go when the model goes)
             rows = [f[0] for f in facts]
-            kept = _LAST_COLUMNS[0]
-            if kept is not None and len(kept[0]) == S and all(map(operator.is_, rows, kept[0])):
-                cols = kept[1].copy()
-            else:
+            keeper = getattr(self._plan_model, "_kept_columns", None) if S >= 256 else None
+            cols = None
+            if keeper is not None:
+                with keeper[0]:
+                    kept = keeper[1]
+                    if kept is not None and len(kept[0]) == S and all(map(operator.is_, rows, kept[0])):
+                        cols = kept[1].copy()
+            if cols is None:
                 cols = np.concatenate(rows, axis=1).reshape(5, S, Lmax)
-                _LAST_COLUMNS[0] = (rows, cols.copy()) if S >= 256 else None
+                if keeper is not None:
+                    with keeper[0]:
+                        keeper[1] = (rows, cols.copy())
         else:
             cols = np.empty((5, S, Lmax))
             cols[0], cols[1], cols[2], cols[3], cols[4] = 1.0, 0.3, 260.0, 1e-4, 0.2   # harmless padding
@@ -876,11 +891,15 @@ class _Solution:
         self.group_of = np.full(n, -1, np.int64)
         self.row_of = np.zeros(n, np.int64)
         self.outputs = []
+        self.columns = []
 
-    def add_group(self, sel, out, sp0):
+    def add_group(self, sel, out, sp0, columns=None):
         self.group_of[sel] = len(self.outputs)
         self.row_of[sel] = np.arange(len(sel))
         self.outputs.append(out)
+        # (snowpack indices of the group, their layer counts and thickness rows AS SOLVED: what the stacked diagnostics are
+        # built from when somebody asks later -- never the live objects, which may have changed since)
+        self.columns.append(columns)
 
     # -- labels ----------------------------------------------------------------------------------------------------
     @staticmethod
@@ -955,7 +974,10 @@ class _Solution:
         return make_result(sensor0, data, other_data=_LazyOther(lambda: self._stacked_other(out, order, lead, shape, sensor0)))
 
     def _stacked_other(self, out, order, lead, shape, sensor0):
-        nl = np.fromiter((sp.nlayer for sp in self.packs), np.int64, len(self.packs))[self.pack_idx]
+        u_packs, nl_solved, thick_solved = self.columns[0]
+        slot = np.full(len(self.packs), -1, np.int64)
+        slot[u_packs] = np.arange(len(u_packs))            # snowpack -> its row in the group's batch
+        nl = nl_solved[slot[self.pack_idx]]
         Lmax = int(nl.max())
         lay = out.layers[order][:, :Lmax].copy()
         lay[np.arange(Lmax)[None, :] >= nl[:, None]] = np.nan      # ragged packs: NaN below the last layer
@@ -964,10 +986,8 @@ class _Solution:
         def stack(values, name=None):
             return LabeledArray(values.reshape(shape + (Lmax,)), lead + layer_dim, name=name)
 
-        thick = np.full((len(self.packs), Lmax), np.nan)
-        for k, sp in enumerate(self.packs):
-            thick[k, :sp.nlayer] = sp.packed()[0]
-        thick_rows = thick[self.pack_idx]
+        thick_rows = thick_solved.reshape(len(u_packs), -1)[slot[self.pack_idx], :Lmax].copy()
+        thick_rows[np.arange(Lmax)[None, :] >= nl[:, None]] = np.nan
         if self.solver.process_coherent_layers:   # per simulation: the layers that were solved, top first, NaN after them
             code = np.nan_to_num(lay[:, :, 4])    # streams + 1024 x index in the input (include/smrt_dort.h)
             kept = code > 0

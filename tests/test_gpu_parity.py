@@ -24,12 +24,14 @@ def batch_from_fixture(d, freqs=None):
     return packed_batch_from_fixture(d, freqs)
 
 
-# The kernel shapes a batch can run through: (workgroup threads, pipeline).  Pipeline 1 = prep / Jacobi / finish (the
-# default: the register-resident finish kernel wherever it applies -- passive, N <= 64, Flat interfaces -- the two-slot
-# finish kernel elsewhere), 4 = the same with the two-slot finish kernel everywhere (so that it stays covered on the
-# passive fixtures), 0 = one fused kernel per pair; 64 threads = one wavefront per workgroup (every wavefront-level
-# assumption of the device code is exercised without a second wavefront to hide it).
-KERNEL_VARIANTS = [(256, 1), (64, 1), (256, 0), (64, 0), (256, 4)]
+# The kernel shapes a batch can run through: (workgroup threads, pipeline).  Pipeline 1 = prep / diagonalisation / finish with
+# the defaults (passive, N <= 64, Flat interfaces: the symmetric eigensolver and the strip finish kernel on four wavefronts;
+# the Jacobi kernel and the two-slot finish kernel elsewhere), 3 = the same with the register-resident finish kernel (the
+# default only where the strip kernel's LDS no longer lets three workgroups share a CU: ~106 ... 150 layers at 32 streams,
+# test_register_resident_finish_kernel_in_its_default_window), 4 = the two-slot finish kernel everywhere (so that it stays
+# covered on the passive fixtures), 0 = one fused kernel per pair; 64 threads = one wavefront per workgroup (every
+# wavefront-level assumption of the device code is exercised without a second wavefront to hide it).
+KERNEL_VARIANTS = [(256, 1), (64, 1), (256, 0), (64, 0), (256, 4), (256, 3)]
 
 
 def run_variant(ctx, batch, threads, pipeline):
@@ -1009,3 +1011,100 @@ def test_wet_weakly_scattering_media_on_the_other_pipelines(ctx):
                 err = max(err, float(np.abs(out.values[fi * S + s] - O.solve(sp, float(f), [25.0, 55.0], n_max_stream=n_stream)).max()))
         worst[(n_stream, pipeline)] = err
     assert max(worst.values()) < TB_TOL, worst
+
+
+@pytest.mark.parametrize("mode,n", [("P", 100), ("P", 150), ("A", 44)])
+def test_large_stream_counts_in_multi_pair_batches(ctx, mode, n):
+    """the N > 128 pipeline with NEIGHBOURS.  N = 200 and 300 (passive) and N = 132 (active) -- none a
+    multiple of 16, the sizes at which the solver scratch behind the work matrices used to overflow into the next
+    workgroup's workspace (fixed in round 5, found with an AddressSanitizer build of the emulator because every multi-pair
+    GPU test above 128 rows was at 256 / 384) -- with eight pairs in one call: every pair against the CPU oracle, a
+    sub-range and a scattered pair list bitwise equal to the rows of the full run."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(170 + n)
+    S, L = 4, 2
+    thick = np.column_stack([rng.uniform(0.05, 0.3, S), np.full(S, 20.0)])
+    dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
+    theta = np.array([30.0, 50.0])
+    freqs = [13.4e9, 17.2e9] if mode == "A" else [18.7e9, 36.5e9]
+    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad(theta), emmodel="iba",
+                    microstructure="exponential", mode=mode, n_max_stream=n, m_max=2)
+    full = ctx.run(b)
+    assert (full.status == 0).all(), full.status
+    assert ctx.launch_info()["pipeline"] == "big" and ctx.launch_info()["n_max"] == n * (3 if mode == "A" else 2)
+    part = ctx.run(b, pair_begin=3, pair_count=4)
+    assert np.array_equal(part.values, full.values[3:7])
+    pick = np.array([6, 1, 4])
+    scattered = ctx.run(b, pairs=pick)
+    assert np.array_equal(scattered.values, full.values[pick])
+    for f, fr in enumerate(freqs):
+        for s in range(S):
+            sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
+            kw = dict(mode=mode, theta_inc_deg=theta, n_max_stream=n, m_max=2)
+            ref = O.solve(sp, fr, theta, method="schur_forcedtriu", **kw)
+            if mode == "P":
+                assert np.abs(full.values[f * S + s] - ref).max() < TB_TOL
+            else:
+                assert_backscatter_close(full.values[f * S + s], ref,
+                                         spread=oracle_method_spread(sp, fr, theta, ref, methods=("half_rank_eig",), **kw))
+
+
+def test_register_resident_finish_kernel_in_its_default_window(ctx):
+    """The register-resident finish kernel (dort_finish_reg.hpp, one wavefront per pair) is the DEFAULT only where the strip
+    kernel's per-layer tables no longer let three of its workgroups share a CU: ~106 ... 150 layers at 32 streams.  Pinned
+    here at 120 layers: the pipeline chosen, and every pair against the oracle (elsewhere set_pipeline(3) selects it:
+    KERNEL_VARIANTS)."""
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(41)
+    S, L = 3, 120
+    thick = np.concatenate([rng.uniform(0.01, 0.05, (S, L - 1)), np.full((S, 1), 30.0)], axis=1)
+    dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
+    freqs = [18.7e9, 36.5e9]
+    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad([55.0]), n_max_stream=32)
+    out = ctx.run(b)
+    assert (out.status == 0).all(), out.status
+    info = ctx.launch_info()
+    assert info["pipeline"] == "lds_reg" and info["diagonalisation"] == "symmetric", info
+    shallow = PackedBatch([20] * S, thick[:, :20], dens[:, :20] / 916.7, temp[:, :20], lc[:, :20], None, freqs, np.deg2rad([55.0]), n_max_stream=32)
+    ctx.upload(shallow)
+    assert ctx.launch_info()["pipeline"] == "lds_strip"
+    for f, fr in enumerate(freqs):
+        for s in range(S):
+            sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
+            assert np.abs(out.values[f * S + s] - O.solve(sp, fr, [55.0], n_max_stream=32)).max() < TB_TOL
+
+
+def test_diagonalisation_choice_and_agreement(ctx):
+    """smrt_dort_set_diagonalisation: passive batches up to 32 streams run the symmetric eigensolver by default, active
+    ones and larger matrices the Jacobi kernels; forced to "jacobi" the same passive batch agrees with the default to
+    1e-8 K (both within 1e-6 K of the oracle: test_passive_golden runs the default on every fixture)."""
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(43)
+    S, L = 64, 6
+    thick = np.concatenate([rng.uniform(0.05, 0.3, (S, L - 1)), np.full((S, 1), 30.0)], axis=1)
+    dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
+    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, [10.65e9, 36.5e9, 89e9], np.deg2rad([55.0]), n_max_stream=32)
+    sym = ctx.run(b)
+    assert ctx.launch_info()["diagonalisation"] == "symmetric"
+    ctx.set_diagonalisation("jacobi")
+    try:
+        jac = ctx.run(b)
+        assert ctx.launch_info()["diagonalisation"] == "jacobi"
+    finally:
+        ctx.set_diagonalisation("default")
+    assert (sym.status == 0).all() and (jac.status == 0).all()
+    assert np.abs(sym.values - jac.values).max() < 1e-8
+    again = ctx.run(b)
+    assert np.array_equal(again.values, sym.values)          # deterministic, whatever ran in between
+    active = PackedBatch([L] * 4, thick[:4], dens[:4] / 916.7, temp[:4], lc[:4], None, [13.4e9], np.deg2rad([35.0]), mode="A",
+                         n_max_stream=16, m_max=2)
+    ctx.upload(active)
+    assert ctx.launch_info()["diagonalisation"] == "jacobi"
+    wide = PackedBatch([L] * 4, thick[:4], dens[:4] / 916.7, temp[:4], lc[:4], None, [36.5e9], np.deg2rad([55.0]), n_max_stream=40)
+    ctx.upload(wide)
+    assert ctx.launch_info()["diagonalisation"] == "jacobi"

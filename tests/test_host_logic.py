@@ -1010,10 +1010,9 @@ def test_snowpack_caches_follow_in_place_changes():
 
 
 def test_packed_columns_of_a_repeated_run_follow_changed_snowpacks(emulated):
-    """DORT._pack keeps the stacked columns of the last group and copies them when a run comes with the very same,
-    unchanged snowpacks (rtsolver/dort.py: _LAST_COLUMNS): the next batch must be the same bytes, a layer changed in place
-    or a snowpack swapped must show in it, and the rows of the others must not move."""
-    import smrt_amd.rtsolver.dort as dort
+    """DORT._pack keeps the stacked columns of the last group ON THE MODEL of the run and copies them when a run comes
+    with the very same, unchanged snowpacks (Model._kept_columns): the next batch must be the same bytes, a layer changed in
+    place or a snowpack swapped must show in it, and the rows of the others must not move."""
     from smrt_amd.runner.hip_batch_runner import HipBatchRunner
 
     emulated.compute = False   # host side only: the batches as packed
@@ -1023,7 +1022,7 @@ def test_packed_columns_of_a_repeated_run_follow_changed_snowpacks(emulated):
                          corr_length=rng.uniform(5e-5, 3e-4, 3)) for _ in range(S)]
     sensor = sensor_list.passive([19e9, 37e9], 55.0)
     m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=8))
-    dort._LAST_COLUMNS[0] = None
+    assert m._kept_columns[1] is None
     cols = ("thickness", "frac_volume", "temperature", "micro_p1", "micro_p2")
 
     def packed():
@@ -1033,7 +1032,8 @@ def test_packed_columns_of_a_repeated_run_follow_changed_snowpacks(emulated):
         return {c: np.array(getattr(b, c), copy=True) for c in cols}
 
     first = packed()
-    assert dort._LAST_COLUMNS[0] is not None and len(dort._LAST_COLUMNS[0][0]) == S
+    assert m._kept_columns[1] is not None and len(m._kept_columns[1][0]) == S
+    assert make_model("iba", "dort")._kept_columns[1] is None      # (another model has its own slot)
     again = packed()                       # served from the kept columns
     assert all(first[c].tobytes() == again[c].tobytes() for c in cols)
     sps[7].layers[1].update(temperature=251.25)          # a layer changed in place
@@ -1043,7 +1043,93 @@ def test_packed_columns_of_a_repeated_run_follow_changed_snowpacks(emulated):
     assert np.array_equal(third["thickness"][200], [0.5, 20.0, 30.0])
     keep = np.ones(S, bool); keep[[7, 200]] = False
     assert all(np.array_equal(third[c][keep], first[c][keep]) for c in cols)
-    fresh = dict(first)
-    dort._LAST_COLUMNS[0] = None
+    m._kept_columns[1] = None
     fresh = packed()                       # packed from scratch: the same bytes as with the kept columns
     assert all(fresh[c].tobytes() == third[c].tobytes() for c in cols)
+
+
+def test_a_layer_changed_after_a_run_shows_in_the_next_batch_of_every_route(emulated):
+    """Model.run used to leave its per-run snapshot of the layer columns ON the Snowpack, and the
+    per-simulation routes (DORT.solve_batch, the runner protocol) then packed the stale tuple.  The snapshot now lives on
+    the solver for the duration of one solve: after a run, a changed layer -- or an appended one -- is what every route
+    packs, and no route leaves anything but its own caches on the snowpack."""
+    from smrt_amd.rtsolver.dort import DORT
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    emulated.compute = False
+    sp = make_snowpack([0.1, 20.0], "exponential", density=[250, 350], temperature=[260.0, 265.0], corr_length=1e-4)
+    sensor = sensor_list.passive([19e9], 55.0)
+    m = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=8))
+    m.run(sensor, [sp], runner=HipBatchRunner())
+    assert "_f" not in sp.__dict__
+    sp.layers[0].temperature = 200.0
+    batch = DORT(n_max_stream=8)._pack(sensor, [sp], np.array([19e9]), "iba")
+    assert list(np.asarray(batch.temperature).reshape(-1)[:2]) == [200.0, 265.0]
+    del emulated.batches[:]
+    DORT(n_max_stream=8).solve_batch([(sensor, sp)], "iba")
+    assert np.asarray(emulated.batches[-1][0].temperature).reshape(-1)[0] == 200.0
+    from smrt_amd.inputs.make_medium import make_snow_layer
+    sp.append(make_snow_layer(0.5, "exponential", density=300, temperature=250.0, corr_length=2e-4))
+    del emulated.batches[:]
+    m.run(sensor, [sp], runner=HipBatchRunner())
+    b = emulated.batches[-1][0]
+    assert int(np.asarray(b.n_layers)[0]) == 3 and np.asarray(b.temperature).reshape(-1)[2] == 250.0
+
+
+def test_two_models_pack_on_two_threads(emulated):
+    """The kept columns are per Model and behind its lock (the process-wide slot raced): two models
+    packing different ensembles on two threads, again and again, always get their own rows."""
+    import threading
+
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    emulated.compute = False
+    rng = np.random.default_rng(9)
+    S = 300
+    sensor = sensor_list.passive([19e9], 55.0)
+    ens, models, errors = [], [], []
+    for k in range(2):
+        ens.append([make_snowpack([0.1, 20.0], "exponential", density=rng.uniform(200, 400, 2), temperature=[240.0 + k, 250.0 + k],
+                                  corr_length=rng.uniform(5e-5, 3e-4, 2)) for _ in range(S)])
+        models.append(make_model("iba", "dort", rtsolver_options=dict(n_max_stream=8)))
+
+    def work(k):
+        try:
+            from smrt_amd.rtsolver.dort import DORT
+            for _ in range(12):
+                r = DORT(n_max_stream=8)
+                r._plan_model = models[k]
+                b = r._pack(sensor, ens[k], np.array([19e9]), "iba")
+                t = np.asarray(b.temperature).reshape(S, 2)
+                if not (np.all(t[:, 0] == 240.0 + k) and np.all(t[:, 1] == 250.0 + k)):
+                    errors.append(k)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(m._kept_columns[1] is not None and len(m._kept_columns[1][0]) == S for m in models)
+
+
+def test_stacked_diagnostics_are_those_of_the_solve_not_of_later_edits(emulated):
+    """Result.other_data of a stacked result is built on first access -- from the layer counts and
+    thickness rows snapshotted AT SOLVE TIME (rtsolver/dort.py: _Solution.columns), not from the live Snowpack objects, which
+    a sensitivity loop changes between the run and the read (the reference builds other_data inside the solve,
+    smrt/rtsolver/rtsolver_utils.py:322-344)."""
+    from smrt_amd.inputs.make_medium import make_snow_layer
+    from smrt_amd.runner.hip_batch_runner import HipBatchRunner
+
+    sps = [make_snowpack([0.1, 0.3, 20.0], "exponential", density=[250, 300, 350], temperature=260.0, corr_length=1e-4),
+           make_snowpack([0.2, 10.0], "exponential", density=[250, 350], temperature=255.0, corr_length=2e-4)]
+    sensor = sensor_list.passive([19e9, 37e9], 55.0)
+    res = make_model("iba", "dort", rtsolver_options=dict(n_max_stream=8)).run(sensor, sps, runner=HipBatchRunner())
+    sps[0].layers[1].thickness = 7.0                       # edits AFTER the run, BEFORE the diagnostics are read
+    sps[1].append(make_snow_layer(0.5, "exponential", density=300, temperature=250.0, corr_length=2e-4))
+    th = np.asarray(res.other_data["thickness"].values)
+    assert th.shape[-1] == 3
+    assert np.array_equal(th[0, 0], [0.1, 0.3, 20.0]) and np.array_equal(th[1, 0], [0.1, 0.3, 20.0])
+    assert np.array_equal(th[0, 1, :2], [0.2, 10.0]) and np.isnan(th[0, 1, 2])

@@ -548,3 +548,26 @@ def test_jacobi_kernel_still_runs_the_passive_pipeline(emu, name):
     assert (st_s == 0).all() and (st_j == 0).all()
     assert np.abs(sym - ref).max() < 1e-6 and np.abs(jac - ref).max() < 1e-6
     assert np.abs(sym - jac).max() < 1e-8
+
+
+def test_emulator_under_address_sanitizer():
+    """The device source under an AddressSanitizer build of the emulator (tests/hostemu/asan_cases.py): an active pair at
+    N = 132 on the N > 128 pipeline and the symmetric eigensolver on odd staging layouts.  No GPU test can see a write
+    into a NEIGHBOUR's workspace when there is no neighbour, or one that lands in padding; this build can (it found the
+    solver-scratch overflow of round 5 and, in round 6, a reflector column written past the leading dimension)."""
+    import sys
+
+    asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan_rt or not os.path.exists(asan_rt):
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    lib_path = os.path.join(EMU_DIR, "libsmrt_emu_asan.so")
+    csrc = os.path.join(ROOT, "smrt_amd", "csrc")
+    srcs = [os.path.join(EMU_DIR, "emu_lib.cpp"), os.path.join(EMU_DIR, "emu_runtime.hpp")] + sorted(
+        os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp"))
+    if not os.path.exists(lib_path) or any(os.path.getmtime(s) > os.path.getmtime(lib_path) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-std=c++17", "-shared", "-fPIC", "-I", EMU_DIR, "-o", lib_path, srcs[0]])
+    env = dict(os.environ, LD_PRELOAD=asan_rt, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, os.path.join(EMU_DIR, "asan_cases.py"), lib_path], capture_output=True, text=True, env=env,
+                         timeout=1500)
+    assert out.returncode == 0 and out.stdout.strip().endswith("asan cases ok"), (out.stdout[-500:], out.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in out.stderr
