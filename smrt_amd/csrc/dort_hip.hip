@@ -432,12 +432,11 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
         if (const char* e = getenv("SMRT_DORT_FINISH_REG")) want = atoi(e) ? 1 : 0;
         ctx->finish_reg_lds_bytes = sizeof(double) * (size_t)finish_reg_lds_doubles(b->n_max_stream, b->n_layers_max);
         // (its per-layer tables grow with n_layers_max: beyond the LDS of a workgroup the two-slot kernel takes over)
-        // By DEFAULT only while at least three of its wavefronts share a CU (<= 160 KB / 3: four up to 40 KB = 40 layers at
-        // 32 streams, three up to ~140 layers -- 4/3 of 13.8 ms is still well ahead of the two-slot kernel's 27.5 ms on
-        // the headline shape); with two per CU (up to the 64 KB a workgroup may take) the two kernels tie, and the
-        // two-slot one is the default there; set_pipeline(3) / SMRT_DORT_FINISH_REG=1 still select it.  In
-        // practice the per-layer tables of the prep / two-slot kernels send a batch to the global-workspace pipeline
-        // before that limit is reached (32 streams: between 100 and 150 layers; test_gpu_bench.py).
+        // NOT a default anywhere since round 5: the strip kernel on four wavefronts below takes every batch this kernel
+        // supports while three of its workgroups share a CU (up to ~105 layers at 32 streams), and the per-layer tables of
+        // the full LDS plan send a batch to the global-workspace pipeline from 92 layers on (32 streams) -- before that.
+        // set_pipeline(3) / SMRT_DORT_FINISH_REG=1 select it (an independent second implementation of the pivot-free
+        // recursion: the hard-input sweeps compare the two; tests/test_gpu_parity.py KERNEL_VARIANTS).
         const size_t cap = (want == 1) ? (size_t)64 * 1024 : (size_t)160 * 1024 / 3;
         ctx->finish_reg = supported && ctx->finish_reg_lds_bytes <= cap &&
                           (want == 1 || (want == -1 && SMRT_FINISH_REG_DEFAULT));

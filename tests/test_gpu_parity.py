@@ -27,8 +27,8 @@ def batch_from_fixture(d, freqs=None):
 # The kernel shapes a batch can run through: (workgroup threads, pipeline).  Pipeline 1 = prep / diagonalisation / finish with
 # the defaults (passive, N <= 64, Flat interfaces: the symmetric eigensolver and the strip finish kernel on four wavefronts;
 # the Jacobi kernel and the two-slot finish kernel elsewhere), 3 = the same with the register-resident finish kernel (the
-# default only where the strip kernel's LDS no longer lets three workgroups share a CU: ~106 ... 150 layers at 32 streams,
-# test_register_resident_finish_kernel_in_its_default_window), 4 = the two-slot finish kernel everywhere (so that it stays
+# default nowhere any more -- an option and the second implementation the hard-input sweeps compare with,
+# test_register_resident_finish_kernel_is_an_option_not_a_default), 4 = the two-slot finish kernel everywhere (so that it stays
 # covered on the passive fixtures), 0 = one fused kernel per pair; 64 threads = one wavefront per workgroup (every
 # wavefront-level assumption of the device code is exercised without a second wavefront to hide it).
 KERNEL_VARIANTS = [(256, 1), (64, 1), (256, 0), (64, 0), (256, 4), (256, 3)]
@@ -1051,11 +1051,14 @@ def test_large_stream_counts_in_multi_pair_batches(ctx, mode, n):
                                          spread=oracle_method_spread(sp, fr, theta, ref, methods=("half_rank_eig",), **kw))
 
 
-def test_register_resident_finish_kernel_in_its_default_window(ctx):
-    """The register-resident finish kernel (dort_finish_reg.hpp, one wavefront per pair) is the DEFAULT only where the strip
-    kernel's per-layer tables no longer let three of its workgroups share a CU: ~106 ... 150 layers at 32 streams.  Pinned
-    here at 120 layers: the pipeline chosen, and every pair against the oracle (elsewhere set_pipeline(3) selects it:
-    KERNEL_VARIANTS)."""
+def test_register_resident_finish_kernel_is_an_option_not_a_default(ctx):
+    """where is the register-resident finish kernel (dort_finish_reg.hpp, one wavefront per pair) the
+    default?  Nowhere: the strip kernel on four wavefronts is the default while three of its workgroups share a CU (up to
+    ~105 layers at 32 streams), and the per-layer tables of the other LDS kernels send a batch to the global-workspace
+    pipeline from 92 layers on -- before that.  It stays as the opt-in set_pipeline(3) (KERNEL_VARIANTS runs every passive
+    fixture through it) and as the independent second implementation of the pivot-free recursion the hard-input sweeps
+    compare against.  Pinned here: the pipelines chosen at 20 / 90 / 120 layers, and pipeline 3 at 90 layers against
+    the oracle."""
     from oracle import dort_oracle as O
     from smrt_amd._native import PackedBatch
 
@@ -1064,17 +1067,26 @@ def test_register_resident_finish_kernel_in_its_default_window(ctx):
     thick = np.concatenate([rng.uniform(0.01, 0.05, (S, L - 1)), np.full((S, 1), 30.0)], axis=1)
     dens, temp, lc = rng.uniform(150, 450, (S, L)), rng.uniform(230, 270, (S, L)), rng.uniform(5e-5, 3e-4, (S, L))
     freqs = [18.7e9, 36.5e9]
-    b = PackedBatch([L] * S, thick, dens / 916.7, temp, lc, None, freqs, np.deg2rad([55.0]), n_max_stream=32)
-    out = ctx.run(b)
+
+    def batch(n_layers):
+        th = thick[:, :n_layers].copy(); th[:, -1] = 30.0
+        return th, PackedBatch([n_layers] * S, th, dens[:, :n_layers] / 916.7, temp[:, :n_layers], lc[:, :n_layers], None, freqs,
+                               np.deg2rad([55.0]), n_max_stream=32)
+
+    for n_layers, pipeline in ((20, "lds_strip"), (90, "lds_strip"), (120, "gmem")):
+        ctx.upload(batch(n_layers)[1])
+        assert ctx.launch_info()["pipeline"] == pipeline, (n_layers, ctx.launch_info())
+    th, b = batch(90)
+    ctx.set_pipeline(3)
+    try:
+        out = ctx.run(b)
+        assert ctx.launch_info()["pipeline"] == "lds_reg" and ctx.launch_info()["diagonalisation"] == "symmetric"
+    finally:
+        ctx.set_pipeline(1)
     assert (out.status == 0).all(), out.status
-    info = ctx.launch_info()
-    assert info["pipeline"] == "lds_reg" and info["diagonalisation"] == "symmetric", info
-    shallow = PackedBatch([20] * S, thick[:, :20], dens[:, :20] / 916.7, temp[:, :20], lc[:, :20], None, freqs, np.deg2rad([55.0]), n_max_stream=32)
-    ctx.upload(shallow)
-    assert ctx.launch_info()["pipeline"] == "lds_strip"
     for f, fr in enumerate(freqs):
         for s in range(S):
-            sp = dict(thickness=thick[s], density=dens[s], temperature=temp[s], microstructure="exponential", corr_length=lc[s])
+            sp = dict(thickness=th[s], density=dens[s, :90], temperature=temp[s, :90], microstructure="exponential", corr_length=lc[s, :90])
             assert np.abs(out.values[f * S + s] - O.solve(sp, fr, [55.0], n_max_stream=32)).max() < TB_TOL
 
 
