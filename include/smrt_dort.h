@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct smrt_dort_ctx smrt_dort_ctx;
 
@@ -435,6 +439,9 @@ int32_t smrt_dort_abi(int32_t* out, int32_t capacity);
 
 const char* smrt_dort_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

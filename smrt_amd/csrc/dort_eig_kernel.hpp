@@ -263,7 +263,7 @@ SMRT_DEV void eig_tridiag_item(const DevStage& stg, long long item) {
 }
 
 // ---- chase: implicit QL on the tridiagonal form, one lane per item ------------------------------------------------
-// dl / el: this lane's d and e in LDS, element i at [64 i] (conflict-free whatever index each lane is at).  (Measured
+// dl / el: this lane's d and e in LDS, element i at [kEigChaseLanes i] (conflict-free whatever index each lane is at).  (Measured
 // with d and e left in global memory instead -- every wavefront of a launch resident at once, loads a step ahead: 11.2
 // against 3.4 ms per 102 400 items; 64 lanes at 64 different indices are 64 cache lines per access.)
 // In: d, e, scale (tridiag).  Out: stg.sigma[item] = singular values sqrt(lambda / scale), and the rotation list
@@ -273,13 +273,18 @@ SMRT_DEV void eig_tridiag_item(const DevStage& stg, long long item) {
 // consumer works in whole groups); other slots of a chunk are never read.  A header with a negative gt ends the list.
 // The algorithm is EISPACK tql2 / LAPACK dsteqr's QL branch; the negligibility tests of an iteration are made while its
 // chase runs (every e[j] of the block is rewritten by it), so that no separate scan is needed afterwards.
+// (Measured with sixteen items per wavefront instead of 64, so that its 16 KB of LDS fit beside three workgroups of the
+// prep or finish kernel of ANOTHER pipeline pass on a CU: 3.62 against 3.38 ms alone and 165.3 k against 169.0 k solves/s
+// with three concurrent passes -- the overlap is not limited by the LDS the kernel holds.)
+constexpr int kEigChaseLanes = 64;
+
 SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, double* el) {
     const int n = stg.n[item];
     if (n <= 0) return;
     const int vs = stg.vec_stride;
     double* gd = stg.sigma + item * vs;
     const double* ge = stg.eig_e + item * 2 * vs;
-    for (int i = 0; i < n; ++i) { dl[64 * i] = gd[i]; el[64 * i] = (i < n - 1) ? ge[i] : 0.0; }
+    for (int i = 0; i < n; ++i) { dl[kEigChaseLanes * i] = gd[i]; el[kEigChaseLanes * i] = (i < n - 1) ? ge[i] : 0.0; }
     const double scale = ge[n - 1];
     double* rp = stg.eig_rot + item * stg.rot_stride;
     double* const rend = rp + stg.rot_stride - 2;   // room for the terminating header
@@ -295,8 +300,8 @@ SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, do
             if (mk < l) {
                 int mm = l;
                 while (mm < n - 1) {
-                    const double em = fabs(el[64 * (mm)]);
-                    if (em <= eps * (fabs(dl[64 * (mm)]) + fabs(dl[64 * ((mm + 1))]))) break;
+                    const double em = fabs(el[kEigChaseLanes * (mm)]);
+                    if (em <= eps * (fabs(dl[kEigChaseLanes * (mm)]) + fabs(dl[kEigChaseLanes * ((mm + 1))]))) break;
                     ++mm;
                 }
                 mk = mm;
@@ -312,41 +317,41 @@ SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, do
         if (rp + 2 * (1 + 16 * (ct - (l >> 4) + 1)) > rend) { fail = true; break; }
         double* const blk = rp + 2;   // first record slot of the block; column I at slot 16 (ct - I / 16) + I mod 16
         // -- Wilkinson shift from the leading 2 x 2 of the block
-        const double dl0 = dl[64 * (l)], el0 = el[64 * (l)];
-        double g = (dl[64 * ((l + 1))] - dl0) / (2.0 * el0);
+        const double dl0 = dl[kEigChaseLanes * (l)], el0 = el[kEigChaseLanes * (l)];
+        double g = (dl[kEigChaseLanes * ((l + 1))] - dl0) / (2.0 * el0);
         double r = sqrt(g * g + 1.0);
-        g = dl[64 * (m)] - dl0 + el0 / (g + (g >= 0.0 ? r : -r));
+        g = dl[kEigChaseLanes * (m)] - dl0 + el0 / (g + (g >= 0.0 ? r : -r));
         double s = 1.0, c = 1.0, p = 0.0;
-        double dip1 = dl[64 * (m)];    // d[i + 1] as it was before this iteration
+        double dip1 = dl[kEigChaseLanes * (m)];    // d[i + 1] as it was before this iteration
         double dfin = 0.0;           // d[i + 2] as this iteration leaves it
         int j1 = -1, j2 = -1;        // smallest / second smallest j in [l, m) whose e[j] is negligible after this iteration
         int bottom = l;
         bool underflow = false;
         double di = 0.0;
-        double en = el[64 * (m - 1)], dn = dl[64 * (m - 1)];   // requested a step ahead of their use
+        double en = el[kEigChaseLanes * (m - 1)], dn = dl[kEigChaseLanes * (m - 1)];   // requested a step ahead of their use
         for (int i = m - 1; i >= l; --i) {
             const double ei = en;
             di = dn;
-            if (i > l) { en = el[64 * (i - 1)]; dn = dl[64 * (i - 1)]; }
+            if (i > l) { en = el[kEigChaseLanes * (i - 1)]; dn = dl[kEigChaseLanes * (i - 1)]; }
             const double f = s * ei, b = c * ei;
             const double r2 = f * f + g * g;
             if (r2 == 0.0) {   // (tql2: recover from underflow)
-                dl[64 * ((i + 1))] = dip1 - p;
-                el[64 * (m)] = 0.0;
+                dl[kEigChaseLanes * ((i + 1))] = dip1 - p;
+                el[kEigChaseLanes * (m)] = 0.0;
                 bottom = i + 1;
                 underflow = true;
                 break;
             }
             const double rinv = fast_rsqrt(r2);
             r = r2 * rinv;
-            el[64 * ((i + 1))] = r;
+            el[kEigChaseLanes * ((i + 1))] = r;
             s = f * rinv;
             c = g * rinv;
             g = dip1 - p;
             const double rr2 = (di - g) * s + 2.0 * c * b;
             p = s * rr2;
             const double dnew = g + p;
-            dl[64 * ((i + 1))] = dnew;
+            dl[kEigChaseLanes * ((i + 1))] = dnew;
             g = c * rr2 - b;
             {
                 double* rec = blk + 2 * (16 * (ct - (i >> 4)) + (i & 15));
@@ -364,9 +369,9 @@ SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, do
         rp = blk + 2 * 16 * (ct - (gb >> 2) + 1);
         if (underflow) { mk = -1; continue; }   // (a fresh scan decides what the next block is)
         const double dlnew = di - p;
-        dl[64 * (l)] = dlnew;
-        el[64 * (l)] = g;
-        el[64 * (m)] = 0.0;
+        dl[kEigChaseLanes * (l)] = dlnew;
+        el[kEigChaseLanes * (l)] = g;
+        el[kEigChaseLanes * (m)] = 0.0;
         if (fabs(g) <= eps * (fabs(dlnew) + fabs(dfin))) { j2 = j1; j1 = l; }
         if (j1 == l) { ++l; mk = (j2 >= 0) ? j2 : m; }
         else if (j1 >= 0) mk = j1;
@@ -376,7 +381,7 @@ SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, do
         // singular values of B: sqrt(lambda / scale)
         const double rs = 1.0 / scale;
         for (int i = 0; i < n; ++i) {
-            const double lam = dl[64 * (i)] * rs;
+            const double lam = dl[kEigChaseLanes * (i)] * rs;
             if (!(lam > 0.0)) fail = true;
             gd[i] = sqrt(lam);
         }

@@ -47,15 +47,15 @@ __global__ __launch_bounds__(64) void dort_eig_vectors_kernel(DevBatch b, DevSta
     SMRT_EIG_ROWS(56, (eig_vectors_item<56>(st, item, ring))) SMRT_EIG_ROWS(64, (eig_vectors_item<64>(st, item, ring)))
 }
 
-// one LANE per item: d and e of the 64 items of a wavefront in LDS, element i of lane t at [64 i + t]
-__global__ __launch_bounds__(64) void dort_eig_chase_kernel(DevBatch b, DevStage st, long long items) {
+// one LANE per item: d and e of the kEigChaseLanes items of a wavefront in LDS, element i of lane t at [kEigChaseLanes i + t]
+__global__ __launch_bounds__(kEigChaseLanes) void dort_eig_chase_kernel(DevBatch b, DevStage st, long long items) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
-    const long long blk = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long blk = (long long)blockIdx.x * kEigChaseLanes + threadIdx.x;
     if (blk >= items) return;
     const long long item = jacobi_item_of_block(b, blk);
     if (eig_item_rows(b, st, item) <= 0) return;
     const int nmax = st.vec_stride;
-    eig_chase_lane(st, item, smrt_lds + threadIdx.x, smrt_lds + 64 * nmax + threadIdx.x);
+    eig_chase_lane(st, item, smrt_lds + threadIdx.x, smrt_lds + kEigChaseLanes * nmax + threadIdx.x);
 }
 
 namespace smrt_launch {
@@ -87,10 +87,10 @@ hipError_t eig(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
     if (nmax > 32 && (e = go_tridiag<32, 48>(ctx, c, items)) != hipSuccess) return e;
     if (nmax > 48 && (e = go_tridiag<48, 64>(ctx, c, items)) != hipSuccess) return e;
     {
-        const size_t lds = (size_t)2 * 64 * nmax * sizeof(double);
+        const size_t lds = (size_t)2 * kEigChaseLanes * nmax * sizeof(double);
         e = hipFuncSetAttribute((const void*)dort_eig_chase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(dort_eig_chase_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), lds, ctx->stream, c, ctx->stage, items);
+        hipLaunchKernelGGL(dort_eig_chase_kernel, dim3((unsigned)((items + kEigChaseLanes - 1) / kEigChaseLanes)), dim3(kEigChaseLanes), lds, ctx->stream, c, ctx->stage, items);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if ((e = go_vectors<0, 32>(ctx, c, items)) != hipSuccess) return e;

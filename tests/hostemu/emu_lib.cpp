@@ -29,8 +29,8 @@ static long run_eig_np(const DevStage& st, long long it, int order) {
     nb += emu::run_block(64, order, [&]() { eig_gram_item<NG>(st, it); });
     nb += emu::run_block(64, order, [&]() { eig_tridiag_item<NP>(st, it); });
     if (st.n[it] <= 0) return nb;
-    std::vector<double> cl((size_t)2 * 64 * st.vec_stride, NAN);
-    nb += emu::run_block(64, order, [&]() { if (emu::tid() == 5) eig_chase_lane(st, it, cl.data() + 5, cl.data() + 64 * st.vec_stride + 5); });
+    std::vector<double> cl((size_t)2 * kEigChaseLanes * st.vec_stride, NAN);
+    nb += emu::run_block(64, order, [&]() { if (emu::tid() == 5) eig_chase_lane(st, it, cl.data() + 5, cl.data() + kEigChaseLanes * st.vec_stride + 5); });
     if (st.n[it] <= 0) return nb;
     std::vector<double> ring((size_t)2 * kEigRingSlots, NAN);
     nb += emu::run_block(64, order, [&]() { eig_vectors_item<NP>(st, it, ring.data()); });
