@@ -397,12 +397,24 @@ SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, do
 // all the lanes by ONE 64-bit DPP move (row_newbcast, K a compile-time constant).
 struct EigChunk { double c, s; };   // this lane's record of a chunk of sixteen
 
-// the group G of four columns with the records of its chunk in registers
+// the group G of four columns: (c, s) from the chunk's records in registers by DPP moves (two vector instructions per
+// rotation on top of its four).  Measured and switched off (SMRT_EIG_LDS_BROADCAST=1 builds it): every other group reading
+// its records from the ring with ONE uniform-address ds_read_b128 each (no vector instruction, eight cycles of the CU's LDS
+// pipe) -- on paper the two pipes share the broadcasts, in the kernel 6.71 against 6.29 ms per 102 400 items.
+#ifndef SMRT_EIG_LDS_BROADCAST
+#define SMRT_EIG_LDS_BROADCAST 0
+#endif
 template <int NP, int G>
-SMRT_DEV void eig_group(double (&z)[NP], const EigChunk& ch) {
+SMRT_DEV void eig_group(double (&z)[NP], const EigChunk& ch, const double* ring, int chunk_slot) {
 #define SMRT_EIG_ROT(I) \
     if constexpr ((I) + 1 < NP) { \
-        const double cc = row_bcast16<(I) & 15>(ch.c), ss = row_bcast16<(I) & 15>(ch.s); \
+        double cc, ss; \
+        if constexpr (SMRT_EIG_LDS_BROADCAST && (G & 1) == 0) { \
+            const int slot = (chunk_slot + ((I) & 15)) & (kEigRingSlots - 1); \
+            cc = ring[2 * slot]; ss = ring[2 * slot + 1]; \
+        } else { \
+            cc = row_bcast16<(I) & 15>(ch.c); ss = row_bcast16<(I) & 15>(ch.s); \
+        } \
         const double t1 = ss * z[(I) + 1 < NP ? (I) : 0], t2 = ss * z[(I) + 1 < NP ? (I) + 1 : 0]; \
         z[(I) + 1 < NP ? (I) + 1 : 0] = fma(cc, z[(I) + 1 < NP ? (I) + 1 : 0], t1); \
         z[(I) + 1 < NP ? (I) : 0] = fma(cc, z[(I) + 1 < NP ? (I) : 0], -t2); \
@@ -414,13 +426,14 @@ SMRT_DEV void eig_group(double (&z)[NP], const EigChunk& ch) {
 template <int NP, int Q>
 SMRT_DEV void eig_chunk(double (&z)[NP], const double* ring, int base_slot, int ct, int gt, int gb, int l16) {
     if (Q <= ct && 4 * Q + 3 >= gb) {   // uniform: the iteration touches this chunk
-        const int slot = (base_slot + 16 * (ct - Q) + l16) & (kEigRingSlots - 1);
+        const int chunk_slot = base_slot + 16 * (ct - Q);
+        const int slot = (chunk_slot + l16) & (kEigRingSlots - 1);
         EigChunk ch;
         ch.c = ring[2 * slot]; ch.s = ring[2 * slot + 1];
-        if (4 * Q + 3 <= gt && 4 * Q + 3 >= gb) eig_group<NP, 4 * Q + 3>(z, ch);
-        if (4 * Q + 2 <= gt && 4 * Q + 2 >= gb) eig_group<NP, 4 * Q + 2>(z, ch);
-        if (4 * Q + 1 <= gt && 4 * Q + 1 >= gb) eig_group<NP, 4 * Q + 1>(z, ch);
-        if (4 * Q <= gt && 4 * Q >= gb) eig_group<NP, 4 * Q>(z, ch);
+        if (4 * Q + 3 <= gt && 4 * Q + 3 >= gb) eig_group<NP, 4 * Q + 3>(z, ch, ring, chunk_slot);
+        if (4 * Q + 2 <= gt && 4 * Q + 2 >= gb) eig_group<NP, 4 * Q + 2>(z, ch, ring, chunk_slot);
+        if (4 * Q + 1 <= gt && 4 * Q + 1 >= gb) eig_group<NP, 4 * Q + 1>(z, ch, ring, chunk_slot);
+        if (4 * Q <= gt && 4 * Q >= gb) eig_group<NP, 4 * Q>(z, ch, ring, chunk_slot);
     }
     if constexpr (Q > 0) eig_chunk<NP, Q - 1>(z, ring, base_slot, ct, gt, gb, l16);
 }
