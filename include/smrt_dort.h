@@ -304,9 +304,13 @@ int32_t smrt_dort_set_diagonalisation(smrt_dort_ctx* ctx, int32_t mode);
  *   STAGED_ITEMS  (pair, azimuth mode, layer) items the LAST chunk of the last launch diagonalised -- known when the
  *                 staging counts are reset per chunk (prune rounds, process_coherent_layers), else -1; synchronises
  *   BLOCK_THREADS workgroup size of the per-pair kernels, N_MAX: padded matrix order (streams x polarisations)
- *   DIAGONALISATION  SMRT_DIAG_*: what runs between the prep and the finish kernels of the three-kernel pipelines */
+ *   DIAGONALISATION  SMRT_DIAG_*: what runs between the prep and the finish kernels of the three-kernel pipelines
+ *   RAYLEIGH_CLOSED_FORM  1: the layers with a Rayleigh phase matrix (dmrt_qca_shortrange, dmrt_qcacp_shortrange,
+ *                 nonscattering, rayleigh-family host emmodels) of this batch skip Cholesky and the iteration: their azimuth
+ *                 mode 0 is "diagonal minus rank two" and is diagonalised in closed form (passive batches on the strip finish
+ *                 kernels; SMRT_DORT_RAYLEIGH=0 switches it off for experiments) */
 enum { SMRT_INFO_PIPELINE = 0, SMRT_INFO_CHUNK_PAIRS, SMRT_INFO_CHUNKS, SMRT_INFO_PRUNE_ROUNDS, SMRT_INFO_STAGED_ITEMS,
-       SMRT_INFO_BLOCK_THREADS, SMRT_INFO_N_MAX, SMRT_INFO_DIAGONALISATION, SMRT_INFO_COUNT };
+       SMRT_INFO_BLOCK_THREADS, SMRT_INFO_N_MAX, SMRT_INFO_DIAGONALISATION, SMRT_INFO_RAYLEIGH_CLOSED_FORM, SMRT_INFO_COUNT };
 enum { SMRT_DIAG_JACOBI = 0,      /* one-sided Jacobi on B = L+^T L- (singular values to high relative accuracy) */
        SMRT_DIAG_SYMMETRIC = 1 }; /* Householder tridiagonalisation + implicit QL on S = B B^T (passive, N <= 64: the default) */
 enum { SMRT_PIPELINE_FUSED = 0,          /* one kernel per pair, matrices in LDS (N <= 64) */

@@ -476,14 +476,16 @@ class DortContext:
 
     def launch_info(self):
         """smrt_dort_launch_info as a dict: pipeline (name), chunk_pairs, chunks, prune_rounds, staged_items (None when
-        unknown), block_threads, n_max."""
+        unknown), block_threads, n_max, diagonalisation (name), rayleigh_closed_form (bool)."""
         v = (C.c_int64 * 16)()
         n = self._lib.smrt_dort_launch_info(self._h, v, 16)
         self._check(0 if n > 0 else -1, "smrt_dort_launch_info")
-        keys = ("pipeline", "chunk_pairs", "chunks", "prune_rounds", "staged_items", "block_threads", "n_max", "diagonalisation")
+        keys = ("pipeline", "chunk_pairs", "chunks", "prune_rounds", "staged_items", "block_threads", "n_max", "diagonalisation",
+                "rayleigh_closed_form")
         d = {k: int(v[i]) for i, k in enumerate(keys[:n])}
         d["pipeline"] = self.PIPELINES[d["pipeline"]]
         d["diagonalisation"] = self.DIAGONALISATIONS[d["diagonalisation"]]
+        d["rayleigh_closed_form"] = bool(d.get("rayleigh_closed_form", 0))
         if d.get("staged_items", -1) < 0:
             d["staged_items"] = None
         return d

@@ -107,6 +107,8 @@ hipError_t finish_strip4(smrt_dort_ctx* ctx, const smrt::DevBatch& c);   // N <=
 hipError_t jacobi(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_eig.hip: the symmetric eigensolver on the same items (N <= 64): tridiag, chase, vectors
 hipError_t eig(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
+// k_rayleigh.hip: the layers with a Rayleigh phase matrix in closed form (passive; the other kernels skip them)
+hipError_t rayleigh(smrt_dort_ctx* ctx, const smrt::DevBatch& c, long long items);
 // k_split_active.hip
 hipError_t active_prep(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);
 hipError_t active_finish(smrt_dort_ctx* ctx, const smrt::DevBatch& c, int nt);

@@ -458,6 +458,9 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         const double* gL = stg.L + item * stg.mat_stride;
         const double* gB = stg.B + item * stg.mat_stride;
         const double* gI = stg.Linv + item * stg.linv_stride;
+        // a layer the Rayleigh kernel diagonalised (dort_rayleigh_kernel.hpp): the matrix slot holds A+ = D V itself and the
+        // vector slot 1 / D^2; A- = -D^-2 A+ Sigma, i.e. W = D^-2 A+ Sigma^2 element by element -- no L+, no triangular stage
+        const bool direct = stage_direct(stg.n[item]);   // (uniform)
         const bool in_e = t < N;
         SMRT_ST(STP_LOAD);
         // (LDS addresses: laundered once per layer, see make_lane; the lane coordinates too -- the row indices and diagonal
@@ -476,7 +479,7 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         // ---- L+ -> LDS (lower tiles, zero above the diagonal and beyond N); the inverses of its diagonal blocks into
         //      free tiles above the diagonal: block i in tile (i, i + 1), the last one in tile (0, 2).  Eight requests in
         //      flight per thread before the first store (a load per iteration waited for its own latency: 45 k cycles per layer).
-        {
+        if (!direct) {
             const int NP = 16 * nt;
             constexpr int CPP = NTH / kVecLen, U = 8;   // columns per pass of the workgroup, passes per batch
             const int r = t % kVecLen, cq = t / kVecLen;
@@ -545,6 +548,7 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         if (t < kVecLen) {
             E0[t] = nrs_e; E1[t] = sg_e; E2[t] = st_e; E3[t] = m3_e; E4[t] = di_e; E5[t] = d_e;
             E6[t] = c_e * di_e;                                    // c^ = D^-1 c
+            if (direct) E11[t] = in_e ? gI[t] : 0.0;               // 1 / D^2 (E11 is free until the first inversion is done)
         }
         block_sync();
         if (l == Lk - 1) {
@@ -559,6 +563,17 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         if (w < nt) {
 #pragma unroll
             for (int ti = 0; ti < NTT; ++ti) rg::mask_tile(X.v[ti], ti, w, ti < nt, lo);
+            if (direct) {
+                // X is A+ already; W = D^-2 A+ Sigma^2: element (16 ti + 4 r + g, 16 w + c) of this wavefront's tile column
+                const double sc = E1[16 * w + Ln.c];
+                const double s2c = sc * sc;
+#pragma unroll
+                for (int ti = 0; ti < NTT; ++ti)
+                    if (ti < nt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) At.v[ti][r] = X.v[ti][r] * (E11[16 * ti + 4 * r + Ln.g] * s2c);
+                    }
+            } else {
             strip_gemm<false, true>(At, X, nt, Lw);                         // W = L+ B'
             // ---- A+ = L+^-T B' in place: blocked back substitution with the diagonal-block inverses of the prep kernel
 #pragma unroll
@@ -579,6 +594,7 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X.v[ti][r] = u[r];
                 }
+            }
             }
             strip_matvec_t(X, E6, E8, nt, w, Ln);                           // A+^T c^ -> E8
             strip_matvec_t(At, E4, E9, nt, w, Ln);                          // W^T D^-1 1 -> E9  (x1 = A-^T D^-1 1 = -Sigma^-1 W^T D^-1 1)

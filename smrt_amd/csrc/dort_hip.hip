@@ -13,6 +13,7 @@
 
 #include "dort_ctx.hpp"
 #include "dort_eig_kernel.hpp"      // eig_rot_doubles
+#include "dort_rayleigh_kernel.hpp" // em_has_rayleigh_phase
 #include "dort_jacobi_big.hpp"      // make_jacobi_plan, make_jacobi_big_plan (templates only: nothing is instantiated here)
 #include "dort_host_common.hpp"
 #include "dort_phase_kernel.hpp"
@@ -145,7 +146,9 @@ static hipError_t launch_pipeline(smrt_dort_ctx* ctx, const DevBatch& d) {
             c.layer_hi = (int)((long long)d.Lmax * (r + 1) / rounds);
             if ((e = timed(0, [&]() { return prep(c, grid); })) != hipSuccess) return e;
             const long long jitems = cn * modes * (c.layer_hi - c.layer_lo);
-            if ((e = timed(1, [&]() { return ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : ctx->eig ? smrt_launch::eig(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems); })) != hipSuccess) return e;
+            if ((e = timed(1, [&]() { hipError_t e1 = ctx->big ? smrt_launch::jacobi_big(ctx, c, jitems) : ctx->eig ? smrt_launch::eig(ctx, c, jitems) : smrt_launch::jacobi(ctx, c, jitems);
+                                           if (e1 == hipSuccess && c.rayleigh_direct) e1 = smrt_launch::rayleigh(ctx, c, jitems);   // (its items leave the other kernels at once)
+                                           return e1; })) != hipSuccess) return e;
             if (r + 1 < rounds && (e = smrt_launch::prune_mark(ctx, c, done_lane)) != hipSuccess) return e;
         }
         c.layer_lo = 0; c.layer_hi = d.Lmax; c.pair_done = nullptr;
@@ -600,6 +603,14 @@ static int32_t upload_impl(smrt_dort_ctx* ctx, const smrt_batch* b, int64_t pair
     if (const char* e = getenv("SMRT_DORT_JACOBI_EXIT2")) d.jacobi_exit2 = atof(e);
     d.out = (double*)ctx->d_out.p; d.status = (int*)ctx->d_status.p; d.layer_out = (double*)ctx->d_layer.p;
     d.stream_out = (double*)ctx->d_stream.p; d.n3_out = (double*)ctx->d_n3.p; d.stage_out = (double*)ctx->d_stage.p;
+    // Layers with a Rayleigh phase matrix in closed form (dort_rayleigh_kernel.hpp) wherever a strip finish kernel reads the
+    // staging area -- it takes A+ = D V as it is -- and the batch can hold such layers; SMRT_DORT_RAYLEIGH=0: the Cholesky +
+    // Jacobi route for them too (A/B switch)
+    {
+        const bool may_hold = b->layer_kind != nullptr || em_has_rayleigh_phase(b->emmodel);
+        const char* e = getenv("SMRT_DORT_RAYLEIGH");
+        d.rayleigh_direct = (!ctx->active && (ctx->finish_strip || ctx->finish_strip4) && ctx->stage.Linv && may_hold && !(e && atoi(e) == 0)) ? 1 : 0;
+    }
     ctx->lds_bytes = lds;
     HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vector `gl` and the caller's arrays may go away
     ctx->uploaded = true;
@@ -750,6 +761,7 @@ int32_t smrt_dort_launch_info(smrt_dort_ctx* ctx, int64_t* info, int32_t n) {
     v[SMRT_INFO_BLOCK_THREADS] = ctx->nt;
     v[SMRT_INFO_N_MAX] = ctx->nmax_rows;
     v[SMRT_INFO_DIAGONALISATION] = (three && ctx->eig) ? SMRT_DIAG_SYMMETRIC : SMRT_DIAG_JACOBI;
+    v[SMRT_INFO_RAYLEIGH_CLOSED_FORM] = (three && d.rayleigh_direct) ? 1 : 0;
     for (int k = 0; k < n && k < SMRT_INFO_COUNT; ++k) info[k] = v[k];
     return SMRT_INFO_COUNT;
 }

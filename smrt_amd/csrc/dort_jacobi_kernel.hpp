@@ -386,7 +386,7 @@ SMRT_DEV void dort_jacobi_item(const DevBatch& b, const DevStage& stg, long long
 template <int NT>
 SMRT_DEV void dort_jacobi_item16(const DevBatch& b, const DevStage& stg, long long item, double* lds) {
     const int rows = stg.n[item];       // <= 0: nothing to do
-    if (rows <= 0) return;
+    if (rows <= 0 || rows > 128) return;   // (> 128: a layer the Rayleigh kernel diagonalises, dort_layout.hpp: kStageDirect)
     if (rows <= 16) { dort_jacobi_item_impl<NT, 1, 16>(b, stg, item, lds); return; }
     if (rows <= 32) { dort_jacobi_item_impl<NT, 2, 16>(b, stg, item, lds); return; }
     if (rows <= 48) { dort_jacobi_item_impl<NT, 3, 16>(b, stg, item, lds); return; }

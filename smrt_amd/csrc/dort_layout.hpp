@@ -5,6 +5,12 @@
 #include <math.h>
 #include <string.h>
 
+#if defined(SMRT_HOST_EMU)
+#define SMRT_HD_EARLY inline
+#else
+#define SMRT_HD_EARLY __host__ __device__ inline
+#endif
+
 namespace smrt {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -66,6 +72,10 @@ struct DevBatch {
     double* stream_out;
     double* n3_out;  // [pair_count] sum_l N_l^3 (work counter for the roofline)
     double* stage_out;  // [pair_count][16] shader cycles per stage (only written by -DSMRT_STAGE_TIMING builds)
+    // Layers with a Rayleigh phase matrix (DMRT-QCA short range, ...) skip Cholesky / B / the Jacobi sweeps: the prep kernel
+    // stages their scalars, dort_rayleigh_kernel.hpp diagonalises them in closed form and the strip finish kernels take
+    // A+ = D V as it is (host: only where a strip finish kernel consumes the staging area)
+    int rayleigh_direct;
 };
 
 // Staging area of the three-kernel pipeline (prep -> jacobi -> finish): per (pair, layer) the Cholesky factor L+,
@@ -86,6 +96,12 @@ struct DevStage {
     double* eig_rot;       // [item][rot_stride] the plane rotations of the QL iterations
     long long rot_stride;
 };
+
+// stg.n[item] of a layer diagonalised by the Rayleigh kernel: its row count + kStageDirect (the Jacobi / eigensolver
+// kernels see a count beyond their sizes and leave; the finish kernel reads the flag)
+constexpr int kStageDirect = 4096;
+SMRT_DEV int stage_rows(int n) { return n > 0 ? (n & (kStageDirect - 1)) : n; }
+SMRT_DEV bool stage_direct(int n) { return n > kStageDirect; }
 
 // index into the flattened (frequency-major) pair list of the batch for the p-th workgroup of a launch
 SMRT_DEV long long global_pair(const DevBatch& b, long long p) {
@@ -115,6 +131,8 @@ constexpr double kPi = 3.14159265358979323846;
 
 enum { EM_IBA = 0, EM_DMRT = 1, EM_QCACP = 2, EM_NONSCAT = 3, EM_HOST = 4, EM_IBA_INV = 5, EM_IBA_HOST = 6, EM_RAYLEIGH_HOST = 7 };  // 1-3 have a Rayleigh phase matrix; 4: host arrays;
 // 5: IBA on the inverted medium (layer_em); pair_setup files such a layer as EM_IBA once its coefficients are computed
+// emmodels whose azimuth mode 0 is the Rayleigh phase matrix (closed form in the prep kernel; dort_rayleigh_kernel.hpp)
+SMRT_HD_EARLY bool em_has_rayleigh_phase(int em) { return em == EM_DMRT || em == EM_QCACP || em == EM_NONSCAT || em == EM_RAYLEIGH_HOST; }
 enum { MS_EXP = 0, MS_SHS = 1, MS_SPHERE = 2, MS_TS = 3, MS_EXPC = 4, MS_SHSC = 5, MS_SPHEREC = 6, MS_TSC = 7 };   // 4 + model: the model at a complex wavenumber (smrt_dort.h)
 enum { ST_OK = 0, ST_EIGEN = 1, ST_NORM = 2, ST_ALBEDO = 3, ST_SINGULAR = 4, ST_INPUT = 5, ST_COHERENT = 6 };
 enum { SUB_NONE = 0, SUB_FLAT = 1, SUB_REFLECTOR = 2, SUB_HOST = 3 };

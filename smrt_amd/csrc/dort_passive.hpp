@@ -25,7 +25,7 @@ SMRT_DEV int pruned_layer_count(const DevStage& stg, long long item0, int L, con
     constexpr int NW = NT / SMRT_LANES;
     for (int l = wave; l < L; l += NW) {
         const long long item = item0 + l;
-        const int N = stg.n[item];   // < 0: the diagonalisation of this layer failed (see first_failed_layer)
+        const int N = stage_rows(stg.n[item]);   // < 0: the diagonalisation of this layer failed (see first_failed_layer)
         double m = 1e300;
         for (int r = lane; r < N; r += SMRT_LANES) {
             const double sg = stg.sigma[item * stg.vec_stride + r];
@@ -66,7 +66,7 @@ SMRT_DEV void prune_mark_pair(const DevBatch& b, const DevStage& stg, long long 
         bool cut = false;
         for (int l = 0; l < upto && !cut; ++l) {   // uniform over the wavefront
             const long long item = (p * nmodes + m) * b.Lmax + l;
-            const int N = stg.n[item];
+            const int N = stage_rows(stg.n[item]);
             if (N < 0) { cut = true; break; }   // failed layer: nothing below it is needed
             if (N == 0) break;                  // not processed (cannot happen above the running round)
             double mn = 1e300;
@@ -554,6 +554,17 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         if (s.ints[0] != ST_OK) {
             if (MODE == 1) { layer_failed(l, s.ints[0]); continue; }
             fail_pair<NT>(b, p, s.ints[0], out_stride); return;
+        }
+        if (MODE == 1 && b.rayleigh_direct && stg->Linv && em_has_rayleigh_phase((int)s.pc[l] & 15)) {
+            // a layer with a Rayleigh phase matrix: X- is diagonal and X+ diagonal minus rank two -- no Cholesky, no B;
+            // dort_rayleigh_kernel.hpp diagonalises it from these scalars (its header has the layout of the slot)
+            const long long item = p * (long long)b.Lmax + l;
+            double* gI = stg->Linv + item * stg->linv_stride;
+            for (int r = t; r < N; r += NT) { gI[2 + n + r] = s.u[r]; stg->d[item * stg->vec_stride + r] = s.d[r]; }
+            for (int j = t; j < n; j += NT) gI[2 + j] = s.mu[j];
+            if (t == 0) { gI[0] = ke; gI[1] = s.pa[l]; stg->n[item] = N + kStageDirect; }
+            block_sync();
+            continue;
         }
         // -- X+- = M^-1/2 T (ke I - c N S+- W) T^-1 M^-1/2, symmetric positive definite (lower triangles)
         for_2d<NT>(N, N, [&](int r, int c) {

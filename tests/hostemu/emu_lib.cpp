@@ -12,6 +12,7 @@
 #include "../../smrt_amd/csrc/dort_finish_reg.hpp"
 #include "../../smrt_amd/csrc/dort_finish_strip.hpp"
 #include "../../smrt_amd/csrc/dort_eig_kernel.hpp"
+#include "../../smrt_amd/csrc/dort_rayleigh_kernel.hpp"
 
 using namespace smrt;
 
@@ -20,6 +21,8 @@ using namespace smrt;
 extern "C" { int smrt_emu_pipeline = 1; }
 // 1: the symmetric eigensolver (dort_eig_kernel.hpp) in place of the Jacobi kernel on the N <= 64 pipelines, like the library's default
 extern "C" { int smrt_emu_eig = 1; }
+// 1: layers with a Rayleigh phase matrix through the closed-form kernel where a strip finish kernel follows (the library's default)
+extern "C" { int smrt_emu_rayleigh = 1; }
 
 // tridiag -> chase -> vectors on one staging item, as k_eig.hip launches them (one wavefront, one lane, one wavefront)
 template <int NP>
@@ -110,6 +113,11 @@ static long run_rounds(DevBatch& d, int order, int nmodes, Staging& sg, Prep pre
         for (long long blk = 0; blk < blocks; ++blk) {
             const long long item = jacobi_item_of_block(d, blk);
             if (sg.n[item] <= 0) continue;   // nothing staged (beyond the snowpack, rejected by prep, or below a cut)
+            if (stage_direct(sg.n[item])) {   // a layer with a Rayleigh phase matrix: the closed-form kernel (k_rayleigh.hip)
+                std::vector<double> rl((size_t)rayleigh_lds_doubles(), NAN);
+                nb += emu::run_block(128, order, [&]() { dort_rayleigh_item<128>(d, sg.st, item, rl.data()); });
+                continue;
+            }
             nb += jac(item);
         }
         if (r + 1 < rounds)
@@ -130,6 +138,7 @@ static long run_split_gmem(DevBatch& d, int order, const LdsPlan& plan) {
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, ACTIVE ? 3 : 2);
     // the strip finish kernel (one workgroup of eight wavefronts per pair) where the library uses it
     const bool strip = !ACTIVE && smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST;
+    d.rayleigh_direct = (strip && smrt_emu_rayleigh) ? 1 : 0;   // like smrt_dort_upload: where the strip finish kernel reads the staging area
     std::vector<double> jl(jp.total);
     auto fresh = [&]() { for (auto& x : lds) x = NAN; for (auto& x : ws) x = NAN; };
     // (passive: the LDS-resident prep kernel with eight wavefronts where its two packed triangles fit, like the library)
@@ -214,6 +223,7 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
     std::vector<double> lds(lds_doubles + finish_reg_lds_doubles(d.n_max_stream, d.Lmax) + finish_strip_lds_doubles(d.n_max_stream, d.Lmax, 4));
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
+    d.rayleigh_direct = (smrt_emu_pipeline == 6 && smrt_emu_rayleigh && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST) ? 1 : 0;
     return run_rounds(d, order, 1, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
         [&](long long it) { return run_jacobi_classes(d, sg.st, it, 2, order, jl); },
@@ -389,6 +399,25 @@ extern "C" int smrt_emu_eig_item(int NMAX, int N, double* Bm, double* sigma, int
         *n_rotations = cnt;
     }
     return n;
+}
+
+// The Rayleigh closed-form kernel on one layer: ke, pa, n cosines (descending), 2 n row scalings in; A+ = D V ([N][LD]
+// column-major, LD = (NMAX + 1) | 1), sigma [N] and 1 / D^2 [N] out.  Returns N, or the negative status of the layer.
+extern "C" int smrt_emu_rayleigh_item(int NMAX, int n, double ke, double pa, const double* mu, const double* u, double* Ap, double* sigma,
+                                      double* inv_d2, int order) {
+    const int N = 2 * n;
+    std::vector<double> slot(2048, NAN), dvec((size_t)NMAX, 1.0);
+    slot[0] = ke; slot[1] = pa;
+    for (int j = 0; j < n; ++j) slot[2 + j] = mu[j];
+    for (int r = 0; r < N; ++r) slot[2 + n + r] = u[r];
+    int nst = N + kStageDirect, nl = 1, status = 0;
+    DevBatch b{};
+    b.S = 1; b.Lmax = 1; b.F = 1; b.n_layers = &nl; b.status = &status; b.pair_count = 1;
+    DevStage st{nullptr, Ap, dvec.data(), sigma, &nst, (long long)NMAX * ((NMAX + 1) | 1), NMAX, slot.data(), nullptr, 2048};
+    std::vector<double> lds((size_t)rayleigh_lds_doubles(), NAN);
+    emu::run_block(128, order, [&]() { dort_rayleigh_item<128>(b, st, 0, lds.data()); });
+    if (nst > 0) for (int r = 0; r < N; ++r) inv_d2[r] = slot[r];
+    return nst > 0 ? stage_rows(nst) : nst;
 }
 
 // ft_even_phase of one layer through the device function (one emulated thread per (scattered, incident) pair)

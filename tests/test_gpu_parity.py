@@ -930,7 +930,7 @@ def test_cfg3_full_batch_size(ctx):
     full = ctx.run(b)
     assert b.n_pairs == 57344 and (full.status == 0).all()
     info = ctx.launch_info()
-    assert info["pipeline"] == "gmem_strip" and info["chunks"] > 1
+    assert info["pipeline"] == "gmem_strip" and info["chunks"] > 1 and info["rayleigh_closed_form"]
     mine = full.values.reshape(len(freqs), S, *full.values.shape[1:])[:, k]
     assert np.abs(mine - d["result"]).max() < TB_TOL
     lo, hi = info["chunk_pairs"] - 700, 2 * info["chunk_pairs"] + 300
@@ -1120,3 +1120,57 @@ def test_diagonalisation_choice_and_agreement(ctx):
     wide = PackedBatch([L] * 4, thick[:4], dens[:4] / 916.7, temp[:4], lc[:4], None, [36.5e9], np.deg2rad([55.0]), n_max_stream=40)
     ctx.upload(wide)
     assert ctx.launch_info()["diagonalisation"] == "jacobi"
+
+
+def test_rayleigh_closed_form_on_hard_dmrt_media(ctx):
+    """The closed-form diagonalisation of the Rayleigh-phase layers (dort_rayleigh_kernel.hpp; launch_info:
+    rayleigh_closed_form) on deliberately hard DMRT-QCA inputs -- 0.1 mm ... 3 m layers, radii 10 um ... 0.5 mm, stickiness
+    0.1 ... 1000, 1.4 ... 89 GHz, 8 ... 64 streams (both strip kernels) -- every pair against the CPU oracle and against the
+    Cholesky + Jacobi / eigensolver route of the same library (SMRT_DORT_RAYLEIGH=0); pairs the oracle refuses (albedo >= 1,
+    renormalisation) must come back with the same status."""
+    import os
+
+    from oracle import dort_oracle as O
+    from smrt_amd._native import PackedBatch
+
+    rng = np.random.default_rng(7)
+    worst = worst_ab = 0.0
+    checked = refused = 0
+    for case in range(10):
+        S, L = 4, int(rng.integers(1, 7))
+        nstr = int(rng.choice([8, 16, 32, 40, 64]))
+        thick = 10.0 ** rng.uniform(-4, 0.5, (S, L)); thick[:, -1] = rng.choice([0.3, 100.0], S)
+        fv = rng.uniform(0.05, 0.4, (S, L)); temp = rng.uniform(200, 272.9, (S, L))
+        radius = 10.0 ** rng.uniform(-5, -3.3, (S, L)); stick = rng.choice([0.1, 0.2, 1000.0], (S, L))
+        freqs = np.sort(rng.choice([1.4e9, 6.9e9, 18.7e9, 36.5e9, 89e9], 2, replace=False))
+        theta = np.array([rng.uniform(0, 20), rng.uniform(40, 75)])
+        b = PackedBatch([L] * S, thick, fv, temp, radius, stick, freqs, np.deg2rad(theta), emmodel="dmrt_qca_shortrange",
+                        microstructure="sticky_hard_spheres", n_max_stream=nstr)
+        out = ctx.run(b)
+        assert ctx.launch_info()["rayleigh_closed_form"]
+        os.environ["SMRT_DORT_RAYLEIGH"] = "0"
+        try:
+            alt = ctx.run(b)
+            assert not ctx.launch_info()["rayleigh_closed_form"]
+        finally:
+            del os.environ["SMRT_DORT_RAYLEIGH"]
+        assert np.array_equal(out.status, alt.status)
+        for fi, f in enumerate(freqs):
+            for s in range(S):
+                p = fi * S + s
+                sp = dict(thickness=thick[s], frac_volume=fv[s], temperature=temp[s], microstructure="sticky_hard_spheres",
+                          radius=radius[s], stickiness=stick[s])
+                try:
+                    ref = O.solve(sp, float(f), theta, emmodel="dmrt_qca_shortrange", n_max_stream=nstr)
+                    st = 0
+                except O.OracleError as e:
+                    st = e.status
+                assert out.status[p] == st, (case, p, st, out.status[p])
+                if st != 0:
+                    refused += 1
+                    continue
+                checked += 1
+                worst = max(worst, float(np.abs(out.values[p] - ref).max()))
+                worst_ab = max(worst_ab, float(np.abs(out.values[p] - alt.values[p]).max()))
+    assert checked >= 40
+    assert worst < 1e-6 and worst_ab < 1e-6, (worst, worst_ab)

@@ -571,3 +571,61 @@ def test_emulator_under_address_sanitizer():
                          timeout=1500)
     assert out.returncode == 0 and out.stdout.strip().endswith("asan cases ok"), (out.stdout[-500:], out.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in out.stderr
+
+
+@pytest.mark.parametrize("n,ke,pa,order", [(8, 1.3, 0.9, 0), (6, 2.0, 0.05, 1), (12, 0.02, 0.01, 2), (16, 0.02, 1e-6, 0), (64, 3.0, 0.2, 1),
+                                           (32, 40.0, 1e-9, 2), (5, 1.0, 0.0, 0)])
+def test_rayleigh_closed_form_kernel(emu, n, ke, pa, order):
+    """dort_rayleigh_kernel.hpp on one synthetic layer: D X+ D = diag(a) - Y Y^T (every pole twice, rank-two update) from the
+    2 x 2 secular problem.  V = D^-1 A+ is orthogonal to rounding, the eigen-equation holds to rounding, sigma^2 are the
+    eigenvalues -- for strong, weak (roots 1e-12 of an interval away from their pole) and no scattering, up to N = 128."""
+    N, NMAX = 2 * n, 128
+    LD = (NMAX + 1) | 1
+    mu = 0.98 - 0.93 * np.arange(n) / n
+    u = 0.3 + 0.01 * np.arange(N)
+    Ap = np.full((NMAX, LD), np.nan); sig = np.zeros(NMAX); inv_d2 = np.zeros(NMAX)
+    dp = lambda x: np.ascontiguousarray(x).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    emu.smrt_emu_rayleigh_item.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 5 + [C.c_int]
+    rc = emu.smrt_emu_rayleigh_item(NMAX, n, ke, pa, dp(mu), dp(u), dp(Ap), dp(sig), dp(inv_d2), order)
+    assert rc == N
+    D = np.sqrt(ke / np.repeat(mu, 2))
+    u1 = np.empty(N); u1[0::2] = mu ** 2; u1[1::2] = 1.0
+    u2 = np.zeros(N); u2[0::2] = 1.0 - mu ** 2
+    Y = np.column_stack([D * np.sqrt(0.5 * pa) * u * u1, D * np.sqrt(pa) * u * u2])
+    M = np.diag(D ** 4) - Y @ Y.T
+    V = Ap[:N, :N].T / D[:, None]
+    lam = sig[:N] ** 2
+    assert np.abs(V.T @ V - np.eye(N)).max() < 5e-13
+    assert np.abs(M @ V - V * lam[None, :]).max() < 1e-13 * np.abs(lam).max()
+    np.testing.assert_allclose(np.sort(lam), np.linalg.eigvalsh(M), rtol=1e-12)
+    np.testing.assert_allclose(inv_d2[:N], 1.0 / D ** 2, rtol=1e-15)
+
+
+def test_rayleigh_closed_form_kernel_flags_an_albedo_above_one(emu):
+    """diag(a) - Y Y^T stops being positive definite exactly when the Cholesky factorisation of X+ would fail: status 3."""
+    n, NMAX = 6, 32
+    mu = np.linspace(0.95, 0.2, n)
+    dp = lambda x: np.ascontiguousarray(x).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    emu.smrt_emu_rayleigh_item.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 5 + [C.c_int]
+    Ap = np.zeros((NMAX, (NMAX + 1) | 1)); sig = np.zeros(NMAX); inv_d2 = np.zeros(NMAX)
+    assert emu.smrt_emu_rayleigh_item(NMAX, n, 1.0, 30.0, dp(mu), dp(np.full(2 * n, 0.8)), dp(Ap), dp(sig), dp(inv_d2), 0) == -3
+
+
+@pytest.mark.parametrize("name,pipeline", [("dmrt_L8_n16", 6), ("dmrtcp_L5_n12", 6), ("dmrt_L4_n12_reflector", 6), ("nonscattering_L3_n10_substrate", 6),
+                                           ("dmrt_wet_L3_n12_passive", 6), ("dmrt_L8_n16", 5)])
+def test_rayleigh_layers_with_and_without_the_closed_form(emu, name, pipeline):
+    """Layers with a Rayleigh phase matrix through the strip pipelines (6: four wavefronts, N <= 64; 5: the global-workspace
+    pipeline with the eight-wavefront strip kernel) with the closed-form kernel (the default) and with the Cholesky +
+    diagonalisation route (smrt_emu_rayleigh = 0, the library's SMRT_DORT_RAYLEIGH=0): both at the reference's numbers,
+    and with each other to 1e-9 K."""
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = pipeline
+    try:
+        closed, st_c, ref = run_fixture(emu, name, nt=256)
+        C.c_int.in_dll(emu, "smrt_emu_rayleigh").value = 0
+        chol, st_j, _ = run_fixture(emu, name, nt=256)
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_rayleigh").value = 1
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert (st_c == 0).all() and (st_j == 0).all()
+    assert np.abs(closed - ref).max() < 1e-6 and np.abs(chol - ref).max() < 1e-6
+    assert np.abs(closed - chol).max() < 1e-9
