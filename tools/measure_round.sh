@@ -9,15 +9,20 @@ cd $R
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 ( cd /tmp; rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_line_under_rocprof.json 2> $O/rocprof.err )
 python tools/rocpd_summary.py $(find $O/prof -name "*.db" | head -1) > $O/bench_kernel_stats.txt 2>&1
+# the same with ONE pipeline pass at a time (the default runs three concurrently: their kernels overlap and stretch each other)
+( cd /tmp; SMRT_DORT_LANES=1 rocprofv3 --kernel-trace --stats -d $O/prof1 -o bench -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_line_under_rocprof_one_pass.json 2> $O/rocprof1.err )
+python tools/rocpd_summary.py $(find $O/prof1 -name "*.db" | head -1) > $O/bench_kernel_stats_one_pass.txt 2>&1
+( cd /tmp; rocprofv3 --kernel-trace --stats -d $O/prof2 -o bench -- python $R/bench.py --config 2 --no-cpu-baseline --no-secondary > $O/bench_line_cfg2_under_rocprof.json 2> $O/rocprof2.err )
+python tools/rocpd_summary.py $(find $O/prof2 -name "*.db" | head -1) > $O/cfg2_kernel_stats.txt 2>&1
 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc ${ROUND_TAG:-r5} > $O/pmc_counters.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc ${ROUND_TAG:-r6} > $O/pmc_counters.txt 2>&1
 # the other BASELINE shapes as driver-style lines (bench.py --config 2 | 3) with their own HBM-traffic passes
 python bench.py --config 2 > $O/bench_line_cfg2.json 2> $O/bench_line_cfg2.err
 python bench.py --config 3 > $O/bench_line_cfg3.json 2> $O/bench_line_cfg3.err
 PMC_CONFIG=2 bash tools/pmc_passes.sh > $O/pmc_passes_cfg2.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_cfg2 ${ROUND_TAG:-r5} 2 7168 > $O/pmc_counters_cfg2.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_cfg2 ${ROUND_TAG:-r6} 2 7168 > $O/pmc_counters_cfg2.txt 2>&1
 PMC_CONFIG=3 bash tools/pmc_passes.sh > $O/pmc_passes_cfg3.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_cfg3 ${ROUND_TAG:-r5} 3 512 > $O/pmc_counters_cfg3.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_cfg3 ${ROUND_TAG:-r6} 3 512 > $O/pmc_counters_cfg3.txt 2>&1
 python bench.py --config 2 --no-secondary > $O/bench_line_cfg2_with_traffic.json 2>> $O/bench_line_cfg2.err
 python bench.py --config 3 --no-secondary > $O/bench_line_cfg3_with_traffic.json 2>> $O/bench_line_cfg3.err
 cp profiles/hbm_traffic.json $O/hbm_traffic.json 2>/dev/null

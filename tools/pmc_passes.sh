@@ -8,6 +8,9 @@ OUT=$R/gpurun_out/pmc
 [ "$CFG" != "1" ] && OUT=$R/gpurun_out/pmc_cfg$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (one pipeline pass at a time: with concurrent passes a launch is several dispatches of every kernel, and the summary adds
+# up the mean per dispatch of the kernels of ONE launch)
+export SMRT_DORT_LANES=1
 CMD="python $R/bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary"
 run() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1; }
 run fetch FETCH_SIZE
