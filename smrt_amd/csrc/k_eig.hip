@@ -75,8 +75,9 @@ static hipError_t go_vectors(smrt_dort_ctx* ctx, const DevBatch& c, long long it
     return hipGetLastError();
 }
 
-// Size classes by row count: (0, 32], (32, 48], (48, 64] -- tridiag's LDS is 8.4 / 18.8 / 33.3 KB per wavefront, the register
-// rows of tridiag / vectors 64 / 96 / 128 registers.
+// Size classes by row count: (0, 32], (32, 48], (48, 64] -- the register rows of tridiag / vectors are 64 / 96 / 128 registers
+// (3 / 3 / 2 wavefronts per SIMD).  Measured and dropped: a class (48, 56] of its own held to three wavefronts per SIMD by
+// __launch_bounds__ (52 / 12 B of scratch): tridiag 2.61 against 2.02 ms for the two classes, vectors 3.34 against 3.47.
 hipError_t eig(smrt_dort_ctx* ctx, const DevBatch& c, long long items) {
     const int nmax = ctx->nmax_rows;
     hipError_t e;
