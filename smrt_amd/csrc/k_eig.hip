@@ -47,7 +47,12 @@ __global__ __launch_bounds__(64) void dort_eig_vectors_kernel(DevBatch b, DevSta
     SMRT_EIG_ROWS(56, (eig_vectors_item<56>(st, item, ring))) SMRT_EIG_ROWS(64, (eig_vectors_item<64>(st, item, ring)))
 }
 
-// one LANE per item: d and e of the kEigChaseLanes items of a wavefront in LDS, element i of lane t at [kEigChaseLanes i + t]
+// one LANE per item: d and e of the kEigChaseLanes items of a wavefront in LDS, element i of lane t at [kEigChaseLanes i + t].
+// Items in their staging order.  Measured and dropped (profiles/r6_eig_steps.txt 7): lists of the items by size class (filled by
+// the tridiag kernel with atomics) so that the 64 items of a wavefront have similar sizes -- a simulation of the wavefront
+// schedule promised 3700 -> 2700 steps per wavefront --, one launch per class with the LDS of its size (3.75 ms: every launch of
+// this latency chain pays its own tail) or one launch through the lists (3.41 ms small classes first, 3.15 ms largest first)
+// against 3.18 ms as it is.
 __global__ __launch_bounds__(kEigChaseLanes) void dort_eig_chase_kernel(DevBatch b, DevStage st, long long items) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     const long long blk = (long long)blockIdx.x * kEigChaseLanes + threadIdx.x;
