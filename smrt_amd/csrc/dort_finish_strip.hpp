@@ -26,6 +26,13 @@
 #include "dort_passive.hpp"
 #include "dort_finish_reg.hpp"
 
+#ifndef SMRT_STRIP_WOODBURY
+#define SMRT_STRIP_WOODBURY 1          // one inversion inside a layer where it is safe (see the layer loop)
+#endif
+#ifndef SMRT_STRIP_WOODBURY_TAU
+#define SMRT_STRIP_WOODBURY_TAU 1e-3   // ... i.e. where min over the streams of sigma x thickness is at least this
+#endif
+
 namespace smrt {
 
 #ifdef SMRT_STRIP_TIMING_INV
@@ -396,7 +403,7 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
     const double* mp1 = b.p1 + (long long)si * b.Lmax;
     const double* mp2 = b.p2 + (long long)si * b.Lmax;
 
-    if (t < 8) s.ints[t] = 0;
+    if (t < 16) s.ints[t] = 0;   // ([8], [9]: the thin-layer flags of the layer loop, by layer parity)
     block_sync();
     {
         const int prev = b.status[p];
@@ -525,8 +532,15 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         const double di_e = fast_rcp(d_e);
         const double nrs_e = -fast_rcp(sg_e);                      // -1 / sigma
         const double tt_e = in_e ? exp(-sg_e * s.thick[l]) : 0.0;
-        const double st_e = sg_e * tt_e;                           // sigma t
-        const double m3_e = in_e ? sg_e * (1.0 - tt_e * tt_e) : 1.0;
+        // One inversion inside the layer instead of two where every stream of the layer is optically thick enough (Woodbury on
+        // M3: Theta = diag((1 + t^2) / (Sigma (1 - t^2))) - 4 G (H + Sigma (1 + t^2) / (1 - t^2))^-1 G, G = t / (1 - t^2) -- a
+        // difference of O(1 / (sigma d)) terms that loses digits in proportion to 1 / (sigma d)^2: tests/studies/
+        // woodbury_per_layer.py -- unchanged at 1e-9 K on the hard inputs with the shortcut for min sigma d >= 1e-4, 6e-6 K
+        // with it everywhere; taken from 1e-3 on).  Decided per layer through an LDS flag: uniform after the barrier below.
+        const double sd_e = sg_e * s.thick[l];
+        if (in_e && !(sd_e >= SMRT_STRIP_WOODBURY_TAU)) lds_or(&s.ints[8 + (l & 1)], 1);
+        if (t == 0) s.ints[8 + ((l + 1) & 1)] = 0;                 // (the flag of the next layer; last read many barriers ago)
+        const double omt2_e = in_e ? -expm1(-2.0 * sd_e) : 1.0;    // 1 - t^2
         if (l == Lk - 1) {
             // what the last layer sees below (rtsolver_utils.py:544-551,579-584,601-603; dort.py:429-441,446-452):
             // I_up = R I_dn + src  ->  C = (1 - R) / (1 + R) (diagonal: C^ = C), c = (C + 1) src
@@ -546,11 +560,12 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
             if (t < kVecLen) E7[t] = cd;
         }
         if (t < kVecLen) {
-            E0[t] = nrs_e; E1[t] = sg_e; E2[t] = st_e; E3[t] = m3_e; E4[t] = di_e; E5[t] = d_e;
+            E0[t] = nrs_e; E1[t] = sg_e; E4[t] = di_e; E5[t] = d_e;   // (E2, E3, E7: set where the layer's matrices are formed)
             E6[t] = c_e * di_e;                                    // c^ = D^-1 c
             if (direct) E11[t] = in_e ? gI[t] : 0.0;               // 1 / D^2 (E11 is free until the first inversion is done)
         }
         block_sync();
+        const bool wood = SMRT_STRIP_WOODBURY && s.ints[8 + (l & 1)] == 0;   // (uniform)
         if (l == Lk - 1) {
 #pragma unroll
             for (int ti = 0; ti < NTT; ++ti)
@@ -632,27 +647,52 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         }
         block_sync();
         SMRT_ST(STP_H);
-        if (t < kVecLen) E8[t] -= 2.0 * Bl * E10[t];                        // r = A+^T (c^ - 2 B C^ 1^)
+        if (t < kVecLen) {
+            const double r_e = E8[t] - 2.0 * Bl * E10[t];                   // r = A+^T (c^ - 2 B C^ 1^)
+            // The matrix inverted next, H + K with K = Sigma (two inversions) or Sigma (1 + t^2) / (1 - t^2) (one), is inverted
+            // as I + s H s, s = K^-1/2: pivots of O(1).  The 16 x 16 elimination loses |pivot|^2 ulps on the diagonal of the
+            // inverse (inv16_step) -- 1e-13 with Sigma, but K is Sigma / (sigma d) for a thin layer and the one-inversion
+            // form amplifies by 1 / (sigma d)^2 on top: 2.5e-4 K on the hard inputs without the scaling, 1e-9 K with it.
+            // With two inversions the second matrix takes the same s: M3 = Sigma (1 - t^2) + 2 Sigma t P t Sigma
+            // = s^-1 (1 - t^2 + 2 t (I + s H s)^-1 t) s^-1.
+            double kk = sg_e, g = tt_e, dg = omt2_e;                        // (padding: 1, 0, 1 in both forms)
+            if (wood) {
+                const double io = fast_rcp(omt2_e), q = (1.0 + tt_e * tt_e) * io;
+                kk = sg_e * q; g = tt_e * io; dg = -nrs_e * q;              // K, G, (1 + t^2) / (Sigma (1 - t^2))
+            }
+            const double ks = fast_rsqrt(kk);
+            E8[t] = r_e * ks;                                               // s r
+            E2[t] = wood ? g * ks : g; E3[t] = dg; E7[t] = ks; E11[t] = 1.0;   // (E11 is free: 1 / D^2 of a direct layer was used above)
+        }
         if (w < nt) put_strip(X, nt, Lw);                                   // A+
         block_sync();
         if (w < nt) {
             strip_gemm<true>(C, X2, nt, Lw);                                // H^T = A+^T (C^^T A+)   (C is free: the work column)
-            strip_scale_add_diag(C, nullptr, nullptr, E1, 1.0, nt, w, Ln);  // H^T + Sigma
+            strip_scale_add_diag(C, E7, E7, E11, 1.0, nt, w, Ln);           // I + s H^T s
         }
         block_sync();
         SMRT_ST(STP_INV1);
-        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // P^T
-        if (w < nt) strip_matvec_t(C, E8, E10, nt, w, Ln);                  // q = P r -> E10
+        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // (I + s H s)^-T
+        if (w < nt) strip_matvec_t(C, E8, E10, nt, w, Ln);                  // (I + s H s)^-1 s r -> E10
         block_sync();
-        if (t < kVecLen) { E11[t] = st_e * E10[t]; E9[t] *= nrs_e; }        // Sigma t q;  x1
-        if (w < nt) strip_scale_add_diag(C, E2, E2, E3, 2.0, nt, w, Ln);    // M3^T
+        if (wood) {
+            if (t < kVecLen) { E10[t] *= E2[t]; E9[t] *= nrs_e; }           // y = G (H + K)^-1 r = G s (I + s H s)^-1 s r;  x1
+            if (w < nt) strip_scale_add_diag(C, E2, E2, E3, -4.0, nt, w, Ln);   // Theta^T = diag - 4 G (H + K)^-T G
+            block_sync();
+            SMRT_ST(STP_INV2);
+            if (w < nt) strip_matvec_t(C, E9, E6, nt, w, Ln);               // x2 = Theta x1 -> E6
+        } else {
+        if (t < kVecLen) { E11[t] = E2[t] * E10[t]; E9[t] *= nrs_e; }       // s Sigma t q = t (I + s H s)^-1 s r;  x1
+        if (w < nt) strip_scale_add_diag(C, E2, E2, E3, 2.0, nt, w, Ln);    // s M3^T s = 1 - t^2 + 2 t (I + s H s)^-T t
         block_sync();
         SMRT_ST(STP_INV2);
-        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // M3^-T
+        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // (s M3 s)^-T
         if (w < nt) {
-            strip_matvec_t(C, E11, E10, nt, w, Ln);                         // y = M3^-1 (Sigma t q) -> E10
-            strip_scale_add_diag(C, nullptr, nullptr, E0, 2.0, nt, w, Ln);  // Theta^T = 2 M3^-T - Sigma^-1
+            strip_scale_add_diag(C, nullptr, E7, nullptr, 1.0, nt, w, Ln);  // (s M3 s)^-T s
+            strip_matvec_t(C, E11, E10, nt, w, Ln);                         // y = M3^-1 (Sigma t q) = s (s M3 s)^-1 (s Sigma t q) -> E10
+            strip_scale_add_diag(C, E7, nullptr, E0, 2.0, nt, w, Ln);       // Theta^T = 2 M3^-T - Sigma^-1
             strip_matvec_t(C, E9, E6, nt, w, Ln);                           // x2 = Theta x1 -> E6 (free since the first phase; E11 is still being read)
+        }
         }
         block_sync();
         SMRT_ST(STP_T2);

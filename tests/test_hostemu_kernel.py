@@ -629,3 +629,43 @@ def test_rayleigh_layers_with_and_without_the_closed_form(emu, name, pipeline):
     assert (st_c == 0).all() and (st_j == 0).all()
     assert np.abs(closed - ref).max() < 1e-6 and np.abs(chol - ref).max() < 1e-6
     assert np.abs(closed - chol).max() < 1e-9
+
+
+def test_strip_layer_step_on_thin_layers_next_to_thick_ones(emu):
+    """The layer step of the strip finish kernels takes ONE inversion where every stream of the layer has sigma d >= 1e-3
+    (Woodbury on M3: a difference of O(1 / (sigma d)) terms) and two elsewhere; every matrix is inverted scaled to unit
+    pivots (dort_finish_strip.hpp; DESIGN 3d -- unscaled, the first build was wrong by 1e-5 K on exactly these media).
+    0.1 mm ... 3 m layers at 89 - 183 GHz, thin ones on top of, between and under thick ones, against the oracle."""
+    from oracle import dort_oracle as O
+    rng = np.random.default_rng(3)
+    theta = np.array([10.0, 55.0])
+    C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 6
+    worst, checked = 0.0, 0
+    try:
+        for trial in range(14):
+            L = int(rng.integers(2, 5))
+            n_str = int(rng.choice([4, 7, 12]))
+            thick = 10.0 ** rng.uniform(-4, 0.5, L)
+            thick[int(rng.integers(0, L))] = 10.0 ** rng.uniform(-4, -3)   # at least one thin layer
+            thick[-1] = rng.choice([0.3, 100.0])
+            fv = rng.uniform(0.05, 0.49, L)
+            temp = rng.uniform(200, 272.9, L)
+            lc = 10.0 ** rng.uniform(-5, -3.2, L)
+            f = float(rng.choice([89e9, 150e9, 183e9]))
+            sp = dict(thickness=thick, frac_volume=fv, temperature=temp, microstructure="exponential", corr_length=lc)
+            try:
+                ref = O.solve(sp, f, theta, n_max_stream=n_str)
+            except O.OracleError:
+                continue
+            b = PackedBatch([L], thick[None], fv[None], temp[None], lc[None], None, np.array([f]), np.deg2rad(theta), n_max_stream=n_str)
+            out = np.empty((1,) + b.out_shape())
+            st = np.empty(1, np.int32)
+            nb = C.c_long()
+            rc = emu.smrt_emu_run(C.byref(b.struct), 0, 1, 256, trial % 3, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                  st.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, C.byref(nb))
+            assert rc == 0 and st[0] == 0
+            worst = max(worst, float(np.abs(out[0] - ref).max()))
+            checked += 1
+    finally:
+        C.c_int.in_dll(emu, "smrt_emu_pipeline").value = 1
+    assert checked >= 10 and worst < 2e-9, (checked, worst)
