@@ -275,8 +275,13 @@ SMRT_DEV void eig_tridiag_item(const DevStage& stg, long long item) {
 // chase runs (every e[j] of the block is rewritten by it), so that no separate scan is needed afterwards.
 // (Measured with sixteen items per wavefront instead of 64, so that its 16 KB of LDS fit beside three workgroups of the
 // prep or finish kernel of ANOTHER pipeline pass on a CU: 3.62 against 3.38 ms alone and 165.3 k against 169.0 k solves/s
-// with three concurrent passes -- the overlap is not limited by the LDS the kernel holds.)
-constexpr int kEigChaseLanes = 64;
+// with three concurrent passes -- the overlap is not limited by the LDS the kernel holds.  48 / 40 / 32 items per wavefront,
+// i.e. 3 / 4 / 5 wavefronts per CU instead of 2 -- a wavefront issues 68 % of its cycles and two of a CU's four SIMDs are
+// idle with 2: the diagonalisation alone 14.6 -> 14.4 ms at 40, but the step with three passes 29.3 -> 29.6 ms.)
+#ifndef SMRT_EIG_CHASE_LANES
+#define SMRT_EIG_CHASE_LANES 64
+#endif
+constexpr int kEigChaseLanes = SMRT_EIG_CHASE_LANES;
 
 SMRT_DEV void eig_chase_lane(const DevStage& stg, long long item, double* dl, double* el) {
     const int n = stg.n[item];
