@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) void dort_eig_vectors_kernel(DevBatch b, DevSta
 // the tridiag kernel with atomics) so that the 64 items of a wavefront have similar sizes -- a simulation of the wavefront
 // schedule promised 3700 -> 2700 steps per wavefront --, one launch per class with the LDS of its size (3.75 ms: every launch of
 // this latency chain pays its own tail) or one launch through the lists (3.41 ms small classes first, 3.15 ms largest first)
-// against 3.18 ms as it is.
+// against 3.18 ms as it is.  The chase of a pass on a high-priority stream of its own (events around it), so that its long
+// chains start as early as the dispatcher allows while other passes fill the chip: 29.4 against 29.2 ms per step -- dropped.
 __global__ __launch_bounds__(kEigChaseLanes) void dort_eig_chase_kernel(DevBatch b, DevStage st, long long items) {
     extern __shared__ __attribute__((aligned(16))) double smrt_lds[];
     const long long blk = (long long)blockIdx.x * kEigChaseLanes + threadIdx.x;
