@@ -675,25 +675,25 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // (I + s H s)^-T
         if (w < nt) strip_matvec_t(C, E8, E10, nt, w, Ln);                  // (I + s H s)^-1 s r -> E10
         block_sync();
-        if (wood) {
-            if (t < kVecLen) { E10[t] *= E2[t]; E9[t] *= nrs_e; }           // y = G (H + K)^-1 r = G s (I + s H s)^-1 s r;  x1
-            if (w < nt) strip_scale_add_diag(C, E2, E2, E3, -4.0, nt, w, Ln);   // Theta^T = diag - 4 G (H + K)^-T G
-            block_sync();
-            SMRT_ST(STP_INV2);
-            if (w < nt) strip_matvec_t(C, E9, E6, nt, w, Ln);               // x2 = Theta x1 -> E6
-        } else {
-        if (t < kVecLen) { E11[t] = E2[t] * E10[t]; E9[t] *= nrs_e; }       // s Sigma t q = t (I + s H s)^-1 s r;  x1
-        if (w < nt) strip_scale_add_diag(C, E2, E2, E3, 2.0, nt, w, Ln);    // s M3^T s = 1 - t^2 + 2 t (I + s H s)^-T t
+        // (one flow for both forms: the second inversion and what hangs on it are skipped with one inversion)
+        if (t < kVecLen) {
+            const double yv = E2[t] * E10[t];                               // y = G (H + K)^-1 r, or s Sigma t q = t (I + s H s)^-1 s r
+            if (wood) E10[t] = yv; else E11[t] = yv;
+            E9[t] *= nrs_e;                                                 // x1
+        }
+        // Theta^T = diag - 4 G (H + K)^-T G, or s M3^T s = 1 - t^2 + 2 t (I + s H s)^-T t
+        if (w < nt) strip_scale_add_diag(C, E2, E2, E3, wood ? -4.0 : 2.0, nt, w, Ln);
         block_sync();
         SMRT_ST(STP_INV2);
-        strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                         // (s M3 s)^-T
-        if (w < nt) {
-            strip_scale_add_diag(C, nullptr, E7, nullptr, 1.0, nt, w, Ln);  // (s M3 s)^-T s
-            strip_matvec_t(C, E11, E10, nt, w, Ln);                         // y = M3^-1 (Sigma t q) = s (s M3 s)^-1 (s Sigma t q) -> E10
-            strip_scale_add_diag(C, E7, nullptr, E0, 2.0, nt, w, Ln);       // Theta^T = 2 M3^-T - Sigma^-1
-            strip_matvec_t(C, E9, E6, nt, w, Ln);                           // x2 = Theta x1 -> E6 (free since the first phase; E11 is still being read)
+        if (!wood) {
+            strip_invert(C, nt, w, Lw, SMRT_SI_PTR);                                     // (s M3 s)^-T
+            if (w < nt) {
+                strip_scale_add_diag(C, nullptr, E7, nullptr, 1.0, nt, w, Ln);  // (s M3 s)^-T s
+                strip_matvec_t(C, E11, E10, nt, w, Ln);                     // y = M3^-1 (Sigma t q) = s (s M3 s)^-1 (s Sigma t q) -> E10
+                strip_scale_add_diag(C, E7, nullptr, E0, 2.0, nt, w, Ln);   // Theta^T = 2 M3^-T - Sigma^-1
+            }
         }
-        }
+        if (w < nt) strip_matvec_t(C, E9, E6, nt, w, Ln);                   // x2 = Theta x1 -> E6 (free since the first phase)
         block_sync();
         SMRT_ST(STP_T2);
         if (kPark) zero(At);
