@@ -138,6 +138,8 @@ def describe_kernels(info):
     prep, finish = PIPELINE_KERNELS[info["pipeline"]]
     if finish is None:
         return "pipeline '%s': %s" % (info["pipeline"], prep)
+    if info["pipeline"] == "lds_strip" and info.get("rayleigh_closed_form"):
+        finish = "dort_finish_strip4_direct_kernel"   # (the instance that also takes layers diagonalised in closed form)
     diag = RAYLEIGH_KERNEL if info.get("rayleigh_closed_form") else DIAG_KERNELS[info["diagonalisation"]]
     return "pipeline '%s': %s + %s + %s; %d pipeline pass(es) of <= %d pairs per launch" % (
         info["pipeline"], prep, diag, finish, info["chunks"], info["chunk_pairs"])

@@ -369,6 +369,7 @@ static SMRT_DEV void strip_invert(Strip& M, int nt, int w, const Lane& L, double
 // Supported: passive mode, N <= 16 NTT, Flat interfaces, no / Flat / Reflector substrate, atmosphere, prune_deep_snowpack.
 // The host routes batches with process_coherent_layers (T != 1 - R), a host-evaluated dense substrate or rough interfaces
 // to the pivoted finish kernels (dort_hip.hip).
+template <bool MAY_DIRECT>
 static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
     constexpr int NT = NTH, P = 2;
     const LaneId Ln0 = rg::lane_id();
@@ -467,7 +468,9 @@ static SMRT_DEV void run(const DevBatch& b, long long p, double* lds_base, const
         const double* gI = stg.Linv + item * stg.linv_stride;
         // a layer the Rayleigh kernel diagonalised (dort_rayleigh_kernel.hpp): the matrix slot holds A+ = D V itself and the
         // vector slot 1 / D^2; A- = -D^-2 A+ Sigma, i.e. W = D^-2 A+ Sigma^2 element by element -- no L+, no triangular stage
-        const bool direct = stage_direct(stg.n[item]);   // (uniform)
+        // (MAY_DIRECT = false: the instance for batches without such layers -- DevBatch::rayleigh_direct = 0 -- has the other
+        //  form of the stage only: 188 -> 160 B of scratch and 10.27 -> 10.0 ms on the headline batch for the four-wavefront kernel)
+        const bool direct = MAY_DIRECT && stage_direct(stg.n[item]);   // (uniform)
         const bool in_e = t < N;
         SMRT_ST(STP_LOAD);
         // (LDS addresses: laundered once per layer, see make_lane; the lane coordinates too -- the row indices and diagonal
@@ -883,10 +886,12 @@ SMRT_HD int finish_strip_lds_doubles(int n_max_stream, int Lmax, int ntt = 8) {
     return ntt * ntt * 16 * 17 + 12 * 16 * ntt + 3 * n_max_stream + 15 * Lmax + 8;
 }
 SMRT_DEV void dort_pair_passive_strip(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
-    StripFinish<8>::run(b, p, lds_base, stg);
+    StripFinish<8>::run<true>(b, p, lds_base, stg);
 }
+// MAY_DIRECT: the batch may hold layers the Rayleigh kernel diagonalised in closed form (DevBatch::rayleigh_direct)
+template <bool MAY_DIRECT>
 SMRT_DEV void dort_pair_passive_strip4(const DevBatch& b, long long p, double* lds_base, const DevStage& stg) {
-    StripFinish<4>::run(b, p, lds_base, stg);
+    StripFinish<4>::run<MAY_DIRECT>(b, p, lds_base, stg);
 }
 
 }  // namespace smrt

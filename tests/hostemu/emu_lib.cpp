@@ -223,13 +223,14 @@ static long run_split(DevBatch& d, int order, size_t lds_doubles, const LdsPlan&
     std::vector<double> lds(lds_doubles + finish_reg_lds_doubles(d.n_max_stream, d.Lmax) + finish_strip_lds_doubles(d.n_max_stream, d.Lmax, 4));
     const JacobiPlan jp = make_jacobi_plan(d.n_max_stream, 2);
     std::vector<double> jl(jp.total);
-    d.rayleigh_direct = (smrt_emu_pipeline == 6 && smrt_emu_rayleigh && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST) ? 1 : 0;
+    d.rayleigh_direct = (smrt_emu_pipeline == 6 && smrt_emu_rayleigh && (d.layer_kind != nullptr || em_has_rayleigh_phase(d.emmodel)) && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST) ? 1 : 0;
     return run_rounds(d, order, 1, sg,
         [&](long long p) { for (auto& x : lds) x = NAN; return emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 1>(d, p, lds.data(), nullptr, &sg.st); }); },
         [&](long long it) { return run_jacobi_classes(d, sg.st, it, 2, order, jl); },
         [&](long long p) { for (auto& x : lds) x = NAN;
                            if (smrt_emu_pipeline == 6 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the strip finish kernel on four wavefronts
-                               return emu::run_block(256, order, [&]() { dort_pair_passive_strip4(d, p, lds.data(), sg.st); });
+                               return d.rayleigh_direct ? emu::run_block(256, order, [&]() { dort_pair_passive_strip4<true>(d, p, lds.data(), sg.st); })
+                                                       : emu::run_block(256, order, [&]() { dort_pair_passive_strip4<false>(d, p, lds.data(), sg.st); });   // (the two instances of k_finish_strip.hip)
                            if (smrt_emu_pipeline == 3 && !d.host_itf_slot && !d.coherent && d.sub_kind != SUB_HOST)   // the register-resident finish kernel: one wavefront per pair (where the library uses it)
                                return emu::run_block(64, order, [&]() { dort_pair_passive_reg(d, p, lds.data(), sg.st); });
                            return smrt_emu_pipeline == 2 ? emu::run_block(NT, order, [&]() { dort_pair_passive<NT, 1, 2>(d, p, lds.data(), nullptr, &sg.st); })

@@ -429,7 +429,7 @@ def test_kernel_occupancy_as_designed():
             "dort_active_big_kernelILi256ELi6ELi2E": 2, "dort_jacobi_big_kernel": 3,
             "dort_finish_reg_kernel": 1,   # one wavefront per SIMD by design: the whole register file
             # the strip finish kernels: eight wavefronts, one workgroup per CU / four wavefronts, three workgroups per CU
-            "dort_finish_strip_kernel": 2, "dort_finish_strip4_kernel": 3, "dort_prep_kernel_wide": 2,
+            "dort_finish_strip_kernel": 2, "dort_finish_strip4_kernel": 3, "dort_finish_strip4_direct_kernel": 3, "dort_prep_kernel_wide": 2,
             # the symmetric eigensolver (k_eig.hip), one wavefront per item and no scratch: the register rows of its largest
             # size class (64 rows: 128 registers for the row alone) still leave two wavefronts per SIMD
             "dort_eig_tridiag_kernel": 2, "dort_eig_vectors_kernel": 2, "dort_eig_gram_kernel": 2, "dort_eig_chase_kernel": 4}
