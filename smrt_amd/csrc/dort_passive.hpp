@@ -462,9 +462,12 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         }
         SMRT_STAGE(SG_ASSEMBLE);
         if (MODE < 2) {
+        // (a layer the Rayleigh kernel will diagonalise in closed form needs neither matrix: its row sums below are two
+        //  sums over the streams -- 18 -> ~4 ms of prep kernel per 7168 solves of the configs[2] shape)
+        const bool ray_direct = MODE == 1 && b.rayleigh_direct && stg->Linv && em_has_rayleigh_phase((int)s.pc[l] & 15);   // (uniform)
         // -- phase matrix, azimuth mode 0: S+ = P(mu,+mu') + P(mu,-mu') -> M0, S- = P(+) - P(-) -> M1
         //    (lower triangle by stream blocks; the matrices are symmetric)
-        {
+        if (!ray_direct) {
             const int T = n * (n + 1) / 2;
             const double pa = s.pa[l], pb = s.pb[l];
             const int lo = (int)s.lo[l];   // the layer's index in the input arrays
@@ -539,8 +542,17 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
         // -- energy-conserving renormalisation (dort.py:782-819): norm_r = ks / (c sum_c S+[r,c] w_c), c = 1/2
         for (int r = t; r < N; r += NT) {
             double rs = 0.0;
+            if (ray_direct) {
+                // S+ = 2 pa (u1 u1^T / 2 + u2 u2^T) (rayleigh.py:70-76): row (i, V) sums to pa (a W2 + 2 (1 - a)(W0 - W2) + a W0),
+                // a = mu_i^2, row (i, H) to pa (W2 + W0), with W0 = sum_j w_j, W2 = sum_j w_j mu_j^2
+                double W0 = 0.0, W2 = 0.0;
+                for (int j = 0; j < n; ++j) { const double wj = s.wrow[2 * j], mj = s.mu[j]; W0 += wj; W2 += wj * mj * mj; }
+                const double a2 = s.mu[r >> 1] * s.mu[r >> 1];
+                rs = s.pa[l] * ((r & 1) ? (W2 + W0) : (a2 * W2 + 2.0 * (1.0 - a2) * (W0 - W2) + a2 * W0));
+            } else {
             for (int c = 0; c <= r; ++c) rs += s.M0[sidx<PK>(r, c, LD)] * s.wrow[c];
             for (int c = r + 1; c < N; ++c) rs += s.M0[sidx<PK>(c, r, LD)] * s.wrow[c];
+            }
             double nr = 1.0;
             if (b.normalization != 0 && ks != 0.0) {
                 nr = ks / (0.5 * rs);
@@ -555,7 +567,7 @@ SMRT_DEV void dort_pair_passive(const DevBatch& b, long long p, double* lds_base
             if (MODE == 1) { layer_failed(l, s.ints[0]); continue; }
             fail_pair<NT>(b, p, s.ints[0], out_stride); return;
         }
-        if (MODE == 1 && b.rayleigh_direct && stg->Linv && em_has_rayleigh_phase((int)s.pc[l] & 15)) {
+        if (ray_direct) {
             // a layer with a Rayleigh phase matrix: X- is diagonal and X+ diagonal minus rank two -- no Cholesky, no B;
             // dort_rayleigh_kernel.hpp diagonalises it from these scalars (its header has the layout of the slot)
             const long long item = p * (long long)b.Lmax + l;
