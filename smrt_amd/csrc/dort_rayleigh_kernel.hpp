@@ -113,7 +113,10 @@ SMRT_DEV void dort_rayleigh_item(const DevBatch& b, const DevStage& stg, long lo
                 eval(origin, sg, x, kap, dkap, e0, e1);
                 const bool below = (sg > 0.0) ? (kap < 0.0) : (kap > 0.0);     // x is below the root
                 if (below) xlo = x; else xhi = x;
-                double step = x - sg * kap / dkap;                              // Newton: d kappa / dx = sg * dkap
+                // Newton on h(x) = x kappa(x), d kappa / dx = sg dkap: kappa ~ 1 - c / x near the pole the distance is measured
+                // from, so h is nearly linear there and a root that hugs its pole is met in a few steps (on kappa itself the
+                // step from the middle of the interval overshoots the bracket and the bisection has to find the scale first)
+                double step = x * (x * sg * dkap) / (kap + x * sg * dkap);
                 if (kap == 0.0 || fabs(step - x) <= 4.0e-16 * x) break;         // converged (x itself is the better point)
                 if (!(step > xlo && step < xhi))   // outside the bracket: bisect -- geometrically while the scale is unknown
                     step = (xlo <= 0.0) ? 0.125 * xhi : (xhi > 4.0 * xlo) ? sqrt(xlo) * sqrt(xhi) : 0.5 * (xlo + xhi);
